@@ -1,0 +1,596 @@
+/*
+ * ecsimd_oracle.c -- CPU restatement of the aguinet/ecsimd hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity checker for the HIP kernels in
+ * ecsimd_amd/csrc/.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it.  The product path (libecsimd_hip.so and include/ecsimd/) never links, loads or calls it.
+ *
+ * Parity status: PINNED.  tests/test_oracle.py checks every function below against
+ *   (1) the known-answer vectors of the reference's own tests (tests/ops.cpp, tests/mgry.cpp,
+ *       tests/curve_point.cpp, tests/curve_group.cpp -- committed as data in tests/golden/reference_kats.json),
+ *   (2) lane-distinct golden vectors produced by the real reference compiled from
+ *       /root/reference (oracle/_ref, recipe oracle/Makefile; vectors in tests/golden/ref_vectors.json),
+ *   (3) the constants of SURVEY.md 8(c).
+ *
+ * Each function cites the reference file:line it follows (paths relative to /root/reference).
+ * One element = 4 x u64 limbs, little-endian limb order (serialization.h:18-21); the reference
+ * processes 4 lanes per eve::wide, this restatement processes one lane at a time and loops.
+ * Arithmetic is done on 32-bit digits held in u64, exactly like the reference's AVX2 code.
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <stdlib.h>
+#include <pthread.h>
+#include <time.h>
+
+#define NL 4   /* u64 limbs per field element */
+#define ND 8   /* u32 digits per field element */
+
+typedef struct { uint64_t l[NL]; } bn256;
+typedef struct { uint64_t l[2 * NL]; } bn512;
+
+typedef struct {
+  bn256 p;          /* field prime                                  curve_nist_p256.h:17-19 */
+  bn256 a, b;       /* curve coefficients (classical)               curve_nist_p256.h:20-26 */
+  bn256 gx, gy;     /* generator (classical)                        curve_nist_p256.h:27-32 */
+  bn256 r_p;        /* R mod p,  R = 2^256                          mgry_csts.h:20 */
+  bn256 rsq_p;      /* R^2 mod p                                    mgry_csts.h:21 */
+  bn256 pm1_r_p;    /* (p-1)*R mod p = -R mod p                     mgry_csts.h:24 */
+  bn256 am, bm;     /* a*R mod p, b*R mod p                         curve_group.h:31-32 */
+  bn256 p_m2;       /* p-2  (inverse exponent)                      gfp.h:79-81 */
+  bn256 p_sqrt;     /* (p+1)/4 (sqrt exponent, p = 3 mod 4)         gfp.h:84-87 */
+  uint32_t mprime;  /* -p^-1 mod 2^32                               mgry_mul.h:33-38 */
+} oracle_curve;
+
+enum { ORACLE_P256 = 0, ORACLE_SECP256K1 = 1, ORACLE_NCURVES = 2 };
+static oracle_curve g_curves[ORACLE_NCURVES];
+static int g_init_done = 0;
+
+/* ---------------------------------------------------------------- bignum layer (L2) */
+
+/* add.h:11-34 -- limb-wise add, carry returned (the reference keeps it as a lane mask). */
+static int bn_add(bn256 *r, const bn256 *a, const bn256 *b) {
+  int carry = 0;
+  for (int i = 0; i < NL; ++i) {
+    uint64_t sum = a->l[i] + b->l[i];
+    if (i == 0) { carry = sum < a->l[i]; r->l[i] = sum; }
+    else { uint64_t res = sum + (uint64_t)carry; carry = (sum < a->l[i]) || (res < sum); r->l[i] = res; }
+  }
+  return carry;
+}
+
+/* sub.h:12-38 -- limb-wise subtract, borrow returned. */
+static int bn_sub(bn256 *r, const bn256 *a, const bn256 *b) {
+  int borrow = 0;
+  for (int i = 0; i < NL; ++i) {
+    uint64_t diff = a->l[i] - b->l[i];
+    if (i == 0) { borrow = diff > a->l[i]; r->l[i] = diff; }
+    else { uint64_t res = diff - (uint64_t)borrow; borrow = (diff > a->l[i]) || (res > diff); r->l[i] = res; }
+  }
+  return borrow;
+}
+
+/* sub.h:46-69 -- return a-p unless (a<p && all extra masks), i.e. keep a only when the borrow
+ * is set AND every additional mask is set.  `keep_allowed` is the AND of the additional masks
+ * (1 when there are none). */
+static void bn_sub_if_above(bn256 *r, const bn256 *a, const bn256 *p, int keep_allowed) {
+  bn256 asub;
+  int borrow = bn_sub(&asub, a, p);
+  int keep = borrow && keep_allowed;
+  *r = keep ? *a : asub;
+}
+
+/* cmp.h:11-13 */
+static int bn_lt(const bn256 *a, const bn256 *b) { bn256 t; return bn_sub(&t, a, b); }
+
+/* shift.h:13-32 -- shift left by one bit, carry-out returned. */
+static int bn_shift_left_one(bn256 *r, const bn256 *a) {
+  int carry = 0;
+  for (int i = 0; i < NL; ++i) {
+    uint64_t l = a->l[i];
+    uint64_t shifted = l << 1;
+    if (i > 0) shifted |= (uint64_t)carry;
+    carry = (int)(l >> 63);
+    r->l[i] = shifted;
+  }
+  return carry;
+}
+
+/* mul.h:63-83 zext_u32x64 -- split u64 limbs into u32 digits held in u64. */
+static void zext_u32x64(uint64_t *d, const uint64_t *l, int nlimbs) {
+  for (int i = 0; i < nlimbs; ++i) { d[2 * i] = l[i] & 0xffffffffu; d[2 * i + 1] = l[i] >> 32; }
+}
+/* mul.h:85-113 trunc_u64x32 -- repack digit pairs (low 32 bits of each) into u64 limbs. */
+static void trunc_u64x32(uint64_t *l, const uint64_t *d, int ndigits) {
+  for (int i = 0; i < ndigits / 2; ++i) l[i] = (d[2 * i] & 0xffffffffu) | (d[2 * i + 1] << 32);
+}
+
+/* mul.h:115-148 mul_u32_zext + mul.h:150-158 mul -- schoolbook on 32-bit digits. */
+static void bn_mul(bn512 *r, const bn256 *a, const bn256 *b) {
+  uint64_t ad[ND], bd[ND], ret[2 * ND];
+  zext_u32x64(ad, a->l, NL); zext_u32x64(bd, b->l, NL);
+  memset(ret, 0, sizeof ret);
+  for (int i = 0; i < ND; ++i) {
+    uint64_t highprev = 0;
+    for (int j = 0; j < ND; ++j) {
+      uint64_t t = ad[i] * bd[j];       /* mullow, mul.h:56-61 */
+      t += ret[i + j];
+      t += highprev;
+      ret[i + j] = t & 0xffffffffu;
+      highprev = t >> 32;
+    }
+    ret[i + ND] = highprev;
+  }
+  trunc_u64x32(r->l, ret, 2 * ND);
+}
+
+/* mul.h:160-212 square_u32_zext + mul.h:214-221 square -- diagonal + doubled cross products. */
+static void bn_square(bn512 *r, const bn256 *a) {
+  uint64_t ad[ND], ret[2 * ND];
+  zext_u32x64(ad, a->l, NL);
+  memset(ret, 0, sizeof ret);
+  for (int i = 0; i < ND; ++i) {
+    uint64_t t = ad[i] * ad[i];
+    t += ret[2 * i];
+    ret[2 * i] = t & 0xffffffffu;
+    uint64_t prevs0 = t >> 32, prevs1 = 0;
+    for (int j = i + 1; j < ND; ++j) {
+      uint64_t u = ad[i] * ad[j];
+      uint64_t carry = u >> 63;
+      u <<= 1;
+      u += ret[i + j];
+      u += prevs0;
+      ret[i + j] = u & 0xffffffffu;
+      prevs0 = prevs1;
+      prevs0 += u >> 32;
+      prevs1 = carry;
+    }
+    ret[i + ND] += prevs0;
+    if (i + ND + 1 < 2 * ND) ret[i + ND + 1] = prevs1;
+  }
+  trunc_u64x32(r->l, ret, 2 * ND);
+}
+
+/* mul.h:223-250 limb_mul_zext -- (digits of a) x one 32-bit digit -> nd+1 digits. */
+static void limb_mul_zext(uint64_t *ret, const uint64_t *ad, int nd, uint64_t b) {
+  uint64_t highprev = 0;
+  for (int i = 0; i < nd; ++i) {
+    uint64_t t = (ad[i] & 0xffffffffu) * (b & 0xffffffffu);
+    if (i > 0) t += highprev;
+    ret[i] = t & 0xffffffffu;
+    highprev = t >> 32;
+  }
+  ret[nd] = highprev & 0xffffffffu;
+}
+
+/* ---------------------------------------------------------------- modular layer */
+
+/* modular.h:10-15 */
+static void mod_add(bn256 *r, const bn256 *a, const bn256 *b, const bn256 *p) {
+  bn256 sum; int carry = bn_add(&sum, a, b);
+  bn_sub_if_above(r, &sum, p, !carry);
+}
+/* modular.h:17-22 */
+static void mod_shift_left_one(bn256 *r, const bn256 *a, const bn256 *p) {
+  bn256 sh; int carry = bn_shift_left_one(&sh, a);
+  bn_sub_if_above(r, &sh, p, !carry);
+}
+/* modular.h:24-41 */
+static void mod_sub(bn256 *r, const bn256 *a, const bn256 *b, const bn256 *p) {
+  bn256 diff, diff_add; int borrow = bn_sub(&diff, a, b);
+  bn_add(&diff_add, &diff, p);
+  *r = borrow ? diff_add : diff;
+}
+
+/* ---------------------------------------------------------------- Montgomery layer (L3) */
+
+/* mgry_mul.h:52-82 add_no_carry_u32_zext -- digit-wise add then renormalise to 32-bit digits. */
+static void add_no_carry_u32_zext(uint64_t *acc, const uint64_t *b, int n) {
+  for (int i = 0; i < n; ++i) acc[i] += b[i];
+  for (int i = 1; i < n; ++i) { acc[i] += acc[i - 1] >> 32; acc[i - 1] &= 0xffffffffu; }
+  acc[n - 1] &= 0xffffffffu;
+}
+
+/* mgry_mul.h:84-121 details::mgry_reduce<P> -- word-serial Montgomery reduction, 32-bit digits:
+ * 8 rounds of accum += P * (accum[i]*m' mod 2^32) << 32i, then >> 256 and one conditional subtract. */
+static void mgry_reduce(bn256 *r, const bn512 *a, const oracle_curve *c) {
+  uint64_t accum[2 * ND + 1], pd[ND];
+  zext_u32x64(accum, a->l, 2 * NL); accum[2 * ND] = 0;          /* pad<1>(zext(a)) */
+  zext_u32x64(pd, c->p.l, NL);
+  for (int i = 0; i < ND; ++i) {
+    uint64_t q = (accum[i] & 0xffffffffu) * (uint64_t)c->mprime;  /* mullow(accum[i], m'); only low 32 bits used */
+    uint64_t prod[ND + 1], prod2[2 * ND + 1];
+    limb_mul_zext(prod, pd, ND, q);
+    memset(prod2, 0, sizeof prod2);                               /* limb_shift_left<17, i>(prod) */
+    for (int k = 0; k < ND + 1 && i + k < 2 * ND + 1; ++k) prod2[i + k] = prod[k];
+    add_no_carry_u32_zext(accum, prod2, 2 * ND + 1);
+  }
+  /* limb_shift_right<8>(accum) -> 9 digits, pad<1> -> 10 digits, trunc -> 5 u64 limbs */
+  uint64_t hi[ND + 2];
+  for (int k = 0; k < ND + 1; ++k) hi[k] = accum[ND + k];
+  hi[ND + 1] = 0;
+  uint64_t res5[NL + 1];
+  trunc_u64x32(res5, hi, ND + 2);
+  /* sub_if_above<4>(result(5 limbs), pad<1>(P)) */
+  uint64_t sub5[NL + 1]; int borrow = 0;
+  for (int i = 0; i < NL + 1; ++i) {
+    uint64_t pi = i < NL ? c->p.l[i] : 0;
+    uint64_t diff = res5[i] - pi;
+    if (i == 0) { borrow = diff > res5[i]; sub5[i] = diff; }
+    else { uint64_t x = diff - (uint64_t)borrow; borrow = (diff > res5[i]) || (x > diff); sub5[i] = x; }
+  }
+  for (int i = 0; i < NL; ++i) r->l[i] = borrow ? res5[i] : sub5[i];
+}
+
+/* mgry_ops.h:31-35 */
+static void mgry_mul(bn256 *r, const bn256 *a, const bn256 *b, const oracle_curve *c) {
+  bn512 m; bn_mul(&m, a, b); mgry_reduce(r, &m, c);
+}
+/* mgry_ops.h:37-42 */
+static void mgry_sqr(bn256 *r, const bn256 *a, const oracle_curve *c) {
+  bn512 s; bn_square(&s, a); mgry_reduce(r, &s, c);
+}
+/* mgry.h:47-50 */
+static void mgry_from_classical(bn256 *r, const bn256 *n, const oracle_curve *c) {
+  bn512 m; bn_mul(&m, n, &c->rsq_p); mgry_reduce(r, &m, c);
+}
+/* mgry.h:52-55 */
+static void mgry_to_classical(bn256 *r, const bn256 *n, const oracle_curve *c) {
+  bn512 z; memset(&z, 0, sizeof z); memcpy(z.l, n->l, sizeof n->l); mgry_reduce(r, &z, c);
+}
+/* mgry_ops.h:10-12, 24-27 and 14-22 */
+static void mgry_add(bn256 *r, const bn256 *a, const bn256 *b, const oracle_curve *c) { mod_add(r, a, b, &c->p); }
+static void mgry_sub(bn256 *r, const bn256 *a, const bn256 *b, const oracle_curve *c) { mod_sub(r, a, b, &c->p); }
+static void mgry_shift_left(bn256 *r, const bn256 *a, int count, const oracle_curve *c) {
+  bn256 t = *a;
+  for (int i = 0; i < count; ++i) { bn256 u; mod_shift_left_one(&u, &t, &c->p); t = u; }
+  *r = t;
+}
+
+/* mgry_ops.h:44-86 mgry_pow -- LSB-first square-and-multiply over the exponent's limbs; the top
+ * non-zero limb stops squaring once its remaining bits are zero. */
+static void mgry_pow(bn256 *r, const bn256 *a, const bn256 *M, const oracle_curve *c) {
+  bn256 result = c->r_p;
+  int top = -1;
+  for (int i = NL - 1; i >= 0; --i) if (M->l[i] != 0) { top = i; break; }
+  if (top < 0) { *r = result; return; }
+  bn256 base = *a, t;
+  for (int li = 0; li < top; ++li) {
+    uint64_t limb = M->l[li];
+    for (int b = 0; b < 64; ++b) {
+      int lsb = (int)(limb & 1); limb >>= 1;
+      if (lsb) { mgry_mul(&t, &result, &base, c); result = t; }
+      mgry_sqr(&t, &base, c); base = t;
+    }
+  }
+  uint64_t limb = M->l[top];
+  while (limb != 0) {
+    int lsb = (int)(limb & 1); limb >>= 1;
+    if (lsb) { mgry_mul(&t, &result, &base, c); result = t; }
+    if (limb == 0) break;
+    mgry_sqr(&t, &base, c); base = t;
+  }
+  *r = result;
+}
+
+/* gfp.h:42-44 */
+static void gfp_inverse(bn256 *r, const bn256 *a, const oracle_curve *c) { mgry_pow(r, a, &c->p_m2, c); }
+/* gfp.h:46-54 -- per-lane validity returned (the reference collapses it with eve::any). */
+static int gfp_sqrt(bn256 *r, const bn256 *a, const oracle_curve *c) {
+  bn256 s, chk; mgry_pow(&s, a, &c->p_sqrt, c); mgry_sqr(&chk, &s, c);
+  *r = s;
+  return memcmp(&chk, a, sizeof chk) == 0;
+}
+/* gfp.h:60-64 */
+static void gfp_opposite(bn256 *r, const bn256 *a, const oracle_curve *c) {
+  bn256 t; mgry_sub(&t, a, &c->r_p, c); mgry_sub(r, &c->pm1_r_p, &t, c);
+}
+
+/* ---------------------------------------------------------------- point layer (L4/L5) */
+
+typedef struct { bn256 x, y, z; } jpoint;   /* jacobian_curve_point.h:64-67, Montgomery form */
+
+#define MUL(r, a, b) mgry_mul(&(r), &(a), &(b), c)
+#define SQR(r, a)    mgry_sqr(&(r), &(a), c)
+#define ADD(r, a, b) mgry_add(&(r), &(a), &(b), c)
+#define SUB(r, a, b) mgry_sub(&(r), &(a), &(b), c)
+#define SHL(r, a, n) mgry_shift_left(&(r), &(a), (n), c)
+
+/* curve_group.h:64-87 DBLU.  P.z must be mgry(1). Returns 2P, rewrites P co-Z with it. */
+static void DBLU(jpoint *ret, jpoint *P, const oracle_curve *c) {
+  bn256 X1 = P->x, Y1 = P->y;
+  bn256 B, E, L, S, M, t, u, Lm8;
+  SQR(B, X1); SQR(E, Y1); SQR(L, E);
+  ADD(t, X1, E); SQR(t, t); SUB(t, t, B); SUB(t, t, L); SHL(S, t, 1);
+  SHL(t, B, 1); ADD(t, t, B); ADD(M, t, c->am);
+  SQR(t, M); SHL(u, S, 1); SUB(ret->x, t, u);
+  SHL(Lm8, L, 3);
+  SUB(t, S, ret->x); MUL(t, M, t); SUB(ret->y, t, Lm8);
+  SHL(ret->z, Y1, 1);
+  P->x = S; P->y = Lm8; P->z = ret->z;
+}
+
+/* curve_group.h:91-116 ZADDU.  Returns P+O (co-Z inputs), rewrites P co-Z with the result. */
+static void ZADDU(jpoint *ret, jpoint *P, const jpoint *O, const oracle_curve *c) {
+  bn256 X1 = P->x, Y1 = P->y, Z = P->z, X2 = O->x, Y2 = O->y;
+  bn256 C, W1, W2, D, A1, dx, dy, t;
+  SUB(dx, X1, X2); SQR(C, dx);
+  MUL(W1, X1, C); MUL(W2, X2, C);
+  SUB(dy, Y1, Y2); SQR(D, dy);
+  SUB(t, W1, W2); MUL(A1, Y1, t);
+  SUB(t, D, W1); SUB(ret->x, t, W2);
+  SUB(t, W1, ret->x); MUL(t, dy, t); SUB(ret->y, t, A1);
+  MUL(ret->z, Z, dx);
+  P->x = W1; P->y = A1; P->z = ret->z;
+}
+
+/* curve_group.h:120-153 ZDAU.  Returns 2P+Q (co-Z inputs), rewrites Q co-Z with the result. */
+static void ZDAU(jpoint *ret, const jpoint *P, jpoint *Q, const oracle_curve *c) {
+  bn256 X1 = P->x, Y1 = P->y, Z = P->z, X2 = Q->x, Y2 = Q->y;
+  bn256 Cp, W1p, W2p, Dp, A1p, X3pc, C, Y3p, W1, W2, D, A1, Dc;
+  bn256 dx, dy, t, u, A1p2, ym, yp;
+  SUB(dx, X1, X2); SQR(Cp, dx);
+  MUL(W1p, X1, Cp); MUL(W2p, X2, Cp);
+  SUB(dy, Y1, Y2); SQR(Dp, dy);
+  SUB(t, W1p, W2p); MUL(A1p, Y1, t);
+  SUB(t, Dp, W1p); SUB(X3pc, t, W2p);
+  SUB(t, X3pc, W1p); SQR(C, t);
+  SHL(A1p2, A1p, 1);
+  SUB(t, W1p, X3pc); ADD(t, dy, t); SQR(t, t); SUB(t, t, Dp); SUB(t, t, C); SUB(Y3p, t, A1p2);
+  SHL(t, X3pc, 2); MUL(W1, t, C);
+  SHL(t, W1p, 2); MUL(W2, t, C);
+  SUB(ym, Y3p, A1p2); SQR(D, ym);
+  SUB(t, W1, W2); MUL(A1, Y3p, t);
+  SUB(t, D, W1); SUB(ret->x, t, W2);
+  SUB(t, W1, ret->x); MUL(t, ym, t); SUB(ret->y, t, A1);
+  /* Z * ((X1-X2+X3pc-W1p)^2 - Cp - C): C++ evaluates ((X1-X2)+X3pc)-W1p left to right */
+  ADD(t, dx, X3pc); SUB(t, t, W1p); SQR(t, t); SUB(t, t, Cp); SUB(t, t, C); MUL(ret->z, Z, t);
+  ADD(yp, Y3p, A1p2); SQR(Dc, yp);
+  SUB(t, Dc, W1); SUB(u, t, W2); Q->x = u;
+  SUB(t, W1, Q->x); MUL(t, yp, t); SUB(Q->y, t, A1);
+  Q->z = ret->z;
+}
+
+/* curve_group.h:155-179 ADD_Z2_1.  Mixed add, B.z must be mgry(1). */
+static void ADD_Z2_1(jpoint *ret, const jpoint *A, const jpoint *B, const oracle_curve *c) {
+  bn256 X1 = A->x, Y1 = A->y, Z1 = A->z, X2 = B->x, Y2 = B->y;
+  bn256 Z1Z1, U2, S2, H, HH, I, J, r, V, t, u;
+  SQR(Z1Z1, Z1); MUL(U2, X2, Z1Z1);
+  MUL(t, Y2, Z1); MUL(S2, t, Z1Z1);
+  SUB(H, U2, X1); SQR(HH, H); SHL(I, HH, 2); MUL(J, H, I);
+  SUB(t, S2, Y1); SHL(r, t, 1);
+  MUL(V, X1, I);
+  SQR(t, r); SUB(t, t, J); SHL(u, V, 1); SUB(ret->x, t, u);
+  SUB(t, V, ret->x); MUL(t, r, t); SHL(u, Y1, 1); MUL(u, u, J); SUB(ret->y, t, u);
+  ADD(t, Z1, H); SQR(t, t); SUB(t, t, Z1Z1); SUB(ret->z, t, HH);
+}
+
+/* curve_group.h:183-186 */
+static void TRPLU(jpoint *ret, jpoint *P, const oracle_curve *c) {
+  jpoint dbl; DBLU(&dbl, P, c); ZADDU(ret, P, &dbl, c);
+}
+
+static void swap_xy(jpoint *A, jpoint *B) {   /* swap.h:47-56 swap_if_same_z (mask true) */
+  bn256 t = A->x; A->x = B->x; B->x = t; t = A->y; A->y = B->y; B->y = t;
+}
+
+/* curve_group.h:189-218 scalar_mult -- co-Z Joye double-add ladder, LSB->MSB, k forced odd then
+ * corrected with ADD_Z2_1(P, -P0).  P.z must be mgry(1).  Accepts any 256-bit k. */
+static void scalar_mult(jpoint *ret, const bn256 *x, const jpoint *P0, const oracle_curve *c) {
+  jpoint P = *P0, oppP, base, nb;
+  oppP = P; gfp_opposite(&oppP.y, &P.y, c);            /* jacobian_curve_point.h:48-54 */
+  TRPLU(&base, &P, c);
+  if ((x->l[0] >> 1) & 1) swap_xy(&P, &base);
+  for (int l = 0; l < NL; ++l) {
+    for (int b = (l == 0 ? 2 : 0); b < 64; ++b) {
+      int bit = (int)((x->l[l] >> b) & 1);
+      if (bit) swap_xy(&P, &base);
+      ZDAU(&nb, &base, &P, c); base = nb;
+      if (bit) swap_xy(&P, &base);
+    }
+  }
+  int even = (x->l[0] & 1) == 0;
+  jpoint Psub; ADD_Z2_1(&Psub, &P, &oppP, c);
+  *ret = even ? Psub : P;                               /* ifelse.h:38 */
+}
+
+/* jacobian_curve_point.h:25-31 */
+static void from_affine(jpoint *r, const bn256 *x, const bn256 *y, const oracle_curve *c) {
+  mgry_from_classical(&r->x, x, c); mgry_from_classical(&r->y, y, c); r->z = c->r_p;
+}
+/* jacobian_curve_point.h:33-42 */
+static void to_affine(bn256 *ax, bn256 *ay, const jpoint *P, const oracle_curve *c) {
+  bn256 invZ, invZ2, invZ3, t;
+  gfp_inverse(&invZ, &P->z, c); SQR(invZ2, invZ); MUL(invZ3, invZ2, invZ);
+  MUL(t, P->x, invZ2); mgry_to_classical(ax, &t, c);
+  MUL(t, P->y, invZ3); mgry_to_classical(ay, &t, c);
+}
+/* curve_group.h:43-58 compute_y, generalised from the hard-coded a=-3 to y^2 = x^3 + a x + b
+ * (identical values for P-256; the reference form is wrong for secp256k1). */
+static int compute_y(bn256 *y, const bn256 *x, const oracle_curve *c) {
+  bn256 xm, t, x3, ax, rhs, ym; int ok;
+  mgry_from_classical(&xm, x, c);
+  SQR(t, xm); MUL(x3, t, xm); MUL(ax, c->am, xm);
+  ADD(rhs, x3, ax); ADD(rhs, rhs, c->bm);
+  ok = gfp_sqrt(&ym, &rhs, c);
+  mgry_to_classical(y, &ym, c);
+  return ok;
+}
+
+/* ---------------------------------------------------------------- constants */
+
+static void bn_from_hex(bn256 *r, const char *hex) {   /* serialization.h:12-24 + literals.h:28-43 */
+  memset(r, 0, sizeof *r);
+  for (int i = 0; i < 64; ++i) {
+    char ch = hex[i]; unsigned v = (ch >= '0' && ch <= '9') ? ch - '0' : (ch | 0x20) - 'a' + 10;
+    int bit = (63 - i) * 4;
+    r->l[bit / 64] |= (uint64_t)v << (bit % 64);
+  }
+}
+
+/* r = (2*a) mod p for a < p, plain shift/compare (used only to derive R, R^2 at init). */
+static void slow_dbl_mod(bn256 *a, const bn256 *p) {
+  bn256 t; int carry = bn_shift_left_one(&t, a);
+  if (carry || !bn_lt(&t, p)) { bn256 u; bn_sub(&u, &t, p); t = u; }
+  *a = t;
+}
+
+static void curve_init(oracle_curve *c, const char *p, const char *a, const char *b, const char *gx, const char *gy) {
+  bn_from_hex(&c->p, p); bn_from_hex(&c->a, a); bn_from_hex(&c->b, b); bn_from_hex(&c->gx, gx); bn_from_hex(&c->gy, gy);
+  /* m' = -p^-1 mod 2^32 by Newton iteration (mgry_mul.h:33-38 computes it with cbn::mod_inv) */
+  uint32_t p0 = (uint32_t)c->p.l[0], inv = p0;
+  for (int i = 0; i < 5; ++i) inv *= 2u - p0 * inv;
+  c->mprime = (uint32_t)(0u - inv);
+  /* R mod p, R^2 mod p by repeated doubling of 1 (mgry_csts.h:15-21 uses cbn::div) */
+  bn256 one; memset(&one, 0, sizeof one); one.l[0] = 1;
+  bn256 t = one;
+  for (int i = 0; i < 256; ++i) slow_dbl_mod(&t, &c->p);
+  c->r_p = t;
+  for (int i = 0; i < 256; ++i) slow_dbl_mod(&t, &c->p);
+  c->rsq_p = t;
+  mod_sub(&c->pm1_r_p, &(bn256){{0, 0, 0, 0}}, &c->r_p, &c->p);      /* (p-1)*R mod p = -R mod p */
+  mgry_from_classical(&c->am, &c->a, c);                              /* to_mgry, mgry.h:18-26 */
+  mgry_from_classical(&c->bm, &c->b, c);
+  bn256 two; memset(&two, 0, sizeof two); two.l[0] = 2;
+  bn_sub(&c->p_m2, &c->p, &two);
+  bn256 pp1; bn_add(&pp1, &c->p, &one);                               /* p+1 < 2^256 for both primes */
+  for (int i = 0; i < NL; ++i) c->p_sqrt.l[i] = (pp1.l[i] >> 2) | (i + 1 < NL ? pp1.l[i + 1] << 62 : 0);
+}
+
+static void oracle_init_once(void) {
+  if (g_init_done) return;
+  curve_init(&g_curves[ORACLE_P256],   /* curve_nist_p256.h:14-32 */
+    "ffffffff00000001000000000000000000000000ffffffffffffffffffffffff",
+    "ffffffff00000001000000000000000000000000fffffffffffffffffffffffc",
+    "5ac635d8aa3a93e7b3ebbd55769886bc651d06b0cc53b0f63bce3c3e27d2604b",
+    "6b17d1f2e12c4247f8bce6e563a440f277037d812deb33a0f4a13945d898c296",
+    "4fe342e2fe1a7f9b8ee7eb4a7c0f9e162bce33576b315ececbb6406837bf51f5");
+  curve_init(&g_curves[ORACLE_SECP256K1],   /* SEC 2 v2 2.4.1; prime as tests/mgry.cpp:25-27 */
+    "fffffffffffffffffffffffffffffffffffffffffffffffffffffffefffffc2f",
+    "0000000000000000000000000000000000000000000000000000000000000000",
+    "0000000000000000000000000000000000000000000000000000000000000007",
+    "79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798",
+    "483ada7726a3c4655da4fbfc0e1108a8fd17b448a68554199c47d08ffb10d4b8");
+  g_init_done = 1;
+}
+
+static const oracle_curve *curve_of(int id) {
+  oracle_init_once();
+  return (id >= 0 && id < ORACLE_NCURVES) ? &g_curves[id] : NULL;
+}
+
+/* ---------------------------------------------------------------- exported batch API
+ * Arrays are AoS: element i = 4 consecutive u64 (LE limb order); 512-bit values = 8 u64.
+ * Same layout as the product's C ABI (include/ecsimd_hip.h) so tests pass identical buffers. */
+#define EXPORT __attribute__((visibility("default")))
+typedef const uint64_t *cu64p;
+#define BN(p, i) ((bn256 *)((p) + 4 * (size_t)(i)))
+#define CBN(p, i) ((const bn256 *)((p) + 4 * (size_t)(i)))
+
+EXPORT int oracle_get_constants(int curve, uint64_t *out /* 12 x 4 u64 */, uint32_t *mprime) {
+  const oracle_curve *c = curve_of(curve); if (!c) return -1;
+  const bn256 *src[12] = {&c->p, &c->a, &c->b, &c->gx, &c->gy, &c->r_p, &c->rsq_p, &c->pm1_r_p, &c->am, &c->bm, &c->p_m2, &c->p_sqrt};
+  for (int i = 0; i < 12; ++i) memcpy(out + 4 * i, src[i]->l, 32);
+  *mprime = c->mprime; return 0;
+}
+
+EXPORT int oracle_add(cu64p a, cu64p b, uint64_t *out, uint8_t *carry, size_t n) {
+  for (size_t i = 0; i < n; ++i) { int cy = bn_add(BN(out, i), CBN(a, i), CBN(b, i)); if (carry) carry[i] = (uint8_t)cy; } return 0; }
+EXPORT int oracle_sub(cu64p a, cu64p b, uint64_t *out, uint8_t *borrow, size_t n) {
+  for (size_t i = 0; i < n; ++i) { int bw = bn_sub(BN(out, i), CBN(a, i), CBN(b, i)); if (borrow) borrow[i] = (uint8_t)bw; } return 0; }
+EXPORT int oracle_sub_if_above(cu64p a, cu64p p, uint64_t *out, size_t n) {
+  for (size_t i = 0; i < n; ++i) bn_sub_if_above(BN(out, i), CBN(a, i), CBN(p, i), 1); return 0; }
+EXPORT int oracle_shift_left_one(cu64p a, uint64_t *out, uint8_t *carry, size_t n) {
+  for (size_t i = 0; i < n; ++i) { int cy = bn_shift_left_one(BN(out, i), CBN(a, i)); if (carry) carry[i] = (uint8_t)cy; } return 0; }
+EXPORT int oracle_mul(cu64p a, cu64p b, uint64_t *out8, size_t n) {
+  for (size_t i = 0; i < n; ++i) bn_mul((bn512 *)(out8 + 8 * i), CBN(a, i), CBN(b, i)); return 0; }
+EXPORT int oracle_square(cu64p a, uint64_t *out8, size_t n) {
+  for (size_t i = 0; i < n; ++i) bn_square((bn512 *)(out8 + 8 * i), CBN(a, i)); return 0; }
+
+#define CURVE_OR_FAIL const oracle_curve *c = curve_of(curve); if (!c) return -1
+EXPORT int oracle_mod_add(int curve, cu64p a, cu64p b, uint64_t *out, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) mod_add(BN(out, i), CBN(a, i), CBN(b, i), &c->p); return 0; }
+EXPORT int oracle_mod_sub(int curve, cu64p a, cu64p b, uint64_t *out, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) mod_sub(BN(out, i), CBN(a, i), CBN(b, i), &c->p); return 0; }
+EXPORT int oracle_mod_shift_left(int curve, cu64p a, int count, uint64_t *out, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) mgry_shift_left(BN(out, i), CBN(a, i), count, c); return 0; }
+EXPORT int oracle_mgry_reduce(int curve, cu64p a8, uint64_t *out, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) mgry_reduce(BN(out, i), (const bn512 *)(a8 + 8 * i), c); return 0; }
+EXPORT int oracle_mgry_mul(int curve, cu64p a, cu64p b, uint64_t *out, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) mgry_mul(BN(out, i), CBN(a, i), CBN(b, i), c); return 0; }
+EXPORT int oracle_mgry_sqr(int curve, cu64p a, uint64_t *out, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) mgry_sqr(BN(out, i), CBN(a, i), c); return 0; }
+EXPORT int oracle_mgry_from_classical(int curve, cu64p a, uint64_t *out, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) mgry_from_classical(BN(out, i), CBN(a, i), c); return 0; }
+EXPORT int oracle_mgry_to_classical(int curve, cu64p a, uint64_t *out, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) mgry_to_classical(BN(out, i), CBN(a, i), c); return 0; }
+EXPORT int oracle_mgry_pow(int curve, cu64p a, cu64p exponent /* one bignum */, uint64_t *out, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) mgry_pow(BN(out, i), CBN(a, i), CBN(exponent, 0), c); return 0; }
+EXPORT int oracle_gfp_inverse(int curve, cu64p a, uint64_t *out, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) gfp_inverse(BN(out, i), CBN(a, i), c); return 0; }
+EXPORT int oracle_gfp_sqrt(int curve, cu64p a, uint64_t *out, uint8_t *ok, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) { int k = gfp_sqrt(BN(out, i), CBN(a, i), c); if (ok) ok[i] = (uint8_t)k; } return 0; }
+EXPORT int oracle_gfp_opposite(int curve, cu64p a, uint64_t *out, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) gfp_opposite(BN(out, i), CBN(a, i), c); return 0; }
+
+static void load_pt(jpoint *P, cu64p x, cu64p y, cu64p z, size_t i) { P->x = *CBN(x, i); P->y = *CBN(y, i); P->z = *CBN(z, i); }
+static void store_pt(uint64_t *x, uint64_t *y, uint64_t *z, size_t i, const jpoint *P) { *BN(x, i) = P->x; *BN(y, i) = P->y; *BN(z, i) = P->z; }
+
+/* In-out point parameters carry the co-Z update exactly like the reference's reference parameters. */
+EXPORT int oracle_dblu(int curve, uint64_t *px, uint64_t *py, uint64_t *pz, uint64_t *rx, uint64_t *ry, uint64_t *rz, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) { jpoint P, R; load_pt(&P, px, py, pz, i); DBLU(&R, &P, c); store_pt(px, py, pz, i, &P); store_pt(rx, ry, rz, i, &R); } return 0; }
+EXPORT int oracle_zaddu(int curve, uint64_t *px, uint64_t *py, uint64_t *pz, cu64p ox, cu64p oy, cu64p oz, uint64_t *rx, uint64_t *ry, uint64_t *rz, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) { jpoint P, O, R; load_pt(&P, px, py, pz, i); load_pt(&O, ox, oy, oz, i); ZADDU(&R, &P, &O, c); store_pt(px, py, pz, i, &P); store_pt(rx, ry, rz, i, &R); } return 0; }
+EXPORT int oracle_zdau(int curve, cu64p px, cu64p py, cu64p pz, uint64_t *qx, uint64_t *qy, uint64_t *qz, uint64_t *rx, uint64_t *ry, uint64_t *rz, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) { jpoint P, Q, R; load_pt(&P, px, py, pz, i); load_pt(&Q, qx, qy, qz, i); ZDAU(&R, &P, &Q, c); store_pt(qx, qy, qz, i, &Q); store_pt(rx, ry, rz, i, &R); } return 0; }
+EXPORT int oracle_add_z2_1(int curve, cu64p ax, cu64p ay, cu64p az, cu64p bx, cu64p by, uint64_t *rx, uint64_t *ry, uint64_t *rz, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) { jpoint A, B, R; load_pt(&A, ax, ay, az, i); B.x = *CBN(bx, i); B.y = *CBN(by, i); B.z = c->r_p; ADD_Z2_1(&R, &A, &B, c); store_pt(rx, ry, rz, i, &R); } return 0; }
+EXPORT int oracle_trplu(int curve, uint64_t *px, uint64_t *py, uint64_t *pz, uint64_t *rx, uint64_t *ry, uint64_t *rz, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) { jpoint P, R; load_pt(&P, px, py, pz, i); TRPLU(&R, &P, c); store_pt(px, py, pz, i, &P); store_pt(rx, ry, rz, i, &R); } return 0; }
+EXPORT int oracle_from_affine(int curve, cu64p x, cu64p y, uint64_t *jx, uint64_t *jy, uint64_t *jz, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) { jpoint P; from_affine(&P, CBN(x, i), CBN(y, i), c); store_pt(jx, jy, jz, i, &P); } return 0; }
+EXPORT int oracle_to_affine(int curve, cu64p jx, cu64p jy, cu64p jz, uint64_t *x, uint64_t *y, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) { jpoint P; load_pt(&P, jx, jy, jz, i); to_affine(BN(x, i), BN(y, i), &P, c); } return 0; }
+EXPORT int oracle_compute_y(int curve, cu64p x, uint64_t *y, uint8_t *ok, size_t n) { CURVE_OR_FAIL;
+  for (size_t i = 0; i < n; ++i) { int k = compute_y(BN(y, i), CBN(x, i), c); if (ok) ok[i] = (uint8_t)k; } return 0; }
+
+/* scalar_mult: k[i] (classical 256-bit), affine classical base point (x[i], y[i]) -> Jacobian
+ * Montgomery (X,Y,Z).  Equivalent to curve_group::scalar_mult(k, WJCP::from_affine({x,y})). */
+typedef struct { const oracle_curve *c; cu64p k, x, y; uint64_t *ox, *oy, *oz; size_t lo, hi; int base_is_mgry; } sm_job;
+static void *sm_worker(void *arg) {
+  sm_job *j = (sm_job *)arg; const oracle_curve *c = j->c;
+  for (size_t i = j->lo; i < j->hi; ++i) {
+    jpoint P, R;
+    if (j->base_is_mgry) { P.x = *CBN(j->x, i); P.y = *CBN(j->y, i); P.z = c->r_p; }
+    else from_affine(&P, CBN(j->x, i), CBN(j->y, i), c);
+    scalar_mult(&R, CBN(j->k, i), &P, c);
+    store_pt(j->ox, j->oy, j->oz, i, &R);
+  }
+  return NULL;
+}
+static int sm_run(int curve, cu64p k, cu64p x, cu64p y, uint64_t *ox, uint64_t *oy, uint64_t *oz, size_t n, int threads, int base_is_mgry) {
+  CURVE_OR_FAIL;
+  if (threads < 1) threads = 1;
+  if ((size_t)threads > n) threads = n ? (int)n : 1;
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+  sm_job *jobs = (sm_job *)malloc(sizeof(sm_job) * (size_t)threads);
+  for (int t = 0; t < threads; ++t) {
+    jobs[t] = (sm_job){c, k, x, y, ox, oy, oz, n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads, base_is_mgry};
+    if (t > 0) pthread_create(&th[t], NULL, sm_worker, &jobs[t]);
+  }
+  sm_worker(&jobs[0]);
+  for (int t = 1; t < threads; ++t) pthread_join(th[t], NULL);
+  free(th); free(jobs);
+  return 0;
+}
+EXPORT int oracle_scalar_mult(int curve, cu64p k, cu64p x, cu64p y, uint64_t *ox, uint64_t *oy, uint64_t *oz, size_t n, int threads) {
+  return sm_run(curve, k, x, y, ox, oy, oz, n, threads, 0);
+}
+/* Same but the base point is already in Montgomery form (what scalar_mult_p256(x, P) receives). */
+EXPORT int oracle_scalar_mult_mgry(int curve, cu64p k, cu64p xm, cu64p ym, uint64_t *ox, uint64_t *oy, uint64_t *oz, size_t n, int threads) {
+  return sm_run(curve, k, xm, ym, ox, oy, oz, n, threads, 1);
+}
+
+/* Wall-clock seconds (CLOCK_MONOTONIC) for bench.py's cpu_baseline leg. */
+EXPORT double oracle_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }

@@ -1,0 +1,273 @@
+"""ctypes front-ends for the two parity checkers.  TEST INFRASTRUCTURE ONLY.
+
+* ``Oracle``      -> oracle/libecsimd_oracle.so  (C restatement, ecsimd_oracle.c)
+* ``Reference``   -> oracle/_ref/libecsimd_ref.so (the real aguinet/ecsimd headers behind ref_driver.cpp;
+                     present only where oracle/Makefile could build it, i.e. the build container, and
+                     shipped to the GPU box as a prebuilt artefact)
+
+Both expose the same method names over numpy ``uint64`` arrays of shape (n, 4) (little-endian limb
+order; 512-bit values are (n, 8)), so a test can run the same call against either and compare.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+P256, SECP256K1 = 0, 1
+CURVES = {"p256": P256, "secp256k1": SECP256K1}
+
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_u64p)
+
+
+def _p8(a):
+    return None if a is None else a.ctypes.data_as(_u8p)
+
+
+def _arr(a, words=4):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.ndim == 2 and a.shape[1] == words, a.shape
+    return a
+
+
+def build(force: bool = False) -> None:
+    """Compile the C restatement (always) and the reference driver (when /root/reference exists)."""
+    args = ["make", "-C", HERE, "-s"] + (["-B"] if force else []) + ["all"]
+    subprocess.run(args, check=True)
+
+
+class _Lib:
+    prefix = ""
+    path = ""
+
+    def __init__(self):
+        if not os.path.exists(self.path):
+            raise FileNotFoundError(self.path)
+        self.lib = C.CDLL(self.path)
+        self.now = getattr(self.lib, self.prefix + "now")
+        self.now.restype = C.c_double
+
+    def _f(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    # ---- constants
+    def constants(self, curve):
+        out = np.zeros((12, 4), dtype=np.uint64)
+        mp = C.c_uint32(0)
+        rc = self._f("get_constants")(C.c_int(curve), _p(out), C.byref(mp))
+        assert rc == 0
+        names = ["p", "a", "b", "gx", "gy", "r_p", "rsq_p", "pm1_r_p", "am", "bm", "p_m2", "p_sqrt"]
+        d = {k: out[i].copy() for i, k in enumerate(names)}
+        d["mprime"] = mp.value
+        return d
+
+    # ---- curve-independent bignum ops
+    def _bin_flag(self, name, a, b):
+        a, b = _arr(a), _arr(b)
+        out = np.empty_like(a)
+        flag = np.zeros(len(a), dtype=np.uint8)
+        assert self._f(name)(_p(a), _p(b), _p(out), _p8(flag), C.c_size_t(len(a))) == 0
+        return out, flag
+
+    def add(self, a, b):
+        return self._bin_flag("add", a, b)
+
+    def sub(self, a, b):
+        return self._bin_flag("sub", a, b)
+
+    def sub_if_above(self, a, p):
+        a, p = _arr(a), _arr(p)
+        out = np.empty_like(a)
+        assert self._f("sub_if_above")(_p(a), _p(p), _p(out), C.c_size_t(len(a))) == 0
+        return out
+
+    def shift_left_one(self, a):
+        a = _arr(a)
+        out = np.empty_like(a)
+        flag = np.zeros(len(a), dtype=np.uint8)
+        assert self._f("shift_left_one")(_p(a), _p(out), _p8(flag), C.c_size_t(len(a))) == 0
+        return out, flag
+
+    def mul(self, a, b):
+        a, b = _arr(a), _arr(b)
+        out = np.empty((len(a), 8), dtype=np.uint64)
+        assert self._f("mul")(_p(a), _p(b), _p(out), C.c_size_t(len(a))) == 0
+        return out
+
+    def square(self, a):
+        a = _arr(a)
+        out = np.empty((len(a), 8), dtype=np.uint64)
+        assert self._f("square")(_p(a), _p(out), C.c_size_t(len(a))) == 0
+        return out
+
+    # ---- field ops
+    def _c2(self, name, curve, a, b):
+        a, b = _arr(a), _arr(b)
+        out = np.empty_like(a)
+        assert self._f(name)(C.c_int(curve), _p(a), _p(b), _p(out), C.c_size_t(len(a))) == 0
+        return out
+
+    def _c1(self, name, curve, a, words=4):
+        a = _arr(a, words)
+        out = np.empty((len(a), 4), dtype=np.uint64)
+        assert self._f(name)(C.c_int(curve), _p(a), _p(out), C.c_size_t(len(a))) == 0
+        return out
+
+    def mod_add(self, curve, a, b):
+        return self._c2("mod_add", curve, a, b)
+
+    def mod_sub(self, curve, a, b):
+        return self._c2("mod_sub", curve, a, b)
+
+    def mod_shift_left(self, curve, a, count):
+        a = _arr(a)
+        out = np.empty_like(a)
+        assert self._f("mod_shift_left")(C.c_int(curve), _p(a), C.c_int(count), _p(out), C.c_size_t(len(a))) == 0
+        return out
+
+    def mgry_reduce(self, curve, a8):
+        return self._c1("mgry_reduce", curve, a8, 8)
+
+    def mgry_mul(self, curve, a, b):
+        return self._c2("mgry_mul", curve, a, b)
+
+    def mgry_sqr(self, curve, a):
+        return self._c1("mgry_sqr", curve, a)
+
+    def mgry_from_classical(self, curve, a):
+        return self._c1("mgry_from_classical", curve, a)
+
+    def mgry_to_classical(self, curve, a):
+        return self._c1("mgry_to_classical", curve, a)
+
+    def mgry_pow(self, curve, a, exponent):
+        a = _arr(a)
+        e = _arr(np.asarray(exponent, dtype=np.uint64).reshape(1, 4))
+        out = np.empty_like(a)
+        assert self._f("mgry_pow")(C.c_int(curve), _p(a), _p(e), _p(out), C.c_size_t(len(a))) == 0
+        return out
+
+    def gfp_inverse(self, curve, a):
+        return self._c1("gfp_inverse", curve, a)
+
+    def gfp_opposite(self, curve, a):
+        return self._c1("gfp_opposite", curve, a)
+
+    def gfp_sqrt(self, curve, a):
+        a = _arr(a)
+        out = np.zeros_like(a)
+        ok = np.zeros(len(a), dtype=np.uint8)
+        assert self._f("gfp_sqrt")(C.c_int(curve), _p(a), _p(out), _p8(ok), C.c_size_t(len(a))) == 0
+        return out, ok
+
+    # ---- points.  In-out arguments are copied first; the updated copies are returned.
+    def dblu(self, curve, p):
+        px, py, pz = (_arr(v).copy() for v in p)
+        r = [np.empty_like(px) for _ in range(3)]
+        assert self._f("dblu")(C.c_int(curve), _p(px), _p(py), _p(pz), _p(r[0]), _p(r[1]), _p(r[2]), C.c_size_t(len(px))) == 0
+        return tuple(r), (px, py, pz)
+
+    def trplu(self, curve, p):
+        px, py, pz = (_arr(v).copy() for v in p)
+        r = [np.empty_like(px) for _ in range(3)]
+        assert self._f("trplu")(C.c_int(curve), _p(px), _p(py), _p(pz), _p(r[0]), _p(r[1]), _p(r[2]), C.c_size_t(len(px))) == 0
+        return tuple(r), (px, py, pz)
+
+    def zaddu(self, curve, p, o):
+        px, py, pz = (_arr(v).copy() for v in p)
+        ox, oy, oz = (_arr(v) for v in o)
+        r = [np.empty_like(px) for _ in range(3)]
+        assert self._f("zaddu")(C.c_int(curve), _p(px), _p(py), _p(pz), _p(ox), _p(oy), _p(oz), _p(r[0]), _p(r[1]), _p(r[2]), C.c_size_t(len(px))) == 0
+        return tuple(r), (px, py, pz)
+
+    def zdau(self, curve, p, q):
+        px, py, pz = (_arr(v) for v in p)
+        qx, qy, qz = (_arr(v).copy() for v in q)
+        r = [np.empty_like(px) for _ in range(3)]
+        assert self._f("zdau")(C.c_int(curve), _p(px), _p(py), _p(pz), _p(qx), _p(qy), _p(qz), _p(r[0]), _p(r[1]), _p(r[2]), C.c_size_t(len(px))) == 0
+        return tuple(r), (qx, qy, qz)
+
+    def add_z2_1(self, curve, a, bxy):
+        ax, ay, az = (_arr(v) for v in a)
+        bx, by = (_arr(v) for v in bxy)
+        r = [np.empty_like(ax) for _ in range(3)]
+        assert self._f("add_z2_1")(C.c_int(curve), _p(ax), _p(ay), _p(az), _p(bx), _p(by), _p(r[0]), _p(r[1]), _p(r[2]), C.c_size_t(len(ax))) == 0
+        return tuple(r)
+
+    def from_affine(self, curve, x, y):
+        x, y = _arr(x), _arr(y)
+        r = [np.empty_like(x) for _ in range(3)]
+        assert self._f("from_affine")(C.c_int(curve), _p(x), _p(y), _p(r[0]), _p(r[1]), _p(r[2]), C.c_size_t(len(x))) == 0
+        return tuple(r)
+
+    def to_affine(self, curve, j):
+        jx, jy, jz = (_arr(v) for v in j)
+        x, y = np.empty_like(jx), np.empty_like(jx)
+        assert self._f("to_affine")(C.c_int(curve), _p(jx), _p(jy), _p(jz), _p(x), _p(y), C.c_size_t(len(jx))) == 0
+        return x, y
+
+    def compute_y(self, curve, x):
+        x = _arr(x)
+        y = np.zeros_like(x)
+        ok = np.zeros(len(x), dtype=np.uint8)
+        assert self._f("compute_y")(C.c_int(curve), _p(x), _p(y), _p8(ok), C.c_size_t(len(x))) == 0
+        return y, ok
+
+    def scalar_mult(self, curve, k, x, y, threads=1, mgry_in=False):
+        k, x, y = _arr(k), _arr(x), _arr(y)
+        r = [np.empty_like(k) for _ in range(3)]
+        name = "scalar_mult_mgry" if mgry_in else "scalar_mult"
+        assert self._f(name)(C.c_int(curve), _p(k), _p(x), _p(y), _p(r[0]), _p(r[1]), _p(r[2]), C.c_size_t(len(k)), C.c_int(threads)) == 0
+        return tuple(r)
+
+
+class Oracle(_Lib):
+    prefix = "oracle_"
+    path = os.path.join(HERE, "libecsimd_oracle.so")
+
+
+class Reference(_Lib):
+    prefix = "ref_"
+    path = os.path.join(HERE, "_ref", "libecsimd_ref.so")
+
+    def scalar_mult_1s(self, curve, k1, x, y):
+        k1 = _arr(np.asarray(k1, dtype=np.uint64).reshape(1, 4))
+        x, y = _arr(x), _arr(y)
+        r = [np.empty_like(x) for _ in range(3)]
+        assert self._f("scalar_mult_1s")(C.c_int(curve), _p(k1), _p(x), _p(y), _p(r[0]), _p(r[1]), _p(r[2]), C.c_size_t(len(x))) == 0
+        return tuple(r)
+
+
+def reference_available() -> bool:
+    return os.path.exists(Reference.path)
+
+
+# ---------------------------------------------------------------- helpers shared by tests
+def to_int(limbs) -> int:
+    return sum(int(v) << (64 * i) for i, v in enumerate(limbs))
+
+
+def from_int(v: int, words: int = 4) -> np.ndarray:
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(words)], dtype=np.uint64)
+
+
+def ints_to_arr(vals, words: int = 4) -> np.ndarray:
+    return np.stack([from_int(int(v), words) for v in vals]) if len(vals) else np.zeros((0, words), dtype=np.uint64)
+
+
+def arr_to_ints(a):
+    return [to_int(row) for row in np.asarray(a)]
+
+
+def from_hex(h: str, words: int = 4) -> np.ndarray:
+    """serialization.h:12-24 bn_from_bytes_BE on a big-endian hex literal."""
+    return from_int(int(h, 16), words)

@@ -1,0 +1,252 @@
+// ref_driver.cpp -- thin extern "C" driver around the REAL aguinet/ecsimd headers.
+//
+// TEST INFRASTRUCTURE ONLY (see oracle/README.md).  This translation unit contains no ecsimd
+// code: it #includes the reference headers where they lie (/root/reference/include and
+// /root/reference/third-party, passed with -I by oracle/Makefile) and exposes the reference's
+// own functions over flat arrays so that (a) the C restatement in ecsimd_oracle.c can be
+// validated against the real thing, (b) golden vectors can be minted (oracle/make_golden.py)
+// and (c) bench.py can time "ecsimd's own eve/AVX2 CPU path" on the GPU box's host cores
+// (cpu_baseline.kind = "reference").  It builds into oracle/_ref/libecsimd_ref.so, which is
+// git-ignored and travels to the GPU box as a built artefact only.
+//
+// Build: g++ -std=c++20 -O2 -mavx2 (never -march=native: AVX-512 breaks the eve ABI the
+// reference relies on -- SURVEY.md section 5).
+//
+// Array layout: AoS, element i = 4 consecutive u64 limbs (little-endian limb order); the driver
+// packs 4 consecutive elements into one eve::wide (lane j of wide w = element 4w+j).  A ragged
+// tail is padded by repeating the last element.
+#include <ecsimd/bignum.h>
+#include <ecsimd/add.h>
+#include <ecsimd/sub.h>
+#include <ecsimd/mul.h>
+#include <ecsimd/shift.h>
+#include <ecsimd/modular.h>
+#include <ecsimd/mgry.h>
+#include <ecsimd/mgry_mul.h>
+#include <ecsimd/mgry_ops.h>
+#include <ecsimd/gfp.h>
+#include <ecsimd/curve.h>
+#include <ecsimd/curve_nist_p256.h>
+#include <ecsimd/curve_point.h>
+#include <ecsimd/curve_point_ops.h>
+#include <ecsimd/jacobian_curve_point.h>
+#include <ecsimd/curve_group.h>
+#include <ecsimd/serialization.h>
+#include <ecsimd/literals.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+using namespace ecsimd;
+using namespace ecsimd::literals;
+
+namespace {
+
+// secp256k1 described with the reference's own curve concept (curve.h:12-15).  The reference
+// ships no such struct; the constants are SEC 2 v2 section 2.4.1 public data.
+struct curve_secp256k1 {
+  using bn_type = bignum_256;
+  struct P  { static constexpr auto value = bn_from_bytes_BE<bn_type>("fffffffffffffffffffffffffffffffffffffffffffffffffffffffefffffc2f"_hex); };
+  struct A  { static constexpr auto value = bn_from_bytes_BE<bn_type>("0000000000000000000000000000000000000000000000000000000000000000"_hex); };
+  struct B  { static constexpr auto value = bn_from_bytes_BE<bn_type>("0000000000000000000000000000000000000000000000000000000000000007"_hex); };
+  struct Gx { static constexpr auto value = bn_from_bytes_BE<bn_type>("79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798"_hex); };
+  struct Gy { static constexpr auto value = bn_from_bytes_BE<bn_type>("483ada7726a3c4655da4fbfc0e1108a8fd17b448a68554199c47d08ffb10d4b8"_hex); };
+};
+
+using BN  = bignum_256;
+using WBN = wide_bignum<BN>;
+using BN512  = bignum_512;
+using WBN512 = wide_bignum<BN512>;
+
+template <class B> B load_bn(const uint64_t* p) {
+  typename B::cbn_type c; for (size_t i = 0; i < B::nlimbs; ++i) c[i] = p[i]; return B::from(c);
+}
+template <class B> void store_bn(uint64_t* p, B const& v) {
+  const auto c = v.cbn(); for (size_t i = 0; i < B::nlimbs; ++i) p[i] = c[i];
+}
+// element index of lane `lane` of wide `w`, clamped for the ragged tail
+inline size_t elem(size_t w, size_t lane, size_t n) { size_t i = 4 * w + lane; return i < n ? i : n - 1; }
+
+template <class B> wide_bignum<B> load_wide(const uint64_t* a, size_t w, size_t n) {
+  return wide_bignum<B>{[&](auto lane, auto) { return load_bn<B>(a + B::nlimbs * elem(w, lane, n)); }};
+}
+template <class W> void store_wide(uint64_t* out, size_t w, size_t n, W const& v) {
+  using B = typename W::value_type;
+  for (size_t lane = 0; lane < 4; ++lane) { size_t i = 4 * w + lane; if (i < n) store_bn<B>(out + B::nlimbs * i, v.get(lane)); }
+}
+template <class M> void store_mask(uint8_t* out, size_t w, size_t n, M const& m) {
+  if (!out) return;
+  for (size_t lane = 0; lane < 4; ++lane) { size_t i = 4 * w + lane; if (i < n) out[i] = m.get(lane) ? 1 : 0; }
+}
+inline size_t nwides(size_t n) { return (n + 3) / 4; }
+
+template <class Curve> struct ops {
+  using P    = typename Curve::P;
+  using WMBN = wide_mgry_bignum<WBN, P>;
+  using gfp  = GFp<WBN, P>;
+  using CG   = curve_group<Curve>;
+  using WCP  = wide_curve_point<Curve>;
+  using WJCP = wide_jacobian_curve_point<Curve>;
+  using csts = mgry_constants<WBN, P>;
+
+  static WJCP load_pt(const uint64_t* x, const uint64_t* y, const uint64_t* z, size_t w, size_t n) {
+    WJCP p; p.x() = gfp{WMBN{load_wide<BN>(x, w, n)}}; p.y() = gfp{WMBN{load_wide<BN>(y, w, n)}}; p.z() = gfp{WMBN{load_wide<BN>(z, w, n)}}; return p;
+  }
+  static void store_pt(uint64_t* x, uint64_t* y, uint64_t* z, size_t w, size_t n, WJCP const& p) {
+    store_wide(x, w, n, p.x().wbn()); store_wide(y, w, n, p.y().wbn()); store_wide(z, w, n, p.z().wbn());
+  }
+
+  static int constants(uint64_t* out, uint32_t* mprime) {
+    using half_P = remap_limb_t<P, uint32_t>;
+    const BN vals[12] = {P::value, Curve::A::value, Curve::B::value, Curve::Gx::value, Curve::Gy::value,
+                         csts::R_p, csts::Rsq_p, csts::Pm1_by_R_p, CG::Am, CG::Bm, BN{}, BN{}};
+    for (int i = 0; i < 10; ++i) store_bn<BN>(out + 4 * i, vals[i]);
+    std::memset(out + 40, 0, 64);   // p-2 and (p+1)/4 are private members of GFp (gfp.h:79-87): left zero
+    *mprime = details::mgry_mul_constants<half_P, eve::fixed<4>>::mprime;
+    return 0;
+  }
+  static int mod_add_(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, mod_add(load_wide<BN>(a, w, n), load_wide<BN>(b, w, n), csts::wide_P)); return 0; }
+  static int mod_sub_(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, mod_sub(load_wide<BN>(a, w, n), load_wide<BN>(b, w, n), csts::wide_P)); return 0; }
+  static int mod_shl_(const uint64_t* a, int count, uint64_t* out, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) {
+      auto v = load_wide<BN>(a, w, n);
+      for (int k = 0; k < count; ++k) v = mod_shift_left_one(v, csts::wide_P);
+      store_wide(out, w, n, v);
+    } return 0; }
+  static int reduce_(const uint64_t* a8, uint64_t* out, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, details::mgry_reduce<P>(load_wide<BN512>(a8, w, n))); return 0; }
+  static int mgry_mul_(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, mgry_mul(WMBN{load_wide<BN>(a, w, n)}, WMBN{load_wide<BN>(b, w, n)}).wbn()); return 0; }
+  static int mgry_sqr_(const uint64_t* a, uint64_t* out, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, mgry_sqr(WMBN{load_wide<BN>(a, w, n)}).wbn()); return 0; }
+  static int from_classical_(const uint64_t* a, uint64_t* out, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, WMBN::from_classical(load_wide<BN>(a, w, n)).wbn()); return 0; }
+  static int to_classical_(const uint64_t* a, uint64_t* out, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, WMBN{load_wide<BN>(a, w, n)}.to_classical()); return 0; }
+  static int pow_(const uint64_t* a, const uint64_t* e, uint64_t* out, size_t n) {
+    const BN M = load_bn<BN>(e);
+    for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, mgry_pow(WMBN{load_wide<BN>(a, w, n)}, M).wbn()); return 0; }
+  static int inverse_(const uint64_t* a, uint64_t* out, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, gfp{WMBN{load_wide<BN>(a, w, n)}}.inverse().wbn()); return 0; }
+  // sqrt: the reference returns nullopt if ANY lane of the wide fails (gfp.h:50); `ok` reports that
+  // all-or-nothing flag per wide (replicated to its lanes); `out` is written only when it succeeded.
+  static int sqrt_(const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) {
+      const auto r = gfp{WMBN{load_wide<BN>(a, w, n)}}.sqrt();
+      for (size_t lane = 0; lane < 4; ++lane) { size_t i = 4 * w + lane; if (i < n && ok) ok[i] = r.has_value(); }
+      if (r) store_wide(out, w, n, r->wbn());
+    } return 0; }
+  static int opposite_(const uint64_t* a, uint64_t* out, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, gfp{WMBN{load_wide<BN>(a, w, n)}}.opposite().wbn()); return 0; }
+
+  static int dblu_(uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) { auto P_ = load_pt(px, py, pz, w, n); const auto R = CG::DBLU(P_); store_pt(px, py, pz, w, n, P_); store_pt(rx, ry, rz, w, n, R); } return 0; }
+  static int zaddu_(uint64_t* px, uint64_t* py, uint64_t* pz, const uint64_t* ox, const uint64_t* oy, const uint64_t* oz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) { auto P_ = load_pt(px, py, pz, w, n); const auto O = load_pt(ox, oy, oz, w, n); const auto R = CG::ZADDU(P_, O); store_pt(px, py, pz, w, n, P_); store_pt(rx, ry, rz, w, n, R); } return 0; }
+  static int zdau_(const uint64_t* px, const uint64_t* py, const uint64_t* pz, uint64_t* qx, uint64_t* qy, uint64_t* qz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) { const auto P_ = load_pt(px, py, pz, w, n); auto Q = load_pt(qx, qy, qz, w, n); const auto R = CG::ZDAU(P_, Q); store_pt(qx, qy, qz, w, n, Q); store_pt(rx, ry, rz, w, n, R); } return 0; }
+  static int add_z2_1_(const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) {
+      const auto A = load_pt(ax, ay, az, w, n);
+      WJCP B; B.x() = gfp{WMBN{load_wide<BN>(bx, w, n)}}; B.y() = gfp{WMBN{load_wide<BN>(by, w, n)}}; B.z() = gfp::one();
+      store_pt(rx, ry, rz, w, n, CG::ADD_Z2_1(A, B));
+    } return 0; }
+  static int trplu_(uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) { auto P_ = load_pt(px, py, pz, w, n); const auto R = CG::TRPLU(P_); store_pt(px, py, pz, w, n, P_); store_pt(rx, ry, rz, w, n, R); } return 0; }
+  static int from_affine_(const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) store_pt(jx, jy, jz, w, n, WJCP::from_affine(WCP{load_wide<BN>(x, w, n), load_wide<BN>(y, w, n)})); return 0; }
+  static int to_affine_(const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) { const auto A = load_pt(jx, jy, jz, w, n).to_affine(); store_wide(x, w, n, A.x()); store_wide(y, w, n, A.y()); } return 0; }
+  static int compute_y_(const uint64_t* x, uint64_t* y, uint8_t* ok, size_t n) {
+    for (size_t w = 0; w < nwides(n); ++w) {
+      const auto r = CG::compute_y(load_wide<BN>(x, w, n));
+      for (size_t lane = 0; lane < 4; ++lane) { size_t i = 4 * w + lane; if (i < n && ok) ok[i] = r.has_value(); }
+      if (r) store_wide(y, w, n, *r);
+    } return 0; }
+
+  // k: classical scalars; (x, y): affine classical base points.  Result: Jacobian, Montgomery form.
+  static void scalar_mult_range(const uint64_t* k, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, size_t w0, size_t w1, bool mgry_in) {
+    for (size_t w = w0; w < w1; ++w) {
+      WJCP P_;
+      if (mgry_in) { P_.x() = gfp{WMBN{load_wide<BN>(x, w, n)}}; P_.y() = gfp{WMBN{load_wide<BN>(y, w, n)}}; P_.z() = gfp::one(); }
+      else P_ = WJCP::from_affine(WCP{load_wide<BN>(x, w, n), load_wide<BN>(y, w, n)});
+      store_pt(ox, oy, oz, w, n, CG::scalar_mult(load_wide<BN>(k, w, n), P_));
+    }
+  }
+  static int scalar_mult_(const uint64_t* k, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int threads, bool mgry_in) {
+    const size_t nw = nwides(n);
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > nw) threads = nw ? (int)nw : 1;
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; ++t) th.emplace_back(scalar_mult_range, k, x, y, ox, oy, oz, n, nw * t / threads, nw * (t + 1) / threads, mgry_in);
+    scalar_mult_range(k, x, y, ox, oy, oz, n, 0, nw / threads, mgry_in);
+    for (auto& t : th) t.join();
+    return 0;
+  }
+  // one scalar for all lanes (curve_group.h:221-251)
+  static int scalar_mult_1s_(const uint64_t* k1, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) {
+    const BN ks = load_bn<BN>(k1);
+    for (size_t w = 0; w < nwides(n); ++w)
+      store_pt(ox, oy, oz, w, n, CG::scalar_mult_1s(ks, WJCP::from_affine(WCP{load_wide<BN>(x, w, n), load_wide<BN>(y, w, n)})));
+    return 0;
+  }
+};
+
+using P256 = ops<curve_nist_p256>;
+using K256 = ops<curve_secp256k1>;
+
+} // namespace
+
+#define DISPATCH(fn, ...) (curve == 0 ? P256::fn(__VA_ARGS__) : curve == 1 ? K256::fn(__VA_ARGS__) : -1)
+
+extern "C" {
+#define EXPORT __attribute__((visibility("default")))
+typedef const uint64_t* cu64p;
+
+EXPORT int ref_get_constants(int curve, uint64_t* out, uint32_t* mprime) { return DISPATCH(constants, out, mprime); }
+
+// curve-independent bignum ops (add.h, sub.h, shift.h, mul.h)
+EXPORT int ref_add(cu64p a, cu64p b, uint64_t* out, uint8_t* carry, size_t n) {
+  for (size_t w = 0; w < nwides(n); ++w) { auto [s, c] = add(load_wide<BN>(a, w, n), load_wide<BN>(b, w, n)); store_wide(out, w, n, s); store_mask(carry, w, n, c); } return 0; }
+EXPORT int ref_sub(cu64p a, cu64p b, uint64_t* out, uint8_t* borrow, size_t n) {
+  for (size_t w = 0; w < nwides(n); ++w) { auto [s, c] = sub(load_wide<BN>(a, w, n), load_wide<BN>(b, w, n)); store_wide(out, w, n, s); store_mask(borrow, w, n, c); } return 0; }
+EXPORT int ref_sub_if_above(cu64p a, cu64p p, uint64_t* out, size_t n) {
+  for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, sub_if_above(load_wide<BN>(a, w, n), load_wide<BN>(p, w, n))); return 0; }
+EXPORT int ref_shift_left_one(cu64p a, uint64_t* out, uint8_t* carry, size_t n) {
+  for (size_t w = 0; w < nwides(n); ++w) { auto [s, c] = shift_left_one(load_wide<BN>(a, w, n)); store_wide(out, w, n, s); store_mask(carry, w, n, c); } return 0; }
+EXPORT int ref_mul(cu64p a, cu64p b, uint64_t* out8, size_t n) {
+  for (size_t w = 0; w < nwides(n); ++w) store_wide(out8, w, n, mul(load_wide<BN>(a, w, n), load_wide<BN>(b, w, n))); return 0; }
+EXPORT int ref_square(cu64p a, uint64_t* out8, size_t n) {
+  for (size_t w = 0; w < nwides(n); ++w) store_wide(out8, w, n, square(load_wide<BN>(a, w, n))); return 0; }
+
+EXPORT int ref_mod_add(int curve, cu64p a, cu64p b, uint64_t* out, size_t n) { return DISPATCH(mod_add_, a, b, out, n); }
+EXPORT int ref_mod_sub(int curve, cu64p a, cu64p b, uint64_t* out, size_t n) { return DISPATCH(mod_sub_, a, b, out, n); }
+EXPORT int ref_mod_shift_left(int curve, cu64p a, int count, uint64_t* out, size_t n) { return DISPATCH(mod_shl_, a, count, out, n); }
+EXPORT int ref_mgry_reduce(int curve, cu64p a8, uint64_t* out, size_t n) { return DISPATCH(reduce_, a8, out, n); }
+EXPORT int ref_mgry_mul(int curve, cu64p a, cu64p b, uint64_t* out, size_t n) { return DISPATCH(mgry_mul_, a, b, out, n); }
+EXPORT int ref_mgry_sqr(int curve, cu64p a, uint64_t* out, size_t n) { return DISPATCH(mgry_sqr_, a, out, n); }
+EXPORT int ref_mgry_from_classical(int curve, cu64p a, uint64_t* out, size_t n) { return DISPATCH(from_classical_, a, out, n); }
+EXPORT int ref_mgry_to_classical(int curve, cu64p a, uint64_t* out, size_t n) { return DISPATCH(to_classical_, a, out, n); }
+EXPORT int ref_mgry_pow(int curve, cu64p a, cu64p e, uint64_t* out, size_t n) { return DISPATCH(pow_, a, e, out, n); }
+EXPORT int ref_gfp_inverse(int curve, cu64p a, uint64_t* out, size_t n) { return DISPATCH(inverse_, a, out, n); }
+EXPORT int ref_gfp_sqrt(int curve, cu64p a, uint64_t* out, uint8_t* ok, size_t n) { return DISPATCH(sqrt_, a, out, ok, n); }
+EXPORT int ref_gfp_opposite(int curve, cu64p a, uint64_t* out, size_t n) { return DISPATCH(opposite_, a, out, n); }
+EXPORT int ref_dblu(int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { return DISPATCH(dblu_, px, py, pz, rx, ry, rz, n); }
+EXPORT int ref_zaddu(int curve, uint64_t* px, uint64_t* py, uint64_t* pz, cu64p ox, cu64p oy, cu64p oz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { return DISPATCH(zaddu_, px, py, pz, ox, oy, oz, rx, ry, rz, n); }
+EXPORT int ref_zdau(int curve, cu64p px, cu64p py, cu64p pz, uint64_t* qx, uint64_t* qy, uint64_t* qz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { return DISPATCH(zdau_, px, py, pz, qx, qy, qz, rx, ry, rz, n); }
+EXPORT int ref_add_z2_1(int curve, cu64p ax, cu64p ay, cu64p az, cu64p bx, cu64p by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { return DISPATCH(add_z2_1_, ax, ay, az, bx, by, rx, ry, rz, n); }
+EXPORT int ref_trplu(int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { return DISPATCH(trplu_, px, py, pz, rx, ry, rz, n); }
+EXPORT int ref_from_affine(int curve, cu64p x, cu64p y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n) { return DISPATCH(from_affine_, x, y, jx, jy, jz, n); }
+EXPORT int ref_to_affine(int curve, cu64p jx, cu64p jy, cu64p jz, uint64_t* x, uint64_t* y, size_t n) { return DISPATCH(to_affine_, jx, jy, jz, x, y, n); }
+EXPORT int ref_compute_y(int curve, cu64p x, uint64_t* y, uint8_t* ok, size_t n) { return DISPATCH(compute_y_, x, y, ok, n); }
+EXPORT int ref_scalar_mult(int curve, cu64p k, cu64p x, cu64p y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int threads) { return DISPATCH(scalar_mult_, k, x, y, ox, oy, oz, n, threads, false); }
+EXPORT int ref_scalar_mult_mgry(int curve, cu64p k, cu64p xm, cu64p ym, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int threads) { return DISPATCH(scalar_mult_, k, xm, ym, ox, oy, oz, n, threads, true); }
+EXPORT int ref_scalar_mult_1s(int curve, cu64p k1, cu64p x, cu64p y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { return DISPATCH(scalar_mult_1s_, k1, x, y, ox, oy, oz, n); }
+EXPORT double ref_now(void) { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}

@@ -1,0 +1,151 @@
+// Instruction-issue-rate microbenchmark for gfx950 (MI355X).
+// Measures wave64 issue cost (cycles per wave-instruction per SIMD) of the integer / fp64
+// VALU instructions the 256-bit field arithmetic is built from.  The result fixes the
+// roofline denominator ("measure it with a dependency-free v_mad_u64_u32 stream").
+//
+// build: hipcc --offload-arch=gfx950 -O3 -o valu_rates valu_rates.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#include <string>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+
+static constexpr int ITERS = 2048;   // loop trips
+static constexpr int UNROLL = 16;    // independent instructions per trip (x REP)
+static constexpr int REP = 4;
+
+// Each kernel keeps 16 independent accumulators so the stream is dependency-free at depth 16.
+#define KERNEL_BEGIN(name) \
+  __global__ void __launch_bounds__(256) name(uint32_t* out, uint32_t seed) { \
+    uint32_t a[16]; uint32_t b = seed * 2654435761u + threadIdx.x; uint32_t c = seed ^ 0x9e3779b9u; \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) a[i] = b * (i + 1) + c; \
+    for (int it = 0; it < ITERS; ++it) { _Pragma("unroll") for (int r = 0; r < REP; ++r) { _Pragma("unroll") for (int i = 0; i < 16; ++i) {
+#define KERNEL_END \
+    } } } uint32_t s = 0; _Pragma("unroll") for (int i = 0; i < 16; ++i) s ^= a[i]; \
+    if (s == 0x12345678u) out[threadIdx.x] = s; }
+
+KERNEL_BEGIN(k_add_u32)      asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); KERNEL_END
+KERNEL_BEGIN(k_add_co)       asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(b) : "vcc"); KERNEL_END
+KERNEL_BEGIN(k_addc_co)      asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc"); KERNEL_END
+KERNEL_BEGIN(k_add3)         asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)); KERNEL_END
+KERNEL_BEGIN(k_mul_lo)       asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); KERNEL_END
+KERNEL_BEGIN(k_mul_hi)       asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); KERNEL_END
+KERNEL_BEGIN(k_mad_u32_u24)  asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)); KERNEL_END
+KERNEL_BEGIN(k_mul_hi_u24)   asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b)); KERNEL_END
+KERNEL_BEGIN(k_cndmask)      asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : ); KERNEL_END
+KERNEL_BEGIN(k_alignbit)     asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(a[i]) : "v"(b)); KERNEL_END
+KERNEL_BEGIN(k_xor)          asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); KERNEL_END
+KERNEL_BEGIN(k_mov)          asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(b)); KERNEL_END
+KERNEL_BEGIN(k_fma_f32)      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)); KERNEL_END
+KERNEL_BEGIN(k_pk_fma_f32_h) if (i < 8) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*(uint64_t*)&a[2*i]) : "v"(*(uint64_t*)&a[0])); KERNEL_END
+
+// 64-bit-register instructions: 8 independent 64-bit accumulators (pairs of the 16 words), two passes
+#define KERNEL64_BEGIN(name) \
+  __global__ void __launch_bounds__(256) name(uint32_t* out, uint32_t seed) { \
+    uint64_t a[16]; uint32_t b = seed * 2654435761u + threadIdx.x; uint32_t c = seed ^ 0x9e3779b9u; \
+    uint64_t b64 = ((uint64_t)b << 32) | c; \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) a[i] = (uint64_t)(b * (i + 1) + c) * 0x100000001ull; \
+    for (int it = 0; it < ITERS; ++it) { _Pragma("unroll") for (int r = 0; r < REP; ++r) { _Pragma("unroll") for (int i = 0; i < 16; ++i) {
+#define KERNEL64_END \
+    } } } uint64_t s = 0; _Pragma("unroll") for (int i = 0; i < 16; ++i) s ^= a[i]; \
+    if (s == 0x12345678u) out[threadIdx.x] = (uint32_t)s; }
+
+KERNEL64_BEGIN(k_mad_u64_u32)     asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c) : "vcc"); KERNEL64_END
+KERNEL64_BEGIN(k_mad_u64_u32_s)   asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c) : "s20", "s21"); KERNEL64_END
+KERNEL64_BEGIN(k_mad_i64_i32)     asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c) : "vcc"); KERNEL64_END
+KERNEL64_BEGIN(k_lshl_add_u64)    asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(a[i]) : "v"(b64)); KERNEL64_END
+KERNEL64_BEGIN(k_fma_f64)         asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b64)); KERNEL64_END
+KERNEL64_BEGIN(k_mul_f64)         asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[i]) : "v"(b64)); KERNEL64_END
+KERNEL64_BEGIN(k_add_f64)         asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[i]) : "v"(b64)); KERNEL64_END
+KERNEL64_BEGIN(k_lshlrev_b64)     asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a[i]) : ); KERNEL64_END
+KERNEL64_BEGIN(k_lshrrev_b64)     asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(a[i]) : ); KERNEL64_END
+KERNEL64_BEGIN(k_pk_add_u32pair)  asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(*(uint32_t*)&a[i]) : "v"(b)); KERNEL64_END
+// mixed: 1 mad + 1 addc (Comba inner step) -- counts as 2 instructions
+KERNEL64_BEGIN(k_comba_step)      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "+v"(a[i]), "+v"(c) : "v"(b), "v"(b) : "vcc"); KERNEL64_END
+
+
+KERNEL_BEGIN(k_cndmask_e64s)  asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(b) : ); KERNEL_END
+KERNEL_BEGIN(k_cmp_cndmask)   asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc"); KERNEL_END
+KERNEL_BEGIN(k_cndmask_vccset) if (i == 0 && r == 0) asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a[0]), "v"(b) : "vcc"); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : ); KERNEL_END
+KERNEL_BEGIN(k_bfi)           asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c)); KERNEL_END
+KERNEL_BEGIN(k_and_or)        asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)); KERNEL_END
+KERNEL_BEGIN(k_and)           asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); KERNEL_END
+KERNEL_BEGIN(k_sub_co)        asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(b) : "vcc"); KERNEL_END
+KERNEL_BEGIN(k_subb_co)       asm volatile("v_subb_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc"); KERNEL_END
+KERNEL_BEGIN(k_addc_e64s)     asm volatile("v_addc_co_u32_e64 %0, s[20:21], %0, %1, s[20:21]" : "+v"(a[i]) : "v"(b) : "s20", "s21"); KERNEL_END
+KERNEL_BEGIN(k_lshl_add_u32)  asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[i]) : "v"(b)); KERNEL_END
+KERNEL_BEGIN(k_lshlrev_b32)   asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a[i]) : ); KERNEL_END
+KERNEL_BEGIN(k_xad)           asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)); KERNEL_END
+KERNEL_BEGIN(k_sub_u32)       asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); KERNEL_END
+KERNEL_BEGIN(k_cmp_only)      asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc"); KERNEL_END
+KERNEL_BEGIN(k_pk_add_u16)    asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b)); KERNEL_END
+// dependent chains: all 16 slots hit the same accumulator(s)
+KERNEL64_BEGIN(k_mad_dep1)    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[0]) : "v"(b), "v"(c) : "vcc"); KERNEL64_END
+KERNEL64_BEGIN(k_mad_dep2)    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[i&1]) : "v"(b), "v"(c) : "vcc"); KERNEL64_END
+KERNEL64_BEGIN(k_mad_dep4)    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[i&3]) : "v"(b), "v"(c) : "vcc"); KERNEL64_END
+KERNEL64_BEGIN(k_comba_dep1)  asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "+v"(a[0]), "+v"(c) : "v"(b), "v"(b) : "vcc"); KERNEL64_END
+KERNEL_BEGIN(k_addc_dep1)     asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[0]) : "v"(b) : "vcc"); KERNEL_END
+KERNEL_BEGIN(k_addc_chain8)   asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[i&7]) : "v"(b) : "vcc"); KERNEL_END
+KERNEL_BEGIN(k_add_dep1)      asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[0]) : "v"(b)); KERNEL_END
+KERNEL64_BEGIN(k_fma64_dep1)  asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a[0]) : "v"(b64)); KERNEL64_END
+
+typedef void (*kern_t)(uint32_t*, uint32_t);
+struct Entry { const char* name; kern_t k; int insts_per_slot; };
+
+int main(int argc, char** argv) {
+  int dev = 0; CHECK(hipSetDevice(dev));
+  hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, dev));
+  int cus = prop.multiProcessorCount;
+  printf("device: %s  CUs=%d  clockRate=%d kHz  arch=%s\n", prop.name, cus, prop.clockRate, prop.gcnArchName);
+  uint32_t* out; CHECK(hipMalloc(&out, 4096));
+  std::vector<Entry> es = {
+    {"v_add_u32", k_add_u32, 1}, {"v_add_co_u32", k_add_co, 1}, {"v_addc_co_u32", k_addc_co, 1},
+    {"v_add3_u32", k_add3, 1}, {"v_mul_lo_u32", k_mul_lo, 1}, {"v_mul_hi_u32", k_mul_hi, 1},
+    {"v_mad_u32_u24", k_mad_u32_u24, 1}, {"v_mul_hi_u32_u24", k_mul_hi_u24, 1},
+    {"v_cndmask_b32", k_cndmask, 1}, {"v_alignbit_b32", k_alignbit, 1}, {"v_xor_b32", k_xor, 1}, {"v_mov_b32", k_mov, 1},
+    {"v_fma_f32", k_fma_f32, 1},
+    {"v_mad_u64_u32(vcc)", k_mad_u64_u32, 1}, {"v_mad_u64_u32(sgpr)", k_mad_u64_u32_s, 1}, {"v_mad_i64_i32", k_mad_i64_i32, 1},
+    {"v_lshl_add_u64", k_lshl_add_u64, 1}, {"v_fma_f64", k_fma_f64, 1}, {"v_mul_f64", k_mul_f64, 1}, {"v_add_f64", k_add_f64, 1},
+    {"v_lshlrev_b64", k_lshlrev_b64, 1}, {"v_lshrrev_b64", k_lshrrev_b64, 1},
+    {"mad_u64_u32+addc", k_comba_step, 2},
+    {"v_cndmask(e64,sgpr)", k_cndmask_e64s, 1}, {"v_cmp+v_cndmask", k_cmp_cndmask, 2}, {"v_cndmask(vcc set once)", k_cndmask_vccset, 1},
+    {"v_bfi_b32", k_bfi, 1}, {"v_and_or_b32", k_and_or, 1}, {"v_and_b32", k_and, 1}, {"v_sub_co_u32", k_sub_co, 1}, {"v_subb_co_u32", k_subb_co, 1},
+    {"v_addc_co(e64,sgpr)", k_addc_e64s, 1}, {"v_lshl_add_u32", k_lshl_add_u32, 1}, {"v_lshlrev_b32", k_lshlrev_b32, 1}, {"v_xad_u32", k_xad, 1},
+    {"v_sub_u32", k_sub_u32, 1}, {"v_cmp_lt_u32", k_cmp_only, 1}, {"v_pk_add_u16", k_pk_add_u16, 1},
+    {"mad_u64 dep-chain x1", k_mad_dep1, 1}, {"mad_u64 dep-chain x2", k_mad_dep2, 1}, {"mad_u64 dep-chain x4", k_mad_dep4, 1},
+    {"mad+addc dep x1", k_comba_dep1, 2}, {"addc dep x1", k_addc_dep1, 1}, {"addc chain(8 regs)", k_addc_chain8, 1}, {"v_add_u32 dep x1", k_add_dep1, 1}, {"v_fma_f64 dep x1", k_fma64_dep1, 1},
+  };
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  const int wps_list[] = {1, 2, 4, 8};   // waves per SIMD
+  printf("%-22s", "instruction");
+  for (int w : wps_list) printf("  w/SIMD=%d: Tinst/s  cyc@2.4GHz", w);
+  printf("\n");
+  for (auto& e : es) {
+    printf("%-22s", e.name);
+    for (int wps : wps_list) {
+      // blocks of 256 threads = 4 waves = one wave per SIMD of a CU; wps blocks per CU
+      int grid = cus * wps;
+      hipLaunchKernelGGL(e.k, dim3(grid), dim3(256), 0, 0, out, 1u);   // warm-up
+      CHECK(hipDeviceSynchronize());
+      float best = 1e30f;
+      for (int rep = 0; rep < 5; ++rep) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(e.k, dim3(grid), dim3(256), 0, 0, out, (uint32_t)rep + 2);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+      }
+      double wave_insts = (double)grid * 4 /*waves*/ * ITERS * REP * UNROLL * e.insts_per_slot;
+      double lane_insts_per_s = wave_insts * 64 / (best * 1e-3);
+      // cycles per wave-instruction per SIMD at 2.4 GHz: each SIMD runs wps waves
+      double insts_per_simd = (double)wps * ITERS * REP * UNROLL * e.insts_per_slot;
+      double cyc = (best * 1e-3) * 2.4e9 / insts_per_simd;
+      printf("  %9.2f T/s %7.2f cyc    ", lane_insts_per_s * 1e-12, cyc);
+    }
+    printf("\n");
+  }
+  return 0;
+}
