@@ -1,0 +1,13 @@
+"""ecsimd_amd -- MI355X (gfx950) batched elliptic-curve engine: Python plumbing over the C ABI.
+
+The product is ``libecsimd_hip.so`` (hand-written HIP kernels + the C ABI of ``include/ecsimd_hip.h``)
+and the C++ headers in ``include/ecsimd/``.  This package only loads the library with ctypes and
+passes device pointers of torch tensors (torch is plumbing: device memory, streams,
+``torch.distributed``).  There is NO CPU fallback: importing works anywhere, but creating an
+``Engine`` fails loudly when the library or a gfx950 device is missing.
+"""
+from .engine import Engine, EcsimdHipError, CURVES, P256, SECP256K1, lib_path, load_library  # noqa: F401
+from .flags import BASE_CLASSICAL, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE  # noqa: F401
+
+__all__ = ["Engine", "EcsimdHipError", "CURVES", "P256", "SECP256K1", "lib_path", "load_library",
+           "BASE_CLASSICAL", "BASE_MGRY", "OUT_JACOBIAN", "OUT_AFFINE"]

@@ -1,0 +1,284 @@
+// capi.hip -- the C ABI of include/ecsimd_hip.h: argument checks, context/stream handling and
+// dispatch to the kernel launchers of kernels.h (gfx950 only; no CPU fallback of any kind).
+//
+// One field element / one curve point per lane, 256-thread workgroups.  The path is integer-VALU
+// bound by three orders of magnitude (~2900 multiplies per byte moved), so there is
+// no LDS staging, no XCD-aware remap and no MFMA: workgroups never share data and HBM sees ~0.1 %
+// of its bandwidth.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+#include "../../include/ecsimd_hip.h"
+#include "kernels.h"
+#include "point.cuh"   // curve constants for ecsimd_hip_get_constant (host-side constexpr use only)
+
+using namespace ecsimd_hip;
+using launch::BLOCK;
+
+namespace {
+// Stream-ordered store of a 256-bit kernel argument into device memory (the shared scalar of
+// scalar_mult_1s): no host buffer has to outlive the call.
+__global__ void k_store_words(launch::words8 w, uint32_t* dst) {
+  if (threadIdx.x < 8) dst[threadIdx.x] = w.w[threadIdx.x];
+}
+void store_words(hipStream_t s, const launch::words8& w, uint32_t* dst) {
+  hipLaunchKernelGGL(k_store_words, dim3(1), dim3(64), 0, s, w, dst);
+}
+}  // namespace
+
+// curve dispatch for the per-curve translation units
+namespace ecsimd_hip { namespace launch {
+#define DISPATCH(fn, ...) do { if (curve == CURVE_P256) point_launch<CURVE_P256>::fn(__VA_ARGS__); else point_launch<CURVE_SECP256K1>::fn(__VA_ARGS__); } while (0)
+void from_affine(hipStream_t s, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n) { DISPATCH(from_affine, s, x, y, jx, jy, jz, n); }
+void to_affine(hipStream_t s, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n) { DISPATCH(to_affine, s, jx, jy, jz, x, y, n); }
+void compute_y(hipStream_t s, int curve, const uint64_t* x, uint64_t* y, uint8_t* ok, size_t n) { DISPATCH(compute_y, s, x, y, ok, n); }
+void dblu(hipStream_t s, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH(dblu, s, px, py, pz, rx, ry, rz, n); }
+void zaddu(hipStream_t s, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, const uint64_t* qx, const uint64_t* qy, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH(zaddu, s, px, py, pz, qx, qy, rx, ry, rz, n); }
+void zdau(hipStream_t s, int curve, const uint64_t* px, const uint64_t* py, const uint64_t* pz, uint64_t* qx, uint64_t* qy, uint64_t* qz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH(zdau, s, px, py, pz, qx, qy, qz, rx, ry, rz, n); }
+void add_z2_1(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH(add_z2_1, s, ax, ay, az, bx, by, rx, ry, rz, n); }
+void trplu(hipStream_t s, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH(trplu, s, px, py, pz, rx, ry, rz, n); }
+void scalar_mult(hipStream_t s, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) { DISPATCH(scalar_mult, s, k, k_stride, x, y, ox, oy, oz, n, flags); }
+#undef DISPATCH
+} }
+
+// ================================================================== host side
+struct ecsimd_hip_ctx {
+  int device;
+  hipStream_t own_stream;
+  hipStream_t stream;
+  int cus;
+  uint32_t* sink;      // 4 KiB scratch: peak-probe sink [0, 1024) and the shared scalar at word 1024-8
+  char err[256];
+};
+
+namespace {
+
+int fail(ecsimd_hip_ctx* ctx, hipError_t e, const char* what) {
+  if (ctx) snprintf(ctx->err, sizeof ctx->err, "%s: %s", what, hipGetErrorString(e));
+  return ECSIMD_HIP_ERR_HIP;
+}
+int bad(ecsimd_hip_ctx* ctx, const char* what) {
+  if (ctx) snprintf(ctx->err, sizeof ctx->err, "bad argument: %s", what);
+  return ECSIMD_HIP_ERR_BAD_ARG;
+}
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define REQUIRE_CTX() do { if (!ctx) return ECSIMD_HIP_ERR_BAD_ARG; } while (0)
+#define REQUIRE_PTR(p) do { if (!(p) && n) return bad(ctx, #p " is null"); if (!aligned16(p)) return bad(ctx, #p " is not 16-byte aligned"); } while (0)
+#define REQUIRE_CURVE() do { if (curve != ECSIMD_HIP_P256 && curve != ECSIMD_HIP_SECP256K1) return bad(ctx, "unknown curve"); } while (0)
+
+// Enqueue one launcher call on the context's stream; report launch errors.
+#define RUN(call) do { \
+    if (n == 0) return ECSIMD_HIP_OK; \
+    if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large"); \
+    hipError_t e0_ = hipSetDevice(ctx->device); if (e0_ != hipSuccess) return fail(ctx, e0_, "hipSetDevice"); \
+    hipStream_t s = ctx->stream; (void)s; \
+    call; \
+    hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(ctx, e_, #call); \
+    return ECSIMD_HIP_OK; } while (0)
+
+void words_to_limbs(const uint32_t (&w)[8], uint64_t out[4]) {
+  for (int i = 0; i < 4; ++i) out[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ecsimd_hip_version(void) { return "ecsimd-hip 0.1 (gfx950)"; }
+
+int ecsimd_hip_init(int device, ecsimd_hip_ctx** out) {
+  if (!out) return ECSIMD_HIP_ERR_BAD_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ECSIMD_HIP_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ECSIMD_HIP_ERR_NO_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ECSIMD_HIP_ERR_NO_DEVICE;   // the code object is gfx950-only
+  ecsimd_hip_ctx* ctx = new (std::nothrow) ecsimd_hip_ctx();
+  if (!ctx) return ECSIMD_HIP_ERR_HIP;
+  ctx->device = device; ctx->cus = prop.multiProcessorCount; ctx->err[0] = 0; ctx->sink = nullptr;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ECSIMD_HIP_ERR_HIP; }
+  ctx->stream = ctx->own_stream;
+  if (hipMalloc(&ctx->sink, 4096) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ECSIMD_HIP_ERR_HIP; }
+  *out = ctx;
+  return ECSIMD_HIP_OK;
+}
+int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
+  REQUIRE_CTX();
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(ctx->sink);
+  (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return ECSIMD_HIP_OK;
+}
+int ecsimd_hip_set_stream(ecsimd_hip_ctx* ctx, void* s) { REQUIRE_CTX(); ctx->stream = (hipStream_t)s; return ECSIMD_HIP_OK; }
+int ecsimd_hip_use_own_stream(ecsimd_hip_ctx* ctx) { REQUIRE_CTX(); ctx->stream = ctx->own_stream; return ECSIMD_HIP_OK; }
+int ecsimd_hip_sync(ecsimd_hip_ctx* ctx) {
+  REQUIRE_CTX();
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "hipStreamSynchronize");
+}
+const char* ecsimd_hip_last_error(const ecsimd_hip_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+int ecsimd_hip_malloc(ecsimd_hip_ctx* ctx, void** p, size_t bytes) {
+  REQUIRE_CTX(); if (!p) return bad(ctx, "dptr is null");
+  (void)hipSetDevice(ctx->device);
+  hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "hipMalloc");
+}
+int ecsimd_hip_free(ecsimd_hip_ctx* ctx, void* p) {
+  REQUIRE_CTX(); (void)hipSetDevice(ctx->device);
+  hipError_t e = hipFree(p);
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "hipFree");
+}
+int ecsimd_hip_memcpy_h2d(ecsimd_hip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  REQUIRE_CTX(); (void)hipSetDevice(ctx->device);
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     // src may be pageable: complete before returning
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "hipMemcpy h2d");
+}
+int ecsimd_hip_memcpy_d2h(ecsimd_hip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  REQUIRE_CTX(); (void)hipSetDevice(ctx->device);
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "hipMemcpy d2h");
+}
+
+int ecsimd_hip_get_constant(int curve, int which, uint64_t out[4]) {
+  if (!out || which < 0 || which > 11) return ECSIMD_HIP_ERR_BAD_ARG;
+#define PICK(C) do { using K = curve_consts<C>; using E = curve_exps<C>; \
+    switch (which) { \
+      case 0: words_to_limbs(K::P, out); break; \
+      case 1: { uint32_t a[8]; for (int i = 0; i < 8; ++i) a[i] = (C == CURVE_P256) ? K::P[i] : 0u; if (C == CURVE_P256) a[0] -= 3u; words_to_limbs(a, out); break; } \
+      case 2: { static const uint32_t b256[8] = {0x27d2604bu, 0x3bce3c3eu, 0xcc53b0f6u, 0x651d06b0u, 0x769886bcu, 0xb3ebbd55u, 0xaa3a93e7u, 0x5ac635d8u}; \
+                static const uint32_t bk1[8] = {7u, 0, 0, 0, 0, 0, 0, 0}; words_to_limbs((C == CURVE_P256) ? b256 : bk1, out); break; } \
+      case 3: words_to_limbs(K::GX, out); break; \
+      case 4: words_to_limbs(K::GY, out); break; \
+      case 5: words_to_limbs(K::R_P, out); break; \
+      case 6: words_to_limbs(K::RSQ, out); break; \
+      case 7: { /* -R mod p = p - (R mod p) */ uint64_t p[4], r[4]; words_to_limbs(K::P, p); words_to_limbs(K::R_P, r); \
+                unsigned __int128 bw = 0; for (int i = 0; i < 4; ++i) { unsigned __int128 d = (unsigned __int128)p[i] - r[i] - (uint64_t)bw; out[i] = (uint64_t)d; bw = (d >> 64) & 1; } break; } \
+      case 8: words_to_limbs(K::AM, out); break; \
+      case 9: words_to_limbs(K::BM, out); break; \
+      case 10: words_to_limbs(E::P_M2, out); break; \
+      default: words_to_limbs(E::P_SQRT, out); break; \
+    } } while (0)
+  if (curve == ECSIMD_HIP_P256) PICK(CURVE_P256);
+  else if (curve == ECSIMD_HIP_SECP256K1) PICK(CURVE_SECP256K1);
+  else return ECSIMD_HIP_ERR_BAD_ARG;
+#undef PICK
+  return ECSIMD_HIP_OK;
+}
+
+// ---- L2
+int ecsimd_hip_add(ecsimd_hip_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* carry, size_t n) {
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::add(s, a, b, out, carry, n)); }
+int ecsimd_hip_sub(ecsimd_hip_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* borrow, size_t n) {
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::sub(s, a, b, out, borrow, n)); }
+int ecsimd_hip_sub_if_above(ecsimd_hip_ctx* ctx, const uint64_t* a, const uint64_t* p, uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(p); REQUIRE_PTR(out); RUN(launch::sub_if_above(s, a, p, out, n)); }
+int ecsimd_hip_cmp_lt(ecsimd_hip_ctx* ctx, const uint64_t* a, const uint64_t* b, uint8_t* flag, size_t n) {
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); if (!flag && n) return bad(ctx, "flag is null");
+  RUN(launch::sub(s, a, b, nullptr, flag, n)); }
+int ecsimd_hip_shift_left_one(ecsimd_hip_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* carry, size_t n) {
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::shift_left_one(s, a, out, carry, n)); }
+int ecsimd_hip_mul(ecsimd_hip_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out8, size_t n) {
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out8); RUN(launch::mul(s, a, b, out8, n)); }
+int ecsimd_hip_square(ecsimd_hip_ctx* ctx, const uint64_t* a, uint64_t* out8, size_t n) {
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(out8); RUN(launch::square(s, a, out8, n)); }
+int ecsimd_hip_swap_if(ecsimd_hip_ctx* ctx, const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n) {
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); if (!mask && n) return bad(ctx, "mask is null"); RUN(launch::swap_if(s, mask, a, b, n)); }
+
+// ---- L3
+int ecsimd_hip_mod_add(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, curve, launch::F_MOD_ADD, a, b, out, n)); }
+int ecsimd_hip_mod_sub(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, curve, launch::F_MOD_SUB, a, b, out, n)); }
+int ecsimd_hip_mod_shift_left(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, int count, uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); if (count < 1) return bad(ctx, "count < 1"); RUN(launch::mod_shift_left(s, curve, a, count, out, n)); }
+int ecsimd_hip_mgry_reduce(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a8, uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a8); REQUIRE_PTR(out); RUN(launch::mgry_reduce(s, curve, a8, out, n)); }
+int ecsimd_hip_mgry_mul(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, curve, launch::F_MGRY_MUL, a, b, out, n)); }
+int ecsimd_hip_mgry_sqr(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, curve, launch::F_MGRY_SQR, a, out, n)); }
+int ecsimd_hip_mgry_from_classical(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, curve, launch::F_FROM_CLASSICAL, a, out, n)); }
+int ecsimd_hip_mgry_to_classical(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, curve, launch::F_TO_CLASSICAL, a, out, n)); }
+int ecsimd_hip_mgry_pow(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t exponent[4], uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); if (!exponent) return bad(ctx, "exponent is null");
+  launch::words8 e; for (int i = 0; i < 4; ++i) { e.w[2 * i] = (uint32_t)exponent[i]; e.w[2 * i + 1] = (uint32_t)(exponent[i] >> 32); }
+  RUN(launch::mgry_pow(s, curve, a, e, out, n)); }
+int ecsimd_hip_gfp_inverse(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, curve, launch::F_INVERSE, a, out, n)); }
+int ecsimd_hip_gfp_opposite(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, curve, launch::F_OPPOSITE, a, out, n)); }
+int ecsimd_hip_gfp_sqrt(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::gfp_sqrt(s, curve, a, out, ok, n)); }
+
+// ---- L4/L5
+int ecsimd_hip_from_affine(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); RUN(launch::from_affine(s, curve, x, y, jx, jy, jz, n)); }
+int ecsimd_hip_to_affine(ecsimd_hip_ctx* ctx, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); REQUIRE_PTR(x); REQUIRE_PTR(y); RUN(launch::to_affine(s, curve, jx, jy, jz, x, y, n)); }
+int ecsimd_hip_compute_y(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, uint64_t* y, uint8_t* ok, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); RUN(launch::compute_y(s, curve, x, y, ok, n)); }
+int ecsimd_hip_dblu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz); RUN(launch::dblu(s, curve, px, py, pz, rx, ry, rz, n)); }
+int ecsimd_hip_zaddu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, const uint64_t* ox, const uint64_t* oy, const uint64_t* oz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(ox); REQUIRE_PTR(oy); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
+  (void)oz;   // co-Z: O.z == P.z by precondition (curve_group.h:92)
+  RUN(launch::zaddu(s, curve, px, py, pz, ox, oy, rx, ry, rz, n)); }
+int ecsimd_hip_zdau(ecsimd_hip_ctx* ctx, int curve, const uint64_t* px, const uint64_t* py, const uint64_t* pz, uint64_t* qx, uint64_t* qy, uint64_t* qz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(qz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
+  RUN(launch::zdau(s, curve, px, py, pz, qx, qy, qz, rx, ry, rz, n)); }
+int ecsimd_hip_add_z2_1(ecsimd_hip_ctx* ctx, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(ax); REQUIRE_PTR(ay); REQUIRE_PTR(az); REQUIRE_PTR(bx); REQUIRE_PTR(by); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
+  RUN(launch::add_z2_1(s, curve, ax, ay, az, bx, by, rx, ry, rz, n)); }
+int ecsimd_hip_trplu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz); RUN(launch::trplu(s, curve, px, py, pz, rx, ry, rz, n)); }
+
+int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_PTR(oy);
+  if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
+  RUN(launch::scalar_mult(s, curve, k, 4, x, y, ox, oy, oz, n, flags)); }
+int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[4], const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_PTR(oy); if (!k1) return bad(ctx, "k1 is null");
+  if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
+  launch::words8 w; for (int i = 0; i < 4; ++i) { w.w[2 * i] = (uint32_t)k1[i]; w.w[2 * i + 1] = (uint32_t)(k1[i] >> 32); }
+  uint32_t* kdev = ctx->sink + 1024 - 8;    // 32-byte aligned slot at the end of the scratch page
+  RUN((store_words(s, w, kdev),
+       launch::scalar_mult(s, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, oz, n, flags))); }
+int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(ox); REQUIRE_PTR(oy);
+  if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
+  RUN(launch::scalar_mult(s, curve, k, 4, nullptr, nullptr, ox, oy, oz, n, flags)); }
+int ecsimd_hip_scalar_mult_p256(ecsimd_hip_ctx* ctx, const uint64_t* k, const uint64_t* xm, const uint64_t* ym, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) {
+  return ecsimd_hip_scalar_mult(ctx, ECSIMD_HIP_P256, k, xm, ym, ox, oy, oz, n, ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN); }
+
+int ecsimd_hip_fill_random(ecsimd_hip_ctx* ctx, uint64_t* out, size_t n, uint64_t seed, uint64_t stream, uint64_t first_index, int clear_top_bits) {
+  REQUIRE_CTX(); REQUIRE_PTR(out); if (clear_top_bits < 0 || clear_top_bits > 63) return bad(ctx, "clear_top_bits");
+  RUN(launch::fill_random(s, out, n, seed, stream, first_index, clear_top_bits)); }
+
+int ecsimd_hip_peak_mad32(ecsimd_hip_ctx* ctx, int iters, double* mads, double* ms) {
+  REQUIRE_CTX(); if (iters < 1 || !mads || !ms) return bad(ctx, "peak_mad32 arguments");
+  (void)hipSetDevice(ctx->device);
+  const int blocks = ctx->cus * 8;          // 8 workgroups of 4 waves per CU = 8 waves per SIMD
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  launch::peak_mad32(ctx->stream, blocks, ctx->sink, 16, 1u);   // warm-up
+  (void)hipEventRecord(e0, ctx->stream);
+  launch::peak_mad32(ctx->stream, blocks, ctx->sink, iters, 2u);
+  (void)hipEventRecord(e1, ctx->stream);
+  hipError_t e = hipEventSynchronize(e1);
+  float t = 0; if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return fail(ctx, e, "peak_mad32");
+  *ms = t; *mads = (double)blocks * BLOCK * (double)iters * launch::PEAK_MADS_PER_LANE_PER_ITER;
+  return ECSIMD_HIP_OK; }
+
+}  // extern "C"

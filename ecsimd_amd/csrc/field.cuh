@@ -1,0 +1,496 @@
+// field.cuh -- 256-bit prime-field arithmetic for gfx950 (CDNA4), one field element per lane.
+//
+// Replaces the reference's L2/L3 layers (include/ecsimd/{add,sub,mul,shift,modular,mgry_mul,
+// mgry_ops}.h) for the two curves on the hot path.  A field element is 8 x u32 words in VGPRs
+// (= the 4 x u64 little-endian limbs of the reference's bignum_256, bignum.h:97-99); every
+// function returns the CANONICAL residue in [0, p), exactly like the reference
+// (sub.h:46-69 sub_if_above ends every op), so any expression DAG evaluated with these
+// functions is bit-identical to the reference's (SURVEY.md 8(a) "parity level J").
+//
+// gfx950 issue costs measured with tools/ubench/valu_rates.hip (cycles per wave64 instruction per
+// SIMD at >= 2 waves/SIMD):  v_mad_u64_u32 4.4, v_addc/subb_co_u32 4.35, v_cndmask_b32 (SGPR mask)
+// 4.1, v_alignbit 4.1, v_mov/v_and/v_xor/v_add_u32 2.2-2.4.  The compiler lowers a carry-checked
+// 64-bit MAC to 4+ instructions (mad + lshl_add_u64 + cmp_lt_u64 + cndmask), so the carry chains
+// below are written as inline asm: each statement is one self-contained chain (VCC defined and
+// consumed inside the statement), the compiler only allocates registers and schedules statements.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ecsimd_hip {
+
+enum : int { CURVE_P256 = 0, CURVE_SECP256K1 = 1 };
+
+struct fe { uint32_t w[8]; };                  // little-endian 32-bit words
+struct fe2 { uint32_t w[16]; };                // 512-bit product
+
+#define ECS_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------- per-curve constants
+// Values pinned against the reference in tests/test_constants.py.
+template <int CURVE> struct curve_consts;
+
+template <> struct curve_consts<CURVE_P256> {
+  // p = 2^256 - 2^224 + 2^192 + 2^96 - 1                       curve_nist_p256.h:17-19
+  static constexpr uint32_t P[8]    = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000001u, 0xffffffffu};
+  static constexpr uint32_t R_P[8]  = {0x00000001u, 0x00000000u, 0x00000000u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xfffffffeu, 0x00000000u};   // R mod p    mgry_csts.h:20
+  static constexpr uint32_t RSQ[8]  = {0x00000003u, 0x00000000u, 0xffffffffu, 0xfffffffbu, 0xfffffffeu, 0xffffffffu, 0xfffffffdu, 0x00000004u};   // R^2 mod p  mgry_csts.h:21
+  static constexpr uint32_t AM[8]   = {0xfffffffcu, 0xffffffffu, 0xffffffffu, 0x00000003u, 0x00000000u, 0x00000000u, 0x00000004u, 0xfffffffcu};   // a*R mod p  curve_group.h:32
+  static constexpr uint32_t BM[8]   = {0x29c4bddfu, 0xd89cdf62u, 0x78843090u, 0xacf005cdu, 0xf7212ed6u, 0xe5a220abu, 0x04874834u, 0xdc30061du};   // b*R mod p  curve_group.h:31
+  static constexpr uint32_t GX[8]   = {0xd898c296u, 0xf4a13945u, 0x2deb33a0u, 0x77037d81u, 0x63a440f2u, 0xf8bce6e5u, 0xe12c4247u, 0x6b17d1f2u};   // curve_nist_p256.h:27-29
+  static constexpr uint32_t GY[8]   = {0x37bf51f5u, 0xcbb64068u, 0x6b315eceu, 0x2bce3357u, 0x7c0f9e16u, 0x8ee7eb4au, 0xfe1a7f9bu, 0x4fe342e2u};   // curve_nist_p256.h:30-32
+  static constexpr uint32_t MPRIME  = 0x00000001u;                                                                                                 // mgry_mul.h:37
+};
+
+template <> struct curve_consts<CURVE_SECP256K1> {
+  // p = 2^256 - 2^32 - 977                                     tests/mgry.cpp:25-27
+  static constexpr uint32_t P[8]    = {0xfffffc2fu, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  static constexpr uint32_t R_P[8]  = {0x000003d1u, 0x00000001u, 0, 0, 0, 0, 0, 0};
+  static constexpr uint32_t RSQ[8]  = {0x000e90a1u, 0x000007a2u, 0x00000001u, 0, 0, 0, 0, 0};
+  static constexpr uint32_t AM[8]   = {0, 0, 0, 0, 0, 0, 0, 0};
+  static constexpr uint32_t BM[8]   = {0x00001ab7u, 0x00000007u, 0, 0, 0, 0, 0, 0};
+  static constexpr uint32_t GX[8]   = {0x16f81798u, 0x59f2815bu, 0x2dce28d9u, 0x029bfcdbu, 0xce870b07u, 0x55a06295u, 0xf9dcbbacu, 0x79be667eu};
+  static constexpr uint32_t GY[8]   = {0xfb10d4b8u, 0x9c47d08fu, 0xa6855419u, 0xfd17b448u, 0x0e1108a8u, 0x5da4fbfcu, 0x26a3c465u, 0x483ada77u};
+  static constexpr uint32_t MPRIME  = 0xd2253531u;
+};
+
+template <int CURVE, const uint32_t (&ARR)[8]> ECS_DEV fe fe_const() {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.w[i] = ARR[i];
+  return r;
+}
+#define FE_CONST(CURVE, NAME) fe_const<CURVE, curve_consts<CURVE>::NAME>()
+
+// ---------------------------------------------------------------- global-memory access
+// HBM layout: element i = 32 contiguous bytes (4 x u64 LE limbs).  Each lane moves its element
+// with two 16-byte accesses; a wave covers 2 KiB contiguous, every fetched cache line is fully used.
+ECS_DEV fe fe_load(const uint64_t* __restrict__ base, size_t i) {
+  const uint4* p = reinterpret_cast<const uint4*>(base + 4 * i);
+  uint4 lo = p[0], hi = p[1];
+  fe r;
+  r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
+  r.w[4] = hi.x; r.w[5] = hi.y; r.w[6] = hi.z; r.w[7] = hi.w;
+  return r;
+}
+ECS_DEV void fe_store(uint64_t* __restrict__ base, size_t i, const fe& v) {
+  uint4* p = reinterpret_cast<uint4*>(base + 4 * i);
+  p[0] = make_uint4(v.w[0], v.w[1], v.w[2], v.w[3]);
+  p[1] = make_uint4(v.w[4], v.w[5], v.w[6], v.w[7]);
+}
+ECS_DEV fe2 fe2_load(const uint64_t* __restrict__ base, size_t i) {
+  const uint4* p = reinterpret_cast<const uint4*>(base + 8 * i);
+  fe2 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { uint4 v = p[k]; r.w[4 * k] = v.x; r.w[4 * k + 1] = v.y; r.w[4 * k + 2] = v.z; r.w[4 * k + 3] = v.w; }
+  return r;
+}
+ECS_DEV void fe2_store(uint64_t* __restrict__ base, size_t i, const fe2& v) {
+  uint4* p = reinterpret_cast<uint4*>(base + 8 * i);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) p[k] = make_uint4(v.w[4 * k], v.w[4 * k + 1], v.w[4 * k + 2], v.w[4 * k + 3]);
+}
+
+// ---------------------------------------------------------------- carry-chain primitives
+// a += b over 8 words; returns the carry-out (0/1).                       add.h:11-34
+ECS_DEV uint32_t add8(fe& a, const fe& b) {
+  uint32_t c;
+  asm("v_add_co_u32 %0, vcc, %0, %9\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %10, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %2, %11, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %3, %12, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %4, %13, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %5, %14, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %6, %15, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, %7, %16, vcc\n\t"
+      "v_addc_co_u32 %8, vcc, 0, 0, vcc"
+      : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(a.w[4]), "+v"(a.w[5]), "+v"(a.w[6]), "+v"(a.w[7]), "=v"(c)
+      : "v"(b.w[0]), "v"(b.w[1]), "v"(b.w[2]), "v"(b.w[3]), "v"(b.w[4]), "v"(b.w[5]), "v"(b.w[6]), "v"(b.w[7])
+      : "vcc");
+  return c;
+}
+// a -= b over 8 words; returns the borrow as an all-ones / all-zeros word.  sub.h:12-38
+ECS_DEV uint32_t sub8(fe& a, const fe& b) {
+  uint32_t m;
+  asm("v_sub_co_u32 %0, vcc, %0, %9\n\t"
+      "v_subb_co_u32 %1, vcc, %1, %10, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %2, %11, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %3, %12, vcc\n\t"
+      "v_subb_co_u32 %4, vcc, %4, %13, vcc\n\t"
+      "v_subb_co_u32 %5, vcc, %5, %14, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %6, %15, vcc\n\t"
+      "v_subb_co_u32 %7, vcc, %7, %16, vcc\n\t"
+      "v_subb_co_u32 %8, vcc, 0, 0, vcc"
+      : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(a.w[4]), "+v"(a.w[5]), "+v"(a.w[6]), "+v"(a.w[7]), "=v"(m)
+      : "v"(b.w[0]), "v"(b.w[1]), "v"(b.w[2]), "v"(b.w[3]), "v"(b.w[4]), "v"(b.w[5]), "v"(b.w[6]), "v"(b.w[7])
+      : "vcc");
+  return m;
+}
+
+// r = (r + top*2^256 >= p) ? r - p : r, for r + top*2^256 < 2p.               sub.h:46-69
+// The borrow of the 9-word subtraction lands in an SGPR pair used as the select mask
+// (v_cndmask with an SGPR-pair mask issues at 4.1 cycles; the implicit-VCC form measured slower).
+template <int CURVE> ECS_DEV void cond_sub_p(fe& r, uint32_t top) {
+  using K = curve_consts<CURVE>;
+  fe d;
+  uint64_t keep;
+  if constexpr (CURVE == CURVE_P256) {
+    // p's words are the inline constants -1, -1, -1, 0, 0, 0, 1, -1
+    asm("v_sub_co_u32 %0, vcc, %10, -1\n\t"
+        "v_subb_co_u32 %1, vcc, %11, -1, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %12, -1, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %13, 0, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %14, 0, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %15, 0, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %16, 1, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %17, -1, vcc\n\t"
+        "v_subb_co_u32 %8, %9, %18, 0, vcc"
+        : "=&v"(d.w[0]), "=&v"(d.w[1]), "=&v"(d.w[2]), "=&v"(d.w[3]), "=&v"(d.w[4]), "=&v"(d.w[5]), "=&v"(d.w[6]), "=&v"(d.w[7]), "=&v"(top), "=&s"(keep)
+        : "v"(r.w[0]), "v"(r.w[1]), "v"(r.w[2]), "v"(r.w[3]), "v"(r.w[4]), "v"(r.w[5]), "v"(r.w[6]), "v"(r.w[7]), "v"(top)
+        : "vcc");
+  } else {
+    // secp256k1: words 2..7 are -1; words 0, 1 come in VGPRs (an SGPR source next to the VCC carry-in
+    // would exceed gfx9's one-scalar-operand constant-bus limit)
+    const uint32_t p0 = K::P[0], p1 = K::P[1];
+    asm("v_sub_co_u32 %0, vcc, %10, %19\n\t"
+        "v_subb_co_u32 %1, vcc, %11, %20, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %12, -1, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %13, -1, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %14, -1, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %15, -1, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %16, -1, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %17, -1, vcc\n\t"
+        "v_subb_co_u32 %8, %9, %18, 0, vcc"
+        : "=&v"(d.w[0]), "=&v"(d.w[1]), "=&v"(d.w[2]), "=&v"(d.w[3]), "=&v"(d.w[4]), "=&v"(d.w[5]), "=&v"(d.w[6]), "=&v"(d.w[7]), "=&v"(top), "=&s"(keep)
+        : "v"(r.w[0]), "v"(r.w[1]), "v"(r.w[2]), "v"(r.w[3]), "v"(r.w[4]), "v"(r.w[5]), "v"(r.w[6]), "v"(r.w[7]), "v"(top), "v"(p0), "v"(p1)
+        : "vcc");
+  }
+  // keep (borrow of the 257-bit subtraction) set  <=>  value < p  <=>  keep r
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    asm("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r.w[i]) : "v"(d.w[i]), "s"(keep));
+}
+
+// ---------------------------------------------------------------- modular linear ops
+// (a + b) mod p                                                            modular.h:10-15
+template <int CURVE> ECS_DEV fe fe_add(fe a, const fe& b) {
+  uint32_t c = add8(a, b);
+  cond_sub_p<CURVE>(a, c);
+  return a;
+}
+// (a - b) mod p: subtract, then add (p & borrow-mask).                     modular.h:24-41
+template <int CURVE> ECS_DEV fe fe_sub(fe a, const fe& b) {
+  uint32_t m = sub8(a, b);
+  if constexpr (CURVE == CURVE_P256) {
+    uint32_t m1 = m & 1u;   // p & mask = {m, m, m, 0, 0, 0, m&1, m}
+    asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %8, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %8, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, 0, %5, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %9, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %7, %8, vcc"
+        : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(a.w[4]), "+v"(a.w[5]), "+v"(a.w[6]), "+v"(a.w[7])
+        : "v"(m), "v"(m1)
+        : "vcc");
+  } else {
+    using K = curve_consts<CURVE>;
+    uint32_t m0 = m & K::P[0], m1 = m & K::P[1];   // p & mask = {m&p0, m&p1, m, m, m, m, m, m}
+    asm("v_add_co_u32 %0, vcc, %0, %9\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %10, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %8, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %8, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %4, %8, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %5, %8, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %8, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %7, %8, vcc"
+        : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(a.w[4]), "+v"(a.w[5]), "+v"(a.w[6]), "+v"(a.w[7])
+        : "v"(m), "v"(m0), "v"(m1)
+        : "vcc");
+  }
+  return a;
+}
+// 2a mod p                                                                 modular.h:17-22
+template <int CURVE> ECS_DEV fe fe_dbl(const fe& a) {
+  fe s;
+  uint32_t c = a.w[7] >> 31;
+#pragma unroll
+  for (int i = 7; i > 0; --i) s.w[i] = __builtin_amdgcn_alignbit(a.w[i], a.w[i - 1], 31);   // (a[i]:a[i-1]) >> 31
+  s.w[0] = a.w[0] << 1;
+  cond_sub_p<CURVE>(s, c);
+  return s;
+}
+// a * 2^N mod p = N successive doublings                                   mgry_ops.h:14-22
+template <int CURVE, int N> ECS_DEV fe fe_shl(fe a) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) a = fe_dbl<CURVE>(a);
+  return a;
+}
+// -a mod p (0 stays 0).  Same value as gfp.h:60-64 (-R - (a - R)).
+template <int CURVE> ECS_DEV fe fe_neg(const fe& a) {
+  fe z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z.w[i] = 0;
+  return fe_sub<CURVE>(z, a);
+}
+
+// ---------------------------------------------------------------- 256 x 256 -> 512 multiply
+// Product scanning (Comba) on 32-bit words with a 96-bit column accumulator: each partial
+// product is one v_mad_u64_u32 (64-bit accumulate, carry-out in VCC) + one v_addc_co_u32 into
+// the third accumulator word.  Replaces mul.h:115-158 (64 vpmuludq + digit renormalisation).
+ECS_DEV void mac(uint64_t& acc, uint32_t& ex, uint32_t a, uint32_t b) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(ex) : "v"(a), "v"(b) : "vcc");
+}
+ECS_DEV void mac_first(uint64_t& acc, uint32_t& ex, uint32_t a, uint32_t b) {   // ex = carry (ex was 0)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, 0, vcc"
+      : "+v"(acc), "=v"(ex) : "v"(a), "v"(b) : "vcc");
+}
+ECS_DEV void mac_nocarry(uint64_t& acc, uint32_t a, uint32_t b) {                // sum provably < 2^64
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+}
+ECS_DEV uint64_t mul_wide(uint32_t a, uint32_t b) {
+  uint64_t r;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b) : "vcc");
+  return r;
+}
+
+ECS_DEV fe2 mul8x8(const fe& a, const fe& b) {
+  fe2 t;
+  uint64_t acc = mul_wide(a.w[0], b.w[0]);
+  t.w[0] = (uint32_t)acc;
+  acc >>= 32;
+  uint32_t ex = 0;
+#pragma unroll
+  for (int k = 1; k < 15; ++k) {
+    bool first = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = k - i;
+      if (j < 0 || j > 7) continue;
+      if (k == 1 && first) mac_nocarry(acc, a.w[i], b.w[j]);        // a*b + (< 2^32) cannot overflow
+      else if (k == 14) mac_nocarry(acc, a.w[i], b.w[j]);           // top column: total < 2^512
+      else if (first || (k == 1)) mac_first(acc, ex, a.w[i], b.w[j]);
+      else mac(acc, ex, a.w[i], b.w[j]);
+      first = false;
+    }
+    t.w[k] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)ex << 32);
+  }
+  t.w[15] = (uint32_t)acc;
+  return t;
+}
+
+// Squaring: 28 cross products, doubled as a whole, plus the 8 diagonal squares.  mul.h:160-221
+ECS_DEV fe2 sqr8(const fe& a) {
+  fe2 t;
+  // cross = sum_{i<j} a_i a_j 2^(32(i+j)), columns 1..13
+  uint32_t c[16];
+  c[0] = 0;
+  uint64_t acc = 0;
+  uint32_t ex = 0;
+#pragma unroll
+  for (int k = 1; k < 14; ++k) {
+    bool first = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = k - i;
+      if (j <= i || j > 7) continue;
+      if (k == 1) acc = mul_wide(a.w[i], a.w[j]);
+      else if (k == 2 && first) mac_nocarry(acc, a.w[i], a.w[j]);
+      else if (first) mac_first(acc, ex, a.w[i], a.w[j]);
+      else mac(acc, ex, a.w[i], a.w[j]);
+      first = false;
+    }
+    c[k] = (uint32_t)acc;
+    if (k == 1 || k == 2) { acc >>= 32; ex = 0; }
+    else acc = (acc >> 32) | ((uint64_t)ex << 32);
+  }
+  c[14] = (uint32_t)acc;            // cross < 2^479: word 14 is the top word
+  // double: (c << 1), 16 words
+  c[15] = c[14] >> 31;
+#pragma unroll
+  for (int i = 14; i > 0; --i) c[i] = __builtin_amdgcn_alignbit(c[i], c[i - 1], 31);
+  // c[0] stays 0.  Add the diagonal squares d_i = a_i^2 at word 2i: two 32-bit carry chains
+  // (words 1..7, then 8..15); the carry between them is folded into d_4 (a_4^2 + 1 < 2^64).
+  uint64_t d[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) d[i] = mul_wide(a.w[i], a.w[i]);
+  t.w[0] = (uint32_t)d[0];
+  uint32_t dh[8], dl[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dl[i] = (uint32_t)d[i]; dh[i] = (uint32_t)(d[i] >> 32); }
+  uint32_t cy;
+  asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %2, %10, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %3, %11, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %4, %12, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %6, %14, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, 0, 0, vcc"
+      : "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "=v"(cy)
+      : "v"(dh[0]), "v"(dl[1]), "v"(dh[1]), "v"(dl[2]), "v"(dh[2]), "v"(dl[3]), "v"(dh[3])
+      : "vcc");
+  d[4] = (uint64_t)cy;
+  mac_nocarry(d[4], a.w[4], a.w[4]);
+#pragma unroll
+  for (int i = 5; i < 8; ++i) d[i] = mul_wide(a.w[i], a.w[i]);
+#pragma unroll
+  for (int i = 4; i < 8; ++i) { dl[i] = (uint32_t)d[i]; dh[i] = (uint32_t)(d[i] >> 32); }
+  asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %2, %10, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %3, %11, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %4, %12, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %6, %14, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, %7, %15, vcc"
+      : "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15])
+      : "v"(dl[4]), "v"(dh[4]), "v"(dl[5]), "v"(dh[5]), "v"(dl[6]), "v"(dh[6]), "v"(dl[7]), "v"(dh[7])
+      : "vcc");
+#pragma unroll
+  for (int i = 1; i < 16; ++i) t.w[i] = c[i];
+  return t;
+}
+
+// ---------------------------------------------------------------- Montgomery reduction
+// T * 2^-256 mod p, canonical.  Same value as mgry_mul.h:84-121 (8 rounds of 32-bit digits + one
+// conditional subtract); the word size and the use of the primes' special form differ, the
+// residue does not (Montgomery reduction is a function of T and p only).
+
+// P-256: p = -1 mod 2^96, so m' = 1 (mgry_mul.h:37 gives mprime = 1) and q = the low 64 bits
+// themselves.  q*p = q*2^256 - q*2^224 + q*2^192 + q*2^96 - q: no multiplies.  Four 64-bit
+// rounds; in each, with M = q*(2^64 - 2^32 + 1) (the p[3] limb 0xffffffff00000001 times q):
+//   t[o+3..o+4] += q,  t[o+6..o+9] += M,  carry out -> word o+10 (folded into the next round's M).
+ECS_DEV fe mgry_reduce_p256(fe2& t) {
+  uint32_t cin = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = 2 * r;
+    const uint32_t q0 = t.w[o], q1 = t.w[o + 1];
+    uint32_t m1, m2, m3;
+    asm("v_sub_co_u32 %0, vcc, %4, %3\n\t"          // M1 = q1 - q0
+        "v_subb_co_u32 %1, vcc, %3, %4, vcc\n\t"    // M2 = q0 - q1 - b
+        "v_subb_co_u32 %2, vcc, %4, 0, vcc"         // M3 = q1 - b
+        : "=&v"(m1), "=&v"(m2), "=&v"(m3) : "v"(q0), "v"(q1) : "vcc");
+    if (r > 0)
+      asm("v_add_co_u32 %0, vcc, %0, %2\n\t"
+          "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+          : "+v"(m2), "+v"(m3) : "v"(cin) : "vcc");
+    asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %8, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %4, %10, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %5, %11, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %12, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, 0, 0, vcc"
+        : "+v"(t.w[o + 3]), "+v"(t.w[o + 4]), "+v"(t.w[o + 5]), "+v"(t.w[o + 6]), "+v"(t.w[o + 7]), "+v"(t.w[o + 8]), "+v"(t.w[o + 9]), "=v"(cin)
+        : "v"(q0), "v"(q1), "v"(m1), "v"(m2), "v"(m3)
+        : "vcc");
+  }
+  fe res;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) res.w[i] = t.w[8 + i];
+  cond_sub_p<CURVE_P256>(res, cin);
+  return res;
+}
+
+// Generic word-serial reduction (any odd p given as constants): 8 rounds of
+//   q = t[i] * m' mod 2^32;  t += q * p * 2^(32 i)
+// with the row q*p accumulated by v_mad_u64_u32 (a*b + t + carry < 2^64, so no carry-out).
+// Used for secp256k1 (m' = 0xd2253531).                                  mgry_mul.h:110-116
+template <int CURVE> ECS_DEV fe mgry_reduce_generic(fe2& t) {
+  using K = curve_consts<CURVE>;
+  uint32_t top = 0;     // carries beyond the current row's last word
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t q = t.w[i] * K::MPRIME;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // acc = q*p[j] + t[i+j] + carry  (fits 64 bits)
+      uint64_t acc = (uint64_t)t.w[i + j] + carry;
+      mac_nocarry(acc, q, K::P[j]);
+      t.w[i + j] = (uint32_t)acc;
+      carry = (uint32_t)(acc >> 32);
+    }
+    // add the row's carry (+ the previous round's overflow) into word i+8; what overflows belongs
+    // to word i+9 and is consumed by the next round (after the last round it is the 257th bit)
+    uint64_t s = (uint64_t)t.w[i + 8] + carry + top;
+    t.w[i + 8] = (uint32_t)s;
+    top = (uint32_t)(s >> 32);
+  }
+  fe res;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) res.w[i] = t.w[8 + i];
+  cond_sub_p<CURVE>(res, top);
+  return res;
+}
+
+template <int CURVE> ECS_DEV fe mgry_reduce(fe2& t) {
+  if constexpr (CURVE == CURVE_P256) return mgry_reduce_p256(t);
+  else return mgry_reduce_generic<CURVE>(t);
+}
+
+// a*b*R^-1 mod p                                                           mgry_ops.h:31-35
+template <int CURVE> ECS_DEV fe fe_mul(const fe& a, const fe& b) {
+  fe2 t = mul8x8(a, b);
+  return mgry_reduce<CURVE>(t);
+}
+// a*a*R^-1 mod p                                                           mgry_ops.h:37-42
+template <int CURVE> ECS_DEV fe fe_sqr(const fe& a) {
+  fe2 t = sqr8(a);
+  return mgry_reduce<CURVE>(t);
+}
+// n*R mod p = mgry_reduce(n * (R^2 mod p))                                 mgry.h:47-50
+template <int CURVE> ECS_DEV fe fe_from_classical(const fe& n) {
+  return fe_mul<CURVE>(n, FE_CONST(CURVE, RSQ));
+}
+// n*R^-1 mod p = mgry_reduce(zero-extended n)                              mgry.h:52-55
+template <int CURVE> ECS_DEV fe fe_to_classical(const fe& n) {
+  fe2 t;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { t.w[i] = n.w[i]; t.w[8 + i] = 0; }
+  return mgry_reduce<CURVE>(t);
+}
+
+// ---------------------------------------------------------------- masked select / swap
+// m is an all-ones / all-zeros word per lane (the reference's lane mask, utility.h:45-51).
+ECS_DEV void fe_cswap(uint32_t m, fe& a, fe& b) {                            // swap.h:15-22
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { uint32_t t = (a.w[i] ^ b.w[i]) & m; a.w[i] ^= t; b.w[i] ^= t; }
+}
+ECS_DEV fe fe_select(uint32_t m, const fe& a, const fe& b) {                 // ifelse.h:15-22 (m ? a : b)
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.w[i] = b.w[i] ^ ((a.w[i] ^ b.w[i]) & m);
+  return r;
+}
+ECS_DEV bool fe_eq(const fe& a, const fe& b) {
+  uint32_t d = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d |= a.w[i] ^ b.w[i];
+  return d == 0;
+}
+
+// a^e for a public, wave-uniform exponent e (256 bits, LE words), LSB first.
+// Same multiplication sequence as mgry_ops.h:44-86 (result *= base when the bit is set, base is
+// squared between bits, squaring stops after the top set bit).
+template <int CURVE> ECS_DEV fe fe_pow(const fe& a, const uint32_t (&e)[8]) {
+  fe result = FE_CONST(CURVE, R_P);
+  int top = -1;
+  for (int i = 255; i >= 0; --i) if ((e[i >> 5] >> (i & 31)) & 1u) { top = i; break; }
+  fe base = a;
+  for (int i = 0; i <= top; ++i) {
+    if ((e[i >> 5] >> (i & 31)) & 1u) result = fe_mul<CURVE>(result, base);
+    if (i < top) base = fe_sqr<CURVE>(base);
+  }
+  return result;
+}
+
+}  // namespace ecsimd_hip

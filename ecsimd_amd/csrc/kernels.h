@@ -1,0 +1,67 @@
+// kernels.h -- host-side launchers, one per kernel family (defined in the k_*.hip files, which are
+// compiled in parallel by the Makefile; the ladder alone takes ~1 min of hipcc time per curve).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace ecsimd_hip {
+namespace launch {
+
+constexpr int BLOCK = 256;   // one wave per SIMD of a CU; several workgroups resident per CU
+inline dim3 grid_for(size_t n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
+
+struct words8 { uint32_t w[8]; };   // a 256-bit kernel argument (exponent / shared scalar)
+
+// k_bignum.hip (curve independent)
+void add(hipStream_t, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* carry, size_t n);
+void sub(hipStream_t, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* borrow, size_t n);
+void sub_if_above(hipStream_t, const uint64_t* a, const uint64_t* p, uint64_t* out, size_t n);
+void shift_left_one(hipStream_t, const uint64_t* a, uint64_t* out, uint8_t* carry, size_t n);
+void mul(hipStream_t, const uint64_t* a, const uint64_t* b, uint64_t* out8, size_t n);
+void square(hipStream_t, const uint64_t* a, uint64_t* out8, size_t n);
+void swap_if(hipStream_t, const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n);
+void fill_random(hipStream_t, uint64_t* out, size_t n, uint64_t seed, uint64_t stream, uint64_t first, int clear_top);
+void peak_mad32(hipStream_t, int blocks, uint32_t* sink, int iters, uint32_t seed);
+constexpr int PEAK_MADS_PER_LANE_PER_ITER = 64;
+
+// k_field.hip
+enum field_op { F_MOD_ADD, F_MOD_SUB, F_MGRY_MUL, F_MGRY_SQR, F_FROM_CLASSICAL, F_TO_CLASSICAL, F_INVERSE, F_OPPOSITE };
+void field_binop(hipStream_t, int curve, field_op op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+void field_unop(hipStream_t, int curve, field_op op, const uint64_t* a, uint64_t* out, size_t n);
+void mod_shift_left(hipStream_t, int curve, const uint64_t* a, int count, uint64_t* out, size_t n);
+void mgry_reduce(hipStream_t, int curve, const uint64_t* a8, uint64_t* out, size_t n);
+void mgry_pow(hipStream_t, int curve, const uint64_t* a, const words8& e, uint64_t* out, size_t n);
+void gfp_sqrt(hipStream_t, int curve, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n);
+
+// k_point_<curve>.hip
+void from_affine(hipStream_t, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n);
+void to_affine(hipStream_t, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n);
+void compute_y(hipStream_t, int curve, const uint64_t* x, uint64_t* y, uint8_t* ok, size_t n);
+void dblu(hipStream_t, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
+void zaddu(hipStream_t, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, const uint64_t* qx, const uint64_t* qy, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
+void zdau(hipStream_t, int curve, const uint64_t* px, const uint64_t* py, const uint64_t* pz, uint64_t* qx, uint64_t* qy, uint64_t* qz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
+void add_z2_1(hipStream_t, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
+void trplu(hipStream_t, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
+
+// k_ladder_<curve>.hip.  k_stride = 4 (u64 per element) for per-element scalars, 0 for one shared
+// scalar (device memory either way).  x == nullptr selects the curve generator as base point.
+// flags: ECSIMD_HIP_BASE_* | ECSIMD_HIP_OUT_*.
+void scalar_mult(hipStream_t, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y,
+                 uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
+
+// per-curve pieces (one translation unit each)
+template <int C> struct point_launch {
+  static void from_affine(hipStream_t, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
+  static void to_affine(hipStream_t, const uint64_t*, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, size_t);
+  static void compute_y(hipStream_t, const uint64_t*, uint64_t*, uint8_t*, size_t);
+  static void dblu(hipStream_t, uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
+  static void zaddu(hipStream_t, uint64_t*, uint64_t*, uint64_t*, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
+  static void zdau(hipStream_t, const uint64_t*, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
+  static void add_z2_1(hipStream_t, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
+  static void trplu(hipStream_t, uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
+  static void scalar_mult(hipStream_t, const uint64_t*, int, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t, int);
+};
+
+}  // namespace launch
+}  // namespace ecsimd_hip

@@ -1,0 +1,174 @@
+// point.cuh -- co-Z Jacobian point formulas and the scalar-multiplication ladder, one point per lane.
+//
+// Replaces include/ecsimd/curve_group.h of the reference (formulas from ePrint 2010/309).  All
+// coordinates are Montgomery-form canonical residues, so every function returns bit-identical
+// X, Y, Z to the reference's (parity level J).  Where a sub-expression of the
+// reference occurs twice it is computed once (u = X3'-W1', W1+W2): the VALUES are unchanged.
+#pragma once
+#include "field.cuh"
+
+namespace ecsimd_hip {
+
+// Two points sharing one Z (the reference asserts P.z == Q.z, curve_group.h:92,121).
+struct coz_pair {
+  fe x1, y1;   // first point  (the one ZDAU doubles / "base")
+  fe x2, y2;   // second point (the one that is updated)
+  fe z;
+};
+
+struct jpoint { fe x, y, z; };
+
+// curve_group.h:64-87 DBLU: P = (x, y, Z = R mod p) affine.  Returns 2P in (rx, ry), rewrites
+// (x, y) so that P and 2P share z.
+template <int C> ECS_DEV void dblu(fe& x, fe& y, fe& rx, fe& ry, fe& z) {
+  const fe B = fe_sqr<C>(x);
+  const fe E = fe_sqr<C>(y);
+  const fe L = fe_sqr<C>(E);
+  fe t = fe_sqr<C>(fe_add<C>(x, E));
+  t = fe_sub<C>(fe_sub<C>(t, B), L);
+  const fe S = fe_dbl<C>(t);
+  fe M = fe_add<C>(fe_dbl<C>(B), B);
+  if constexpr (C == CURVE_SECP256K1) { /* a = 0: M = 3B + 0 */ } else { M = fe_add<C>(M, FE_CONST(C, AM)); }
+  rx = fe_sub<C>(fe_sqr<C>(M), fe_dbl<C>(S));
+  const fe Lm8 = fe_shl<C, 3>(L);
+  ry = fe_sub<C>(fe_mul<C>(M, fe_sub<C>(S, rx)), Lm8);
+  z = fe_dbl<C>(y);
+  x = S;
+  y = Lm8;
+}
+
+// curve_group.h:91-116 ZADDU: returns (x1,y1)+(x2,y2) in (rx, ry), rewrites (x1, y1) and z so that
+// all share the new z.
+template <int C> ECS_DEV void zaddu(fe& x1, fe& y1, const fe& x2, const fe& y2, fe& z, fe& rx, fe& ry) {
+  const fe dx = fe_sub<C>(x1, x2);
+  const fe Cc = fe_sqr<C>(dx);
+  const fe W1 = fe_mul<C>(x1, Cc);
+  const fe W2 = fe_mul<C>(x2, Cc);
+  const fe dy = fe_sub<C>(y1, y2);
+  const fe D = fe_sqr<C>(dy);
+  const fe A1 = fe_mul<C>(y1, fe_sub<C>(W1, W2));
+  rx = fe_sub<C>(fe_sub<C>(D, W1), W2);
+  ry = fe_sub<C>(fe_mul<C>(dy, fe_sub<C>(W1, rx)), A1);
+  z = fe_mul<C>(z, dx);
+  x1 = W1;
+  y1 = A1;
+}
+
+// curve_group.h:120-153 ZDAU: (x1,y1) <- 2*(x1,y1) + (x2,y2); (x2,y2) re-expressed with the new z.
+// 9M + 7S.
+template <int C> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe& y2, fe& z) {
+  const fe dx = fe_sub<C>(x1, x2);
+  const fe Cp = fe_sqr<C>(dx);
+  const fe W1p = fe_mul<C>(x1, Cp);
+  const fe W2p = fe_mul<C>(x2, Cp);
+  const fe dy = fe_sub<C>(y1, y2);
+  const fe Dp = fe_sqr<C>(dy);
+  const fe A1p = fe_mul<C>(y1, fe_sub<C>(W1p, W2p));
+  const fe X3pc = fe_sub<C>(fe_sub<C>(Dp, W1p), W2p);
+  const fe u = fe_sub<C>(X3pc, W1p);
+  const fe Cc = fe_sqr<C>(u);
+  const fe A1p2 = fe_dbl<C>(A1p);
+  // Y3' = (dy + (W1' - X3'))^2 - D' - C - 2A1'
+  fe Y3p = fe_sqr<C>(fe_sub<C>(dy, u));
+  Y3p = fe_sub<C>(fe_sub<C>(fe_sub<C>(Y3p, Dp), Cc), A1p2);
+  const fe W1 = fe_mul<C>(fe_shl<C, 2>(X3pc), Cc);
+  const fe W2 = fe_mul<C>(fe_shl<C, 2>(W1p), Cc);
+  const fe ym = fe_sub<C>(Y3p, A1p2);
+  const fe D = fe_sqr<C>(ym);
+  const fe A1 = fe_mul<C>(Y3p, fe_sub<C>(W1, W2));
+  const fe W12 = fe_add<C>(W1, W2);
+  // Z3 = Z * ((dx + X3' - W1')^2 - C' - C)
+  fe zz = fe_sqr<C>(fe_add<C>(dx, u));
+  zz = fe_sub<C>(fe_sub<C>(zz, Cp), Cc);
+  z = fe_mul<C>(z, zz);
+  x1 = fe_sub<C>(D, W12);
+  y1 = fe_sub<C>(fe_mul<C>(ym, fe_sub<C>(W1, x1)), A1);
+  const fe yp = fe_add<C>(Y3p, A1p2);
+  const fe Dc = fe_sqr<C>(yp);
+  x2 = fe_sub<C>(Dc, W12);
+  y2 = fe_sub<C>(fe_mul<C>(yp, fe_sub<C>(W1, x2)), A1);
+}
+
+// curve_group.h:155-179 ADD_Z2_1: (X1,Y1,Z1) + affine (x2, y2) [Z2 = R mod p].  7M + 4S.
+template <int C> ECS_DEV jpoint add_z2_1(const fe& X1, const fe& Y1, const fe& Z1, const fe& x2, const fe& y2) {
+  const fe Z1Z1 = fe_sqr<C>(Z1);
+  const fe U2 = fe_mul<C>(x2, Z1Z1);
+  const fe S2 = fe_mul<C>(fe_mul<C>(y2, Z1), Z1Z1);
+  const fe H = fe_sub<C>(U2, X1);
+  const fe HH = fe_sqr<C>(H);
+  const fe I = fe_shl<C, 2>(HH);
+  const fe J = fe_mul<C>(H, I);
+  const fe r = fe_dbl<C>(fe_sub<C>(S2, Y1));
+  const fe V = fe_mul<C>(X1, I);
+  jpoint R;
+  R.x = fe_sub<C>(fe_sub<C>(fe_sqr<C>(r), J), fe_dbl<C>(V));
+  R.y = fe_sub<C>(fe_mul<C>(r, fe_sub<C>(V, R.x)), fe_mul<C>(fe_dbl<C>(Y1), J));
+  R.z = fe_sub<C>(fe_sub<C>(fe_sqr<C>(fe_add<C>(Z1, H)), Z1Z1), HH);
+  return R;
+}
+
+// a^(p-2) and a^((p+1)/4): exponents as compile-time word arrays (gfp.h:79-87).
+template <int C> struct curve_exps;
+template <> struct curve_exps<CURVE_P256> {
+  static constexpr uint32_t P_M2[8]   = {0xfffffffdu, 0xffffffffu, 0xffffffffu, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000001u, 0xffffffffu};
+  static constexpr uint32_t P_SQRT[8] = {0x00000000u, 0x00000000u, 0x40000000u, 0x00000000u, 0x00000000u, 0x40000000u, 0xc0000000u, 0x3fffffffu};
+};
+template <> struct curve_exps<CURVE_SECP256K1> {
+  static constexpr uint32_t P_M2[8]   = {0xfffffc2du, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  static constexpr uint32_t P_SQRT[8] = {0xbfffff0cu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
+};
+
+template <int C> ECS_DEV fe fe_inverse(const fe& a) { return fe_pow<C>(a, curve_exps<C>::P_M2); }     // gfp.h:42-44
+
+// jacobian_curve_point.h:33-42 to_affine: one inversion per lane; returns classical (x, y).
+template <int C> ECS_DEV void to_affine(const jpoint& P, fe& ax, fe& ay) {
+  const fe invZ = fe_inverse<C>(P.z);
+  const fe invZ2 = fe_sqr<C>(invZ);
+  const fe invZ3 = fe_mul<C>(invZ2, invZ);
+  ax = fe_to_classical<C>(fe_mul<C>(P.x, invZ2));
+  ay = fe_to_classical<C>(fe_mul<C>(P.y, invZ3));
+}
+
+// curve_group.h:189-218 scalar_mult: co-Z Joye double-add ladder, LSB -> MSB, fixed 254 ZDAU
+// iterations, k forced odd and corrected at the end with ADD_Z2_1(P, -P0).  (xm, ym) is the base
+// point in Montgomery form with implicit Z = R mod p.  `kwords` points at this lane's 8 scalar
+// words in global memory: one word is (re)read per 32 iterations so the scalar does not occupy
+// VGPRs across the ZDAU body.
+template <int C> ECS_DEV jpoint scalar_mult_ladder(const uint32_t* __restrict__ kwords, const fe& xm, const fe& ym) {
+  fe px = xm, py = ym, bx, by, z;
+  // base = TRPLU(P): DBLU then ZADDU (curve_group.h:183-186)
+  {
+    fe dx2, dy2;
+    dblu<C>(px, py, dx2, dy2, z);
+    zaddu<C>(px, py, dx2, dy2, z, bx, by);
+  }
+  uint32_t kw = kwords[0];
+  const uint32_t k0 = kw;
+  {
+    const uint32_t m = 0u - ((kw >> 1) & 1u);
+    fe_cswap(m, px, bx);
+    fe_cswap(m, py, by);
+  }
+  for (int w = 0; w < 8; ++w) {
+    if (w > 0) kw = kwords[w];
+    for (int b = (w == 0 ? 2 : 0); b < 32; ++b) {
+      const uint32_t m = 0u - ((kw >> b) & 1u);       // utility.h:45-51 wide_mask_bit
+      fe_cswap(m, px, bx);                             // swap.h:47-56 swap_if_same_z
+      fe_cswap(m, py, by);
+      zdau<C>(bx, by, px, py, z);                      // base = ZDAU(base, P)
+      fe_cswap(m, px, bx);
+      fe_cswap(m, py, by);
+    }
+  }
+  // even k: subtract the original point once (curve_group.h:214-217)
+  const fe oppy = fe_neg<C>(ym);
+  const jpoint Psub = add_z2_1<C>(px, py, z, xm, oppy);
+  const uint32_t meven = 0u - (uint32_t)((k0 & 1u) == 0u);
+  jpoint R;
+  R.x = fe_select(meven, Psub.x, px);
+  R.y = fe_select(meven, Psub.y, py);
+  R.z = fe_select(meven, Psub.z, z);
+  return R;
+}
+
+}  // namespace ecsimd_hip

@@ -1,0 +1,264 @@
+"""ctypes binding of include/ecsimd_hip.h over torch device tensors.
+
+Tensors are ``torch.int64`` (bit pattern of the u64 limbs) or ``torch.uint64`` of shape (n, 4)
+[(n, 8) for 512-bit products], contiguous, on the engine's device.  Every method enqueues on
+torch's CURRENT stream and returns without synchronising, like any torch op.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+P256, SECP256K1 = 0, 1
+CURVES = {"p256": P256, "secp256k1": SECP256K1}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class EcsimdHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libecsimd_hip.so")
+
+
+_SYMBOLS = None
+
+
+def declared_symbols():
+    """Every function name declared in include/ecsimd_hip.h (parsed from the header)."""
+    global _SYMBOLS
+    if _SYMBOLS is None:
+        import re
+        hdr = os.path.join(os.path.dirname(_HERE), "include", "ecsimd_hip.h")
+        text = open(hdr).read()
+        _SYMBOLS = sorted(set(re.findall(r"\b(ecsimd_hip_[a-z0-9_]+)\s*\(", text)))
+    return _SYMBOLS
+
+
+def load_library() -> C.CDLL:
+    path = lib_path()
+    if not os.path.exists(path):
+        raise EcsimdHipError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU fallback for the HIP path)")
+    lib = C.CDLL(path)
+    lib.ecsimd_hip_last_error.restype = C.c_char_p
+    lib.ecsimd_hip_version.restype = C.c_char_p
+    return lib
+
+
+def _u64(v):
+    return C.c_uint64(int(v) & 0xFFFFFFFFFFFFFFFF)
+
+
+class Engine:
+    """One context (HIP stream owner) on one GPU."""
+
+    def __init__(self, device: int = 0):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        self.device = int(device)
+        self.ctx = C.c_void_p()
+        rc = self.lib.ecsimd_hip_init(C.c_int(self.device), C.byref(self.ctx))
+        if rc != 0:
+            raise EcsimdHipError(f"ecsimd_hip_init(device={device}) failed with {rc} "
+                                 "(-2 = no gfx950 device visible; the HIP path has no CPU fallback)")
+        self.tdev = torch.device("cuda", self.device)
+
+    def close(self):
+        if self.ctx:
+            self.lib.ecsimd_hip_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plumbing
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.ecsimd_hip_last_error(self.ctx)
+            raise EcsimdHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def _bind_stream(self):
+        s = self.torch.cuda.current_stream(self.tdev).cuda_stream
+        self.lib.ecsimd_hip_set_stream(self.ctx, C.c_void_p(s))
+
+    def _ptr(self, t, words=4, dtype_ok=None):
+        torch = self.torch
+        if t is None:
+            return C.c_void_p(0)
+        assert t.is_cuda and t.device.index == self.device, "tensor on the wrong device"
+        assert t.is_contiguous(), "tensor must be contiguous"
+        if words:
+            assert t.dtype in (torch.int64, torch.uint64) and t.dim() == 2 and t.shape[1] == words, (t.dtype, t.shape)
+        else:
+            assert t.dtype == torch.uint8 and t.dim() == 1
+        return C.c_void_p(t.data_ptr())
+
+    def empty(self, n, words=4):
+        return self.torch.empty((n, words), dtype=self.torch.int64, device=self.tdev)
+
+    def flags(self, n):
+        return self.torch.zeros((n,), dtype=self.torch.uint8, device=self.tdev)
+
+    def to_device(self, arr):
+        """numpy uint64 (n, w) -> device int64 tensor with the same bits."""
+        a = np.ascontiguousarray(arr, dtype=np.uint64)
+        return self.torch.from_numpy(a.view(np.int64)).to(self.tdev)
+
+    @staticmethod
+    def to_numpy(t):
+        a = t.detach().cpu().numpy()
+        return a if a.dtype == np.uint8 else a.view(np.uint64)
+
+    def _call(self, name, *args):
+        self._bind_stream()
+        self._check(getattr(self.lib, "ecsimd_hip_" + name)(self.ctx, *args), name)
+
+    def sync(self):
+        self._bind_stream()
+        self._check(self.lib.ecsimd_hip_sync(self.ctx), "sync")
+
+    def constant(self, curve, which):
+        out = (C.c_uint64 * 4)()
+        rc = self.lib.ecsimd_hip_get_constant(C.c_int(curve), C.c_int(which), out)
+        if rc != 0:
+            raise EcsimdHipError(f"get_constant({curve},{which}) -> {rc}")
+        return np.array(list(out), dtype=np.uint64)
+
+    # ---- L2
+    def add(self, a, b):
+        n = a.shape[0]; out = self.empty(n); f = self.flags(n)
+        self._call("add", self._ptr(a), self._ptr(b), self._ptr(out), self._ptr(f, 0), C.c_size_t(n)); return out, f
+
+    def sub(self, a, b):
+        n = a.shape[0]; out = self.empty(n); f = self.flags(n)
+        self._call("sub", self._ptr(a), self._ptr(b), self._ptr(out), self._ptr(f, 0), C.c_size_t(n)); return out, f
+
+    def sub_if_above(self, a, p):
+        n = a.shape[0]; out = self.empty(n)
+        self._call("sub_if_above", self._ptr(a), self._ptr(p), self._ptr(out), C.c_size_t(n)); return out
+
+    def cmp_lt(self, a, b):
+        n = a.shape[0]; f = self.flags(n)
+        self._call("cmp_lt", self._ptr(a), self._ptr(b), self._ptr(f, 0), C.c_size_t(n)); return f
+
+    def shift_left_one(self, a):
+        n = a.shape[0]; out = self.empty(n); f = self.flags(n)
+        self._call("shift_left_one", self._ptr(a), self._ptr(out), self._ptr(f, 0), C.c_size_t(n)); return out, f
+
+    def mul(self, a, b):
+        n = a.shape[0]; out = self.empty(n, 8)
+        self._call("mul", self._ptr(a), self._ptr(b), self._ptr(out, 8), C.c_size_t(n)); return out
+
+    def square(self, a):
+        n = a.shape[0]; out = self.empty(n, 8)
+        self._call("square", self._ptr(a), self._ptr(out, 8), C.c_size_t(n)); return out
+
+    def swap_if(self, mask, a, b):
+        self._call("swap_if", self._ptr(mask, 0), self._ptr(a), self._ptr(b), C.c_size_t(a.shape[0]))
+
+    # ---- L3
+    def _bin(self, name, curve, a, b):
+        n = a.shape[0]; out = self.empty(n)
+        self._call(name, C.c_int(curve), self._ptr(a), self._ptr(b), self._ptr(out), C.c_size_t(n)); return out
+
+    def _un(self, name, curve, a, words=4):
+        n = a.shape[0]; out = self.empty(n)
+        self._call(name, C.c_int(curve), self._ptr(a, words), self._ptr(out), C.c_size_t(n)); return out
+
+    def mod_add(self, curve, a, b): return self._bin("mod_add", curve, a, b)
+    def mod_sub(self, curve, a, b): return self._bin("mod_sub", curve, a, b)
+    def mgry_mul(self, curve, a, b): return self._bin("mgry_mul", curve, a, b)
+    def mgry_sqr(self, curve, a): return self._un("mgry_sqr", curve, a)
+    def mgry_reduce(self, curve, a8): return self._un("mgry_reduce", curve, a8, 8)
+    def mgry_from_classical(self, curve, a): return self._un("mgry_from_classical", curve, a)
+    def mgry_to_classical(self, curve, a): return self._un("mgry_to_classical", curve, a)
+    def gfp_inverse(self, curve, a): return self._un("gfp_inverse", curve, a)
+    def gfp_opposite(self, curve, a): return self._un("gfp_opposite", curve, a)
+
+    def mod_shift_left(self, curve, a, count):
+        n = a.shape[0]; out = self.empty(n)
+        self._call("mod_shift_left", C.c_int(curve), self._ptr(a), C.c_int(count), self._ptr(out), C.c_size_t(n)); return out
+
+    def mgry_pow(self, curve, a, exponent):
+        n = a.shape[0]; out = self.empty(n)
+        e = (C.c_uint64 * 4)(*[int(v) for v in np.asarray(exponent, dtype=np.uint64).reshape(4)])
+        self._call("mgry_pow", C.c_int(curve), self._ptr(a), e, self._ptr(out), C.c_size_t(n)); return out
+
+    def gfp_sqrt(self, curve, a):
+        n = a.shape[0]; out = self.empty(n); ok = self.flags(n)
+        self._call("gfp_sqrt", C.c_int(curve), self._ptr(a), self._ptr(out), self._ptr(ok, 0), C.c_size_t(n)); return out, ok
+
+    # ---- points (in-out arguments are updated IN PLACE, like the reference's reference parameters)
+    def from_affine(self, curve, x, y):
+        n = x.shape[0]; j = [self.empty(n) for _ in range(3)]
+        self._call("from_affine", C.c_int(curve), self._ptr(x), self._ptr(y), *[self._ptr(t) for t in j], C.c_size_t(n)); return tuple(j)
+
+    def to_affine(self, curve, j):
+        n = j[0].shape[0]; x, y = self.empty(n), self.empty(n)
+        self._call("to_affine", C.c_int(curve), *[self._ptr(t) for t in j], self._ptr(x), self._ptr(y), C.c_size_t(n)); return x, y
+
+    def compute_y(self, curve, x):
+        n = x.shape[0]; y = self.empty(n); ok = self.flags(n)
+        self._call("compute_y", C.c_int(curve), self._ptr(x), self._ptr(y), self._ptr(ok, 0), C.c_size_t(n)); return y, ok
+
+    def dblu(self, curve, p):
+        n = p[0].shape[0]; r = [self.empty(n) for _ in range(3)]
+        self._call("dblu", C.c_int(curve), *[self._ptr(t) for t in p], *[self._ptr(t) for t in r], C.c_size_t(n)); return tuple(r)
+
+    def trplu(self, curve, p):
+        n = p[0].shape[0]; r = [self.empty(n) for _ in range(3)]
+        self._call("trplu", C.c_int(curve), *[self._ptr(t) for t in p], *[self._ptr(t) for t in r], C.c_size_t(n)); return tuple(r)
+
+    def zaddu(self, curve, p, o):
+        n = p[0].shape[0]; r = [self.empty(n) for _ in range(3)]
+        self._call("zaddu", C.c_int(curve), *[self._ptr(t) for t in p], *[self._ptr(t) for t in o], *[self._ptr(t) for t in r], C.c_size_t(n)); return tuple(r)
+
+    def zdau(self, curve, p, q):
+        n = p[0].shape[0]; r = [self.empty(n) for _ in range(3)]
+        self._call("zdau", C.c_int(curve), *[self._ptr(t) for t in p], *[self._ptr(t) for t in q], *[self._ptr(t) for t in r], C.c_size_t(n)); return tuple(r)
+
+    def add_z2_1(self, curve, a, bxy):
+        n = a[0].shape[0]; r = [self.empty(n) for _ in range(3)]
+        self._call("add_z2_1", C.c_int(curve), *[self._ptr(t) for t in a], *[self._ptr(t) for t in bxy], *[self._ptr(t) for t in r], C.c_size_t(n)); return tuple(r)
+
+    def scalar_mult(self, curve, k, x, y, flags=0, out=None):
+        n = k.shape[0]
+        r = out if out is not None else [self.empty(n) for _ in range(3)]
+        self._call("scalar_mult", C.c_int(curve), self._ptr(k), self._ptr(x), self._ptr(y), *[self._ptr(t) for t in r], C.c_size_t(n), C.c_int(flags))
+        return tuple(r[:2]) if flags & 2 else tuple(r)
+
+    def scalar_mult_1s(self, curve, k1, x, y, flags=0):
+        n = x.shape[0]; r = [self.empty(n) for _ in range(3)]
+        e = (C.c_uint64 * 4)(*[int(v) for v in np.asarray(k1, dtype=np.uint64).reshape(4)])
+        self._call("scalar_mult_1s", C.c_int(curve), e, self._ptr(x), self._ptr(y), *[self._ptr(t) for t in r], C.c_size_t(n), C.c_int(flags))
+        return tuple(r[:2]) if flags & 2 else tuple(r)
+
+    def scalar_mult_base(self, curve, k, flags=0):
+        n = k.shape[0]; r = [self.empty(n) for _ in range(3)]
+        self._call("scalar_mult_base", C.c_int(curve), self._ptr(k), *[self._ptr(t) for t in r], C.c_size_t(n), C.c_int(flags))
+        return tuple(r[:2]) if flags & 2 else tuple(r)
+
+    def scalar_mult_p256(self, k, xm, ym, out=None):
+        n = k.shape[0]
+        r = out if out is not None else [self.empty(n) for _ in range(3)]
+        self._call("scalar_mult_p256", self._ptr(k), self._ptr(xm), self._ptr(ym), *[self._ptr(t) for t in r], C.c_size_t(n))
+        return tuple(r)
+
+    # ---- synthetic inputs / measurement
+    def fill_random(self, n, seed, stream, first_index=0, clear_top_bits=0, out=None):
+        t = out if out is not None else self.empty(n)
+        self._call("fill_random", self._ptr(t), C.c_size_t(n), _u64(seed), _u64(stream), _u64(first_index), C.c_int(clear_top_bits)); return t
+
+    def peak_mad32(self, iters=2048):
+        mads, ms = C.c_double(0), C.c_double(0)
+        self._call("peak_mad32", C.c_int(iters), C.byref(mads), C.byref(ms))
+        return mads.value, ms.value

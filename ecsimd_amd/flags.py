@@ -1,0 +1,5 @@
+"""Flag values of include/ecsimd_hip.h (scalar_mult `flags`)."""
+BASE_CLASSICAL = 0
+BASE_MGRY = 1
+OUT_JACOBIAN = 0
+OUT_AFFINE = 2

@@ -1,0 +1,161 @@
+/*
+ * ecsimd_hip.h -- C ABI of the MI355X (gfx950) batched elliptic-curve engine.
+ *
+ * This is the drop-in boundary for the hot path of aguinet/ecsimd.  The
+ * reference is header-only C++ with no ABI of its own: its single linkable symbol is
+ * scalar_mult_p256 (lib/scalar_mult_p256.cpp:10-12).  Every entry point below replaces one
+ * reference function (cited per declaration) over a RUNTIME-LENGTH batch; n = 4 reproduces one
+ * eve::wide of the reference.  The C++ headers in include/ecsimd/ bind these symbols and keep
+ * the reference's names (curve_group<Curve>::scalar_mult, DBLU, ZADDU, ZDAU, ADD_Z2_1,
+ * scalar_mult_p256, ...).  INTEGRATION.md shows the binding a maintainer of the reference adds.
+ *
+ * Data layout (all pointers are DEVICE pointers, 16-byte aligned):
+ *   field element / scalar : 4 x uint64_t, little-endian limb order (limb 0 least significant),
+ *                            = the reference's bignum<uint64_t,4> (bignum.h:38-99,
+ *                            serialization.h:18-21).  A batch is AoS: element i at p + 4*i.
+ *   512-bit product        : 8 x uint64_t per element.
+ *   point batch            : one array per coordinate (x[], y[], z[]).  Jacobian coordinates are
+ *                            in Montgomery form (jacobian_curve_point.h:25-31), affine ones are
+ *                            classical unless the function name says _mgry.
+ *   flags                  : one uint8_t per element (0/1).
+ * Preconditions the reference only asserts in debug builds (co-Z inputs, Z = mgry(1) for
+ * DBLU / ADD_Z2_1 / scalar_mult) are the caller's responsibility here too.
+ *
+ * Every call enqueues kernels on the context's stream and returns without synchronising;
+ * ecsimd_hip_sync() waits.  Return value: 0 on success, negative ecsimd_hip_status otherwise.
+ * Nothing throws across this boundary.  A context is not thread-safe: one per host thread/GPU.
+ */
+#ifndef ECSIMD_HIP_H
+#define ECSIMD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ecsimd_hip_ctx ecsimd_hip_ctx;
+
+enum ecsimd_hip_curve {
+  ECSIMD_HIP_P256 = 0,      /* curve_nist_p256.h:14-32 */
+  ECSIMD_HIP_SECP256K1 = 1  /* prime of tests/mgry.cpp:25-27 with a=0, b=7 (SEC 2) */
+};
+
+enum ecsimd_hip_status {
+  ECSIMD_HIP_OK = 0,
+  ECSIMD_HIP_ERR_BAD_ARG = -1,     /* null pointer, unknown curve, misaligned pointer */
+  ECSIMD_HIP_ERR_NO_DEVICE = -2,   /* no HIP device / wrong architecture (gfx950 code object only) */
+  ECSIMD_HIP_ERR_HIP = -3          /* a HIP runtime call failed; see ecsimd_hip_last_error() */
+};
+
+/* scalar_mult flags */
+enum {
+  ECSIMD_HIP_BASE_CLASSICAL = 0,   /* base point (x, y) classical: from_affine is applied first */
+  ECSIMD_HIP_BASE_MGRY = 1,        /* base point already Montgomery form (what scalar_mult_p256 receives) */
+  ECSIMD_HIP_OUT_JACOBIAN = 0,     /* out = (X, Y, Z) Montgomery form, as curve_group::scalar_mult returns */
+  ECSIMD_HIP_OUT_AFFINE = 2        /* out = to_affine(): (x, y) classical; oz may be NULL */
+};
+
+/* ---- context, stream and memory ------------------------------------------------------- */
+int ecsimd_hip_init(int device, ecsimd_hip_ctx** ctx);
+int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream).  NULL is HIP's default (null)
+ * stream -- which is what torch's default stream is -- not "none". */
+int ecsimd_hip_set_stream(ecsimd_hip_ctx* ctx, void* hip_stream);
+/* Go back to the non-blocking stream the context created in ecsimd_hip_init (the default). */
+int ecsimd_hip_use_own_stream(ecsimd_hip_ctx* ctx);
+int ecsimd_hip_sync(ecsimd_hip_ctx* ctx);
+const char* ecsimd_hip_last_error(const ecsimd_hip_ctx* ctx);
+const char* ecsimd_hip_version(void);
+int ecsimd_hip_malloc(ecsimd_hip_ctx* ctx, void** dptr, size_t bytes);
+int ecsimd_hip_free(ecsimd_hip_ctx* ctx, void* dptr);
+int ecsimd_hip_memcpy_h2d(ecsimd_hip_ctx* ctx, void* dst, const void* src, size_t bytes);
+int ecsimd_hip_memcpy_d2h(ecsimd_hip_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* Curve constants as the engine uses them (host memory, 4 x u64 each):
+ * which = 0 p, 1 a, 2 b, 3 Gx, 4 Gy, 5 R mod p, 6 R^2 mod p, 7 -R mod p, 8 a*R, 9 b*R, 10 p-2, 11 (p+1)/4
+ * (mgry_csts.h:15-24, curve_group.h:31-32, gfp.h:79-87). */
+int ecsimd_hip_get_constant(int curve, int which, uint64_t out[4]);
+
+/* ---- L2: bignum ops (curve independent) ----------------------------------------------- */
+/* add.h:11-34  add: out = a + b mod 2^256, carry[i] = carry-out (carry may be NULL) */
+int ecsimd_hip_add(ecsimd_hip_ctx*, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* carry, size_t n);
+/* sub.h:12-38  sub: out = a - b mod 2^256, borrow[i] = borrow-out */
+int ecsimd_hip_sub(ecsimd_hip_ctx*, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* borrow, size_t n);
+/* sub.h:46-75  sub_if_above: out = a >= p ? a - p : a (p is per element, like the reference's wide p) */
+int ecsimd_hip_sub_if_above(ecsimd_hip_ctx*, const uint64_t* a, const uint64_t* p, uint64_t* out, size_t n);
+/* cmp.h:11-13  cmp_lt: flag[i] = a < b */
+int ecsimd_hip_cmp_lt(ecsimd_hip_ctx*, const uint64_t* a, const uint64_t* b, uint8_t* flag, size_t n);
+/* shift.h:13-32  shift_left_one: out = a << 1 mod 2^256, carry[i] = bit 255 of a */
+int ecsimd_hip_shift_left_one(ecsimd_hip_ctx*, const uint64_t* a, uint64_t* out, uint8_t* carry, size_t n);
+/* mul.h:150-158  mul: out8 = a * b (512 bits) */
+int ecsimd_hip_mul(ecsimd_hip_ctx*, const uint64_t* a, const uint64_t* b, uint64_t* out8, size_t n);
+/* mul.h:214-221  square: out8 = a * a */
+int ecsimd_hip_square(ecsimd_hip_ctx*, const uint64_t* a, uint64_t* out8, size_t n);
+/* swap.h:15-22  swap_if: swap a[i] and b[i] in place where mask[i] != 0 */
+int ecsimd_hip_swap_if(ecsimd_hip_ctx*, const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n);
+
+/* ---- L3: GF(p) ------------------------------------------------------------------------ */
+/* modular.h:10-15 mod_add, :24-41 mod_sub, mgry_ops.h:14-22 mgry_shift_left<count> (count >= 1) */
+int ecsimd_hip_mod_add(ecsimd_hip_ctx*, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int ecsimd_hip_mod_sub(ecsimd_hip_ctx*, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int ecsimd_hip_mod_shift_left(ecsimd_hip_ctx*, int curve, const uint64_t* a, int count, uint64_t* out, size_t n);
+/* mgry_mul.h:84-121 details::mgry_reduce<P>: out = a8 * 2^-256 mod p (a8 < p * 2^256) */
+int ecsimd_hip_mgry_reduce(ecsimd_hip_ctx*, int curve, const uint64_t* a8, uint64_t* out, size_t n);
+/* mgry_ops.h:31-42 mgry_mul / mgry_sqr */
+int ecsimd_hip_mgry_mul(ecsimd_hip_ctx*, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int ecsimd_hip_mgry_sqr(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t* out, size_t n);
+/* mgry.h:47-55 from_classical / to_classical */
+int ecsimd_hip_mgry_from_classical(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t* out, size_t n);
+int ecsimd_hip_mgry_to_classical(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t* out, size_t n);
+/* mgry_ops.h:44-86 mgry_pow: out = a^e (Montgomery), e = ONE public exponent (host pointer, 4 x u64) */
+int ecsimd_hip_mgry_pow(ecsimd_hip_ctx*, int curve, const uint64_t* a, const uint64_t exponent[4], uint64_t* out, size_t n);
+/* gfp.h:42-44 inverse, :60-64 opposite, :46-54 sqrt.  sqrt reports validity PER ELEMENT in ok[]
+ * (the reference collapses a wide to all-or-nothing; the C++ header reproduces that on top). */
+int ecsimd_hip_gfp_inverse(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t* out, size_t n);
+int ecsimd_hip_gfp_opposite(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t* out, size_t n);
+int ecsimd_hip_gfp_sqrt(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n);
+
+/* ---- L4/L5: points and the group ------------------------------------------------------ */
+/* jacobian_curve_point.h:25-31 from_affine (Z := R mod p), :33-42 to_affine (one inversion per element) */
+int ecsimd_hip_from_affine(ecsimd_hip_ctx*, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n);
+int ecsimd_hip_to_affine(ecsimd_hip_ctx*, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n);
+/* curve_group.h:43-58 compute_y for y^2 = x^3 + a x + b (classical in/out), per-element ok[] */
+int ecsimd_hip_compute_y(ecsimd_hip_ctx*, int curve, const uint64_t* x, uint64_t* y, uint8_t* ok, size_t n);
+/* curve_group.h:64-87 DBLU: r = 2P, P rewritten in place with r's Z.  P.z must be mgry(1). */
+int ecsimd_hip_dblu(ecsimd_hip_ctx*, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
+/* curve_group.h:91-116 ZADDU: r = P + O (co-Z), P rewritten in place with r's Z. */
+int ecsimd_hip_zaddu(ecsimd_hip_ctx*, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, const uint64_t* ox, const uint64_t* oy, const uint64_t* oz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
+/* curve_group.h:120-153 ZDAU: r = 2P + Q (co-Z), Q rewritten in place with r's Z. */
+int ecsimd_hip_zdau(ecsimd_hip_ctx*, int curve, const uint64_t* px, const uint64_t* py, const uint64_t* pz, uint64_t* qx, uint64_t* qy, uint64_t* qz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
+/* curve_group.h:155-179 ADD_Z2_1: r = A + B with B = (bx, by) Montgomery-form affine (Z2 = mgry(1)). */
+int ecsimd_hip_add_z2_1(ecsimd_hip_ctx*, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
+/* curve_group.h:183-186 TRPLU: r = 3P, P rewritten in place with r's Z.  P.z must be mgry(1). */
+int ecsimd_hip_trplu(ecsimd_hip_ctx*, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
+
+/* curve_group.h:189-218 scalar_mult (per-element scalar k[i], per-element base point (x[i], y[i])):
+ * the co-Z Joye double-add ladder of the reference, any 256-bit k.  flags = BASE_* | OUT_*. */
+int ecsimd_hip_scalar_mult(ecsimd_hip_ctx*, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y,
+                           uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
+/* curve_group.h:221-251 scalar_mult_1s: ONE scalar (host pointer) for all points. */
+int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx*, int curve, const uint64_t k1[4], const uint64_t* x, const uint64_t* y,
+                              uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
+/* curve_group.h:35-41 WJG + scalar_mult: k[i] * G (base = the curve generator). */
+int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx*, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
+/* lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P) -- P-256, base in Montgomery form with
+ * Z = mgry(1), Jacobian Montgomery output. */
+int ecsimd_hip_scalar_mult_p256(ecsimd_hip_ctx*, const uint64_t* k, const uint64_t* xm, const uint64_t* ym,
+                                uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
+
+/* ---- synthetic inputs and measurement (bench / tests) --------------------------------- */
+/* word w of element i of stream s = splitmix64(seed ^ (s << 56) ^ (4 i + w));
+ * clear_top_bits > 0 clears that many top bits of limb 3 (field elements < 2^255 < p). */
+int ecsimd_hip_fill_random(ecsimd_hip_ctx*, uint64_t* out, size_t n, uint64_t seed, uint64_t stream, uint64_t first_index, int clear_top_bits);
+/* Dependency-free v_mad_u64_u32 stream: the integer-multiply roofline denominator.  Returns the
+ * number of mad32 executed in *mads; elapsed device time in *ms (HIP events on the ctx stream). */
+int ecsimd_hip_peak_mad32(ecsimd_hip_ctx*, int iters, double* mads, double* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECSIMD_HIP_H */
