@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- P-256 scalar mults/sec (batched) on N MI355X + fraction of the integer-VALU roofline.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch: scalar_mult_p256(k, P) (the reference's
+exported entry point, lib/scalar_mult_p256.cpp:10-12 -> curve_group.h:189-218, the co-Z Joye
+ladder) over 2^22 lane-distinct (scalar, point) pairs PER GPU, Jacobian Montgomery output, inputs
+resident in HBM before the timed region.  Weak scaling: rank r owns global indices
+[r*2^22, (r+1)*2^22) of the synthetic streams; no collective on the data path.
+For N > 1 each step's result shard is gathered to rank 0 with ONE RCCL gather on a side stream,
+overlapped with the next step's compute (BASELINE.json north_star: "RCCL over xGMI only for the
+final gather"); the gathers are inside the timed region.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : integer-VALU bound.  achieved = scalar-mults/s x 555 968 mad32 (SURVEY.md 8(d):
+                 (2299 M + 1789 S) x 136), kernel time from HIP events on the launch stream;
+                 peak = the dependency-free v_mad_u64_u32 stream measured live on the same GPU.
+  cpu_baseline : the REAL reference (oracle/_ref, eve/AVX2) -- or the C port if that library did
+                 not travel -- timed on the host cores on a bounded sample of the same workload,
+                 and compared bit-for-bit with the GPU result on that sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MAD32_PER_SCALAR_MULT = 555968          # 4088 field mults x 136 mad32
+ALGO_BYTES_PER_SCALAR_MULT = 192        # 32 B scalar + 64 B point in, 96 B Jacobian out
+SEED = 0x5EEDEC51D0000001
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2-batch", type=int, default=22, help="scalar mults per GPU per step = 2^this")
+    ap.add_argument("--curve", default="p256", choices=["p256", "secp256k1"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from ecsimd_amd import Engine, CURVES, BASE_MGRY, OUT_JACOBIAN
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    curve = CURVES[args.curve]
+    eng = Engine(local_rank)            # raises if the HIP library / a gfx950 device is missing: no fallback
+    n = 1 << args.log2_batch
+    first = rank * n                    # this rank's slice of the global synthetic streams
+
+    # ---- inputs, resident in HBM before anything is timed
+    k = eng.fill_random(n, SEED, 1, first_index=first)                       # scalars: uniform 256-bit
+    s = eng.fill_random(n, SEED, 2, first_index=first)                       # point seeds: P_i = s_i * G
+    bx, by = eng.scalar_mult_base(curve, s, flags=2)                          # affine classical (x, y)
+    P = eng.from_affine(curve, bx, by)                                        # Montgomery form, Z = mgry(1)
+    xm, ym = P[0], P[1]
+    del s, P
+    outs = [torch.empty((3, n, 4), dtype=torch.int64, device=eng.tdev) for _ in range(2)]
+    flags = BASE_MGRY | OUT_JACOBIAN
+
+    comm = torch.cuda.Stream() if world > 1 else None
+    gathered = [torch.empty((3, n, 4), dtype=torch.int64, device=eng.tdev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    done = [None, None]                 # per output buffer: event marking the end of its last gather
+
+    def step(i, ev0=None, ev1=None):
+        o = outs[i & 1]
+        if done[i & 1] is not None:
+            torch.cuda.current_stream().wait_event(done[i & 1])               # buffer free again?
+        if ev0 is not None:
+            ev0.record()
+        eng.scalar_mult(curve, k, xm, ym, flags=flags, out=[o[0], o[1], o[2]])
+        if ev1 is not None:
+            ev1.record()
+        if world > 1:
+            ready = torch.cuda.Event(); ready.record()
+            with torch.cuda.stream(comm):
+                comm.wait_event(ready)
+                dist.gather(o, gathered, dst=0)
+                fin = torch.cuda.Event(); fin.record()
+            done[i & 1] = fin
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, *evs[i])
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]                            # same stream as the launches
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total = float(n) * world * args.steps
+    value = total / elapsed
+    result = {
+        "metric": "P-256 scalar mults/sec (batched)" if args.curve == "p256" else "secp256k1 scalar mults/sec (batched)",
+        "value": value, "unit": "scalar_mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32x8 (256-bit integers, 4xu64 limbs)", "data": "synthetic",
+        "config": {"workload": f"scalar_mult_{args.curve} variable-base co-Z ladder (reference algorithm), "
+                               f"batch=2^{args.log2_batch} per GPU, Jacobian Montgomery out",
+                   "global_batch": n * world, "per_gpu_batch": n, "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (k_scalar_mult), measured live
+        avg_ms = float(np.mean(kernel_ms))
+        mads, ms = eng.peak_mad32(4096)
+        peak = mads / (ms * 1e-3) / 1e12
+        achieved = n / (avg_ms * 1e-3) * MAD32_PER_SCALAR_MULT / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")             # written from rocprofv3 --pmc passes
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"k_scalar_mult_{args.curve}_2^{args.log2_batch}")
+            except Exception:
+                traffic = None
+        result["roofline"] = {
+            "bound": "valu", "kernel": "k_scalar_mult", "achieved": achieved, "peak": peak, "unit": "Tmad32/s", "frac": achieved / peak,
+            "traffic": traffic, "kernel_ms": avg_ms, "algorithmic_mad32_per_unit": MAD32_PER_SCALAR_MULT,
+            "hbm": {"achieved": n / (avg_ms * 1e-3) * ALGO_BYTES_PER_SCALAR_MULT / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "algorithmic_bytes_per_unit": ALGO_BYTES_PER_SCALAR_MULT},
+            "peak_source": "ecsimd_hip_peak_mad32: dependency-free v_mad_u64_u32 stream, 8 waves/SIMD, same GPU, same run",
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, outs[(args.steps - 1) & 1], args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def usable_cores():
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def cpu_baseline(eng, curve, k, bx, by, gpu_out, target_s):
+    """ecsimd's own CPU path (or the C port) on the host cores, bounded sample, rank 0 only; the
+    sample's CPU result is also compared bit-for-bit with what the GPU produced for those elements."""
+    import numpy as np
+    from oracle import loader
+    cores = usable_cores()
+    if loader.reference_available():
+        impl, kind = loader.Reference(), "reference"
+    else:
+        if not os.path.exists(loader.Oracle.path):
+            loader.build()
+        impl, kind = loader.Oracle(), "port"
+    to_np = eng.to_numpy
+    # calibrate on a small sample, then size the real one for ~target_s seconds
+    m0 = 256 * cores
+    kn, xn, yn = (to_np(t[:m0]) for t in (k, bx, by))
+    t = time.perf_counter(); impl.scalar_mult(curve, kn, xn, yn, threads=cores); dt = time.perf_counter() - t
+    m = int(min(k.shape[0], max(m0, (target_s / dt) * m0)))
+    m -= m % 4
+    kn, xn, yn = (to_np(t[:m]) for t in (k, bx, by))
+    t = time.perf_counter(); ref = impl.scalar_mult(curve, kn, xn, yn, threads=cores); dt = time.perf_counter() - t
+    got = [to_np(gpu_out[j][:m]) for j in range(3)]
+    bad = np.nonzero((got[0] != ref[0]).any(axis=1) | (got[1] != ref[1]).any(axis=1) | (got[2] != ref[2]).any(axis=1))[0]
+    # The reference's square() drops a carry with probability ~4e-6 per random scalar mult
+    # (mul.h:186-190,207; oracle/ecsimd_oracle.c bn_square; DESIGN.md "Reference defect").  Every
+    # lane where the reference and the GPU differ must be such a lane: there the exact oracle has
+    # to agree with the GPU and the bug-for-bug oracle with the reference.
+    explained = True
+    if len(bad):
+        if not os.path.exists(loader.Oracle.path):
+            loader.build()
+        ex, fa = loader.Oracle(faithful=False), loader.Oracle(faithful=True)
+        sub = lambda arrs: [a[bad] for a in arrs]
+        e_ = ex.scalar_mult(curve, kn[bad], xn[bad], yn[bad], threads=min(cores, len(bad)))
+        f_ = fa.scalar_mult(curve, kn[bad], xn[bad], yn[bad], threads=min(cores, len(bad)))
+        explained = all(np.array_equal(u, v) for u, v in zip(e_, sub(got))) and all(np.array_equal(u, v) for u, v in zip(f_, sub(ref)))
+    return {"value": m / dt, "unit": "scalar_mults/s", "cores": cores, "kind": kind,
+            "sample": f"first {m} (scalar, point) pairs of the GPU batch, {dt:.1f} s wall, {cores} threads, "
+                      + ("g++ -O2 -mavx2 build of the reference headers" if kind == "reference" else "gcc -O2 C restatement"),
+            "lanes_compared": int(m), "lanes_differing_from_gpu": int(len(bad)),
+            "differences_all_explained_by_reference_square_defect": bool(explained)}
+
+
+if __name__ == "__main__":
+    main()

@@ -125,9 +125,30 @@ static void bn_mul(bn512 *r, const bn256 *a, const bn256 *b) {
   trunc_u64x32(r->l, ret, 2 * ND);
 }
 
-/* mul.h:160-212 square_u32_zext + mul.h:214-221 square -- diagonal + doubled cross products. */
+/* mul.h:160-212 square_u32_zext + mul.h:214-221 square -- diagonal + doubled cross products.
+ *
+ * REFERENCE DEFECT (found by this project's GPU parity tests, reproduced on the real reference):
+ * at mul.h:186-190 the doubled cross product `t <<= 1; t += ret[..]; t += prevs[0];` is formed in a
+ * 64-bit lane and can exceed 2^64 -- the reference's own comment at mul.h:207 says "TODO: carry?".
+ * When it does, a carry of weight 2^(32(i+j)+64) is silently dropped and square(a) != mul(a, a),
+ * so mgry_sqr(a) != mgry_mul(a, a) and every formula above it returns a wrong value.  It needs
+ * 2*a_i*a_j mod 2^64 within ~2^33 of 2^64: ~2^-25 per random squaring, ~1e-5..1e-4 per random
+ * scalar multiplication (1789 squarings), and it is certain for digit patterns such as
+ * a = (p256-1)/2.  This restatement therefore has two modes (oracle_set_square_mode):
+ *   FAITHFUL (1): bug-for-bug what the reference computes -- used to prove the restatement equals
+ *                 the compiled reference on every input, including the ones it gets wrong;
+ *   EXACT    (0, default): the value the reference specifies and its own tests assume,
+ *                 square(a) == mul(a, a) -- the arithmetic the HIP path is checked against.
+ * The two modes agree whenever no carry is dropped; oracle_dropped_carries() counts the events
+ * so a test can tell "differs from the reference" apart from "differs because of this defect". */
+static int g_square_faithful = 0;
+static unsigned long long g_dropped_carries = 0;
+
+static void bn_mul(bn512 *r, const bn256 *a, const bn256 *b);
+
 static void bn_square(bn512 *r, const bn256 *a) {
   uint64_t ad[ND], ret[2 * ND];
+  int dropped = 0;
   zext_u32x64(ad, a->l, NL);
   memset(ret, 0, sizeof ret);
   for (int i = 0; i < ND; ++i) {
@@ -139,6 +160,8 @@ static void bn_square(bn512 *r, const bn256 *a) {
       uint64_t u = ad[i] * ad[j];
       uint64_t carry = u >> 63;
       u <<= 1;
+      unsigned __int128 wide = (unsigned __int128)u + ret[i + j] + prevs0;   /* what a wider lane would hold */
+      if (wide >> 64) dropped = 1;
       u += ret[i + j];
       u += prevs0;
       ret[i + j] = u & 0xffffffffu;
@@ -149,6 +172,8 @@ static void bn_square(bn512 *r, const bn256 *a) {
     ret[i + ND] += prevs0;
     if (i + ND + 1 < 2 * ND) ret[i + ND + 1] = prevs1;
   }
+  if (dropped) __atomic_fetch_add(&g_dropped_carries, 1ull, __ATOMIC_RELAXED);
+  if (dropped && !g_square_faithful) { bn_mul(r, a, a); return; }   /* EXACT mode: the specified value */
   trunc_u64x32(r->l, ret, 2 * ND);
 }
 
@@ -591,6 +616,12 @@ EXPORT int oracle_scalar_mult(int curve, cu64p k, cu64p x, cu64p y, uint64_t *ox
 EXPORT int oracle_scalar_mult_mgry(int curve, cu64p k, cu64p xm, cu64p ym, uint64_t *ox, uint64_t *oy, uint64_t *oz, size_t n, int threads) {
   return sm_run(curve, k, xm, ym, ox, oy, oz, n, threads, 1);
 }
+
+/* See bn_square: 1 = bug-for-bug reference squaring, 0 = exact squaring (default). */
+EXPORT void oracle_set_square_mode(int faithful) { g_square_faithful = faithful; }
+EXPORT int oracle_get_square_mode(void) { return g_square_faithful; }
+EXPORT unsigned long long oracle_dropped_carries(void) { return __atomic_load_n(&g_dropped_carries, __ATOMIC_RELAXED); }
+EXPORT void oracle_reset_dropped_carries(void) { __atomic_store_n(&g_dropped_carries, 0ull, __ATOMIC_RELAXED); }
 
 /* Wall-clock seconds (CLOCK_MONOTONIC) for bench.py's cpu_baseline leg. */
 EXPORT double oracle_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }

@@ -231,8 +231,26 @@ class _Lib:
 
 
 class Oracle(_Lib):
+    """The C restatement.  ``faithful=False`` (default): exact squaring, the arithmetic the reference
+    specifies -- what the HIP path is checked against.  ``faithful=True``: bug-for-bug restatement of
+    the reference's square() including its dropped carry (ecsimd_oracle.c, bn_square)."""
     prefix = "oracle_"
     path = os.path.join(HERE, "libecsimd_oracle.so")
+
+    def __init__(self, faithful: bool = False):
+        super().__init__()
+        self.faithful = bool(faithful)
+        self.lib.oracle_dropped_carries.restype = C.c_ulonglong
+
+    def _f(self, name):
+        self.lib.oracle_set_square_mode(C.c_int(1 if self.faithful else 0))   # one shared library: select per call
+        return super()._f(name)
+
+    def dropped_carries(self) -> int:
+        return int(self.lib.oracle_dropped_carries())
+
+    def reset_dropped_carries(self) -> None:
+        self.lib.oracle_reset_dropped_carries()
 
 
 class Reference(_Lib):

@@ -1,0 +1,76 @@
+"""CPU suite, part 2: the C-ABI library builds, loads and exports every symbol include/ecsimd_hip.h
+declares; the product path fails loudly (no CPU fallback) where there is no GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import ecsimd_amd
+    if not os.path.exists(ecsimd_amd.lib_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    return ecsimd_amd.load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from ecsimd_amd.engine import declared_symbols
+    syms = declared_symbols()
+    assert len(syms) >= 40
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    # and nothing is exported that the header does not declare
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "ecsimd_amd", "libecsimd_hip.so")], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (ecsimd_hip_\w+)", out))
+    assert exported == set(syms), exported ^ set(syms)
+
+
+def test_header_is_plain_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "ecsimd_hip.h"\nint main(void) { return sizeof(ecsimd_hip_ctx*) ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "t.o")], check=True)
+
+
+def test_constants_without_a_gpu(lib, oracle):
+    """ecsimd_hip_get_constant is host-only: the engine's constants equal the oracle's / the reference's."""
+    names = ["p", "a", "b", "gx", "gy", "r_p", "rsq_p", "pm1_r_p", "am", "bm", "p_m2", "p_sqrt"]
+    for cv in (0, 1):
+        c = oracle.constants(cv)
+        for i, nm in enumerate(names):
+            out = (C.c_uint64 * 4)()
+            assert lib.ecsimd_hip_get_constant(C.c_int(cv), C.c_int(i), out) == 0
+            assert list(out) == [int(v) for v in c[nm]], (cv, nm)
+    assert lib.ecsimd_hip_get_constant(C.c_int(2), C.c_int(0), (C.c_uint64 * 4)()) == -1
+    assert lib.ecsimd_hip_get_constant(C.c_int(0), C.c_int(12), (C.c_uint64 * 4)()) == -1
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product must refuse to run rather than compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import ecsimd_amd
+    with pytest.raises(ecsimd_amd.EcsimdHipError):
+        ecsimd_amd.Engine(0)
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    bad = []
+    for base in ("ecsimd_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".h", ".hpp", ".cuh", ".hip", ".inc", ".cpp", "Makefile")):
+                    text = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"oracle[/.]|libecsimd_oracle|libecsimd_ref|/root/reference", text):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+    nm = subprocess.run(["ldd", os.path.join(ROOT, "ecsimd_amd", "libecsimd_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in nm and "ecsimd_ref" not in nm

@@ -1,0 +1,356 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against
+  * the reference-minted fixtures and the reference's own KATs (tests/golden/),
+  * the CPU oracle on seeded lane-distinct inputs (sizes the oracle finishes in seconds),
+  * size-independent properties at BASELINE.json's full batch sizes.
+Bit-exact everywhere (integer arithmetic): no tolerances."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import (CURVE_PARAMS, CURVE_NAMES, P256, SECP256K1, SEED, hexes_to_arr, arr_to_hexes, from_int, to_int, ints_to_arr,
+                     arr_to_ints, from_hex, fill_random_np, ec_mul, ec_add, jacobian_mgry_to_affine_int)
+from test_oracle import run_against_golden, structured_words
+
+pytestmark = pytest.mark.gpu
+CURVES = [P256, SECP256K1]
+THREADS = min(16, os.cpu_count() or 1)
+
+
+@pytest.fixture(scope="module")
+def gpu(engine):
+    from gpu_adapter import EngineNP
+    return EngineNP(engine)
+
+
+def test_native_library_is_loaded(engine):
+    import ecsimd_amd
+    maps = open("/proc/self/maps").read()
+    assert os.path.realpath(ecsimd_amd.lib_path()) in maps, "libecsimd_hip.so is not mapped: the HIP path is not the one running"
+    assert b"gfx950" in engine.lib.ecsimd_hip_version()
+
+
+def test_fixtures_from_the_reference(gpu, golden):
+    run_against_golden(gpu, golden)
+
+
+def test_reference_kats_on_gpu(gpu, kats):
+    k = kats["p256"]; cv = P256; c = CURVE_PARAMS[cv]
+    gx, gy = ints_to_arr([c["gx"]] * 4), ints_to_arr([c["gy"]] * 4)          # n = 4 = one eve::wide of the reference
+    G = gpu.from_affine(cv, gx, gy)
+    aff = lambda J: tuple(format(to_int(v[0]), "064x") for v in gpu.to_affine(cv, J))
+    dbl, Gu = gpu.dblu(cv, G)
+    assert np.array_equal(dbl[2], Gu[2]) and aff(dbl) == (k["2G"]["x"], k["2G"]["y"]) and aff(Gu) == aff(G)
+    tri, Gu2 = gpu.zaddu(cv, Gu, dbl)
+    assert aff(tri) == (k["3G"]["x"], k["3G"]["y"])
+    five, _ = gpu.zdau(cv, dbl, Gu)
+    assert aff(five) == (k["5G"]["x"], k["5G"]["y"])
+    for s in k["scalar_mult"]:
+        kk = np.tile(from_hex(s["k"]), (4, 1))
+        for J in (gpu.scalar_mult(cv, kk, gx, gy), gpu.scalar_mult_1s(cv, from_hex(s["k"]), gx, gy), gpu.scalar_mult_base(cv, kk)):
+            assert aff(J) == (s["x"], s["y"]), s["src"]
+        ax, ay = gpu.scalar_mult(cv, kk, gx, gy, affine=True)[:2]
+        assert format(to_int(ax[3]), "064x") == s["x"] and format(to_int(ay[3]), "064x") == s["y"]
+    y, ok = gpu.compute_y(cv, hexes_to_arr([k["from_x"]["x"]] * 4))
+    assert ok.tolist() == [1] * 4 and format(to_int(y[0]), "064x") == k["from_x"]["y"]
+    km = kats["mgry_secp256k1"]; cv = SECP256K1
+    vals = hexes_to_arr(km["from_to_roundtrip"]["values"])
+    assert np.array_equal(gpu.mgry_to_classical(cv, gpu.mgry_from_classical(cv, vals)), vals)
+    ma = gpu.mgry_from_classical(cv, hexes_to_arr([km["ops"]["a"]]))
+    for c_ in km["ops"]["pow"]:
+        assert format(to_int(gpu.mgry_to_classical(cv, gpu.mgry_pow(cv, ma, from_hex(c_["e"])))[0]), "064x") == c_["r"]
+    s, ok = gpu.gfp_sqrt(cv, gpu.mgry_from_classical(cv, hexes_to_arr([km["gfp"]["sqrt"]["a"]])))
+    assert ok[0] == 1 and format(to_int(gpu.mgry_to_classical(cv, s)[0]), "064x") == km["gfp"]["sqrt"]["r"]
+
+
+def test_constants_match_the_oracle(engine, oracle):
+    names = ["p", "a", "b", "gx", "gy", "r_p", "rsq_p", "pm1_r_p", "am", "bm", "p_m2", "p_sqrt"]
+    for cv in CURVES:
+        c = oracle.constants(cv)
+        for i, nm in enumerate(names):
+            assert np.array_equal(engine.constant(cv, i), c[nm]), (cv, nm)
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 63, 64, 65, 255, 256, 257, 1000])
+def test_ragged_and_empty_batches(gpu, oracle, n):
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); b = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    a[:, 3] >>= np.uint64(1); b[:, 3] >>= np.uint64(1)       # < 2^255 < p for both primes
+    for cv in CURVES:
+        assert np.array_equal(gpu.mgry_mul(cv, a, b), oracle.mgry_mul(cv, a, b))
+        assert np.array_equal(gpu.mod_sub(cv, a, b), oracle.mod_sub(cv, a, b))
+    assert np.array_equal(gpu.mul(a, b), oracle.mul(a, b))
+
+
+@pytest.mark.parametrize("cv", CURVES)
+def test_field_ops_vs_oracle(gpu, oracle, cv):
+    n = 20000; p = CURVE_PARAMS[cv]["p"]; rng = np.random.default_rng(11 + cv)
+    a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); b = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    a[:, 3] >>= np.uint64(1); b[:, 3] >>= np.uint64(1)
+    # edge values: 0, 1, p-1, p-2, 2^255-1 and values whose words are all-ones / carry-heavy
+    edge = [0, 1, 2, p - 1, p - 2, p - 3, (p - 1) // 2, (p + 1) // 2, 2**255 - 1, 2**128 - 1, 2**224, 2**96 - 1, 2**192 + 2**96]
+    for i, v in enumerate(edge):
+        a[i] = from_int(v % p); b[len(edge) - 1 - i] = from_int(v % p)
+    a[40:80] = ints_to_arr([(p - 1 - j) for j in range(40)]); b[40:80] = ints_to_arr([(p - 1 - 3 * j) for j in range(40)])
+    for name in ("mod_add", "mod_sub", "mgry_mul"):
+        assert np.array_equal(getattr(gpu, name)(cv, a, b), getattr(oracle, name)(cv, a, b)), name
+    for name in ("mgry_sqr", "mgry_from_classical", "mgry_to_classical", "gfp_opposite"):
+        assert np.array_equal(getattr(gpu, name)(cv, a), getattr(oracle, name)(cv, a)), name
+    for cnt in (1, 2, 3, 7):
+        assert np.array_equal(gpu.mod_shift_left(cv, a, cnt), oracle.mod_shift_left(cv, a, cnt))
+    t8 = rng.integers(0, 2**64, size=(n, 8), dtype=np.uint64)
+    t8[:, 7] &= np.uint64(2**63 - 1)                                   # < 2^511 < p * 2^256
+    t8[0] = 0; t8[1] = ints_to_arr([p * (2**256) - 1], 8)[0]; t8[2] = ints_to_arr([(p - 1) * (p - 1)], 8)[0]
+    assert np.array_equal(gpu.mgry_reduce(cv, t8), oracle.mgry_reduce(cv, t8))
+    # non-canonical input to from_classical (n >= p), as tests/ops.cpp:232 feeds mod_add
+    big = ints_to_arr([p, p + 1, 2**256 - 1, 2**256 - 2])
+    assert np.array_equal(gpu.mgry_from_classical(cv, big), oracle.mgry_from_classical(cv, big))
+    m = 512
+    assert np.array_equal(gpu.gfp_inverse(cv, a[:m]), oracle.gfp_inverse(cv, a[:m]))
+    s, ok = gpu.gfp_sqrt(cv, a[:m]); so, oko = oracle.gfp_sqrt(cv, a[:m])
+    assert np.array_equal(ok, oko) and np.array_equal(s, so) and 0 < ok.sum() < m     # residues and non-residues both present
+    e = from_int(0x1234567890abcdef_0fedcba987654321_00000000ffffffff_8000000000000001)
+    assert np.array_equal(gpu.mgry_pow(cv, a[:m], e), oracle.mgry_pow(cv, a[:m], e))
+    for e in (from_int(0), from_int(1), from_int(2**255)):
+        assert np.array_equal(gpu.mgry_pow(cv, a[:64], e), oracle.mgry_pow(cv, a[:64], e))
+
+
+def test_bignum_ops_vs_oracle(gpu, oracle):
+    n = 20000; rng = np.random.default_rng(5)
+    a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); b = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    a[0] = from_int(2**256 - 1); b[0] = from_int(2**256 - 1); a[1] = from_int(0); b[2] = from_int(0); a[3] = b[3]
+    a[4] = from_int(2**256 - 1); b[4] = from_int(1)
+    for name in ("add", "sub"):
+        s, f = getattr(gpu, name)(a, b); so, fo = getattr(oracle, name)(a, b)
+        assert np.array_equal(s, so) and np.array_equal(f, fo), name
+    s, f = gpu.shift_left_one(a); so, fo = oracle.shift_left_one(a)
+    assert np.array_equal(s, so) and np.array_equal(f, fo)
+    assert np.array_equal(gpu.sub_if_above(a, b), oracle.sub_if_above(a, b))
+    assert np.array_equal(gpu.mul(a, b), oracle.mul(a, b)) and np.array_equal(gpu.square(a), oracle.square(a))
+
+
+def test_carry_heavy_operands(gpu, oracle, golden):
+    """Digits of 0 / ff..f / 80..0 / 7f..f: every carry chain saturates.  This is the operand class on
+    which the REFERENCE's square() drops a carry (mul.h:186-190, "TODO: carry?" :207 -- pinned in
+    tests/golden ref_vectors.json "square_defect"); the HIP path must return the exact value a*a."""
+    a = structured_words(200000); b = np.roll(a, 7, axis=0)
+    sq = gpu.square(a)
+    assert np.array_equal(sq, oracle.square(a)) and np.array_equal(sq, gpu.mul(a, a))
+    assert np.array_equal(gpu.mul(a, b), oracle.mul(a, b))
+    for name in ("add", "sub"):
+        s, f = getattr(gpu, name)(a, b); so, fo = getattr(oracle, name)(a, b)
+        assert np.array_equal(s, so) and np.array_equal(f, fo)
+    d = golden["square_defect"]; x = hexes_to_arr(d["a"])
+    assert arr_to_hexes(gpu.square(x), 8) == d["exact_square"]
+    assert arr_to_hexes(gpu.mgry_sqr(P256, x)) == d["p256_exact_mgry_sqr"]
+    for cv in CURVES:
+        p = CURVE_PARAMS[cv]["p"]; m = 20000
+        ar = ints_to_arr([v % p for v in arr_to_ints(a[:m])]); br = ints_to_arr([v % p for v in arr_to_ints(b[:m])])
+        assert np.array_equal(gpu.mgry_sqr(cv, ar), oracle.mgry_sqr(cv, ar))
+        assert np.array_equal(gpu.mgry_sqr(cv, ar), gpu.mgry_mul(cv, ar, ar))
+        for nm in ("mgry_mul", "mod_add", "mod_sub"):
+            assert np.array_equal(getattr(gpu, nm)(cv, ar, br), getattr(oracle, nm)(cv, ar, br)), nm
+        assert np.array_equal(gpu.mod_shift_left(cv, ar, 3), oracle.mod_shift_left(cv, ar, 3))
+        t8 = np.concatenate([a[:m], b[:m]], axis=1); t8[:, 7] &= np.uint64(2**63 - 1)
+        assert np.array_equal(gpu.mgry_reduce(cv, t8), oracle.mgry_reduce(cv, t8))
+        # carry-heavy points are not on the curve, but the formulas are polynomial maps: still bit-exact
+        P = (ar[:4096], br[:4096], np.tile(oracle.constants(cv)["r_p"], (4096, 1)))
+        (R, Pu), (Rg, Pug) = oracle.trplu(cv, P), gpu.trplu(cv, P)
+        assert all(np.array_equal(u, v) for u, v in zip(Rg + Pug, R + Pu))
+        (Rz, Qu), (Rzg, Qug) = oracle.zdau(cv, R, Pu), gpu.zdau(cv, R, Pu)
+        assert all(np.array_equal(u, v) for u, v in zip(Rzg + Qug, Rz + Qu))
+        Ra, Rag = oracle.add_z2_1(cv, Rz, (ar[:4096], br[:4096])), gpu.add_z2_1(cv, Rz, (ar[:4096], br[:4096]))
+        assert all(np.array_equal(u, v) for u, v in zip(Rag, Ra))
+
+
+def test_cmp_and_swap(engine, oracle):
+    n = 1000; rng = np.random.default_rng(9)
+    a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); b = a.copy(); b[::2] = rng.integers(0, 2**64, size=(n // 2, 4), dtype=np.uint64)
+    da, db = engine.to_device(a), engine.to_device(b)
+    lt = engine.to_numpy(engine.cmp_lt(da, db))
+    assert lt.tolist() == [int(to_int(x) < to_int(y)) for x, y in zip(a, b)]          # cmp.h:11-13
+    import torch
+    mask = torch.from_numpy((rng.integers(0, 2, size=n) * 255).astype(np.uint8)).to(da.device)
+    engine.swap_if(mask, da, db)                                                        # tests/ops.cpp:179-208
+    m = mask.cpu().numpy().astype(bool)
+    assert np.array_equal(engine.to_numpy(da), np.where(m[:, None], b, a)) and np.array_equal(engine.to_numpy(db), np.where(m[:, None], a, b))
+
+
+def _lane_distinct_points(gpu, cv, n, stream=2):
+    """P_i = s_i * G, affine classical, from the synthetic generator."""
+    s = fill_random_np(n, SEED, stream)
+    return gpu.scalar_mult_base(cv, s, affine=True)[:2]
+
+
+@pytest.mark.parametrize("cv", CURVES)
+def test_point_formulas_vs_oracle(gpu, oracle, cv):
+    n = 4096
+    bx, by = _lane_distinct_points(gpu, cv, n)
+    P = oracle.from_affine(cv, bx, by)
+    assert all(np.array_equal(u, v) for u, v in zip(gpu.from_affine(cv, bx, by), P))
+    (R, Pu), (Rg, Pug) = oracle.dblu(cv, P), gpu.dblu(cv, P)
+    assert all(np.array_equal(u, v) for u, v in zip(Rg + Pug, R + Pu)), "DBLU"
+    (R3, Pu2), (R3g, Pu2g) = oracle.zaddu(cv, Pu, R), gpu.zaddu(cv, Pu, R)
+    assert all(np.array_equal(u, v) for u, v in zip(R3g + Pu2g, R3 + Pu2)), "ZADDU"
+    (Rt, Put), (Rtg, Putg) = oracle.trplu(cv, P), gpu.trplu(cv, P)
+    assert all(np.array_equal(u, v) for u, v in zip(Rtg + Putg, Rt + Put)), "TRPLU"
+    assert all(np.array_equal(u, v) for u, v in zip(Rt, R3)), "TRPLU == DBLU;ZADDU"
+    (Rz, Qu), (Rzg, Qug) = oracle.zdau(cv, Rt, Put), gpu.zdau(cv, Rt, Put)
+    assert all(np.array_equal(u, v) for u, v in zip(Rzg + Qug, Rz + Qu)), "ZDAU"
+    assert np.array_equal(Rzg[2], Qug[2]), "co-Z invariant"
+    Ra, Rag = oracle.add_z2_1(cv, Rz, (P[0], P[1])), gpu.add_z2_1(cv, Rz, (P[0], P[1]))
+    assert all(np.array_equal(u, v) for u, v in zip(Rag, Ra)), "ADD_Z2_1"
+    m = 512
+    Jm = tuple(v[:m] for v in Ra)
+    assert all(np.array_equal(u, v) for u, v in zip(gpu.to_affine(cv, Jm), oracle.to_affine(cv, Jm))), "to_affine"
+    # 7P + P = 8P: check a few lanes against the independent affine model
+    ax, ay = gpu.to_affine(cv, tuple(v[:8] for v in Ra))
+    for i in range(8):
+        assert (to_int(ax[i]), to_int(ay[i])) == ec_mul(cv, 8, (to_int(bx[i]), to_int(by[i])))
+    y, ok = gpu.compute_y(cv, bx[:m])
+    assert ok.all()
+    p = CURVE_PARAMS[cv]["p"]
+    assert all(to_int(u) in (to_int(v), p - to_int(v)) for u, v in zip(y, by[:m]))
+    yo, oko = oracle.compute_y(cv, bx[:m])
+    assert np.array_equal(y, yo) and np.array_equal(ok, oko)
+
+
+@pytest.mark.parametrize("cv", CURVES)
+def test_scalar_mult_vs_oracle(gpu, oracle, cv):
+    c = CURVE_PARAMS[cv]; order = c["n"]
+    edge = [0, 1, 2, 3, 4, 5, 6, 7, 8, order - 2, order - 1, order, order + 1, order + 2, 2**256 - 1, 2**256 - 2, 2**255, 2**255 - 1,
+            2**64, 2**64 - 1, 2**128, 2**192 + 1, int("55" * 32, 16), int("aa" * 32, 16)]
+    n = 4096
+    k = fill_random_np(n, SEED, 1); k[:len(edge)] = ints_to_arr(edge)
+    gx, gy = ints_to_arr([c["gx"]] * n), ints_to_arr([c["gy"]] * n)
+    exp = oracle.scalar_mult(cv, k, gx, gy, threads=THREADS)
+    assert all(np.array_equal(u, v) for u, v in zip(gpu.scalar_mult(cv, k, gx, gy), exp)), "fixed base G"
+    assert all(np.array_equal(u, v) for u, v in zip(gpu.scalar_mult_base(cv, k), exp)), "scalar_mult_base"
+    # variable (lane-distinct) base, both input forms, both output forms
+    bx, by = _lane_distinct_points(gpu, cv, n)
+    exp = oracle.scalar_mult(cv, k, bx, by, threads=THREADS)
+    assert all(np.array_equal(u, v) for u, v in zip(gpu.scalar_mult(cv, k, bx, by), exp)), "variable base"
+    Pm = oracle.from_affine(cv, bx, by)
+    assert all(np.array_equal(u, v) for u, v in zip(gpu.scalar_mult(cv, k, Pm[0], Pm[1], mgry_in=True), exp)), "Montgomery-form base"
+    ax, ay = oracle.to_affine(cv, exp)
+    gax, gay = gpu.scalar_mult(cv, k, bx, by, affine=True)[:2]
+    assert np.array_equal(gax, ax) and np.array_equal(gay, ay), "affine output"
+    # a few lanes against the independent affine model (non-degenerate scalars only)
+    for i in list(range(1, 9)) + [len(edge) + 3, n - 1]:
+        kk = to_int(k[i]) % order
+        if kk in (0, order - 1): continue
+        assert (to_int(gax[i]), to_int(gay[i])) == ec_mul(cv, kk, (to_int(bx[i]), to_int(by[i]))), i
+    # one scalar for all lanes (curve_group.h:221-251)
+    k1 = k[len(edge) + 1]
+    exp1 = oracle.scalar_mult(cv, np.tile(k1, (256, 1)), bx[:256], by[:256], threads=THREADS)
+    assert all(np.array_equal(u, v) for u, v in zip(gpu.scalar_mult_1s(cv, k1, bx[:256], by[:256]), exp1)), "scalar_mult_1s"
+
+
+def test_scalar_mult_p256_entry_point(engine, oracle):
+    """lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P), P Jacobian Montgomery with Z = mgry(1)."""
+    n = 1024; c = CURVE_PARAMS[P256]
+    k = fill_random_np(n, SEED, 7)
+    s = fill_random_np(n, SEED, 8)
+    bx, by = engine.scalar_mult_base(P256, engine.to_device(s), flags=2)
+    P = engine.from_affine(P256, bx, by)
+    got = engine.scalar_mult_p256(engine.to_device(k), P[0], P[1])
+    exp = oracle.scalar_mult(P256, k, engine.to_numpy(P[0]), engine.to_numpy(P[1]), threads=THREADS, mgry_in=True)
+    assert all(np.array_equal(engine.to_numpy(u), v) for u, v in zip(got, exp))
+
+
+def test_fill_random_matches_numpy_twin(engine):
+    for stream, first, clear in ((1, 0, 0), (2, 12345, 1), (3, 2**40, 8)):
+        got = engine.to_numpy(engine.fill_random(1000, SEED, stream, first_index=first, clear_top_bits=clear))
+        assert np.array_equal(got, fill_random_np(1000, SEED, stream, first, clear))
+
+
+def test_bad_arguments_are_rejected(engine):
+    import ctypes as C
+    lib, ctx = engine.lib, engine.ctx
+    a = engine.empty(4)
+    p = C.c_void_p(a.data_ptr())
+    assert lib.ecsimd_hip_mod_add(ctx, C.c_int(7), p, p, p, C.c_size_t(4)) == -1            # unknown curve
+    assert lib.ecsimd_hip_mod_add(ctx, C.c_int(0), C.c_void_p(0), p, p, C.c_size_t(4)) == -1  # null pointer
+    assert lib.ecsimd_hip_mod_add(ctx, C.c_int(0), C.c_void_p(a.data_ptr() + 8), p, p, C.c_size_t(2)) == -1  # misaligned
+    assert lib.ecsimd_hip_mod_shift_left(ctx, C.c_int(0), p, C.c_int(0), p, C.c_size_t(4)) == -1
+    assert b"bad argument" in lib.ecsimd_hip_last_error(ctx)
+    assert lib.ecsimd_hip_mod_add(ctx, C.c_int(0), p, p, p, C.c_size_t(0)) == 0                # empty batch is fine
+
+
+# ---------------------------------------------------------------- full BASELINE sizes: properties
+def _aff_ints(gpu, cv, J, idx):
+    ax, ay = gpu.to_affine(cv, tuple(v[idx] for v in J))
+    return [(to_int(x), to_int(y)) for x, y in zip(ax, ay)]
+
+
+def test_config2_point_add_double_2pow20(engine, oracle):
+    """BASELINE configs[1]: P-256 point add+double, batch 2^20 random points: TRPLU (DBLU+ZADDU) then ZDAU.
+    Level J vs the oracle on a 4096-element strided sample; co-Z invariants on the whole batch."""
+    import torch
+    n = 1 << 20; cv = P256
+    s = engine.fill_random(n, SEED, 2)
+    bx, by = engine.scalar_mult_base(cv, s, flags=2)
+    P = engine.from_affine(cv, bx, by)
+    P0 = tuple(t.clone() for t in P)
+    T = engine.trplu(cv, P)                 # T = 3P, P rewritten co-Z
+    assert torch.equal(T[2], P[2])
+    Z = engine.zdau(cv, T, P)               # Z = 2T + P = 7P, P rewritten co-Z
+    assert torch.equal(Z[2], P[2])
+    idx = np.arange(0, n, n // 4096)
+    tidx = torch.from_numpy(idx).to(bx.device)
+    sub = lambda pts: tuple(engine.to_numpy(t[tidx]) for t in pts)
+    Rt, Put = oracle.trplu(cv, sub(P0))
+    Rz, Qu = oracle.zdau(cv, Rt, Put)
+    assert all(np.array_equal(u, v) for u, v in zip(sub(T), Rt)) and all(np.array_equal(u, v) for u, v in zip(sub(Z) + sub(P), Rz + Qu))
+    # size-independent property: 7P computed by the formulas equals 7*P from the ladder (affine level)
+    seven = engine.to_device(np.tile(from_int(7), (n, 1)))
+    lx, ly = engine.scalar_mult(cv, seven, bx, by, flags=2)
+    fx, fy = engine.to_affine(cv, Z)
+    assert torch.equal(lx, fx) and torch.equal(ly, fy)
+
+
+@pytest.mark.parametrize("cv,log2n", [(P256, 22), (SECP256K1, 22)])
+def test_config3_and_5_fixed_base_2pow22(engine, oracle, cv, log2n):
+    """BASELINE configs[2] and [4]: k*G for 2^22 random scalars.  Oracle on a strided sample (level J)
+    plus linearity on the whole batch: (k + 1)*G == k*G + G, checked through ADD_Z2_1 at affine level."""
+    import torch
+    n = 1 << log2n
+    k = engine.fill_random(n, SEED, 1)
+    J = engine.scalar_mult_base(cv, k)
+    idx = np.arange(0, n, n // 2048)
+    tidx = torch.from_numpy(idx).to(k.device)
+    kn = engine.to_numpy(k[tidx]); c = CURVE_PARAMS[cv]
+    exp = oracle.scalar_mult(cv, kn, ints_to_arr([c["gx"]] * len(idx)), ints_to_arr([c["gy"]] * len(idx)), threads=THREADS)
+    assert all(np.array_equal(engine.to_numpy(t[tidx]), v) for t, v in zip(J, exp))
+    # linearity: k*G + G == (k+1)*G  (k+1 computed on the host side of the device: add with carry)
+    one = engine.to_device(np.tile(from_int(1), (n, 1)))
+    k1, _ = engine.add(k, one)
+    J1 = engine.scalar_mult_base(cv, k1)
+    Gm = engine.from_affine(cv, engine.to_device(ints_to_arr([c["gx"]] * n)), engine.to_device(ints_to_arr([c["gy"]] * n)))
+    S = engine.add_z2_1(cv, J, (Gm[0], Gm[1]))
+    ax, ay = engine.to_affine(cv, S); bx, by = engine.to_affine(cv, J1)
+    assert torch.equal(ax, bx) and torch.equal(ay, by)
+
+
+def test_config4_variable_base_shard_2pow21(engine, oracle):
+    """BASELINE configs[3]: variable base, 2^24 over 8 GPUs = 2^21 per GPU.  This is rank 3's shard:
+    inputs regenerated from (seed, global index), oracle on a strided sample, and the round trip
+    k^-1 * (k * P) == P on the whole shard (scalars made invertible mod n by construction)."""
+    import torch
+    cv = P256; n = 1 << 21; rank = 3; order = CURVE_PARAMS[cv]["n"]
+    k = engine.fill_random(n, SEED, 1, first_index=rank * n)
+    s = engine.fill_random(n, SEED, 2, first_index=rank * n)
+    bx, by = engine.scalar_mult_base(cv, s, flags=2)
+    J = engine.scalar_mult(cv, k, bx, by)
+    idx = np.arange(0, n, n // 1024); tidx = torch.from_numpy(idx).to(k.device)
+    kn, bxn, byn = (engine.to_numpy(t[tidx]) for t in (k, bx, by))
+    assert np.array_equal(kn, fill_random_np(n, SEED, 1, first_index=rank * n)[idx])
+    exp = oracle.scalar_mult(cv, kn, bxn, byn, threads=THREADS)
+    assert all(np.array_equal(engine.to_numpy(t[tidx]), v) for t, v in zip(J, exp))
+    # round trip on a 2^16 slice (host computes the modular inverses of the scalars)
+    m = 1 << 16
+    ks = arr_to_ints(engine.to_numpy(k[:m]))
+    kinv = ints_to_arr([pow(v % order, -1, order) for v in ks])
+    ax, ay = engine.to_affine(cv, tuple(t[:m].contiguous() for t in J))
+    rx, ry = engine.scalar_mult(cv, engine.to_device(kinv), ax, ay, flags=2)
+    assert torch.equal(rx, bx[:m]) and torch.equal(ry, by[:m])
