@@ -75,35 +75,17 @@ def main():
     P = eng.from_affine(curve, bx, by)                                        # Montgomery form, Z = mgry(1)
     xm, ym = P[0], P[1]
     del s, P
-    outs = [torch.empty((3, n, 4), dtype=torch.int64, device=eng.tdev) for _ in range(2)]
     flags = BASE_MGRY | OUT_JACOBIAN
+    from ecsimd_amd.shard import ShardedRunner
+    runner = ShardedRunner((3, n, 4), torch.int64, eng.tdev, world, rank)
 
-    comm = torch.cuda.Stream() if world > 1 else None
-    gathered = [torch.empty((3, n, 4), dtype=torch.int64, device=eng.tdev) for _ in range(world)] if (world > 1 and rank == 0) else None
-    done = [None, None]                 # per output buffer: event marking the end of its last gather
+    def compute(o):
+        eng.scalar_mult(curve, k, xm, ym, flags=flags, out=[o[0], o[1], o[2]])
 
     def step(i, ev0=None, ev1=None):
-        o = outs[i & 1]
-        if done[i & 1] is not None:
-            torch.cuda.current_stream().wait_event(done[i & 1])               # buffer free again?
-        if ev0 is not None:
-            ev0.record()
-        eng.scalar_mult(curve, k, xm, ym, flags=flags, out=[o[0], o[1], o[2]])
-        if ev1 is not None:
-            ev1.record()
-        if world > 1:
-            ready = torch.cuda.Event(); ready.record()
-            with torch.cuda.stream(comm):
-                comm.wait_event(ready)
-                dist.gather(o, gathered, dst=0)
-                fin = torch.cuda.Event(); fin.record()
-            done[i & 1] = fin
+        runner.step(compute, before=(ev0.record if ev0 is not None else None), after=(ev1.record if ev1 is not None else None))
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+    fence = runner.fence
 
     for i in range(args.warmup):
         step(i)
@@ -153,7 +135,7 @@ def main():
             "peak_source": "ecsimd_hip_peak_mad32: dependency-free v_mad_u64_u32 stream, 8 waves/SIMD, same GPU, same run",
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, outs[(args.steps - 1) & 1], args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, runner.last_result(), args.cpu_seconds)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

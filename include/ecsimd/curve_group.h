@@ -1,0 +1,72 @@
+// ecsimd/curve_group.h -- curve_group<Curve>: the co-Z formulas and the ladder (reference curve_group.h:20-252).
+// Same static member names and parameter conventions: reference parameters that the reference
+// updates in place (DBLU's P, ZADDU's P, ZDAU's Q, TRPLU's P) are updated in place here too.
+#ifndef ECSIMD_CURVE_GROUP_H
+#define ECSIMD_CURVE_GROUP_H
+#include <ecsimd/jacobian_curve_point.h>
+#include <optional>
+
+namespace ecsimd {
+template <class Curve>
+struct curve_group {
+  using WBN = curve_wide_bn_t<Curve>;
+  using BN = typename WBN::value_type;
+  using WMBN = wide_mgry_bignum<WBN, typename Curve::P>;
+  using gfp = GFp<WBN, typename Curve::P>;
+  using WCP = wide_curve_point<Curve>;
+  using WJCP = wide_jacobian_curve_point<Curve>;
+  static constexpr int curve_id = WJCP::curve_id;
+
+  static BN Am() { return mgry_constants<typename Curve::P>::get(8); }      // curve_group.h:32
+  static BN Bm() { return mgry_constants<typename Curve::P>::get(9); }      // curve_group.h:31
+  static WCP WG(size_t lanes = default_lanes) { return WCP{WBN(lanes, Curve::Gx::value), WBN(lanes, Curve::Gy::value)}; }   // :35-37
+  static WJCP WJG(size_t lanes = default_lanes) { return WJCP::from_affine(WG(lanes)); }                                     // :39-41
+
+  static std::optional<WBN> compute_y(WBN const& x) {                        // :52-58 (all lanes or nothing, like the reference)
+    hip::mask ok; WBN y = compute_y_lanes(x, ok); if (!all(ok)) return {}; return {y};
+  }
+  static WBN compute_y_lanes(WBN const& x, hip::mask& ok) {                  // per-lane validity; y^2 = x^3 + a x + b for either curve
+    auto y = WBN::uninitialized(x.size()); ok = hip::mask(x.size());
+    hip::check(ecsimd_hip_compute_y(hip::context(), curve_id, x.data(), y.data(), ok.data(), x.size()), "ecsimd_hip_compute_y"); return y;
+  }
+
+  static WJCP DBLU(WJCP& P) {                                                // :64-87
+    P.unshare(); WJCP r = fresh(P.size());
+    hip::check(ecsimd_hip_dblu(hip::context(), curve_id, px(P), py(P), pz(P), px(r), py(r), pz(r), P.size()), "ecsimd_hip_dblu"); return r;
+  }
+  static WJCP ZADDU(WJCP& P, WJCP const& O) {                                // :91-116
+    P.unshare(); WJCP r = fresh(P.size());
+    hip::check(ecsimd_hip_zaddu(hip::context(), curve_id, px(P), py(P), pz(P), px(O), py(O), pz(O), px(r), py(r), pz(r), P.size()), "ecsimd_hip_zaddu"); return r;
+  }
+  static WJCP ZDAU(WJCP const& P, WJCP& Q) {                                 // :120-153
+    Q.unshare(); WJCP r = fresh(P.size());
+    hip::check(ecsimd_hip_zdau(hip::context(), curve_id, px(P), py(P), pz(P), px(Q), py(Q), pz(Q), px(r), py(r), pz(r), P.size()), "ecsimd_hip_zdau"); return r;
+  }
+  static WJCP ADD_Z2_1(WJCP const& A, WJCP const& B) {                       // :155-179 (B.z must be mgry(1))
+    WJCP r = fresh(A.size());
+    hip::check(ecsimd_hip_add_z2_1(hip::context(), curve_id, px(A), py(A), pz(A), px(B), py(B), px(r), py(r), pz(r), A.size()), "ecsimd_hip_add_z2_1"); return r;
+  }
+  static WJCP TRPLU(WJCP& P) {                                               // :183-186
+    P.unshare(); WJCP r = fresh(P.size());
+    hip::check(ecsimd_hip_trplu(hip::context(), curve_id, px(P), py(P), pz(P), px(r), py(r), pz(r), P.size()), "ecsimd_hip_trplu"); return r;
+  }
+  // k[i] * P[i], P.z must be mgry(1) (:189-218).  One kernel: the whole ladder stays in registers.
+  static WJCP scalar_mult(WBN const& x, WJCP P) {
+    WJCP r = fresh(P.size());
+    hip::check(ecsimd_hip_scalar_mult(hip::context(), curve_id, x.data(), px(P), py(P), px(r), py(r), pz(r), P.size(), ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN), "ecsimd_hip_scalar_mult"); return r;
+  }
+  // one scalar for every lane (:221-251)
+  static WJCP scalar_mult_1s(BN const& x, WJCP P) {
+    WJCP r = fresh(P.size());
+    hip::check(ecsimd_hip_scalar_mult_1s(hip::context(), curve_id, x.limbs.data(), px(P), py(P), px(r), py(r), pz(r), P.size(), ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN), "ecsimd_hip_scalar_mult_1s"); return r;
+  }
+ private:
+  static WJCP fresh(size_t n) {
+    WJCP r; r.x() = gfp{WMBN{WBN::uninitialized(n)}}; r.y() = gfp{WMBN{WBN::uninitialized(n)}}; r.z() = gfp{WMBN{WBN::uninitialized(n)}}; return r;
+  }
+  static uint64_t* px(WJCP const& p) { return p.x().wbn().data(); }
+  static uint64_t* py(WJCP const& p) { return p.y().wbn().data(); }
+  static uint64_t* pz(WJCP const& p) { return p.z().wbn().data(); }
+};
+}  // namespace ecsimd
+#endif

@@ -1,0 +1,121 @@
+// ecsimd/hip_runtime.h -- host-side plumbing shared by the C++ API headers: the process-wide
+// engine context and a reference-counted device buffer.  Everything here sits on the C ABI of
+// <ecsimd_hip.h>; there is no CPU implementation behind these headers -- if the HIP library or a
+// gfx950 device is missing, the first use throws.
+#ifndef ECSIMD_HIP_RUNTIME_H
+#define ECSIMD_HIP_RUNTIME_H
+
+#include <ecsimd_hip.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace ecsimd {
+namespace hip {
+
+struct error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// One context per process (device from ECSIMD_HIP_DEVICE, default 0), created on first use.
+inline ecsimd_hip_ctx* context() {
+  struct holder {
+    ecsimd_hip_ctx* ctx = nullptr;
+    holder() {
+      const char* d = std::getenv("ECSIMD_HIP_DEVICE");
+      const int rc = ecsimd_hip_init(d ? std::atoi(d) : 0, &ctx);
+      if (rc != ECSIMD_HIP_OK)
+        throw error("ecsimd_hip_init failed (" + std::to_string(rc) + "): no gfx950 device or HIP runtime; this library has no CPU fallback");
+    }
+    ~holder() { if (ctx) ecsimd_hip_destroy(ctx); }
+  };
+  static holder h;
+  return h.ctx;
+}
+
+inline void check(int rc, const char* what) {
+  if (rc != ECSIMD_HIP_OK) throw error(std::string(what) + " failed (" + std::to_string(rc) + "): " + ecsimd_hip_last_error(context()));
+}
+inline void sync() { check(ecsimd_hip_sync(context()), "ecsimd_hip_sync"); }
+
+// Device array of 64-bit words, shared between copies of a wide value (values are immutable once
+// produced, like registers; in-place updates clone first -- see wide_bignum::unshare()).
+class buffer {
+ public:
+  buffer() = default;
+  explicit buffer(size_t words) : words_(words) {
+    void* p = nullptr;
+    check(ecsimd_hip_malloc(context(), &p, words * sizeof(uint64_t)), "ecsimd_hip_malloc");
+    ecsimd_hip_ctx* ctx = context();
+    mem_ = std::shared_ptr<uint64_t>(static_cast<uint64_t*>(p), [ctx](uint64_t* q) { ecsimd_hip_free(ctx, q); });
+  }
+  uint64_t* data() const { return mem_.get(); }
+  size_t words() const { return words_; }
+  bool shared() const { return mem_.use_count() > 1; }
+  void upload(const uint64_t* src) { check(ecsimd_hip_memcpy_h2d(context(), mem_.get(), src, words_ * 8), "h2d"); }
+  void download(uint64_t* dst) const { check(ecsimd_hip_memcpy_d2h(context(), dst, mem_.get(), words_ * 8), "d2h"); }
+  buffer clone() const {
+    buffer b(words_);
+    std::vector<uint64_t> tmp(words_);
+    download(tmp.data()); b.upload(tmp.data());
+    return b;
+  }
+ private:
+  std::shared_ptr<uint64_t> mem_;
+  size_t words_ = 0;
+};
+
+// One flag per lane (the reference's eve::logical lane mask, bignum.h:136-137).
+class mask {
+ public:
+  mask() = default;
+  explicit mask(size_t n) : n_(n) {
+    void* p = nullptr;
+    check(ecsimd_hip_malloc(context(), &p, n ? n : 1), "ecsimd_hip_malloc");
+    ecsimd_hip_ctx* ctx = context();
+    mem_ = std::shared_ptr<uint8_t>(static_cast<uint8_t*>(p), [ctx](uint8_t* q) { ecsimd_hip_free(ctx, q); });
+  }
+  mask(std::initializer_list<bool> v) : mask(v.size()) {
+    std::vector<uint8_t> h; for (bool b : v) h.push_back(b ? 1 : 0);
+    check(ecsimd_hip_memcpy_h2d(context(), mem_.get(), h.data(), h.size()), "h2d");
+  }
+  static mask filled(size_t n, bool v) {
+    mask m(n); std::vector<uint8_t> h(n, v ? 1 : 0);
+    check(ecsimd_hip_memcpy_h2d(context(), m.mem_.get(), h.data(), n), "h2d"); return m;
+  }
+  uint8_t* data() const { return mem_.get(); }
+  size_t size() const { return n_; }
+  std::vector<uint8_t> host() const {
+    std::vector<uint8_t> h(n_);
+    if (n_) check(ecsimd_hip_memcpy_d2h(context(), h.data(), mem_.get(), n_), "d2h");
+    return h;
+  }
+  bool get(size_t i) const { return host().at(i) != 0; }
+  mask operator!() const { auto h = host(); mask m(n_); for (auto& b : h) b = !b; check(ecsimd_hip_memcpy_h2d(context(), m.mem_.get(), h.data(), n_), "h2d"); return m; }
+  friend mask operator==(mask const& a, mask const& b) {
+    auto x = a.host(), y = b.host(); mask m(a.n_);
+    for (size_t i = 0; i < x.size(); ++i) x[i] = (x[i] != 0) == (y[i] != 0);
+    check(ecsimd_hip_memcpy_h2d(context(), m.mem_.get(), x.data(), x.size()), "h2d"); return m;
+  }
+  friend mask operator&&(mask const& a, mask const& b) {
+    auto x = a.host(), y = b.host(); mask m(a.n_);
+    for (size_t i = 0; i < x.size(); ++i) x[i] = x[i] && y[i];
+    check(ecsimd_hip_memcpy_h2d(context(), m.mem_.get(), x.data(), x.size()), "h2d"); return m;
+  }
+ private:
+  std::shared_ptr<uint8_t> mem_;
+  size_t n_ = 0;
+};
+
+}  // namespace hip
+
+// eve::all / eve::any / eve::none over a lane mask (the reference's tests use exactly these).
+inline bool all(hip::mask const& m) { for (auto b : m.host()) if (!b) return false; return true; }
+inline bool any(hip::mask const& m) { for (auto b : m.host()) if (b) return true; return false; }
+inline bool none(hip::mask const& m) { return !any(m); }
+
+}  // namespace ecsimd
+#endif

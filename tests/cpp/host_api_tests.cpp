@@ -1,0 +1,220 @@
+// host_api_tests.cpp -- the reference's known-answer scenarios (tests/ops.cpp, mgry.cpp, curve_point.cpp,
+// curve_group.cpp of aguinet/ecsimd) driven through THIS repo's include/ecsimd headers, i.e. through
+// the C ABI and the HIP kernels.  The hex vectors are the reference's (cited per test); the harness is
+// this repo's mini_test.h.  Built and run by tests/test_cpp_host_api.py on the GPU box.
+#include <ecsimd/ecsimd.h>
+#include "mini_test.h"
+
+using namespace ecsimd;
+using namespace ecsimd::literals;
+
+namespace {
+template <class WBN, size_t N> WBN splat(std::array<uint8_t, N> const& be) {                 // tests/tests.h:10-14 wide_bignum_set1
+  static_assert(N == sizeof(uint64_t) * WBN::nlimbs);
+  return WBN{bn_from_bytes_BE<typename WBN::value_type>(be)};
+}
+template <class WBN, size_t N> WBN lanes(std::array<uint8_t, N> const& l0, std::array<uint8_t, N> const& l1, std::array<uint8_t, N> const& l2, std::array<uint8_t, N> const& l3) {
+  const std::array<uint8_t, N> be[4] = {l0, l1, l2, l3};
+  return WBN{[&](size_t i, size_t) { return bn_from_bytes_BE<typename WBN::value_type>(be[i % 4]); }};
+}
+using W128 = wide_bignum<bignum_128>;
+using W256 = wide_bignum<bignum_256>;
+using W512 = wide_bignum<bignum_512>;
+struct K1P { static constexpr auto value = bn_from_bytes_BE<bignum_256>("FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2F"_hex); };   // tests/mgry.cpp:25-27
+}  // namespace
+
+// ------------------------------------------------------------------ tests/ops.cpp:71-153
+TEST(Ops128, AddSub) {
+  EXPECT_TRUE(all(add_no_carry(splat<W128>("00000000000000000000000500000005"_hex), splat<W128>("0000000000000000FFFFFFFFFFFFFFFF"_hex)) == splat<W128>("00000000000000010000000500000004"_hex)));
+  EXPECT_TRUE(all(add_no_carry(splat<W128>("909680e1f399ca5916134a18b816399b"_hex), splat<W128>("0e36dfecf5e7f74363c453efc1cbc153"_hex)) == splat<W128>("9ecd60cee981c19c79d79e0879e1faee"_hex)));
+  EXPECT_TRUE(all(sub_no_carry(splat<W128>("00000000000000000000000500000005"_hex), splat<W128>("0000000000000000FFFFFFFFFFFFFFFF"_hex)) == splat<W128>("ffffffffffffffff0000000500000006"_hex)));
+}
+TEST(Ops128, SubIfAbove) {
+  const auto p = splat<W128>("F0000000000000000000000000000004"_hex);
+  EXPECT_TRUE(all(sub_if_above(splat<W128>("F0000000000000000000000000000005"_hex), p) == splat<W128>("00000000000000000000000000000001"_hex)));
+  EXPECT_TRUE(all(sub_if_above(p, p) == splat<W128>("00000000000000000000000000000000"_hex)));
+  EXPECT_TRUE(all(sub_if_above(splat<W128>("F0000000000000000000000000000003"_hex), p) == splat<W128>("F0000000000000000000000000000003"_hex)));
+  // lane-distinct (tests/ops.cpp:93-119)
+  const auto a = lanes<W128>("F0000000000000000000000000000005"_hex, "F0000000000000000000000000000004"_hex, "F0000000000000000000000000000003"_hex, "F0000000000000000000000000000002"_hex);
+  const auto r = lanes<W128>("00000000000000000000000000000001"_hex, "00000000000000000000000000000000"_hex, "F0000000000000000000000000000003"_hex, "F0000000000000000000000000000002"_hex);
+  EXPECT_TRUE(all(sub_if_above(a, p) == r));
+}
+TEST(Ops128, MulSquare) {
+  EXPECT_TRUE(all(mul(splat<W128>("ffffffffffffffffffffffffffffffff"_hex), splat<W128>("eeeeeeeeeeeeeeeeeeeeeeeeeeeeeeee"_hex)) ==
+                  splat<W256>("EEEEEEEEEEEEEEEEEEEEEEEEEEEEEEED11111111111111111111111111111112"_hex)));
+  using W192 = wide_bignum<bignum<uint64_t, 3>>;
+  EXPECT_TRUE(all(limb_mul(splat<W128>("e43aba669166dad6a334ad6bb13a2c9c"_hex), {198769}) == splat<W192>("000000000002b436c2f33005f5c13775b7eefdc191e690dc"_hex)));
+  EXPECT_TRUE(all(square(splat<W128>("00000000000000000000000000000004"_hex)) == splat<W256>("0000000000000000000000000000000000000000000000000000000000000010"_hex)));
+  EXPECT_TRUE(all(square(splat<W128>("ffffffffffffffffffffffffffffffff"_hex)) == splat<W256>("fffffffffffffffffffffffffffffffe00000000000000000000000000000001"_hex)));
+  EXPECT_TRUE(all(square(splat<W128>("b59edca51009bb15c309b23171c102da"_hex)) == splat<W256>("80da06968299ac8e1bc23ef95d49c1469d01bb136df7c96b75ba357dc0bc21a4"_hex)));
+}
+TEST(Ops128, Compare) {
+  const auto lo = splat<W128>("AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA"_hex), hi = splat<W128>("BAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA"_hex);
+  EXPECT_TRUE(all(lo < hi)); EXPECT_TRUE(all(lo <= hi)); EXPECT_TRUE(all(lo <= lo));
+  EXPECT_TRUE(all(hi > lo)); EXPECT_TRUE(all(hi >= lo)); EXPECT_TRUE(all(lo >= lo));
+  EXPECT_TRUE(none(splat<W128>("AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAB"_hex) < lo));
+}
+// tests/ops.cpp:155-177 (the carry mask is what the reference pins; the shifted value is checked here
+// against the arithmetically correct a << 1, the reference's own value check being vacuous)
+TEST(Ops128, Shifts) {
+  const auto a = lanes<W128>("80000000800000008000000080000000"_hex, "70000000800000001000000000000001"_hex, "00000000000000000000000000000001"_hex, "FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF"_hex);
+  auto [shifted, carry] = shift_left_one(a);
+  EXPECT_TRUE(all(carry == cmp_res_t<W128>{true, false, false, true}));
+  EXPECT_TRUE(all(shifted == lanes<W128>("00000001000000010000000100000000"_hex, "E0000001000000002000000000000002"_hex, "00000000000000000000000000000002"_hex, "FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFE"_hex)));
+}
+TEST(Ops128, Swap) {                                                                          // tests/ops.cpp:179-208
+  const auto a = lanes<W128>("00000001000000010000000100000000"_hex, "80000001000000002000000000000002"_hex, "00000000000000000000000000000002"_hex, "FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFE"_hex);
+  const auto b = lanes<W128>("FFFEEEE100AAAAA100DDDDD10FFFAAAA"_hex, "8BBBB001000FFF002000AAAAAAA00002"_hex, "DDDDDDDAAAAAAAFFFFFFF24566660002"_hex, "0000000111111144444555555FFFFFFE"_hex);
+  const auto Z = hip::mask::filled(4, false);
+  auto aa = a, bb = b;
+  swap_if(Z, aa, bb);
+  EXPECT_TRUE(all(aa == a)); EXPECT_TRUE(all(bb == b));
+  swap_if(!Z, aa, bb);
+  EXPECT_TRUE(all(aa == b)); EXPECT_TRUE(all(bb == a));
+  EXPECT_TRUE(all(a == lanes<W128>("00000001000000010000000100000000"_hex, "80000001000000002000000000000002"_hex, "00000000000000000000000000000002"_hex, "FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFE"_hex)));   // the originals are untouched
+}
+TEST(Ops256, Mul) {                                                                           // tests/ops.cpp:210-219
+  EXPECT_TRUE(all(mul(splat<W256>("ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff"_hex), splat<W256>("eeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeee"_hex)) ==
+                  splat<W512>("EEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEEED1111111111111111111111111111111111111111111111111111111111111112"_hex)));
+}
+TEST(Ops256, Mod) {                                                                           // tests/ops.cpp:221-252
+  const auto p = splat<W256>("FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2F"_hex);
+  EXPECT_TRUE(all(mod_add(splat<W256>("FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2E"_hex), splat<W256>("0000000000000000000000000000000000000000000000000000000000000002"_hex), p) ==
+                  splat<W256>("0000000000000000000000000000000000000000000000000000000000000001"_hex)));
+  const auto a = splat<W256>("fffffffffffffffffffffffffffffffffffffffffffffffffffffff000000000"_hex);
+  const auto b = splat<W256>("ffeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeee"_hex);
+  EXPECT_TRUE(all(mod_add(a, b, p) == splat<W256>("ffeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeedfeeeef2bf"_hex)));
+  EXPECT_TRUE(all(mod_sub(a, b, p) == splat<W256>("0011111111111111111111111111111111111111111111111111110111111112"_hex)));
+  EXPECT_TRUE(all(mod_shift_left_one(a, p) == splat<W256>("ffffffffffffffffffffffffffffffffffffffffffffffffffffffe1000003d1"_hex)));
+}
+
+// ------------------------------------------------------------------ tests/mgry.cpp
+TEST(Mgry, FromTo) {                                                                          // :32-50
+  using WMBN = wide_mgry_bignum<W256, K1P>;
+  for (auto const& v : {"eeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeeee"_hex, "0168db3a8eca3fd7d4d08943182e189aef318068ba8853d77cb49c17bae00c0e"_hex,
+                        "2714dac0b974321b75d6ef64e7c3b118adb2801bf674282df5712cd2af390f79"_hex, "a3fc64fece6f3e1effab4045a9a54faa49a228f787025f0ecb761145755cb2d0"_hex,
+                        "3af178b78710adae9cc096188ed09c210078aaa7e965ef83d22a91f21fec4eb5"_hex, "688c743cde3987e299d2b028038ddc12dc02e7033c9d3c8f4d20edf9544232aa"_hex,
+                        "45e29166c6441f0fd27e3b85a205f1e102b025cc8e8ea158ab4885a22ed68905"_hex}) {
+    const auto a = splat<W256>(v);
+    EXPECT_TRUE(all(WMBN::from_classical(a).to_classical() == a));
+  }
+}
+TEST(Mgry, Reduce) {                                                                          // :52-76: reduce(mul(a,b)) == a*b*R^-1 == mgry_mul
+  using WMBN = wide_mgry_bignum<W256, K1P>;
+  const auto a = splat<W256>("00000000000AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA"_hex), b = splat<W256>("00000000000BBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBB"_hex);
+  EXPECT_TRUE(all(details::mgry_reduce<K1P>(mul(a, b)) == mgry_mul(WMBN{a}, WMBN{b}).wbn()));
+  const auto four = splat<W256>("0000000000000000000000000000000000000000000000000000000000000004"_hex), five = splat<W256>("0000000000000000000000000000000000000000000000000000000000000005"_hex);
+  // 4*5*R^-1, brought back with one from_classical (x R), is 20
+  const auto r = details::mgry_reduce<K1P>(mul(four, five));
+  EXPECT_TRUE(all(WMBN::from_classical(r).wbn() == splat<W256>("0000000000000000000000000000000000000000000000000000000000000014"_hex)));
+}
+TEST(Mgry, Ops) {                                                                             // :78-120
+  using WMBN = wide_mgry_bignum<W256, K1P>;
+  const auto ma = WMBN::from_classical(splat<W256>("FFFFFFFFFFFFFFFFFFFFFF000000000000000000000000000000000000000004"_hex));
+  const auto mb = WMBN::from_classical(splat<W256>("FFFFFFFFFFFFFFFFFFFFFF000000000000000000000000000000000000000005"_hex));
+  EXPECT_TRUE(all((ma + mb).to_classical() == splat<W256>("fffffffffffffffffffffe0000000000000000000000000000000001000003da"_hex)));
+  EXPECT_TRUE(all((ma - mb).to_classical() == splat<W256>("fffffffffffffffffffffffffffffffffffffffffffffffffffffffefffffc2e"_hex)));
+  EXPECT_TRUE(all((mb - ma).to_classical() == splat<W256>("0000000000000000000000000000000000000000000000000000000000000001"_hex)));
+  struct { std::array<uint8_t, 32> e, r; } pows[] = {
+    {"FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2D"_hex, "DC1B98237FD316F9AEE7342E6DC7629A75A99A9E9EF591170282CE3E1D8E26ED"_hex},
+    {"0000000000000000000000000000000000000000000000000000000000000002"_hex, "fffffffffffffdfffff85600000000000001000003d10001000007a9000eab68"_hex},
+    {"00000000000F0000000000000000000000000000000000000000000000000001"_hex, "a51e978903ca7fcd788382ff283366ad7457d27c7aac417127a8723626773516"_hex},
+    {"0000000000000000000000000000000000000000000000000000000000000000"_hex, "0000000000000000000000000000000000000000000000000000000000000001"_hex}};
+  for (auto const& c : pows) EXPECT_TRUE(all(mgry_pow(ma, bn_from_bytes_BE<bignum_256>(c.e)).to_classical() == splat<W256>(c.r)));
+}
+TEST(Mgry, Gfp) {                                                                             // :122-150
+  using GFP = GFp<W256, K1P>;
+  EXPECT_TRUE(all(GFP::from_classical(splat<W256>("FFFFFFFFFFFFFFFFFFFFFF000000000000000000000000000000000000000004"_hex)).inverse().to_classical() ==
+                  splat<W256>("DC1B98237FD316F9AEE7342E6DC7629A75A99A9E9EF591170282CE3E1D8E26ED"_hex)));
+  const auto ma = GFP::from_classical(splat<W256>("b560fd7b259468b53c3a1623f35786a491fcb1fcdfbb0165da4dccce1f185b60"_hex));
+  const auto root = ma.sqrt();
+  EXPECT_TRUE(root.has_value());
+  if (root) EXPECT_TRUE(all(root->to_classical() == splat<W256>("a59f1be7c1f892ff2adf14187e9cff7666112af579bc1a11b63e248098567e71"_hex)));
+  const auto Z = ma + ma.opposite();
+  EXPECT_TRUE(all(Z.wbn() == W256{bignum_256{}}));
+}
+
+// ------------------------------------------------------------------ tests/curve_point.cpp
+TEST(CurvePoint, FromXAndRoundTrip) {
+  using Curve = curve_nist_p256; using WCP = wide_curve_point<Curve>; using WJCP = wide_jacobian_curve_point<Curve>;
+  const auto x = splat<W256>("ce11d601ec0e947529e66021a0cd3d57518d58d0d5f2eb7ed75805d78c986e60"_hex);
+  const auto pt = WCP::from_x(x);
+  EXPECT_TRUE(pt.has_value());
+  if (!pt) return;
+  EXPECT_TRUE(all(pt->y() == splat<W256>("f2a40cfbb248ae2c7749c76641b51b7137ccad8916931adf83b857e418fad591"_hex)));
+  EXPECT_TRUE(all(WJCP::from_affine(*pt).to_affine() == *pt));
+  EXPECT_FALSE(WCP::from_x(splat<W256>("0000000000000000000000000000000000000000000000000000000000000005"_hex)).has_value() &&
+               WCP::from_x(splat<W256>("0000000000000000000000000000000000000000000000000000000000000006"_hex)).has_value() &&
+               WCP::from_x(splat<W256>("0000000000000000000000000000000000000000000000000000000000000007"_hex)).has_value());   // not every x is on the curve
+}
+
+// ------------------------------------------------------------------ tests/curve_group.cpp
+namespace {
+using Curve = curve_nist_p256; using CG = curve_group<Curve>;
+const auto G2x = "7cf27b188d034f7e8a52380304b51ac3c08969e277f21b35a60b48fc47669978"_hex, G2y = "07775510db8ed040293d9ac69f7430dbba7dade63ce982299e04b79d227873d1"_hex;
+const auto G3x = "5ecbe4d1a6330a44c8f7ef951d4bf165e6c6b721efada985fb41661bc6e7fd6c"_hex, G3y = "8734640c4998ff7e374b06ce1a64a2ecd82ab036384fb83d9a79b127a27d5032"_hex;
+const auto G5x = "51590b7a515140d2d784c85608668fdfef8c82fd1f5be52421554a0dc3d033ed"_hex, G5y = "e0c17da8904a727d8ae1bf36bf8a79260d012f00d4d80888d1d0bb44fda16da4"_hex;
+template <class WJ, class A> bool affine_is(WJ const& J, A const& x, A const& y) { const auto p = J.to_affine(); return all(p.x() == splat<W256>(x)) && all(p.y() == splat<W256>(y)); }
+}
+TEST(CurveGroup, DBLU) {                                                                      // :38-52
+  auto G = CG::WJG();
+  const auto D = CG::DBLU(G);
+  EXPECT_TRUE(all(G.z().wbn() == D.z().wbn()));
+  EXPECT_TRUE(all(G.to_affine() == CG::WG()));
+  EXPECT_TRUE(affine_is(D, G2x, G2y));
+}
+TEST(CurveGroup, ZADDU_TRPLU) {                                                               // :54-76
+  auto G = CG::WJG();
+  const auto D = CG::DBLU(G);
+  const auto T = CG::ZADDU(G, D);
+  EXPECT_TRUE(all(T.z().wbn() == G.z().wbn()));
+  EXPECT_TRUE(affine_is(T, G3x, G3y));
+  G = CG::WJG();
+  EXPECT_TRUE(affine_is(CG::TRPLU(G), G3x, G3y));
+}
+TEST(CurveGroup, ZDAU) {                                                                      // :78-94
+  auto G = CG::WJG();
+  auto D = CG::DBLU(G);
+  const auto F = CG::ZDAU(D, G);
+  EXPECT_TRUE(all(F.z().wbn() == G.z().wbn()));
+  EXPECT_TRUE(affine_is(F, G5x, G5y));
+}
+TEST(CurveGroup, Swap) {                                                                      // :96-115
+  auto G = CG::WJG();
+  auto D = CG::DBLU(G);
+  const auto Z = hip::mask::filled(4, false);
+  auto a = G, b = D;
+  swap_if(Z, a, b);
+  EXPECT_TRUE(all(a == G)); EXPECT_TRUE(all(b == D));
+  swap_if(!Z, a, b);
+  EXPECT_TRUE(all(a == D)); EXPECT_TRUE(all(b == G));
+}
+TEST(CurveGroup, ScalarMult) {                                                                // :117-173
+  const auto G = CG::WJG();
+  struct { std::array<uint8_t, 32> k, x, y; } cases[] = {
+    {"0000000000000000000000000000000000000000000000000000000000000005"_hex, G5x, G5y},
+    {"0bc1b1f28709decb543d9677d2cc9942348f6b984deff409430740942ff38827"_hex, "1b7721565b2c4a9f203bbccc6b531df2789fde0d135c76db71e4a7bbab9e85b2"_hex, "393655bcc30f67f3a4e257b39685657d7c8df7b2a132b49c848003e300c8dcd1"_hex},
+    {"0a891cecc2bf13b0aca744434a9c9f4bd7bf5c8ed86e2f76e7df72bad813bd80"_hex, "f411d79e2997b2954975046d23b0e4a69ce580a4a81e1bed18fef6fd9ea4a912"_hex, "43895f527937e816c3d7c0a2370002796d3cd4860cb034df86cbe7da227d9113"_hex}};
+  for (auto const& c : cases) {
+    const auto xs = bn_from_bytes_BE<bignum_256>(c.k);
+    EXPECT_TRUE(affine_is(CG::scalar_mult(W256{xs}, G), c.x, c.y));
+    EXPECT_TRUE(affine_is(CG::scalar_mult_1s(xs, G), c.x, c.y));
+    EXPECT_TRUE(affine_is(scalar_mult_p256(W256{xs}, G), c.x, c.y));                          // lib/scalar_mult_p256.cpp:10-12
+    EXPECT_TRUE(all(CG::scalar_mult(W256{xs}, G) == CG::scalar_mult_1s(xs, G)));             // Jacobian level too
+  }
+}
+// Beyond the reference's tests: runtime-length batches and the second curve through the same API.
+TEST(Batch, RuntimeLengthAndSecp256k1) {
+  using K = curve_secp256k1; using KG = curve_group<K>;
+  const size_t n = 1000;
+  W256 k(n, [](size_t i, size_t) { bignum_256 b; b.limbs = {0x9e3779b97f4a7c15ull * (i + 1), i, ~i, 0x0123456789abcdefull ^ (i << 20)}; return b; });
+  const auto J = KG::scalar_mult(k, KG::WJG(n));
+  const auto J1 = KG::scalar_mult(W256(n, k.get(17)), KG::WJG(n));
+  EXPECT_TRUE(J.size() == n);
+  EXPECT_TRUE(J.x().wbn().get(17) == J1.x().wbn().get(0) && J.z().wbn().get(17) == J1.z().wbn().get(999));
+  const auto five = KG::scalar_mult(W256(n, bignum_256::from(5)), KG::WJG(n)).to_affine();   // 5G on secp256k1
+  EXPECT_TRUE(all(five.x() == W256(n, bn_from_bytes_BE<bignum_256>("2f8bde4d1a07209355b4a7250a5c5128e88b84bddc619ab7cba8d569b240efe4"_hex))));
+  EXPECT_TRUE(all(five.y() == W256(n, bn_from_bytes_BE<bignum_256>("d8ac222636e5e3d6d4dba9dda6c9c426f788271bab0d6840dca87d3aa6ac62d6"_hex))));
+}
+
+int main() { return mini::run_all(); }
