@@ -19,7 +19,11 @@
 
 namespace ecsimd_hip {
 
-enum : int { CURVE_P256 = 0, CURVE_SECP256K1 = 1 };
+// CURVE_SECP256K1_CLASSICAL is internal: the same field and curve as CURVE_SECP256K1 with elements
+// kept in the CLASSICAL domain (x instead of x*R), where p = 2^256 - 2^32 - 977 allows a
+// pseudo-Mersenne reduction.  x -> x*R is a field isomorphism, so a formula evaluated in either
+// domain yields the same element; kernels convert at their boundary and the C ABI never sees it.
+enum : int { CURVE_P256 = 0, CURVE_SECP256K1 = 1, CURVE_SECP256K1_CLASSICAL = 2 };
 
 struct fe { uint32_t w[8]; };                  // little-endian 32-bit words
 struct fe2 { uint32_t w[16]; };                // 512-bit product
@@ -53,6 +57,19 @@ template <> struct curve_consts<CURVE_SECP256K1> {
   static constexpr uint32_t GY[8]   = {0xfb10d4b8u, 0x9c47d08fu, 0xa6855419u, 0xfd17b448u, 0x0e1108a8u, 0x5da4fbfcu, 0x26a3c465u, 0x483ada77u};
   static constexpr uint32_t MPRIME  = 0xd2253531u;
 };
+
+template <> struct curve_consts<CURVE_SECP256K1_CLASSICAL> {
+  static constexpr uint32_t P[8]    = {0xfffffc2fu, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  static constexpr uint32_t R_P[8]  = {1u, 0, 0, 0, 0, 0, 0, 0};      // "one"
+  static constexpr uint32_t RSQ[8]  = {1u, 0, 0, 0, 0, 0, 0, 0};      // from_classical is the identity here
+  static constexpr uint32_t AM[8]   = {0, 0, 0, 0, 0, 0, 0, 0};
+  static constexpr uint32_t BM[8]   = {7u, 0, 0, 0, 0, 0, 0, 0};
+  static constexpr uint32_t GX[8]   = {0x16f81798u, 0x59f2815bu, 0x2dce28d9u, 0x029bfcdbu, 0xce870b07u, 0x55a06295u, 0xf9dcbbacu, 0x79be667eu};
+  static constexpr uint32_t GY[8]   = {0xfb10d4b8u, 0x9c47d08fu, 0xa6855419u, 0xfd17b448u, 0x0e1108a8u, 0x5da4fbfcu, 0x26a3c465u, 0x483ada77u};
+  static constexpr uint32_t MPRIME  = 0u;                             // unused
+};
+template <int CURVE> struct curve_domain { static constexpr int fast = CURVE; };                       // domain the hot loops run in
+template <> struct curve_domain<CURVE_SECP256K1> { static constexpr int fast = CURVE_SECP256K1_CLASSICAL; };
 
 template <int CURVE, const uint32_t (&ARR)[8]> ECS_DEV fe fe_const() {
   fe r;
@@ -432,8 +449,62 @@ template <int CURVE> ECS_DEV fe mgry_reduce_generic(fe2& t) {
   return res;
 }
 
+// secp256k1, classical domain: T mod p with p = 2^256 - c, c = 2^32 + 977.
+//   T = H*2^256 + L  ==  L + H*c       (first fold, S < 2^289)
+//   S = h2*2^256 + S_lo == S_lo + h2*c  (second fold, h2 < 2^33, result < 2^256 + 2^67)
+// then the usual conditional subtraction.  8 + 2 multiplies by the 10-bit constant 977 instead of
+// the 72 of a generic Montgomery reduction; H*2^32 is a word shift.
+ECS_DEV fe reduce_secp256k1_classical(fe2& t) {
+  const uint32_t K = 977u;
+  fe lo, hi, H, A;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint64_t pj = mul_wide(t.w[8 + j], K);
+    lo.w[j] = (uint32_t)pj; hi.w[j] = (uint32_t)(pj >> 32);        // hi < 2^10
+    H.w[j] = t.w[8 + j]; A.w[j] = t.w[j];
+  }
+  const uint32_t ca = add8(A, lo);         // A = L + sum lo_j 2^(32 j)
+  const uint32_t cb = add8(H, hi);         // H = H + sum hi_j 2^(32 j)     (enters one word higher)
+  // S = A + (H << 32) + ca*2^256 + cb*2^288: words s0 = A0, s_j = A_j + H_(j-1), s8 = ca + H_7, s9 = cb
+  uint32_t s8 = ca, s9 = cb;
+  asm("v_add_co_u32 %0, vcc, %0, %9\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %10, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %2, %11, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %3, %12, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %4, %13, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %5, %14, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %6, %15, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, %7, %16, vcc\n\t"
+      "v_addc_co_u32 %8, vcc, 0, %8, vcc"
+      : "+v"(A.w[1]), "+v"(A.w[2]), "+v"(A.w[3]), "+v"(A.w[4]), "+v"(A.w[5]), "+v"(A.w[6]), "+v"(A.w[7]), "+v"(s8), "+v"(s9)
+      : "v"(H.w[0]), "v"(H.w[1]), "v"(H.w[2]), "v"(H.w[3]), "v"(H.w[4]), "v"(H.w[5]), "v"(H.w[6]), "v"(H.w[7])
+      : "vcc");
+  // second fold: F = h2*977 + (h2 << 32) with h2 = s8 + s9*2^32 (s9 <= 2), three words
+  const uint64_t m0 = mul_wide(s8, K);
+  uint64_t m1 = (uint64_t)(uint32_t)(m0 >> 32);
+  mac_nocarry(m1, s9, K);
+  uint32_t f0 = (uint32_t)m0, f1 = (uint32_t)m1, f2 = (uint32_t)(m1 >> 32), top;
+  asm("v_add_co_u32 %1, vcc, %1, %12\n\t"          // f1 += s8
+      "v_addc_co_u32 %2, vcc, %2, %13, vcc\n\t"    // f2 += s9 + carry
+      "v_add_co_u32 %3, vcc, %3, %0\n\t"           // A0 += f0
+      "v_addc_co_u32 %4, vcc, %4, %1, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %5, %2, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, 0, %7, vcc\n\t"
+      "v_addc_co_u32 %8, vcc, 0, %8, vcc\n\t"
+      "v_addc_co_u32 %9, vcc, 0, %9, vcc\n\t"
+      "v_addc_co_u32 %10, vcc, 0, %10, vcc\n\t"
+      "v_addc_co_u32 %11, vcc, 0, 0, vcc"
+      : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(A.w[0]), "+v"(A.w[1]), "+v"(A.w[2]), "+v"(A.w[3]), "+v"(A.w[4]), "+v"(A.w[5]), "+v"(A.w[6]), "+v"(A.w[7]), "=v"(top)
+      : "v"(s8), "v"(s9)
+      : "vcc");
+  cond_sub_p<CURVE_SECP256K1_CLASSICAL>(A, top);
+  return A;
+}
+
 template <int CURVE> ECS_DEV fe mgry_reduce(fe2& t) {
   if constexpr (CURVE == CURVE_P256) return mgry_reduce_p256(t);
+  else if constexpr (CURVE == CURVE_SECP256K1_CLASSICAL) return reduce_secp256k1_classical(t);
   else return mgry_reduce_generic<CURVE>(t);
 }
 

@@ -28,7 +28,7 @@ template <int C> ECS_DEV void dblu(fe& x, fe& y, fe& rx, fe& ry, fe& z) {
   t = fe_sub<C>(fe_sub<C>(t, B), L);
   const fe S = fe_dbl<C>(t);
   fe M = fe_add<C>(fe_dbl<C>(B), B);
-  if constexpr (C == CURVE_SECP256K1) { /* a = 0: M = 3B + 0 */ } else { M = fe_add<C>(M, FE_CONST(C, AM)); }
+  if constexpr (C != CURVE_P256) { /* secp256k1, a = 0: M = 3B + 0 */ } else { M = fe_add<C>(M, FE_CONST(C, AM)); }
   rx = fe_sub<C>(fe_sqr<C>(M), fe_dbl<C>(S));
   const fe Lm8 = fe_shl<C, 3>(L);
   ry = fe_sub<C>(fe_mul<C>(M, fe_sub<C>(S, rx)), Lm8);
@@ -71,8 +71,10 @@ template <int C> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe& y2, fe& z) {
   // Y3' = (dy + (W1' - X3'))^2 - D' - C - 2A1'
   fe Y3p = fe_sqr<C>(fe_sub<C>(dy, u));
   Y3p = fe_sub<C>(fe_sub<C>(fe_sub<C>(Y3p, Dp), Cc), A1p2);
-  const fe W1 = fe_mul<C>(fe_shl<C, 2>(X3pc), Cc);
-  const fe W2 = fe_mul<C>(fe_shl<C, 2>(W1p), Cc);
+  // W1 = 4*X3'*C and W2 = 4*W1'*C: quadruple C once instead of X3' and W1' (same residues)
+  const fe C4 = fe_shl<C, 2>(Cc);
+  const fe W1 = fe_mul<C>(X3pc, C4);
+  const fe W2 = fe_mul<C>(W1p, C4);
   const fe ym = fe_sub<C>(Y3p, A1p2);
   const fe D = fe_sqr<C>(ym);
   const fe A1 = fe_mul<C>(Y3p, fe_sub<C>(W1, W2));
@@ -118,6 +120,8 @@ template <> struct curve_exps<CURVE_SECP256K1> {
   static constexpr uint32_t P_SQRT[8] = {0xbfffff0cu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
 };
 
+template <> struct curve_exps<CURVE_SECP256K1_CLASSICAL> : curve_exps<CURVE_SECP256K1> {};
+
 template <int C> ECS_DEV fe fe_inverse(const fe& a) { return fe_pow<C>(a, curve_exps<C>::P_M2); }     // gfp.h:42-44
 
 // jacobian_curve_point.h:33-42 to_affine: one inversion per lane; returns classical (x, y).
@@ -149,17 +153,23 @@ template <int C> ECS_DEV jpoint scalar_mult_ladder(const uint32_t* __restrict__ 
     fe_cswap(m, px, bx);
     fe_cswap(m, py, by);
   }
+  // Each iteration is swap(m); ZDAU; swap(m) in the reference (curve_group.h:206-210).  The second
+  // swap of iteration i and the first of iteration i+1 compose into ONE swap with mask m_i ^ m_{i+1}
+  // (swapping twice is the identity), which halves the select work without changing any value.
+  uint32_t prev = 0;
   for (int w = 0; w < 8; ++w) {
     if (w > 0) kw = kwords[w];
     for (int b = (w == 0 ? 2 : 0); b < 32; ++b) {
       const uint32_t m = 0u - ((kw >> b) & 1u);       // utility.h:45-51 wide_mask_bit
-      fe_cswap(m, px, bx);                             // swap.h:47-56 swap_if_same_z
-      fe_cswap(m, py, by);
+      const uint32_t sw = m ^ prev;
+      fe_cswap(sw, px, bx);                            // swap.h:47-56 swap_if_same_z
+      fe_cswap(sw, py, by);
       zdau<C>(bx, by, px, py, z);                      // base = ZDAU(base, P)
-      fe_cswap(m, px, bx);
-      fe_cswap(m, py, by);
+      prev = m;
     }
   }
+  fe_cswap(prev, px, bx);
+  fe_cswap(prev, py, by);
   // even k: subtract the original point once (curve_group.h:214-217)
   const fe oppy = fe_neg<C>(ym);
   const jpoint Psub = add_z2_1<C>(px, py, z, xm, oppy);
