@@ -41,6 +41,9 @@ void zdau(hipStream_t s, int curve, const uint64_t* px, const uint64_t* py, cons
 void add_z2_1(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH(add_z2_1, s, ax, ay, az, bx, by, rx, ry, rz, n); }
 void trplu(hipStream_t s, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH(trplu, s, px, py, pz, rx, ry, rz, n); }
 void scalar_mult(hipStream_t s, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) { DISPATCH(scalar_mult, s, k, k_stride, x, y, ox, oy, oz, n, flags); }
+void to_affine_batched(hipStream_t s, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool in_fast) { DISPATCH(to_affine_batched, s, jx, jy, jz, x, y, n, in_fast); }
+void pack_table(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table, s, tx, ty, table); }
+void base_windowed(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed, s, k, table, ox, oy, oz, n); }
 #undef DISPATCH
 } }
 
@@ -51,6 +54,9 @@ struct ecsimd_hip_ctx {
   hipStream_t stream;
   int cus;
   uint32_t* sink;      // 4 KiB scratch: peak-probe sink [0, 1024) and the shared scalar at word 1024-8
+  uint32_t* window_table[2];   // per curve: 64 x 16 affine multiples d*16^w*G (built on first use)
+  uint64_t* workspace;         // grow-only scratch for the windowed path's Jacobian intermediates
+  size_t workspace_bytes;
   char err[256];
 };
 
@@ -84,6 +90,68 @@ void words_to_limbs(const uint32_t (&w)[8], uint64_t out[4]) {
   for (int i = 0; i < 4; ++i) out[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
 }
 
+// Grow-only device scratch.  hipMalloc synchronises: callers that capture graphs warm the path up once.
+int ensure_workspace(ecsimd_hip_ctx* ctx, size_t bytes) {
+  if (ctx->workspace_bytes >= bytes) return ECSIMD_HIP_OK;
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess && ctx->workspace) e = hipFree(ctx->workspace);
+  ctx->workspace = nullptr; ctx->workspace_bytes = 0;
+  if (e == hipSuccess) e = hipMalloc(&ctx->workspace, bytes);
+  if (e != hipSuccess) return fail(ctx, e, "workspace hipMalloc");
+  ctx->workspace_bytes = bytes;
+  return ECSIMD_HIP_OK;
+}
+
+// 64 x 16 table of d * 16^w * G, produced with the (parity-checked) ladder kernel itself.
+int ensure_window_table(ecsimd_hip_ctx* ctx, int curve) {
+  if (ctx->window_table[curve]) return ECSIMD_HIP_OK;
+  const size_t entries = 64 * 16;
+  uint64_t host_k[entries * 4];
+  memset(host_k, 0, sizeof host_k);
+  for (int w = 0; w < 64; ++w)
+    for (int d = 0; d < 16; ++d) host_k[((size_t)w * 16 + d) * 4 + (4 * w) / 64] = (uint64_t)d << ((4 * w) % 64);
+  int rc = ensure_workspace(ctx, 6 * entries * 32);
+  if (rc != ECSIMD_HIP_OK) return rc;
+  uint64_t* kd = ctx->workspace; uint64_t* tx = kd + entries * 4; uint64_t* ty = tx + entries * 4;
+  uint32_t* table = nullptr;
+  hipError_t e = hipMalloc(&table, launch::WINDOW_TABLE_BYTES);
+  if (e == hipSuccess) e = hipMemcpyAsync(kd, host_k, sizeof host_k, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // host_k is a stack buffer
+  if (e != hipSuccess) return fail(ctx, e, "window table setup");
+  {   // ladder (Jacobian, fast domain) into scratch, then affine classical (x, y); d = 0 rows are unused
+    uint64_t* jx = ty + entries * 4; uint64_t* jy = jx + entries * 4; uint64_t* jz = jy + entries * 4;
+    launch::scalar_mult(ctx->stream, curve, kd, 4, nullptr, nullptr, jx, jy, jz, entries, ECSIMD_HIP_OUT_AFFINE);
+    launch::to_affine_batched(ctx->stream, curve, jx, jy, jz, tx, ty, entries, true);
+  }
+  launch::pack_table(ctx->stream, curve, tx, ty, table);
+  e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) { (void)hipFree(table); return fail(ctx, e, "window table build"); }
+  ctx->window_table[curve] = table;
+  return ECSIMD_HIP_OK;
+}
+
+bool overlaps(const void* a, const void* b) { return a == b; }
+
+// The reference ladder, then (for OUT_AFFINE) one simultaneous inversion over the whole batch.
+int run_ladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y,
+               uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
+  if (n == 0) return ECSIMD_HIP_OK;
+  if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e != hipSuccess) return fail(ctx, e, "hipSetDevice");
+  if (flags & ECSIMD_HIP_OUT_AFFINE) {
+    int rc = ensure_workspace(ctx, 3 * n * 32);
+    if (rc != ECSIMD_HIP_OK) return rc;
+    uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
+    launch::scalar_mult(ctx->stream, curve, k, k_stride, x, y, jx, jy, jz, n, flags);
+    launch::to_affine_batched(ctx->stream, curve, jx, jy, jz, ox, oy, n, true);
+  } else {
+    launch::scalar_mult(ctx->stream, curve, k, k_stride, x, y, ox, oy, oz, n, flags);
+  }
+  e = hipGetLastError();
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult launch");
+}
 }  // namespace
 
 extern "C" {
@@ -101,6 +169,7 @@ int ecsimd_hip_init(int device, ecsimd_hip_ctx** out) {
   ecsimd_hip_ctx* ctx = new (std::nothrow) ecsimd_hip_ctx();
   if (!ctx) return ECSIMD_HIP_ERR_HIP;
   ctx->device = device; ctx->cus = prop.multiProcessorCount; ctx->err[0] = 0; ctx->sink = nullptr;
+  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ECSIMD_HIP_ERR_HIP; }
   ctx->stream = ctx->own_stream;
   if (hipMalloc(&ctx->sink, 4096) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ECSIMD_HIP_ERR_HIP; }
@@ -112,6 +181,7 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->sink);
+  (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->workspace);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return ECSIMD_HIP_OK;
@@ -225,7 +295,11 @@ int ecsimd_hip_gfp_sqrt(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint6
 int ecsimd_hip_from_affine(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); RUN(launch::from_affine(s, curve, x, y, jx, jy, jz, n)); }
 int ecsimd_hip_to_affine(ecsimd_hip_ctx* ctx, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); REQUIRE_PTR(x); REQUIRE_PTR(y); RUN(launch::to_affine(s, curve, jx, jy, jz, x, y, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); REQUIRE_PTR(x); REQUIRE_PTR(y);
+  // Simultaneous inversion uses x[] as scratch: only when the outputs do not alias the inputs.
+  const bool alias = overlaps(x, jx) || overlaps(x, jy) || overlaps(x, jz) || overlaps(y, jx) || overlaps(y, jy) || overlaps(y, jz) || overlaps(x, y);
+  if (alias) RUN(launch::to_affine(s, curve, jx, jy, jz, x, y, n));
+  RUN(launch::to_affine_batched(s, curve, jx, jy, jz, x, y, n, false)); }
 int ecsimd_hip_compute_y(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, uint64_t* y, uint8_t* ok, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); RUN(launch::compute_y(s, curve, x, y, ok, n)); }
 int ecsimd_hip_dblu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
@@ -246,18 +320,33 @@ int ecsimd_hip_trplu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py,
 int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_PTR(oy);
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
-  RUN(launch::scalar_mult(s, curve, k, 4, x, y, ox, oy, oz, n, flags)); }
+  return run_ladder(ctx, curve, k, 4, x, y, ox, oy, oz, n, flags); }
 int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[4], const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_PTR(oy); if (!k1) return bad(ctx, "k1 is null");
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
   launch::words8 w; for (int i = 0; i < 4; ++i) { w.w[2 * i] = (uint32_t)k1[i]; w.w[2 * i + 1] = (uint32_t)(k1[i] >> 32); }
   uint32_t* kdev = ctx->sink + 1024 - 8;    // 32-byte aligned slot at the end of the scratch page
-  RUN((store_words(s, w, kdev),
-       launch::scalar_mult(s, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, oz, n, flags))); }
+  if (n == 0) return ECSIMD_HIP_OK;
+  (void)hipSetDevice(ctx->device);
+  store_words(ctx->stream, w, kdev);
+  return run_ladder(ctx, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, oz, n, flags); }
 int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(ox); REQUIRE_PTR(oy);
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
-  RUN(launch::scalar_mult(s, curve, k, 4, nullptr, nullptr, ox, oy, oz, n, flags)); }
+  if (flags & ECSIMD_HIP_ALG_WINDOWED) {
+    // 4-bit windows over an LDS-resident table, then one simultaneous inversion: affine output only
+    // (the Jacobian representative differs from the reference ladder's -- SURVEY.md 8(a) level A).
+    if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
+    if (n == 0) return ECSIMD_HIP_OK;
+    (void)hipSetDevice(ctx->device);
+    int rc = ensure_window_table(ctx, curve);
+    if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 3 * n * 32);
+    if (rc != ECSIMD_HIP_OK) return rc;
+    uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
+    RUN((launch::base_windowed(s, curve, k, ctx->window_table[curve], jx, jy, jz, n),
+         launch::to_affine_batched(s, curve, jx, jy, jz, ox, oy, n, true)));
+  }
+  return run_ladder(ctx, curve, k, 4, nullptr, nullptr, ox, oy, oz, n, flags); }
 int ecsimd_hip_scalar_mult_p256(ecsimd_hip_ctx* ctx, const uint64_t* k, const uint64_t* xm, const uint64_t* ym, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) {
   return ecsimd_hip_scalar_mult(ctx, ECSIMD_HIP_P256, k, xm, ym, ox, oy, oz, n, ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN); }
 

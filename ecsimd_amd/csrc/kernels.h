@@ -49,6 +49,11 @@ void trplu(hipStream_t, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uin
 // flags: ECSIMD_HIP_BASE_* | ECSIMD_HIP_OUT_*.
 void scalar_mult(hipStream_t, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y,
                  uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
+// k_affine_<curve>.hip: simultaneous-inversion to_affine (x, y must not alias the inputs), the
+// 4-bit-window table packer and the fixed-base windowed multiplication (Jacobian out, fast domain).
+void to_affine_batched(hipStream_t, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool in_fast_domain);
+void pack_table(hipStream_t, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
+void base_windowed(hipStream_t, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
 
 // per-curve pieces (one translation unit each)
 template <int C> struct point_launch {
@@ -61,7 +66,12 @@ template <int C> struct point_launch {
   static void add_z2_1(hipStream_t, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
   static void trplu(hipStream_t, uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
   static void scalar_mult(hipStream_t, const uint64_t*, int, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t, int);
+  // k_affine_<curve>.hip
+  static void to_affine_batched(hipStream_t, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool in_fast_domain);
+  static void pack_table(hipStream_t, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
+  static void base_windowed(hipStream_t, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
 };
+constexpr size_t WINDOW_TABLE_BYTES = 64 * 16 * 64;   // 64 windows x 16 digits x (x, y)
 
 }  // namespace launch
 }  // namespace ecsimd_hip

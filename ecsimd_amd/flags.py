@@ -3,3 +3,4 @@ BASE_CLASSICAL = 0
 BASE_MGRY = 1
 OUT_JACOBIAN = 0
 OUT_AFFINE = 2
+ALG_WINDOWED = 4

@@ -54,7 +54,11 @@ enum {
   ECSIMD_HIP_BASE_CLASSICAL = 0,   /* base point (x, y) classical: from_affine is applied first */
   ECSIMD_HIP_BASE_MGRY = 1,        /* base point already Montgomery form (what scalar_mult_p256 receives) */
   ECSIMD_HIP_OUT_JACOBIAN = 0,     /* out = (X, Y, Z) Montgomery form, as curve_group::scalar_mult returns */
-  ECSIMD_HIP_OUT_AFFINE = 2        /* out = to_affine(): (x, y) classical; oz may be NULL */
+  ECSIMD_HIP_OUT_AFFINE = 2,       /* out = to_affine(): (x, y) classical; oz may be NULL */
+  ECSIMD_HIP_ALG_WINDOWED = 4      /* scalar_mult_base + OUT_AFFINE only: 4-bit windows over an LDS-resident table of
+                                      d*16^w*G and one simultaneous inversion instead of the reference's ladder.  Same
+                                      affine result for every k with k mod n not in {0, n-1} (the ladder's degenerate
+                                      scalars, where the reference itself returns a meaningless point); k = 0 mod n -> (0, 0) */
 };
 
 /* ---- context, stream and memory ------------------------------------------------------- */
@@ -117,7 +121,8 @@ int ecsimd_hip_gfp_opposite(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint6
 int ecsimd_hip_gfp_sqrt(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n);
 
 /* ---- L4/L5: points and the group ------------------------------------------------------ */
-/* jacobian_curve_point.h:25-31 from_affine (Z := R mod p), :33-42 to_affine (one inversion per element) */
+/* jacobian_curve_point.h:25-31 from_affine (Z := R mod p), :33-42 to_affine.  to_affine uses Montgomery's
+ * simultaneous inversion (one inversion per ~32 elements; identical values) unless x/y alias the inputs. */
 int ecsimd_hip_from_affine(ecsimd_hip_ctx*, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n);
 int ecsimd_hip_to_affine(ecsimd_hip_ctx*, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n);
 /* curve_group.h:43-58 compute_y for y^2 = x^3 + a x + b (classical in/out), per-element ok[] */

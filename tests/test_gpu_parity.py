@@ -246,6 +246,64 @@ def test_scalar_mult_vs_oracle(gpu, oracle, cv):
     assert all(np.array_equal(u, v) for u, v in zip(gpu.scalar_mult_1s(cv, k1, bx[:256], by[:256]), exp1)), "scalar_mult_1s"
 
 
+@pytest.mark.parametrize("cv", CURVES)
+def test_windowed_fixed_base_matches_the_ladder_at_affine_level(engine, oracle, cv):
+    """BASELINE configs[2] algorithm: 4-bit windows over an LDS table + simultaneous inversion.  A different
+    algorithm from the reference's ladder, so parity is affine-level (SURVEY.md 8(a) level A): identical
+    (x, y) for every non-degenerate scalar; k = 0 mod n gives (0, 0)."""
+    import torch
+    from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED
+    c = CURVE_PARAMS[cv]; order = c["n"]
+    edge = [1, 2, 3, 15, 16, 17, 255, 256, 2**64 - 1, 2**64, 2**128 + 1, 2**252, 15 * 2**252, order - 2, order + 1, order + 2, 2**256 - 1,
+            int("f0" * 32, 16), int("0f" * 32, 16), int("10" * 32, 16), 2**255, 0x1000000000000000000000000000000000000000000000000000000000000000]
+    n = (1 << 18) + 77                                      # ragged, and large enough for several elements per lane in the inversion
+    k = fill_random_np(n, SEED, 5); k[:len(edge)] = ints_to_arr(edge)
+    k[100] = from_int(0); k[101] = from_int(order); k[102] = from_int(order - 1)       # degenerate scalars
+    dk = engine.to_device(k)
+    wx, wy = engine.scalar_mult_base(cv, dk, flags=OUT_AFFINE | ALG_WINDOWED)
+    lx, ly = engine.scalar_mult_base(cv, dk, flags=OUT_AFFINE)                        # reference ladder + (batched) to_affine
+    wxn, wyn, lxn, lyn = (engine.to_numpy(t) for t in (wx, wy, lx, ly))
+    keep = np.ones(n, dtype=bool); keep[100:103] = False
+    assert np.array_equal(wxn[keep], lxn[keep]) and np.array_equal(wyn[keep], lyn[keep])
+    assert to_int(wxn[100]) == 0 and to_int(wyn[100]) == 0 and to_int(wxn[101]) == 0 and to_int(wyn[101]) == 0
+    G = (c["gx"], c["gy"])
+    assert (to_int(wxn[102]), to_int(wyn[102])) == (c["gx"], c["p"] - c["gy"])                  # (n-1)G = -G: the windowed path is right where the ladder degenerates
+    for i in list(range(len(edge))) + [n - 1]:
+        assert (to_int(wxn[i]), to_int(wyn[i])) == ec_mul(cv, to_int(k[i]) % order, G), hex(to_int(k[i]))
+    m = 2048
+    ex, ey = oracle.to_affine(cv, oracle.scalar_mult(cv, k[200:200 + m], ints_to_arr([c["gx"]] * m), ints_to_arr([c["gy"]] * m), threads=THREADS))
+    assert np.array_equal(wxn[200:200 + m], ex) and np.array_equal(wyn[200:200 + m], ey)
+    import ctypes as C
+    assert engine.lib.ecsimd_hip_scalar_mult_base(engine.ctx, C.c_int(cv), C.c_void_p(dk.data_ptr()), C.c_void_p(wx.data_ptr()), C.c_void_p(wy.data_ptr()),
+                                                   C.c_void_p(wx.data_ptr()), C.c_size_t(4), C.c_int(ALG_WINDOWED)) == -1      # Jacobian out is not offered
+
+
+@pytest.mark.parametrize("cv", CURVES)
+def test_simultaneous_inversion_to_affine(engine, oracle, cv):
+    """to_affine with Montgomery's trick (non-aliasing outputs) == one inversion per element (aliasing
+    outputs force the per-element kernel) == the oracle; Z = 0 elements give (0, 0) and do not poison
+    their neighbours."""
+    import torch
+    n = (1 << 19) + 5
+    k = engine.fill_random(n, SEED, 6); s = engine.fill_random(n, SEED, 2)
+    bx, by = engine.scalar_mult_base(cv, s, flags=2)
+    J = [t.clone() for t in engine.scalar_mult(cv, k, bx, by)]
+    for i in (0, 1, 77, n - 1, n // 2):
+        J[2][i] = 0                                                             # Z = 0
+    ax, ay = engine.to_affine(cv, J)                                            # batched
+    Jc = [t.clone() for t in J]
+    import ctypes as C
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert engine.lib.ecsimd_hip_to_affine(engine.ctx, C.c_int(cv), p(Jc[0]), p(Jc[1]), p(Jc[2]), p(Jc[0]), p(Jc[1]), C.c_size_t(n)) == 0   # in place
+    assert torch.equal(ax, Jc[0]) and torch.equal(ay, Jc[1])
+    for i in (0, 1, 77, n - 1, n // 2):
+        assert int(ax[i].abs().sum()) == 0 and int(ay[i].abs().sum()) == 0
+    idx = np.concatenate([np.arange(0, 64), np.arange(n - 64, n), np.arange(0, n, n // 1024)])
+    tidx = torch.from_numpy(idx).to(ax.device)
+    ex, ey = oracle.to_affine(cv, tuple(engine.to_numpy(t[tidx]) for t in J))
+    assert np.array_equal(engine.to_numpy(ax[tidx]), ex) and np.array_equal(engine.to_numpy(ay[tidx]), ey)
+
+
 def test_scalar_mult_p256_entry_point(engine, oracle):
     """lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P), P Jacobian Montgomery with Z = mgry(1)."""
     n = 1024; c = CURVE_PARAMS[P256]

@@ -29,7 +29,15 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
         t = time.time(); e.scalar_mult(cv, k, P[0], P[1], flags=1, out=out); torch.cuda.synchronize(); ts.append(time.time() - t)
     dt = min(ts)
     print(f"{nm}: ladder {n/dt/1e6:.2f} M/s  ({dt*1e3:.2f} ms for 2^21)")
-    for extra in sys.argv[1:]:
-        pass
+    ox, oy = e.scalar_mult_base(cv, k, flags=2 | 4); torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        t = time.time(); e.scalar_mult_base(cv, k, flags=2 | 4); torch.cuda.synchronize(); ts.append(time.time() - t)
+    print(f"{nm}: fixed-base windowed (affine out) {n/min(ts)/1e6:.2f} M/s")
+    J = e.scalar_mult(cv, k, P[0], P[1], flags=1)
+    ts = []
+    for _ in range(5):
+        t = time.time(); e.to_affine(cv, J); torch.cuda.synchronize(); ts.append(time.time() - t)
+    print(f"{nm}: to_affine (simultaneous inversion) {n/min(ts)/1e6:.2f} M/s")
 mads, ms = e.peak_mad32(4096); print(f"peak mad32: {mads/ms/1e9:.2f} T/s")
 sys.exit(0 if ok else 1)
