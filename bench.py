@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2-batch", type=int, default=22, help="scalar mults per GPU per step = 2^this")
     ap.add_argument("--curve", default="p256", choices=["p256", "secp256k1"])
+    ap.add_argument("--workload", default="ladder", choices=["ladder", "fixed-base"],
+                    help="ladder: scalar_mult_p256 variable base, the reference's co-Z ladder, Jacobian out (headline, BASELINE configs[3] shape per GPU); "
+                         "fixed-base: k*G with the 4-bit-window LDS table + simultaneous inversion, affine out (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
@@ -49,7 +52,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from ecsimd_amd import Engine, CURVES, BASE_MGRY, OUT_JACOBIAN
+    from ecsimd_amd import Engine, CURVES, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, ALG_WINDOWED
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -79,8 +82,13 @@ def main():
     from ecsimd_amd.shard import ShardedRunner
     runner = ShardedRunner((3, n, 4), torch.int64, eng.tdev, world, rank)
 
-    def compute(o):
-        eng.scalar_mult(curve, k, xm, ym, flags=flags, out=[o[0], o[1], o[2]])
+    if args.workload == "ladder":
+        def compute(o):
+            eng.scalar_mult(curve, k, xm, ym, flags=flags, out=[o[0], o[1], o[2]])
+    else:
+        def compute(o):                                     # affine (x, y); o[2] is unused
+            eng.scalar_mult_base(curve, k, flags=OUT_AFFINE | ALG_WINDOWED, out=[o[0], o[1], o[2]])
+        eng.scalar_mult_base(curve, k[:1024].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED)   # builds the table and the workspace
 
     def step(i, ev0=None, ev1=None):
         runner.step(compute, before=(ev0.record if ev0 is not None else None), after=(ev1.record if ev1 is not None else None))
@@ -109,8 +117,10 @@ def main():
         "value": value, "unit": "scalar_mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32x8 (256-bit integers, 4xu64 limbs)", "data": "synthetic",
-        "config": {"workload": f"scalar_mult_{args.curve} variable-base co-Z ladder (reference algorithm), "
-                               f"batch=2^{args.log2_batch} per GPU, Jacobian Montgomery out",
+        "config": {"workload": (f"scalar_mult_{args.curve} variable-base co-Z ladder (reference algorithm), "
+                                f"batch=2^{args.log2_batch} per GPU, Jacobian Montgomery out") if args.workload == "ladder" else
+                               (f"scalar_mult_{args.curve} fixed-base (G), batch=2^{args.log2_batch} random scalars per GPU, 4-bit window table in LDS "
+                                f"+ simultaneous inversion, affine out"),
                    "global_batch": n * world, "per_gpu_batch": n, "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
     }
 
@@ -119,27 +129,66 @@ def main():
         avg_ms = float(np.mean(kernel_ms))
         mads, ms = eng.peak_mad32(4096)
         peak = mads / (ms * 1e-3) / 1e12
-        achieved = n / (avg_ms * 1e-3) * MAD32_PER_SCALAR_MULT / 1e12
+        if args.workload == "ladder":
+            mad32_unit, bytes_unit, kname = MAD32_PER_SCALAR_MULT, ALGO_BYTES_PER_SCALAR_MULT, "k_scalar_mult"
+        else:
+            # what THIS algorithm needs per scalar: 64 mixed additions x 11 field mults,
+            # 7 mults of the simultaneous-inversion walk and 383/32 of the shared inversion; 32 B in, 64 B out.
+            mad32_unit, bytes_unit, kname = int((64 * 11 + 7 + 383 / 32) * 136), 96, "k_base_windowed + k_to_affine_batched"
+        achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")             # written from rocprofv3 --pmc passes
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"k_scalar_mult_{args.curve}_2^{args.log2_batch}")
+                traffic = json.load(open(tpath)).get(f"{'k_scalar_mult' if args.workload == 'ladder' else 'fixed_base'}_{args.curve}_2^{args.log2_batch}")
             except Exception:
                 traffic = None
         result["roofline"] = {
-            "bound": "valu", "kernel": "k_scalar_mult", "achieved": achieved, "peak": peak, "unit": "Tmad32/s", "frac": achieved / peak,
-            "traffic": traffic, "kernel_ms": avg_ms, "algorithmic_mad32_per_unit": MAD32_PER_SCALAR_MULT,
-            "hbm": {"achieved": n / (avg_ms * 1e-3) * ALGO_BYTES_PER_SCALAR_MULT / 1e9, "peak": 8000.0, "unit": "GB/s",
-                    "algorithmic_bytes_per_unit": ALGO_BYTES_PER_SCALAR_MULT},
+            "bound": "valu", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "Tmad32/s", "frac": achieved / peak,
+            "traffic": traffic, "kernel_ms": avg_ms, "algorithmic_mad32_per_unit": mad32_unit,
+            "hbm": {"achieved": n / (avg_ms * 1e-3) * bytes_unit / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "algorithmic_bytes_per_unit": bytes_unit},
             "peak_source": "ecsimd_hip_peak_mad32: dependency-free v_mad_u64_u32 stream, 8 waves/SIMD, same GPU, same run",
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, runner.last_result(), args.cpu_seconds)
+            if args.workload == "ladder":
+                result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, runner.last_result(), args.cpu_seconds)
+            else:
+                result["cpu_baseline"] = cpu_baseline_fixed_base(eng, curve, k, runner.last_result(), args.cpu_seconds)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline_fixed_base(eng, curve, k, gpu_out, target_s):
+    """Config 3 on the CPU: the reference has ONE way to compute k*G -- scalar_mult(k, WJG) followed by
+    to_affine() (exactly what its benchmark times, benchs/curve_group.cpp:23-35).  Compared with the GPU's
+    windowed result at the affine level; k = 0 / -1 mod n (degenerate in the ladder) are skipped."""
+    import numpy as np
+    from oracle import loader
+    cores = usable_cores()
+    impl, kind = (loader.Reference(), "reference") if loader.reference_available() else (loader.Oracle(), "port")
+    c = impl.constants(curve)
+    m0 = 256 * cores
+    kn = eng.to_numpy(k[:m0])
+    gx, gy = np.tile(c["gx"], (m0, 1)), np.tile(c["gy"], (m0, 1))
+    t = time.perf_counter(); impl.to_affine(curve, impl.scalar_mult(curve, kn, gx, gy, threads=cores)); dt = time.perf_counter() - t
+    m = int(min(k.shape[0], max(m0, (target_s / dt) * m0))); m -= m % 4
+    kn = eng.to_numpy(k[:m]); gx, gy = np.tile(c["gx"], (m, 1)), np.tile(c["gy"], (m, 1))
+    t = time.perf_counter(); J = impl.scalar_mult(curve, kn, gx, gy, threads=cores); ax, ay = impl.to_affine(curve, J); dt = time.perf_counter() - t
+    gx_, gy_ = eng.to_numpy(gpu_out[0][:m]), eng.to_numpy(gpu_out[1][:m])
+    bad = np.nonzero((gx_ != ax).any(axis=1) | (gy_ != ay).any(axis=1))[0]
+    explained = True
+    if len(bad):                                        # reference square() defect (DESIGN.md section 5): the exact oracle must side with the GPU
+        ex = loader.Oracle(faithful=False)
+        ea = ex.to_affine(curve, ex.scalar_mult(curve, kn[bad], gx[bad], gy[bad], threads=min(cores, len(bad))))
+        explained = np.array_equal(ea[0], gx_[bad]) and np.array_equal(ea[1], gy_[bad])
+    return {"value": m / dt, "unit": "scalar_mults/s", "cores": cores, "kind": kind,
+            "sample": f"first {m} scalars of the GPU batch through scalar_mult(k, G) + to_affine (the reference's only fixed-base path), "
+                      f"{dt:.1f} s wall, {cores} threads (to_affine single-threaded)",
+            "lanes_compared": int(m), "lanes_differing_from_gpu": int(len(bad)),
+            "differences_all_explained_by_reference_square_defect": bool(explained)}
 
 
 def usable_cores():

@@ -242,8 +242,9 @@ class Engine:
         self._call("scalar_mult_1s", C.c_int(curve), e, self._ptr(x), self._ptr(y), *[self._ptr(t) for t in r], C.c_size_t(n), C.c_int(flags))
         return tuple(r[:2]) if flags & 2 else tuple(r)
 
-    def scalar_mult_base(self, curve, k, flags=0):
-        n = k.shape[0]; r = [self.empty(n) for _ in range(3)]
+    def scalar_mult_base(self, curve, k, flags=0, out=None):
+        n = k.shape[0]
+        r = out if out is not None else [self.empty(n) for _ in range(3)]
         self._call("scalar_mult_base", C.c_int(curve), self._ptr(k), *[self._ptr(t) for t in r], C.c_size_t(n), C.c_int(flags))
         return tuple(r[:2]) if flags & 2 else tuple(r)
 
