@@ -268,6 +268,8 @@ int ecsimd_hip_mod_add(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const 
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, curve, launch::F_MOD_ADD, a, b, out, n)); }
 int ecsimd_hip_mod_sub(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, curve, launch::F_MOD_SUB, a, b, out, n)); }
+int ecsimd_hip_mod_mul(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::mod_mul(s, curve, a, b, out, n)); }
 int ecsimd_hip_mod_shift_left(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, int count, uint64_t* out, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); if (count < 1) return bad(ctx, "count < 1"); RUN(launch::mod_shift_left(s, curve, a, count, out, n)); }
 int ecsimd_hip_mgry_reduce(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a8, uint64_t* out, size_t n) {

@@ -21,9 +21,17 @@ template <int C, int OP> __global__ void __launch_bounds__(BLOCK) k_unop(const u
   if constexpr (OP == launch::F_MGRY_SQR) r = fe_sqr<C>(x);
   else if constexpr (OP == launch::F_FROM_CLASSICAL) r = fe_from_classical<C>(x);
   else if constexpr (OP == launch::F_TO_CLASSICAL) r = fe_to_classical<C>(x);
-  else if constexpr (OP == launch::F_INVERSE) r = fe_inverse<C>(x);
+  else if constexpr (OP == launch::F_INVERSE) r = from_fast<C>(fe_inverse<curve_domain<C>::fast>(to_fast<C>(x)));
   else r = fe_neg<C>(x);
   fe_store(out, i, r);
+}
+// classical a*b mod p (an extension: the reference has mod_add / mod_sub but no mod_mul).
+// secp256k1: one multiply + pseudo-Mersenne reduction; P-256: two Montgomery multiplies (ab/R, then *R^2/R).
+template <int C> __global__ void __launch_bounds__(BLOCK) k_mod_mul(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  GID; const fe x = fe_load(a, i), y = fe_load(b, i);
+  constexpr int CI = curve_domain<C>::fast;
+  if constexpr (CI == C) fe_store(out, i, fe_mul<C>(fe_mul<C>(x, y), FE_CONST(C, RSQ)));
+  else fe_store(out, i, fe_mul<CI>(x, y));
 }
 template <int C> __global__ void __launch_bounds__(BLOCK) k_shift_left(const uint64_t* a, int count, uint64_t* out, size_t n) {
   GID; fe x = fe_load(a, i);
@@ -34,12 +42,14 @@ template <int C> __global__ void __launch_bounds__(BLOCK) k_reduce(const uint64_
   GID; fe2 t = fe2_load(a8, i); fe_store(out, i, mgry_reduce<C>(t));
 }
 template <int C> __global__ void __launch_bounds__(BLOCK) k_pow(const uint64_t* a, launch::words8 e, uint64_t* out, size_t n) {
-  GID; fe_store(out, i, fe_pow<C>(fe_load(a, i), e.w));
+  GID; fe_store(out, i, from_fast<C>(fe_pow<curve_domain<C>::fast>(to_fast<C>(fe_load(a, i)), e.w)));
 }
 template <int C> __global__ void __launch_bounds__(BLOCK) k_sqrt(const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n) {
   GID; const fe x = fe_load(a, i);
-  const fe s = fe_pow<C>(x, curve_exps<C>::P_SQRT);                 // gfp.h:46-54
-  fe_store(out, i, s); if (ok) ok[i] = (uint8_t)fe_eq(fe_sqr<C>(s), x);
+  constexpr int CI = curve_domain<C>::fast;
+  const fe xf = to_fast<C>(x);
+  const fe s = fe_pow<CI>(xf, curve_exps<CI>::P_SQRT);              // gfp.h:46-54
+  fe_store(out, i, from_fast<C>(s)); if (ok) ok[i] = (uint8_t)fe_eq(fe_sqr<CI>(s), xf);
 }
 }  // namespace
 
@@ -64,6 +74,7 @@ void field_unop(hipStream_t s, int curve, field_op op, const uint64_t* a, uint64
     default: BY_CURVE_OP(k_unop, F_OPPOSITE, a, out, n); break;
   }
 }
+void mod_mul(hipStream_t s, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { BY_CURVE(k_mod_mul, a, b, out, n); }
 void mod_shift_left(hipStream_t s, int curve, const uint64_t* a, int count, uint64_t* out, size_t n) { BY_CURVE(k_shift_left, a, count, out, n); }
 void mgry_reduce(hipStream_t s, int curve, const uint64_t* a8, uint64_t* out, size_t n) { BY_CURVE(k_reduce, a8, out, n); }
 void mgry_pow(hipStream_t s, int curve, const uint64_t* a, const words8& e, uint64_t* out, size_t n) { BY_CURVE(k_pow, a, e, out, n); }

@@ -30,6 +30,7 @@ enum field_op { F_MOD_ADD, F_MOD_SUB, F_MGRY_MUL, F_MGRY_SQR, F_FROM_CLASSICAL, 
 void field_binop(hipStream_t, int curve, field_op op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 void field_unop(hipStream_t, int curve, field_op op, const uint64_t* a, uint64_t* out, size_t n);
 void mod_shift_left(hipStream_t, int curve, const uint64_t* a, int count, uint64_t* out, size_t n);
+void mod_mul(hipStream_t, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 void mgry_reduce(hipStream_t, int curve, const uint64_t* a8, uint64_t* out, size_t n);
 void mgry_pow(hipStream_t, int curve, const uint64_t* a, const words8& e, uint64_t* out, size_t n);
 void gfp_sqrt(hipStream_t, int curve, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n);

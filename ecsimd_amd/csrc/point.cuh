@@ -124,13 +124,31 @@ template <> struct curve_exps<CURVE_SECP256K1_CLASSICAL> : curve_exps<CURVE_SECP
 
 template <int C> ECS_DEV fe fe_inverse(const fe& a) { return fe_pow<C>(a, curve_exps<C>::P_M2); }     // gfp.h:42-44
 
+// API domain (Montgomery form) <-> the domain the multiplication-heavy code runs in
+// (curve_domain<C>::fast: Montgomery for P-256, classical for secp256k1 -- field.cuh).
+template <int C> ECS_DEV fe to_fast(const fe& v) {
+  if constexpr (curve_domain<C>::fast == C) return v; else return fe_to_classical<C>(v);
+}
+template <int C> ECS_DEV fe from_fast(const fe& v) {
+  if constexpr (curve_domain<C>::fast == C) return v; else return fe_from_classical<C>(v);
+}
+// fast domain -> classical
+template <int C> ECS_DEV fe fast_to_classical(const fe& v) {
+  if constexpr (curve_domain<C>::fast == C) return fe_to_classical<C>(v); else return v;
+}
+// classical -> fast domain
+template <int C> ECS_DEV fe classical_to_fast(const fe& v) {
+  if constexpr (curve_domain<C>::fast == C) return fe_from_classical<C>(v); else return v;
+}
+
 // jacobian_curve_point.h:33-42 to_affine: one inversion per lane; returns classical (x, y).
-template <int C> ECS_DEV void to_affine(const jpoint& P, fe& ax, fe& ay) {
-  const fe invZ = fe_inverse<C>(P.z);
-  const fe invZ2 = fe_sqr<C>(invZ);
-  const fe invZ3 = fe_mul<C>(invZ2, invZ);
-  ax = fe_to_classical<C>(fe_mul<C>(P.x, invZ2));
-  ay = fe_to_classical<C>(fe_mul<C>(P.y, invZ3));
+template <int C> ECS_DEV void to_affine(const jpoint& P, fe& ax, fe& ay) {     // P in the API's Montgomery form
+  constexpr int CI = curve_domain<C>::fast;
+  const fe invZ = fe_inverse<CI>(to_fast<C>(P.z));
+  const fe invZ2 = fe_sqr<CI>(invZ);
+  const fe invZ3 = fe_mul<CI>(invZ2, invZ);
+  ax = fast_to_classical<C>(fe_mul<CI>(to_fast<C>(P.x), invZ2));
+  ay = fast_to_classical<C>(fe_mul<CI>(to_fast<C>(P.y), invZ3));
 }
 
 // curve_group.h:189-218 scalar_mult: co-Z Joye double-add ladder, LSB -> MSB, fixed 254 ZDAU

@@ -176,6 +176,7 @@ class Engine:
 
     def mod_add(self, curve, a, b): return self._bin("mod_add", curve, a, b)
     def mod_sub(self, curve, a, b): return self._bin("mod_sub", curve, a, b)
+    def mod_mul(self, curve, a, b): return self._bin("mod_mul", curve, a, b)
     def mgry_mul(self, curve, a, b): return self._bin("mgry_mul", curve, a, b)
     def mgry_sqr(self, curve, a): return self._un("mgry_sqr", curve, a)
     def mgry_reduce(self, curve, a8): return self._un("mgry_reduce", curve, a8, 8)

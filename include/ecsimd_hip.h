@@ -104,6 +104,8 @@ int ecsimd_hip_swap_if(ecsimd_hip_ctx*, const uint8_t* mask, uint64_t* a, uint64
 int ecsimd_hip_mod_add(ecsimd_hip_ctx*, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int ecsimd_hip_mod_sub(ecsimd_hip_ctx*, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int ecsimd_hip_mod_shift_left(ecsimd_hip_ctx*, int curve, const uint64_t* a, int count, uint64_t* out, size_t n);
+/* Extension (the reference stops at mod_add / mod_sub, modular.h): classical a * b mod p, canonical. */
+int ecsimd_hip_mod_mul(ecsimd_hip_ctx*, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* mgry_mul.h:84-121 details::mgry_reduce<P>: out = a8 * 2^-256 mod p (a8 < p * 2^256) */
 int ecsimd_hip_mgry_reduce(ecsimd_hip_ctx*, int curve, const uint64_t* a8, uint64_t* out, size_t n);
 /* mgry_ops.h:31-42 mgry_mul / mgry_sqr */

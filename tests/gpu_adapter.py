@@ -30,6 +30,7 @@ class EngineNP:
     def square(self, a): return self._dn(self.e.square(self._up(a)))
     def mod_add(self, cv, a, b): return self._dn(self.e.mod_add(cv, self._up(a), self._up(b)))
     def mod_sub(self, cv, a, b): return self._dn(self.e.mod_sub(cv, self._up(a), self._up(b)))
+    def mod_mul(self, cv, a, b): return self._dn(self.e.mod_mul(cv, self._up(a), self._up(b)))
     def mod_shift_left(self, cv, a, c): return self._dn(self.e.mod_shift_left(cv, self._up(a), c))
     def mgry_reduce(self, cv, a8): return self._dn(self.e.mgry_reduce(cv, self._up(a8, 8)))
     def mgry_mul(self, cv, a, b): return self._dn(self.e.mgry_mul(cv, self._up(a), self._up(b)))

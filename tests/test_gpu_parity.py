@@ -151,6 +151,17 @@ def test_carry_heavy_operands(gpu, oracle, golden):
         for nm in ("mgry_mul", "mod_add", "mod_sub"):
             assert np.array_equal(getattr(gpu, nm)(cv, ar, br), getattr(oracle, nm)(cv, ar, br)), nm
         assert np.array_equal(gpu.mod_shift_left(cv, ar, 3), oracle.mod_shift_left(cv, ar, 3))
+        # classical a*b mod p: on secp256k1 this is the pseudo-Mersenne reduction the ladder runs on
+        ai, bi = arr_to_ints(ar), arr_to_ints(br)
+        assert arr_to_ints(gpu.mod_mul(cv, ar, br)) == [x * y % p for x, y in zip(ai, bi)]
+        worst = ints_to_arr([p - 1, p - 1, p - 2, 2**255, 2**128, (p - 1) // 2, 2**32 + 977, p - 2**32, 1, 0])
+        wi = arr_to_ints(worst)
+        assert arr_to_ints(gpu.mod_mul(cv, worst, worst[::-1].copy())) == [x * y % p for x, y in zip(wi, wi[::-1])]
+        assert arr_to_ints(gpu.mod_mul(cv, worst, worst)) == [x * x % p for x in wi]
+        mm = 2000
+        assert np.array_equal(gpu.gfp_inverse(cv, ar[:mm]), oracle.gfp_inverse(cv, ar[:mm]))
+        sg, okg = gpu.gfp_sqrt(cv, ar[:mm]); so, oko = oracle.gfp_sqrt(cv, ar[:mm])
+        assert np.array_equal(okg, oko) and np.array_equal(sg, so)
         t8 = np.concatenate([a[:m], b[:m]], axis=1); t8[:, 7] &= np.uint64(2**63 - 1)
         assert np.array_equal(gpu.mgry_reduce(cv, t8), oracle.mgry_reduce(cv, t8))
         # carry-heavy points are not on the curve, but the formulas are polynomial maps: still bit-exact
