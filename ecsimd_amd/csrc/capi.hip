@@ -263,6 +263,19 @@ int ecsimd_hip_square(ecsimd_hip_ctx* ctx, const uint64_t* a, uint64_t* out8, si
 int ecsimd_hip_swap_if(ecsimd_hip_ctx* ctx, const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n) {
   REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); if (!mask && n) return bad(ctx, "mask is null"); RUN(launch::swap_if(s, mask, a, b, n)); }
 
+// ---- wire formats
+int ecsimd_hip_from_bytes_be(ecsimd_hip_ctx* ctx, const uint8_t* bytes, uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_PTR(bytes); REQUIRE_PTR(out); RUN(launch::bytes_be(s, bytes, out, n)); }
+int ecsimd_hip_to_bytes_be(ecsimd_hip_ctx* ctx, const uint64_t* in, uint8_t* bytes, size_t n) {
+  REQUIRE_CTX(); REQUIRE_PTR(in); REQUIRE_PTR(bytes); RUN(launch::bytes_be(s, in, bytes, n)); }
+int ecsimd_hip_mask_bit(ecsimd_hip_ctx* ctx, const uint64_t* a, int bit, uint8_t* flag, size_t n) {
+  REQUIRE_CTX(); REQUIRE_PTR(a); if (!flag && n) return bad(ctx, "flag is null"); if (bit < 0 || bit > 255) return bad(ctx, "bit index");
+  RUN(launch::mask_bit(s, a, bit, flag, n)); }
+int ecsimd_hip_sec1_encode(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, uint8_t* out, size_t n, int compressed) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(out); RUN(launch::sec1_encode(s, curve, x, y, out, n, compressed != 0)); }
+int ecsimd_hip_sec1_decode(ecsimd_hip_ctx* ctx, int curve, const uint8_t* in, uint64_t* x, uint64_t* y, uint8_t* ok, size_t n, int compressed) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(in); REQUIRE_PTR(x); REQUIRE_PTR(y); RUN(launch::sec1_decode(s, curve, in, x, y, ok, n, compressed != 0)); }
+
 // ---- L3
 int ecsimd_hip_mod_add(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, curve, launch::F_MOD_ADD, a, b, out, n)); }

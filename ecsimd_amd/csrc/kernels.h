@@ -25,6 +25,12 @@ void fill_random(hipStream_t, uint64_t* out, size_t n, uint64_t seed, uint64_t s
 void peak_mad32(hipStream_t, int blocks, uint32_t* sink, int iters, uint32_t seed);
 constexpr int PEAK_MADS_PER_LANE_PER_ITER = 64;
 
+// k_serial.hip (wire formats; HBM-bound)
+void bytes_be(hipStream_t, const void* in, void* out, size_t n);
+void mask_bit(hipStream_t, const uint64_t* a, int bit, uint8_t* flag, size_t n);
+void sec1_encode(hipStream_t, int curve, const uint64_t* x, const uint64_t* y, uint8_t* out, size_t n, bool compressed);
+void sec1_decode(hipStream_t, int curve, const uint8_t* in, uint64_t* x, uint64_t* y, uint8_t* ok, size_t n, bool compressed);
+
 // k_field.hip
 enum field_op { F_MOD_ADD, F_MOD_SUB, F_MGRY_MUL, F_MGRY_SQR, F_FROM_CLASSICAL, F_TO_CLASSICAL, F_INVERSE, F_OPPOSITE };
 void field_binop(hipStream_t, int curve, field_op op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);

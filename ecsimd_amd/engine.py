@@ -165,6 +165,31 @@ class Engine:
     def swap_if(self, mask, a, b):
         self._call("swap_if", self._ptr(mask, 0), self._ptr(a), self._ptr(b), C.c_size_t(a.shape[0]))
 
+    # ---- wire formats
+    def _bytes_ptr(self, t):
+        assert t.is_cuda and t.is_contiguous() and t.dtype == self.torch.uint8
+        return C.c_void_p(t.data_ptr())
+
+    def from_bytes_be(self, b):
+        n = b.numel() // 32; out = self.empty(n)
+        self._call("from_bytes_be", self._bytes_ptr(b), self._ptr(out), C.c_size_t(n)); return out
+
+    def to_bytes_be(self, a):
+        n = a.shape[0]; out = self.torch.empty((n, 32), dtype=self.torch.uint8, device=self.tdev)
+        self._call("to_bytes_be", self._ptr(a), self._bytes_ptr(out), C.c_size_t(n)); return out
+
+    def mask_bit(self, a, bit):
+        n = a.shape[0]; f = self.flags(n)
+        self._call("mask_bit", self._ptr(a), C.c_int(bit), self._ptr(f, 0), C.c_size_t(n)); return f
+
+    def sec1_encode(self, curve, x, y, compressed=False):
+        n = x.shape[0]; out = self.torch.empty((n, 33 if compressed else 65), dtype=self.torch.uint8, device=self.tdev)
+        self._call("sec1_encode", C.c_int(curve), self._ptr(x), self._ptr(y), self._bytes_ptr(out), C.c_size_t(n), C.c_int(int(compressed))); return out
+
+    def sec1_decode(self, curve, rec, compressed=False):
+        n = rec.shape[0]; x, y, ok = self.empty(n), self.empty(n), self.flags(n)
+        self._call("sec1_decode", C.c_int(curve), self._bytes_ptr(rec), self._ptr(x), self._ptr(y), self._ptr(ok, 0), C.c_size_t(n), C.c_int(int(compressed))); return x, y, ok
+
     # ---- L3
     def _bin(self, name, curve, a, b):
         n = a.shape[0]; out = self.empty(n)

@@ -19,8 +19,10 @@
 #include <ecsimd/modular.h>
 #include <ecsimd/mul.h>
 #include <ecsimd/scalar_mult_p256.h>
+#include <ecsimd/sec1.h>
 #include <ecsimd/serialization.h>
 #include <ecsimd/shift.h>
 #include <ecsimd/sub.h>
 #include <ecsimd/swap.h>
+#include <ecsimd/utility.h>
 #endif

@@ -99,6 +99,21 @@ int ecsimd_hip_square(ecsimd_hip_ctx*, const uint64_t* a, uint64_t* out8, size_t
 /* swap.h:15-22  swap_if: swap a[i] and b[i] in place where mask[i] != 0 */
 int ecsimd_hip_swap_if(ecsimd_hip_ctx*, const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n);
 
+/* ---- wire formats on the device ------------------------------- */
+/* serialization.h:12-24 bn_from_bytes_BE / :26-48 bn_to_bytes_BE over a batch: 32 big-endian bytes per
+ * element <-> 4 x u64 little-endian limbs.  `bytes` is a device pointer, 16-byte aligned. */
+int ecsimd_hip_from_bytes_be(ecsimd_hip_ctx*, const uint8_t* bytes, uint64_t* out, size_t n);
+int ecsimd_hip_to_bytes_be(ecsimd_hip_ctx*, const uint64_t* in, uint8_t* bytes, size_t n);
+/* utility.h:45-51 wide_mask_bit: flag[i] = bit `bit` (0..255, 0 = least significant) of a[i] */
+int ecsimd_hip_mask_bit(ecsimd_hip_ctx*, const uint64_t* a, int bit, uint8_t* flag, size_t n);
+/* SEC 1 v2 2.3.3: affine classical (x, y) -> 04||X||Y (65 B per point) or, compressed, 02/03||X (33 B). */
+int ecsimd_hip_sec1_encode(ecsimd_hip_ctx*, int curve, const uint64_t* x, const uint64_t* y, uint8_t* out, size_t n, int compressed);
+/* SEC 1 v2 2.3.4: the inverse.  ok[i] = 1 iff the record is well formed, x (and y) < p and the point is on
+ * the curve (uncompressed) / x^3 + a x + b is a square (compressed: y recovered with the prefix's parity;
+ * generalises curve_point_ops.h:12-22 from_x to per-lane validity and both curves).  The point at infinity
+ * (single byte 00) has no fixed-size record and is not representable here. */
+int ecsimd_hip_sec1_decode(ecsimd_hip_ctx*, int curve, const uint8_t* in, uint64_t* x, uint64_t* y, uint8_t* ok, size_t n, int compressed);
+
 /* ---- L3: GF(p) ------------------------------------------------------------------------ */
 /* modular.h:10-15 mod_add, :24-41 mod_sub, mgry_ops.h:14-22 mgry_shift_left<count> (count >= 1) */
 int ecsimd_hip_mod_add(ecsimd_hip_ctx*, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);

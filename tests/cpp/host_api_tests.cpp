@@ -217,4 +217,32 @@ TEST(Batch, RuntimeLengthAndSecp256k1) {
   EXPECT_TRUE(all(five.y() == W256(n, bn_from_bytes_BE<bignum_256>("d8ac222636e5e3d6d4dba9dda6c9c426f788271bab0d6840dca87d3aa6ac62d6"_hex))));
 }
 
+// utility.h:45-51 wide_mask_bit and the device wire formats (beyond the reference's tests)
+TEST(Batch, MaskBitAndWireFormats) {
+  using K = curve_nist_p256; using KG = curve_group<K>;
+  const auto a = lanes<W128>("00000000000000000000000000000001"_hex, "00000000000000008000000000000000"_hex, "00000000000000010000000000000000"_hex, "80000000000000000000000000000000"_hex);
+  EXPECT_TRUE(all(wide_mask_bit(a, 0, 0) == cmp_res_t<W128>{true, false, false, false}));
+  EXPECT_TRUE(all(wide_mask_bit(a, 0, 63) == cmp_res_t<W128>{false, true, false, false}));
+  EXPECT_TRUE(all(wide_mask_bit(a, 1, 0) == cmp_res_t<W128>{false, false, true, false}));
+  EXPECT_TRUE(all(wide_mask_bit(a, 1, 63) == cmp_res_t<W128>{false, false, false, true}));
+  const size_t n = 300;
+  W256 k(n, [](size_t i, size_t) { bignum_256 b; b.limbs = {i * 0x9e3779b97f4a7c15ull + 1, ~i, i << 40, 0x7fffffff00000000ull ^ i}; return b; });
+  const auto be = wide_to_bytes_BE(k);
+  EXPECT_TRUE(be.size() == n * 32);
+  EXPECT_TRUE(bn_from_bytes_BE<bignum_256>(&be[32 * 123]) == k.get(123));                       // agrees with the host-side single-value codec
+  EXPECT_TRUE(all(wide_from_bytes_BE(be) == k));
+  const auto pts = KG::scalar_mult(k, KG::WJG(n)).to_affine();
+  for (bool compressed : {false, true}) {
+    auto wire = sec1_encode(pts, compressed);
+    hip::mask ok;
+    const auto back = sec1_decode<K>(wire, compressed, ok);
+    EXPECT_TRUE(all(ok)); EXPECT_TRUE(all(back == pts));
+    wire[(compressed ? 33 : 65) * 7 + 5] ^= 0x40;                                               // corrupt one X
+    const auto bad = sec1_decode<K>(wire, compressed, ok);
+    (void)bad;
+    size_t nbad = 0; for (auto b : ok.host()) nbad += !b;
+    EXPECT_TRUE(compressed ? nbad <= 1 : nbad == 1);        // uncompressed: certainly off the curve; compressed: half of all x decompress
+  }
+}
+
 int main() { return mini::run_all(); }

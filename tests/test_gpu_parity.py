@@ -174,6 +174,19 @@ def test_carry_heavy_operands(gpu, oracle, golden):
         assert all(np.array_equal(u, v) for u, v in zip(Rag, Ra))
 
 
+def test_config0_ops_bench_batch8_on_gpu(gpu, oracle):
+    """BASELINE configs[0] shapes (benchs/ops.cpp:106-116, batch = 8) through the HIP path."""
+    n = 8; rng = np.random.default_rng(8)
+    a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); b = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    t8 = rng.integers(0, 2**64, size=(n, 8), dtype=np.uint64)
+    a0 = a.copy(); a0[:, 0] &= np.uint64(0xFFFFFFFFFFFFFF00); t8[:, 0] &= np.uint64(0xFFFFFFFFFFFFFF00)
+    s, c = gpu.add(a, b); so, co = oracle.add(a, b)
+    assert np.array_equal(s, so) and np.array_equal(c, co)
+    assert np.array_equal(gpu.mul(a, b), oracle.mul(a, b)) and np.array_equal(gpu.square(a), oracle.square(a))
+    assert np.array_equal(gpu.mgry_sqr(SECP256K1, a0), oracle.mgry_sqr(SECP256K1, a0))
+    assert np.array_equal(gpu.mgry_reduce(SECP256K1, t8), oracle.mgry_reduce(SECP256K1, t8))
+
+
 def test_cmp_and_swap(engine, oracle):
     n = 1000; rng = np.random.default_rng(9)
     a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); b = a.copy(); b[::2] = rng.integers(0, 2**64, size=(n // 2, 4), dtype=np.uint64)
@@ -325,6 +338,47 @@ def test_scalar_mult_p256_entry_point(engine, oracle):
     got = engine.scalar_mult_p256(engine.to_device(k), P[0], P[1])
     exp = oracle.scalar_mult(P256, k, engine.to_numpy(P[0]), engine.to_numpy(P[1]), threads=THREADS, mgry_in=True)
     assert all(np.array_equal(engine.to_numpy(u), v) for u, v in zip(got, exp))
+
+
+@pytest.mark.parametrize("cv", CURVES)
+def test_wire_formats(engine, oracle, cv):
+    """Device byte codecs: 32 big-endian bytes <-> limbs (serialization.h:12-48 over a batch), wide_mask_bit
+    (utility.h:45-51) and SEC1 points, against numpy / the oracle's compute_y."""
+    import torch
+    n = 1000 + 77                                              # ragged: the last workgroup moves a partial LDS tile
+    k = fill_random_np(n, SEED, 9)
+    dk = engine.to_device(k)
+    be = engine.to_bytes_be(dk).cpu().numpy()
+    exp = np.stack([np.frombuffer(int(v).to_bytes(32, "big"), dtype=np.uint8) for v in arr_to_ints(k)])
+    assert np.array_equal(be, exp)
+    assert np.array_equal(engine.to_numpy(engine.from_bytes_be(torch.from_numpy(exp).to(dk.device))), k)
+    for bit in (0, 1, 31, 32, 63, 64, 200, 255):
+        assert engine.to_numpy(engine.mask_bit(dk, bit)).tolist() == [(v >> bit) & 1 for v in arr_to_ints(k)]
+    bx, by = engine.scalar_mult_base(cv, dk, flags=2)
+    xs, ys = arr_to_ints(engine.to_numpy(bx)), arr_to_ints(engine.to_numpy(by))
+    p = CURVE_PARAMS[cv]["p"]
+    for compressed in (False, True):
+        wire = engine.sec1_encode(cv, bx, by, compressed)
+        w = wire.cpu().numpy()
+        for i in (0, 1, 255, 256, n - 1):
+            rec = bytes(w[i])
+            assert rec == ((bytes([2 | (ys[i] & 1)]) + xs[i].to_bytes(32, "big")) if compressed else (b"\x04" + xs[i].to_bytes(32, "big") + ys[i].to_bytes(32, "big")))
+        dx, dy, ok = engine.sec1_decode(cv, wire, compressed)
+        assert bool(ok.all()) and torch.equal(dx, bx) and torch.equal(dy, by)
+        # malformed records: bad prefix, x >= p, point off the curve / non-residue
+        bad = wire.clone()
+        bad[3, 0] = 0x05
+        bad[4, 1:33] = torch.from_numpy(np.frombuffer(p.to_bytes(32, "big"), dtype=np.uint8).copy()).to(bad.device)      # x = p
+        bad[5, 32] ^= 1                                                                                                  # x + 1: off the curve or (compressed) maybe another point
+        _, _, ok2 = engine.sec1_decode(cv, bad, compressed)
+        ok2 = ok2.cpu().numpy()
+        assert ok2[3] == 0 and ok2[4] == 0 and ok2[:3].all() and ok2[6:].all()
+        if not compressed:
+            assert ok2[5] == 0
+        else:                                                   # compare with the oracle's square-root test for x + 1
+            x5 = from_int(int.from_bytes(bytes(bad[5, 1:33].cpu().numpy()), "big"))
+            _, oko = oracle.compute_y(cv, x5[None])
+            assert ok2[5] == oko[0]
 
 
 def test_fill_random_matches_numpy_twin(engine):

@@ -284,3 +284,19 @@ def test_fill_random_twin():
     z = fill_random_np(3, SEED, 1, first_index=5)
     assert int(z[2, 3]) == splitmix64(SEED ^ (1 << 56) ^ ((5 + 2) * 4 + 3))
     assert int(fill_random_np(2, SEED, 2, clear_top_bits=1)[:, 3].max()) < 2**63
+
+
+def test_config0_ops_bench_batch8(oracle, oracle_faithful, reference):
+    """BASELINE configs[0]: the workload of benchs/ops.cpp (add_256, mul_256, sqr_256, mgry_sqr_256,
+    mgry_reduce_512 on the secp256k1 prime, :22-24,106-116) on batch = 8 = two wides, CPU only: the real
+    reference against the restatement.  bench_mgry_sqr / bench_mgry_reduce zero the last BYTE (LastZero, :26-34)."""
+    n = 8; rng = np.random.default_rng(8)
+    a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); b = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    t8 = rng.integers(0, 2**64, size=(n, 8), dtype=np.uint64)
+    a0 = a.copy(); a0[:, 0] &= np.uint64(0xFFFFFFFFFFFFFF00); t8[:, 0] &= np.uint64(0xFFFFFFFFFFFFFF00)   # the last big-endian byte is limb 0's low byte
+    s_o, c_o = oracle.add(a, b); s_r, c_r = reference.add(a, b)
+    assert np.array_equal(s_o, s_r) and np.array_equal(c_o, c_r)
+    assert np.array_equal(oracle.mul(a, b), reference.mul(a, b))
+    assert np.array_equal(oracle_faithful.square(a), reference.square(a)) and np.array_equal(oracle.square(a), reference.mul(a, a))
+    assert np.array_equal(oracle_faithful.mgry_sqr(SECP256K1, a0), reference.mgry_sqr(SECP256K1, a0))
+    assert np.array_equal(oracle.mgry_reduce(SECP256K1, t8), reference.mgry_reduce(SECP256K1, t8))
