@@ -127,7 +127,7 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel (k_scalar_mult), measured live
         avg_ms = float(np.mean(kernel_ms))
-        mads, ms = eng.peak_mad32(4096)
+        mads, ms = eng.peak_mad32(8192, reps=5)
         peak = mads / (ms * 1e-3) / 1e12
         if args.workload == "ladder":
             mad32_unit, bytes_unit, kname = MAD32_PER_SCALAR_MULT, ALGO_BYTES_PER_SCALAR_MULT, "k_scalar_mult"

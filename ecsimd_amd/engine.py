@@ -285,7 +285,13 @@ class Engine:
         t = out if out is not None else self.empty(n)
         self._call("fill_random", self._ptr(t), C.c_size_t(n), _u64(seed), _u64(stream), _u64(first_index), C.c_int(clear_top_bits)); return t
 
-    def peak_mad32(self, iters=2048):
-        mads, ms = C.c_double(0), C.c_double(0)
-        self._call("peak_mad32", C.c_int(iters), C.byref(mads), C.byref(ms))
-        return mads.value, ms.value
+    def peak_mad32(self, iters=2048, reps=1):
+        """(mad32 executed, milliseconds) of the fastest of `reps` runs of the dependency-free
+        v_mad_u64_u32 stream (several runs let the clock settle: the probe is only a few ms long)."""
+        best = None
+        for _ in range(max(1, reps)):
+            mads, ms = C.c_double(0), C.c_double(0)
+            self._call("peak_mad32", C.c_int(iters), C.byref(mads), C.byref(ms))
+            if best is None or mads.value / ms.value > best[0] / best[1]:
+                best = (mads.value, ms.value)
+        return best

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Secondary kernels: throughput and roofline fraction on one MI355X (the headline lives in bench.py).
+Writes one JSON object (stdout) -- committed as profiles/rNN/secondary_kernels.json."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from ecsimd_amd import Engine, P256, SECP256K1
+
+SEED = 0x5EEDEC51D0000001
+e = Engine(0)
+
+
+def timeit(fn, reps=7):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) * 1e-3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+mads, ms = e.peak_mad32(8192, reps=5)
+peak_mad = mads / (ms * 1e-3)
+out = {"device": torch.cuda.get_device_name(0), "peak_mad32_per_s": peak_mad, "hbm_peak_GBps": 8000.0, "kernels": []}
+
+
+def row(name, n, t, mad32_per_unit, bytes_per_unit, unit):
+    r = {"kernel": name, "n": n, "seconds": t, "rate": n / t, "unit": unit + "/s",
+         "valu": {"algorithmic_mad32_per_unit": mad32_per_unit, "achieved_Tmad32_s": n / t * mad32_per_unit / 1e12, "frac_of_measured_peak": n / t * mad32_per_unit / peak_mad},
+         "hbm": {"algorithmic_bytes_per_unit": bytes_per_unit, "achieved_GBps": n / t * bytes_per_unit / 1e9, "frac_of_8TBps": n / t * bytes_per_unit / 8e12}}
+    r["bound"] = "hbm" if r["hbm"]["frac_of_8TBps"] > r["valu"]["frac_of_measured_peak"] else "valu"
+    out["kernels"].append(r)
+    print(f"{name:44s} n=2^{n.bit_length()-1:<2d} {n/t/1e6:10.1f} M {unit}/s   valu {r['valu']['frac_of_measured_peak']:.2f}  hbm {r['hbm']['frac_of_8TBps']:.3f}", file=sys.stderr)
+
+
+n = 1 << 24
+a = e.fill_random(n, SEED, 11, clear_top_bits=1); b = e.fill_random(n, SEED, 12, clear_top_bits=1)
+by = e.to_bytes_be(a)
+row("to_bytes_be (HBM-bound codec)", n, timeit(lambda: e.to_bytes_be(a)), 0, 64, "elements")
+row("from_bytes_be", n, timeit(lambda: e.from_bytes_be(by)), 0, 64, "elements")
+for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
+    row(f"mod_add<{nm}>", n, timeit(lambda: e.mod_add(cv, a, b)), 0, 96, "elements")
+    row(f"mgry_mul<{nm}> element-wise", n, timeit(lambda: e.mgry_mul(cv, a, b)), 136, 96, "field mults")
+    row(f"mgry_sqr<{nm}> element-wise", n, timeit(lambda: e.mgry_sqr(cv, a)), 136, 64, "field mults")
+del by
+n = 1 << 20                                                   # BASELINE configs[1]: point add + double, batch 2^20
+for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
+    s = e.fill_random(n, SEED, 2)
+    bx, byy = e.scalar_mult_base(cv, s, flags=2)
+    P = e.from_affine(cv, bx, byy)
+    def trplu():
+        Q = tuple(t.clone() for t in P); return e.trplu(cv, Q), Q
+    T, Pu = trplu()
+    clone_t = timeit(lambda: tuple(t.clone() for t in P))
+    row(f"TRPLU<{nm}> (DBLU + ZADDU, config 2)", n, timeit(lambda: trplu()) - clone_t, 13 * 136, 64 + 192 + 96, "points")
+    def zdau():
+        Q = tuple(t.clone() for t in Pu); return e.zdau(cv, T, Q)
+    row(f"ZDAU<{nm}> (config 2)", n, timeit(zdau) - clone_t, 16 * 136, 160 + 192, "points")
+    row(f"ADD_Z2_1<{nm}>", n, timeit(lambda: e.add_z2_1(cv, T, (P[0], P[1]))), 11 * 136, 160 + 96, "points")
+    n2 = 1 << 22
+    k = e.fill_random(n2, SEED, 1); s2 = e.fill_random(n2, SEED, 2)
+    b2x, b2y = e.scalar_mult_base(cv, s2, flags=2); P2 = e.from_affine(cv, b2x, b2y)
+    outj = [e.empty(n2) for _ in range(3)]
+    row(f"scalar_mult<{nm}> ladder, Jacobian out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=1, out=outj), 5), 555968, 192, "scalar mults")
+    row(f"scalar_mult<{nm}> ladder, affine out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=3, out=outj), 5), 555968 + 19 * 136, 160, "scalar mults")
+    row(f"to_affine<{nm}> (simultaneous inversion)", n2, timeit(lambda: e.to_affine(cv, outj)), int((7 + 383 / 32) * 136), 256, "points")
+    row(f"scalar_mult_base<{nm}> windowed, affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=6, out=outj)), int((64 * 11 + 7 + 383 / 32) * 136), 96, "scalar mults")
+    wire = e.sec1_encode(cv, b2x, b2y, True)
+    row(f"sec1_decode<{nm}> compressed (decompression)", n2, timeit(lambda: e.sec1_decode(cv, wire, True)), (255 + 128 + 4) * 136, 33 + 64, "points")
+    wire = e.sec1_encode(cv, b2x, b2y, False)
+    row(f"sec1_decode<{nm}> uncompressed (validation)", n2, timeit(lambda: e.sec1_decode(cv, wire, False)), 4 * 136, 65 + 64, "points")
+    del k, s2, b2x, b2y, P2, outj, wire
+print(json.dumps(out, indent=1))
