@@ -62,7 +62,10 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # ECSIMD_BENCH_FORCE_DIST=1 runs the process-group + gather path even with one rank (a single-GPU
+    # rehearsal of the N > 1 code: RCCL init, side stream, dist.gather, barrier).
+    force_dist = os.environ.get("ECSIMD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -80,7 +83,7 @@ def main():
     del s, P
     flags = BASE_MGRY | OUT_JACOBIAN
     from ecsimd_amd.shard import ShardedRunner
-    runner = ShardedRunner((3, n, 4), torch.int64, eng.tdev, world, rank)
+    runner = ShardedRunner((3, n, 4), torch.int64, eng.tdev, world, rank, always_gather=force_dist)
 
     if args.workload == "ladder":
         def compute(o):
@@ -105,7 +108,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in evs]                            # same stream as the launches
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=eng.tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -156,7 +159,9 @@ def main():
             else:
                 result["cpu_baseline"] = cpu_baseline_fixed_base(eng, curve, k, runner.last_result(), args.cpu_seconds)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
+        if force_dist and rank == 0:
+            assert torch.equal(runner.gathered[0], runner.last_result()), "gathered shard differs from the computed one"
         dist.barrier()
         dist.destroy_process_group()
 

@@ -29,13 +29,14 @@ class ShardedRunner:
     All ranks must use the same `shape`; rank 0 ends up with `gathered[r]` = rank r's last result.
     """
 
-    def __init__(self, shape, dtype, device, world: int, rank: int, group=None):
+    def __init__(self, shape, dtype, device, world: int, rank: int, group=None, always_gather: bool = False):
         self.world, self.rank, self.group = world, rank, group
+        self.dist = world > 1 or always_gather          # always_gather: rehearse the collective path with one rank
         self.cuda = torch.device(device).type == "cuda"
         self.outs = [torch.empty(shape, dtype=dtype, device=device) for _ in range(2)]
         self.gathered = ([torch.empty(shape, dtype=dtype, device=device) for _ in range(world)]
-                         if (world > 1 and rank == 0) else None)
-        self.comm = torch.cuda.Stream(device=device) if (self.cuda and world > 1) else None
+                         if (self.dist and rank == 0) else None)
+        self.comm = torch.cuda.Stream(device=device) if (self.cuda and self.dist) else None
         self._gather_done = [None, None]      # per buffer: event after its last gather (GPU only)
         self.steps = 0
 
@@ -49,7 +50,7 @@ class ShardedRunner:
         compute(out)
         if after is not None:
             after()
-        if self.world > 1:
+        if self.dist:
             if self.cuda:
                 ready = torch.cuda.Event()
                 ready.record()
@@ -68,7 +69,7 @@ class ShardedRunner:
         """Everything enqueued so far has finished on every rank."""
         if self.cuda:
             torch.cuda.synchronize()
-        if self.world > 1:
+        if self.dist:
             dist.barrier(group=self.group)
             if self.cuda:
                 torch.cuda.synchronize()
