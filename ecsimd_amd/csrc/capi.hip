@@ -43,6 +43,7 @@ void trplu(hipStream_t s, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, u
 void scalar_mult(hipStream_t s, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) { DISPATCH(scalar_mult, s, k, k_stride, x, y, ox, oy, oz, n, flags); }
 void to_affine_batched(hipStream_t s, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool in_fast) { DISPATCH(to_affine_batched, s, jx, jy, jz, x, y, n, in_fast); }
 void pack_table(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table, s, tx, ty, table); }
+void affine_add_batched(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) { DISPATCH(affine_add_batched, s, ax, ay, bx, by, rx, ry, finite, n); }
 void base_windowed(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed, s, k, table, ox, oy, oz, n); }
 #undef DISPATCH
 } }
@@ -362,6 +363,34 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* 
          launch::to_affine_batched(s, curve, jx, jy, jz, ox, oy, n, true)));
   }
   return run_ladder(ctx, curve, k, 4, nullptr, nullptr, ox, oy, oz, n, flags); }
+int ecsimd_hip_affine_add(ecsimd_hip_ctx* ctx, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by,
+                          uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(ax); REQUIRE_PTR(ay); REQUIRE_PTR(bx); REQUIRE_PTR(by); REQUIRE_PTR(rx);
+  if (ry && !aligned16(ry)) return bad(ctx, "ry is not 16-byte aligned");
+  if (overlaps(rx, ax) || overlaps(rx, ay) || overlaps(rx, bx) || overlaps(rx, by)) return bad(ctx, "rx must not alias an input (it is the inversion scratch)");
+  RUN(launch::affine_add_batched(s, curve, ax, ay, bx, by, rx, ry, finite, n)); }
+
+// u1[i]*G + u2[i]*Q[i]: windowed fixed-base product + ladder product + one batched affine addition.
+int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
+                                  uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(u1); REQUIRE_PTR(u2); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(rx);
+  if (ry && !aligned16(ry)) return bad(ctx, "ry is not 16-byte aligned");
+  if (n == 0) return ECSIMD_HIP_OK;
+  (void)hipSetDevice(ctx->device);
+  int rc = ensure_window_table(ctx, curve);
+  if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 7 * n * 32);        // 3 Jacobian + 2 x 2 affine intermediates
+  if (rc != ECSIMD_HIP_OK) return rc;
+  uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
+  uint64_t* gx = jz + 4 * n; uint64_t* gy = gx + 4 * n; uint64_t* px = gy + 4 * n; uint64_t* py = px + 4 * n;
+  hipStream_t s = ctx->stream;
+  launch::base_windowed(s, curve, u1, ctx->window_table[curve], jx, jy, jz, n);          // u1*G
+  launch::to_affine_batched(s, curve, jx, jy, jz, gx, gy, n, true);
+  launch::scalar_mult(s, curve, u2, 4, qx, qy, jx, jy, jz, n, ECSIMD_HIP_OUT_AFFINE);    // u2*Q (reference ladder)
+  launch::to_affine_batched(s, curve, jx, jy, jz, px, py, n, true);
+  launch::affine_add_batched(s, curve, gx, gy, px, py, rx, ry, finite, n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "double_scalar_mult launch"); }
+
 int ecsimd_hip_scalar_mult_p256(ecsimd_hip_ctx* ctx, const uint64_t* k, const uint64_t* xm, const uint64_t* ym, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) {
   return ecsimd_hip_scalar_mult(ctx, ECSIMD_HIP_P256, k, xm, ym, ox, oy, oz, n, ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN); }
 

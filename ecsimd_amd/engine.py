@@ -274,6 +274,16 @@ class Engine:
         self._call("scalar_mult_base", C.c_int(curve), self._ptr(k), *[self._ptr(t) for t in r], C.c_size_t(n), C.c_int(flags))
         return tuple(r[:2]) if flags & 2 else tuple(r)
 
+    def affine_add(self, curve, a, b):
+        n = a[0].shape[0]; rx, ry, fin = self.empty(n), self.empty(n), self.flags(n)
+        self._call("affine_add", C.c_int(curve), self._ptr(a[0]), self._ptr(a[1]), self._ptr(b[0]), self._ptr(b[1]), self._ptr(rx), self._ptr(ry), self._ptr(fin, 0), C.c_size_t(n))
+        return rx, ry, fin
+
+    def double_scalar_mult(self, curve, u1, u2, qx, qy, x_only=False):
+        n = u1.shape[0]; rx, fin = self.empty(n), self.flags(n); ry = None if x_only else self.empty(n)
+        self._call("double_scalar_mult", C.c_int(curve), self._ptr(u1), self._ptr(u2), self._ptr(qx), self._ptr(qy), self._ptr(rx), self._ptr(ry), self._ptr(fin, 0), C.c_size_t(n))
+        return rx, ry, fin
+
     def scalar_mult_p256(self, k, xm, ym, out=None):
         n = k.shape[0]
         r = out if out is not None else [self.empty(n) for _ in range(3)]

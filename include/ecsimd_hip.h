@@ -164,6 +164,17 @@ int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx*, int curve, const uint64_t k1[4], 
                               uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
 /* curve_group.h:35-41 WJG + scalar_mult: k[i] * G (base = the curve generator). */
 int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx*, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
+/* Extensions built on the kernels above (not in the reference):
+ * affine_add: R = A + B for affine classical points, one inversion per ~32 points.  (0, 0) encodes the point
+ * at infinity on input and output; finite[i] = 0 marks an infinite result (finite and ry may be NULL; rx must
+ * not alias an input). */
+int ecsimd_hip_affine_add(ecsimd_hip_ctx*, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by,
+                          uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
+/* double_scalar_mult: R[i] = u1[i]*G + u2[i]*Q[i], affine classical (the ECDSA-verification shape; pass
+ * ry = NULL for x only).  u1*G uses the windowed fixed-base kernel, u2*Q the reference ladder.  Scalars with
+ * u2 mod n in {0, n-1} hit the ladder's degenerate cases exactly as scalar_mult does. */
+int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx*, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
+                                  uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
 /* lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P) -- P-256, base in Montgomery form with
  * Z = mgry(1), Jacobian Montgomery output. */
 int ecsimd_hip_scalar_mult_p256(ecsimd_hip_ctx*, const uint64_t* k, const uint64_t* xm, const uint64_t* ym,

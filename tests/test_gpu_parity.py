@@ -328,6 +328,47 @@ def test_simultaneous_inversion_to_affine(engine, oracle, cv):
     assert np.array_equal(engine.to_numpy(ax[tidx]), ex) and np.array_equal(engine.to_numpy(ay[tidx]), ey)
 
 
+@pytest.mark.parametrize("cv", CURVES)
+def test_affine_add_and_double_scalar_mult(engine, oracle, cv):
+    """u1*G + u2*Q (the ECDSA-verification shape) = windowed fixed base + reference ladder + one batched affine
+    addition, against the independent affine big-int model; the addition's special cases (doubling, inverse
+    points, infinity operands) one by one."""
+    import torch
+    c = CURVE_PARAMS[cv]; order = c["n"]; p = c["p"]; G = (c["gx"], c["gy"])
+    n = (1 << 17) + 33
+    u1 = fill_random_np(n, SEED, 21); u2 = fill_random_np(n, SEED, 22); s = fill_random_np(n, SEED, 2)
+    u1[0] = from_int(0); u2[1] = from_int(1); u1[2] = from_int(order)
+    qx, qy = engine.scalar_mult_base(cv, engine.to_device(s), flags=2)
+    rx, ry, fin = engine.double_scalar_mult(cv, engine.to_device(u1), engine.to_device(u2), qx, qy)
+    rxn, ryn, qxn, qyn = (engine.to_numpy(t) for t in (rx, ry, qx, qy))
+    assert bool(fin.all())
+    for i in list(range(8)) + [n // 2, n - 1]:
+        Q = (to_int(qxn[i]), to_int(qyn[i]))
+        exp = ec_add(cv, ec_mul(cv, to_int(u1[i]) % order, G), ec_mul(cv, to_int(u2[i]) % order, Q))
+        assert (to_int(rxn[i]), to_int(ryn[i])) == exp, i
+    xo, _, _ = engine.double_scalar_mult(cv, engine.to_device(u1), engine.to_device(u2), qx, qy, x_only=True)
+    assert torch.equal(xo, rx)
+    # consistency on the whole batch: the same sum from the two affine products and affine_add
+    gx_, gy_ = engine.scalar_mult_base(cv, engine.to_device(u1), flags=6)
+    px_, py_ = engine.scalar_mult(cv, engine.to_device(u2), qx, qy, flags=2)
+    sx, sy, sf = engine.affine_add(cv, (gx_, gy_), (px_, py_))
+    assert torch.equal(sx, rx) and torch.equal(sy, ry) and bool(sf.all())
+    # special cases of the addition
+    P1 = ec_mul(cv, 5, G); P2 = ec_mul(cv, 7, G); negP1 = (P1[0], p - P1[1])
+    A = [P1, P1, P1, (0, 0), P1, (0, 0)]
+    B = [P2, P1, negP1, P2, (0, 0), (0, 0)]
+    E = [ec_add(cv, P1, P2), ec_add(cv, P1, P1), None, P2, P1, None]
+    ax = engine.to_device(ints_to_arr([a[0] for a in A])); ay = engine.to_device(ints_to_arr([a[1] for a in A]))
+    bx = engine.to_device(ints_to_arr([b[0] for b in B])); by = engine.to_device(ints_to_arr([b[1] for b in B]))
+    tx, ty, tf = engine.affine_add(cv, (ax, ay), (bx, by))
+    txn, tyn, tfn = engine.to_numpy(tx), engine.to_numpy(ty), engine.to_numpy(tf)
+    for i, e_ in enumerate(E):
+        if e_ is None:
+            assert tfn[i] == 0 and to_int(txn[i]) == 0 and to_int(tyn[i]) == 0
+        else:
+            assert tfn[i] == 1 and (to_int(txn[i]), to_int(tyn[i])) == e_, i
+
+
 def test_scalar_mult_p256_entry_point(engine, oracle):
     """lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P), P Jacobian Montgomery with Z = mgry(1)."""
     n = 1024; c = CURVE_PARAMS[P256]
