@@ -43,6 +43,8 @@ void trplu(hipStream_t s, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, u
 void scalar_mult(hipStream_t s, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) { DISPATCH(scalar_mult, s, k, k_stride, x, y, ox, oy, oz, n, flags); }
 void to_affine_batched(hipStream_t s, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool in_fast) { DISPATCH(to_affine_batched, s, jx, jy, jz, x, y, n, in_fast); }
 void pack_table(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table, s, tx, ty, table); }
+void pack_table6(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table6, s, tx, ty, table); }
+void base_windowed6(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed6, s, k, table, ox, oy, oz, n); }
 void affine_add_batched(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) { DISPATCH(affine_add_batched, s, ax, ay, bx, by, rx, ry, finite, n); }
 void base_windowed(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed, s, k, table, ox, oy, oz, n); }
 #undef DISPATCH
@@ -56,6 +58,7 @@ struct ecsimd_hip_ctx {
   int cus;
   uint32_t* sink;      // 4 KiB scratch: peak-probe sink [0, 1024) and the shared scalar at word 1024-8
   uint32_t* window_table[2];   // per curve: 64 x 16 affine multiples d*16^w*G (built on first use)
+  uint32_t* window6_table[2];  // per curve: 43 x 32 affine multiples m*64^i*G, m = 1..32
   uint64_t* workspace;         // grow-only scratch for the windowed path's Jacobian intermediates
   size_t workspace_bytes;
   char err[256];
@@ -103,32 +106,59 @@ int ensure_workspace(ecsimd_hip_ctx* ctx, size_t bytes) {
   return ECSIMD_HIP_OK;
 }
 
-// 64 x 16 table of d * 16^w * G, produced with the (parity-checked) ladder kernel itself.
-int ensure_window_table(ecsimd_hip_ctx* ctx, int curve) {
-  if (ctx->window_table[curve]) return ECSIMD_HIP_OK;
-  const size_t entries = 64 * 16;
-  uint64_t host_k[entries * 4];
+// Window tables, produced with the (parity-checked) ladder kernel itself.
+//   bits = 4: 64 x 16 entries d * 16^w * G (d = 0 unused);  bits = 6: 43 x 32 entries m * 64^i * G, m = slot + 1.
+int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
+  uint32_t** slot = (bits == 4) ? &ctx->window_table[curve] : &ctx->window6_table[curve];
+  if (*slot) return ECSIMD_HIP_OK;
+  const int windows = (bits == 4) ? 64 : 43, per = (bits == 4) ? 16 : 32;
+  const size_t entries = (size_t)windows * per;
+  static uint64_t host_k[64 * 32 * 4];
   memset(host_k, 0, sizeof host_k);
-  for (int w = 0; w < 64; ++w)
-    for (int d = 0; d < 16; ++d) host_k[((size_t)w * 16 + d) * 4 + (4 * w) / 64] = (uint64_t)d << ((4 * w) % 64);
+  for (int w = 0; w < windows; ++w)
+    for (int d = 0; d < per; ++d) {
+      const unsigned mult = (bits == 4) ? (unsigned)d : (unsigned)d + 1u;             // multiplier m
+      const int pos = bits * w;                                                         // entry = m * 2^pos * G
+      uint64_t* e = &host_k[((size_t)w * per + d) * 4];
+      const int limb = pos / 64, off = pos % 64;
+      const unsigned __int128 v = (unsigned __int128)mult << off;
+      e[limb] = (uint64_t)v;
+      if (limb + 1 < 4) e[limb + 1] = (uint64_t)(v >> 64);
+      else if ((uint64_t)(v >> 64) != 0) {
+        // m * 2^pos >= 2^256: only the top signed window, where 15 + carry = 16 asks for 2^256 * G.  That
+        // point cannot come from the ladder: k = 2^256 mod n is one of its degenerate scalars (the Joye
+        // ladder keeps R0 + R1 = 2^i * P, so at i = 256 it meets n * P = infinity; the reference's ladder
+        // fails there too).  The slot is filled below as T(15) + T(1) with the affine-addition kernel.
+        for (int l = 0; l < 4; ++l) e[l] = 0;
+      }
+    }
   int rc = ensure_workspace(ctx, 6 * entries * 32);
   if (rc != ECSIMD_HIP_OK) return rc;
   uint64_t* kd = ctx->workspace; uint64_t* tx = kd + entries * 4; uint64_t* ty = tx + entries * 4;
   uint32_t* table = nullptr;
-  hipError_t e = hipMalloc(&table, launch::WINDOW_TABLE_BYTES);
-  if (e == hipSuccess) e = hipMemcpyAsync(kd, host_k, sizeof host_k, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // host_k is a stack buffer
+  hipError_t e = hipMalloc(&table, entries * 64);
+  if (e == hipSuccess) e = hipMemcpyAsync(kd, host_k, entries * 32, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // host_k is reused by the next build
   if (e != hipSuccess) return fail(ctx, e, "window table setup");
-  {   // ladder (Jacobian, fast domain) into scratch, then affine classical (x, y); d = 0 rows are unused
+  {   // ladder (Jacobian, fast domain) into scratch, then affine classical (x, y)
     uint64_t* jx = ty + entries * 4; uint64_t* jy = jx + entries * 4; uint64_t* jz = jy + entries * 4;
     launch::scalar_mult(ctx->stream, curve, kd, 4, nullptr, nullptr, jx, jy, jz, entries, ECSIMD_HIP_OUT_AFFINE);
     launch::to_affine_batched(ctx->stream, curve, jx, jy, jz, tx, ty, entries, true);
   }
-  launch::pack_table(ctx->stream, curve, tx, ty, table);
+  if (bits == 6) {   // entry (42, m = 16) = 16 * 2^252 * G = T(42, 15) + T(42, 1)
+    uint64_t* sx = ty + entries * 4; uint64_t* sy = sx + 4;                                  // scratch (the Jacobian area is free again)
+    const size_t e15 = ((size_t)42 * per + 14) * 4, e1 = ((size_t)42 * per + 0) * 4, e16 = ((size_t)42 * per + 15) * 4;
+    launch::affine_add_batched(ctx->stream, curve, tx + e15, ty + e15, tx + e1, ty + e1, sx, sy, nullptr, 1);
+    (void)hipMemcpyAsync(tx + e16, sx, 32, hipMemcpyDeviceToDevice, ctx->stream);
+    (void)hipMemcpyAsync(ty + e16, sy, 32, hipMemcpyDeviceToDevice, ctx->stream);
+    launch::pack_table6(ctx->stream, curve, tx, ty, table);
+  } else {
+    launch::pack_table(ctx->stream, curve, tx, ty, table);
+  }
   e = hipStreamSynchronize(ctx->stream);
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) { (void)hipFree(table); return fail(ctx, e, "window table build"); }
-  ctx->window_table[curve] = table;
+  *slot = table;
   return ECSIMD_HIP_OK;
 }
 
@@ -170,7 +200,7 @@ int ecsimd_hip_init(int device, ecsimd_hip_ctx** out) {
   ecsimd_hip_ctx* ctx = new (std::nothrow) ecsimd_hip_ctx();
   if (!ctx) return ECSIMD_HIP_ERR_HIP;
   ctx->device = device; ctx->cus = prop.multiProcessorCount; ctx->err[0] = 0; ctx->sink = nullptr;
-  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0;
+  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->window6_table[0] = ctx->window6_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ECSIMD_HIP_ERR_HIP; }
   ctx->stream = ctx->own_stream;
   if (hipMalloc(&ctx->sink, 4096) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ECSIMD_HIP_ERR_HIP; }
@@ -182,7 +212,7 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->sink);
-  (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->workspace);
+  (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->workspace);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return ECSIMD_HIP_OK;
@@ -349,17 +379,19 @@ int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[
 int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(ox); REQUIRE_PTR(oy);
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
-  if (flags & ECSIMD_HIP_ALG_WINDOWED) {
+  if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED6)) {
+    const bool six = (flags & ECSIMD_HIP_ALG_WINDOWED6) != 0;
     // 4-bit windows over an LDS-resident table, then one simultaneous inversion: affine output only
     // (the Jacobian representative differs from the reference ladder's -- SURVEY.md 8(a) level A).
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
     if (n == 0) return ECSIMD_HIP_OK;
     (void)hipSetDevice(ctx->device);
-    int rc = ensure_window_table(ctx, curve);
+    int rc = ensure_window_table(ctx, curve, six ? 6 : 4);
     if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 3 * n * 32);
     if (rc != ECSIMD_HIP_OK) return rc;
     uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
-    RUN((launch::base_windowed(s, curve, k, ctx->window_table[curve], jx, jy, jz, n),
+    RUN(((six ? launch::base_windowed6(s, curve, k, ctx->window6_table[curve], jx, jy, jz, n)
+              : launch::base_windowed(s, curve, k, ctx->window_table[curve], jx, jy, jz, n)),
          launch::to_affine_batched(s, curve, jx, jy, jz, ox, oy, n, true)));
   }
   return run_ladder(ctx, curve, k, 4, nullptr, nullptr, ox, oy, oz, n, flags); }
@@ -377,13 +409,13 @@ int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t
   if (ry && !aligned16(ry)) return bad(ctx, "ry is not 16-byte aligned");
   if (n == 0) return ECSIMD_HIP_OK;
   (void)hipSetDevice(ctx->device);
-  int rc = ensure_window_table(ctx, curve);
+  int rc = ensure_window_table(ctx, curve, 6);
   if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 7 * n * 32);        // 3 Jacobian + 2 x 2 affine intermediates
   if (rc != ECSIMD_HIP_OK) return rc;
   uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
   uint64_t* gx = jz + 4 * n; uint64_t* gy = gx + 4 * n; uint64_t* px = gy + 4 * n; uint64_t* py = px + 4 * n;
   hipStream_t s = ctx->stream;
-  launch::base_windowed(s, curve, u1, ctx->window_table[curve], jx, jy, jz, n);          // u1*G
+  launch::base_windowed6(s, curve, u1, ctx->window6_table[curve], jx, jy, jz, n);        // u1*G
   launch::to_affine_batched(s, curve, jx, jy, jz, gx, gy, n, true);
   launch::scalar_mult(s, curve, u2, 4, qx, qy, jx, jy, jz, n, ECSIMD_HIP_OUT_AFFINE);    // u2*Q (reference ladder)
   launch::to_affine_batched(s, curve, jx, jy, jz, px, py, n, true);

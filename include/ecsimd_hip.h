@@ -55,10 +55,13 @@ enum {
   ECSIMD_HIP_BASE_MGRY = 1,        /* base point already Montgomery form (what scalar_mult_p256 receives) */
   ECSIMD_HIP_OUT_JACOBIAN = 0,     /* out = (X, Y, Z) Montgomery form, as curve_group::scalar_mult returns */
   ECSIMD_HIP_OUT_AFFINE = 2,       /* out = to_affine(): (x, y) classical; oz may be NULL */
-  ECSIMD_HIP_ALG_WINDOWED = 4      /* scalar_mult_base + OUT_AFFINE only: 4-bit windows over an LDS-resident table of
+  ECSIMD_HIP_ALG_WINDOWED = 4,     /* scalar_mult_base + OUT_AFFINE only: 4-bit windows over an LDS-resident table of
                                       d*16^w*G and one simultaneous inversion instead of the reference's ladder.  Same
-                                      affine result for every k with k mod n not in {0, n-1} (the ladder's degenerate
-                                      scalars, where the reference itself returns a meaningless point); k = 0 mod n -> (0, 0) */
+                                      affine result for every k except the ladder's degenerate scalars k = n-1, 2^256-n-1,
+                                      2^256-n (there the reference returns a meaningless point, this path the right one);
+                                      k = 0 mod n -> (0, 0) */
+  ECSIMD_HIP_ALG_WINDOWED6 = 8     /* as ALG_WINDOWED with signed 6-bit windows: 43 mixed additions instead of 64, an 88 KB
+                                      table of m*64^i*G (m = 1..32) in LDS; same results */
 };
 
 /* ---- context, stream and memory ------------------------------------------------------- */
@@ -171,8 +174,8 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx*, int curve, const uint64_t* k, u
 int ecsimd_hip_affine_add(ecsimd_hip_ctx*, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by,
                           uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
 /* double_scalar_mult: R[i] = u1[i]*G + u2[i]*Q[i], affine classical (the ECDSA-verification shape; pass
- * ry = NULL for x only).  u1*G uses the windowed fixed-base kernel, u2*Q the reference ladder.  Scalars with
- * u2 mod n in {0, n-1} hit the ladder's degenerate cases exactly as scalar_mult does. */
+ * ry = NULL for x only).  u1*G uses the windowed fixed-base kernel, u2*Q the reference ladder, whose
+ * degenerate scalars (u2 = n-1, 2^256-n-1, 2^256-n; u2 = 0 mod n gives infinity) behave as in scalar_mult. */
 int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx*, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                                   uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
 /* lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P) -- P-256, base in Montgomery form with

@@ -243,7 +243,8 @@ def test_point_formulas_vs_oracle(gpu, oracle, cv):
 def test_scalar_mult_vs_oracle(gpu, oracle, cv):
     c = CURVE_PARAMS[cv]; order = c["n"]
     edge = [0, 1, 2, 3, 4, 5, 6, 7, 8, order - 2, order - 1, order, order + 1, order + 2, 2**256 - 1, 2**256 - 2, 2**255, 2**255 - 1,
-            2**64, 2**64 - 1, 2**128, 2**192 + 1, int("55" * 32, 16), int("aa" * 32, 16)]
+            2**64, 2**64 - 1, 2**128, 2**192 + 1, int("55" * 32, 16), int("aa" * 32, 16),
+            2**256 - order, 2**256 - order - 1, 2**256 - order + 1]      # k = 2^256 mod n (and k + 1): the ladder meets n*P at its last step
     n = 4096
     k = fill_random_np(n, SEED, 1); k[:len(edge)] = ints_to_arr(edge)
     gx, gy = ints_to_arr([c["gx"]] * n), ints_to_arr([c["gy"]] * n)
@@ -262,7 +263,7 @@ def test_scalar_mult_vs_oracle(gpu, oracle, cv):
     # a few lanes against the independent affine model (non-degenerate scalars only)
     for i in list(range(1, 9)) + [len(edge) + 3, n - 1]:
         kk = to_int(k[i]) % order
-        if kk in (0, order - 1): continue
+        if kk in (0, order - 1, 2**256 - order, 2**256 - order - 1): continue          # the ladder's degenerate scalars (level J only)
         assert (to_int(gax[i]), to_int(gay[i])) == ec_mul(cv, kk, (to_int(bx[i]), to_int(by[i]))), i
     # one scalar for all lanes (curve_group.h:221-251)
     k1 = k[len(edge) + 1]
@@ -283,16 +284,20 @@ def test_windowed_fixed_base_matches_the_ladder_at_affine_level(engine, oracle, 
     n = (1 << 18) + 77                                      # ragged, and large enough for several elements per lane in the inversion
     k = fill_random_np(n, SEED, 5); k[:len(edge)] = ints_to_arr(edge)
     k[100] = from_int(0); k[101] = from_int(order); k[102] = from_int(order - 1)       # degenerate scalars
+    k[103] = from_int(2**256 - order); k[104] = from_int(2**256 - order - 1)           # ... of the ladder only
     dk = engine.to_device(k)
     wx, wy = engine.scalar_mult_base(cv, dk, flags=OUT_AFFINE | ALG_WINDOWED)
+    from ecsimd_amd import ALG_WINDOWED6
+    w6x, w6y = engine.scalar_mult_base(cv, dk, flags=OUT_AFFINE | ALG_WINDOWED6)       # signed 6-bit windows: same points
+    assert torch.equal(w6x, wx) and torch.equal(w6y, wy)
     lx, ly = engine.scalar_mult_base(cv, dk, flags=OUT_AFFINE)                        # reference ladder + (batched) to_affine
     wxn, wyn, lxn, lyn = (engine.to_numpy(t) for t in (wx, wy, lx, ly))
-    keep = np.ones(n, dtype=bool); keep[100:103] = False
+    keep = np.ones(n, dtype=bool); keep[100:105] = False
     assert np.array_equal(wxn[keep], lxn[keep]) and np.array_equal(wyn[keep], lyn[keep])
     assert to_int(wxn[100]) == 0 and to_int(wyn[100]) == 0 and to_int(wxn[101]) == 0 and to_int(wyn[101]) == 0
     G = (c["gx"], c["gy"])
     assert (to_int(wxn[102]), to_int(wyn[102])) == (c["gx"], c["p"] - c["gy"])                  # (n-1)G = -G: the windowed path is right where the ladder degenerates
-    for i in list(range(len(edge))) + [n - 1]:
+    for i in list(range(len(edge))) + [103, 104, n - 1]:                 # 103/104: right where the reference ladder is wrong
         assert (to_int(wxn[i]), to_int(wyn[i])) == ec_mul(cv, to_int(k[i]) % order, G), hex(to_int(k[i]))
     m = 2048
     ex, ey = oracle.to_affine(cv, oracle.scalar_mult(cv, k[200:200 + m], ints_to_arr([c["gx"]] * m), ints_to_arr([c["gy"]] * m), threads=THREADS))
