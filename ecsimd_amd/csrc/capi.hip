@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <new>
+#include <vector>
 
 #include "../../include/ecsimd_hip.h"
 #include "kernels.h"
@@ -94,7 +95,9 @@ void words_to_limbs(const uint32_t (&w)[8], uint64_t out[4]) {
   for (int i = 0; i < 4; ++i) out[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
 }
 
-// Grow-only device scratch.  hipMalloc synchronises: callers that capture graphs warm the path up once.
+// Grow-only device scratch, ordered by the context's stream (synchronise before switching streams with
+// ecsimd_hip_set_stream while a scratch-using call is in flight).  hipMalloc synchronises: callers that
+// capture graphs warm the path up once.
 int ensure_workspace(ecsimd_hip_ctx* ctx, size_t bytes) {
   if (ctx->workspace_bytes >= bytes) return ECSIMD_HIP_OK;
   hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -113,8 +116,7 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
   if (*slot) return ECSIMD_HIP_OK;
   const int windows = (bits == 4) ? 64 : 43, per = (bits == 4) ? 16 : 32;
   const size_t entries = (size_t)windows * per;
-  static uint64_t host_k[64 * 32 * 4];
-  memset(host_k, 0, sizeof host_k);
+  std::vector<uint64_t> host_k(entries * 4, 0);
   for (int w = 0; w < windows; ++w)
     for (int d = 0; d < per; ++d) {
       const unsigned mult = (bits == 4) ? (unsigned)d : (unsigned)d + 1u;             // multiplier m
@@ -137,8 +139,8 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
   uint64_t* kd = ctx->workspace; uint64_t* tx = kd + entries * 4; uint64_t* ty = tx + entries * 4;
   uint32_t* table = nullptr;
   hipError_t e = hipMalloc(&table, entries * 64);
-  if (e == hipSuccess) e = hipMemcpyAsync(kd, host_k, entries * 32, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // host_k is reused by the next build
+  if (e == hipSuccess) e = hipMemcpyAsync(kd, host_k.data(), entries * 32, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // host_k must outlive the copy
   if (e != hipSuccess) return fail(ctx, e, "window table setup");
   {   // ladder (Jacobian, fast domain) into scratch, then affine classical (x, y)
     uint64_t* jx = ty + entries * 4; uint64_t* jy = jx + entries * 4; uint64_t* jz = jy + entries * 4;
