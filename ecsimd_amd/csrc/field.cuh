@@ -39,6 +39,7 @@ template <> struct curve_consts<CURVE_P256> {
   static constexpr uint32_t P[8]    = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000001u, 0xffffffffu};
   static constexpr uint32_t R_P[8]  = {0x00000001u, 0x00000000u, 0x00000000u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xfffffffeu, 0x00000000u};   // R mod p    mgry_csts.h:20
   static constexpr uint32_t RSQ[8]  = {0x00000003u, 0x00000000u, 0xffffffffu, 0xfffffffbu, 0xfffffffeu, 0xffffffffu, 0xfffffffdu, 0x00000004u};   // R^2 mod p  mgry_csts.h:21
+  static constexpr uint32_t NEG_R[8] = {0xfffffffeu, 0xffffffffu, 0xffffffffu, 0x00000001u, 0x00000000u, 0x00000000u, 0x00000002u, 0xfffffffeu};  // (p-1)*R mod p  mgry_csts.h:24
   static constexpr uint32_t AM[8]   = {0xfffffffcu, 0xffffffffu, 0xffffffffu, 0x00000003u, 0x00000000u, 0x00000000u, 0x00000004u, 0xfffffffcu};   // a*R mod p  curve_group.h:32
   static constexpr uint32_t BM[8]   = {0x29c4bddfu, 0xd89cdf62u, 0x78843090u, 0xacf005cdu, 0xf7212ed6u, 0xe5a220abu, 0x04874834u, 0xdc30061du};   // b*R mod p  curve_group.h:31
   static constexpr uint32_t GX[8]   = {0xd898c296u, 0xf4a13945u, 0x2deb33a0u, 0x77037d81u, 0x63a440f2u, 0xf8bce6e5u, 0xe12c4247u, 0x6b17d1f2u};   // curve_nist_p256.h:27-29
@@ -51,6 +52,7 @@ template <> struct curve_consts<CURVE_SECP256K1> {
   static constexpr uint32_t P[8]    = {0xfffffc2fu, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
   static constexpr uint32_t R_P[8]  = {0x000003d1u, 0x00000001u, 0, 0, 0, 0, 0, 0};
   static constexpr uint32_t RSQ[8]  = {0x000e90a1u, 0x000007a2u, 0x00000001u, 0, 0, 0, 0, 0};
+  static constexpr uint32_t NEG_R[8] = {0xfffff85eu, 0xfffffffdu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
   static constexpr uint32_t AM[8]   = {0, 0, 0, 0, 0, 0, 0, 0};
   static constexpr uint32_t BM[8]   = {0x00001ab7u, 0x00000007u, 0, 0, 0, 0, 0, 0};
   static constexpr uint32_t GX[8]   = {0x16f81798u, 0x59f2815bu, 0x2dce28d9u, 0x029bfcdbu, 0xce870b07u, 0x55a06295u, 0xf9dcbbacu, 0x79be667eu};
@@ -62,6 +64,7 @@ template <> struct curve_consts<CURVE_SECP256K1_CLASSICAL> {
   static constexpr uint32_t P[8]    = {0xfffffc2fu, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
   static constexpr uint32_t R_P[8]  = {1u, 0, 0, 0, 0, 0, 0, 0};      // "one"
   static constexpr uint32_t RSQ[8]  = {1u, 0, 0, 0, 0, 0, 0, 0};      // from_classical is the identity here
+  static constexpr uint32_t NEG_R[8] = {0xfffffc2eu, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};   // -1
   static constexpr uint32_t AM[8]   = {0, 0, 0, 0, 0, 0, 0, 0};
   static constexpr uint32_t BM[8]   = {7u, 0, 0, 0, 0, 0, 0, 0};
   static constexpr uint32_t GX[8]   = {0x16f81798u, 0x59f2815bu, 0x2dce28d9u, 0x029bfcdbu, 0xce870b07u, 0x55a06295u, 0xf9dcbbacu, 0x79be667eu};
@@ -244,7 +247,12 @@ template <int CURVE, int N> ECS_DEV fe fe_shl(fe a) {
   for (int i = 0; i < N; ++i) a = fe_dbl<CURVE>(a);
   return a;
 }
-// -a mod p (0 stays 0).  Same value as gfp.h:60-64 (-R - (a - R)).
+// gfp.h:60-64 opposite(): (-R) - (a - R), two modular subtractions.  Equal to fe_neg for canonical a; kept in
+// the reference's two-step form so that even an unreduced operand (a >= p) yields the reference's bits.
+template <int CURVE> ECS_DEV fe fe_opposite(const fe& a) {
+  return fe_sub<CURVE>(FE_CONST(CURVE, NEG_R), fe_sub<CURVE>(a, FE_CONST(CURVE, R_P)));
+}
+// -a mod p for canonical a (0 stays 0).
 template <int CURVE> ECS_DEV fe fe_neg(const fe& a) {
   fe z;
 #pragma unroll

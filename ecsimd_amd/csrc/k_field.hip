@@ -22,7 +22,7 @@ template <int C, int OP> __global__ void __launch_bounds__(BLOCK) k_unop(const u
   else if constexpr (OP == launch::F_FROM_CLASSICAL) r = fe_from_classical<C>(x);
   else if constexpr (OP == launch::F_TO_CLASSICAL) r = fe_to_classical<C>(x);
   else if constexpr (OP == launch::F_INVERSE) r = from_fast<C>(fe_inverse<curve_domain<C>::fast>(to_fast<C>(x)));
-  else r = fe_neg<C>(x);
+  else r = fe_opposite<C>(x);
   fe_store(out, i, r);
 }
 // classical a*b mod p (an extension: the reference has mod_add / mod_sub but no mod_mul).

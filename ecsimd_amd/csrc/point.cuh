@@ -189,7 +189,7 @@ template <int C> ECS_DEV jpoint scalar_mult_ladder(const uint32_t* __restrict__ 
   fe_cswap(prev, px, bx);
   fe_cswap(prev, py, by);
   // even k: subtract the original point once (curve_group.h:214-217)
-  const fe oppy = fe_neg<C>(ym);
+  const fe oppy = fe_opposite<C>(ym);                    // jacobian_curve_point.h:48-54 via gfp.h:60-64
   const jpoint Psub = add_z2_1<C>(px, py, z, xm, oppy);
   const uint32_t meven = 0u - (uint32_t)((k0 & 1u) == 0u);
   jpoint R;

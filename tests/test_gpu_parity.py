@@ -174,6 +174,22 @@ def test_carry_heavy_operands(gpu, oracle, golden):
         assert all(np.array_equal(u, v) for u, v in zip(Rag, Ra))
 
 
+def test_non_canonical_operands_behave_like_the_reference(gpu, oracle):
+    """Operands >= p (the reference never rejects them: tests/ops.cpp:232 feeds mod_add an unreduced value).
+    Every op performs ONE conditional subtraction like the reference, so the results -- possibly
+    non-canonical -- must still be identical."""
+    a = structured_words(50000, seed=3); b = np.roll(structured_words(50000, seed=4), 11, axis=0)      # anything in [0, 2^256)
+    a[:4] = ints_to_arr([2**256 - 1] * 4); b[:2] = ints_to_arr([2**256 - 1, 2**256 - 2])
+    for cv in CURVES:
+        for nm in ("mod_add", "mod_sub", "mgry_mul"):
+            assert np.array_equal(getattr(gpu, nm)(cv, a, b), getattr(oracle, nm)(cv, a, b)), (cv, nm)
+        for nm in ("mgry_sqr", "mgry_from_classical", "mgry_to_classical", "gfp_opposite"):
+            assert np.array_equal(getattr(gpu, nm)(cv, a), getattr(oracle, nm)(cv, a)), (cv, nm)
+        assert np.array_equal(gpu.mod_shift_left(cv, a, 2), oracle.mod_shift_left(cv, a, 2))
+        t8 = np.concatenate([a, b], axis=1)                                                            # up to 2^512 - 1
+        assert np.array_equal(gpu.mgry_reduce(cv, t8), oracle.mgry_reduce(cv, t8))
+
+
 def test_config0_ops_bench_batch8_on_gpu(gpu, oracle):
     """BASELINE configs[0] shapes (benchs/ops.cpp:106-116, batch = 8) through the HIP path."""
     n = 8; rng = np.random.default_rng(8)
