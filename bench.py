@@ -42,10 +42,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2-batch", type=int, default=22, help="scalar mults per GPU per step = 2^this")
     ap.add_argument("--curve", default="p256", choices=["p256", "secp256k1"])
-    ap.add_argument("--workload", default="ladder", choices=["ladder", "fixed-base", "fixed-base6"],
+    ap.add_argument("--workload", default="ladder", choices=["ladder", "fixed-base", "fixed-base-signed"],
                     help="ladder: scalar_mult_p256 variable base, the reference's co-Z ladder, Jacobian out (headline, BASELINE configs[3] shape per GPU); "
                          "fixed-base: k*G with the 4-bit-window LDS table + simultaneous inversion, affine out (BASELINE configs[2]); "
-                         "fixed-base6: the same with signed 6-bit windows (43 additions instead of 64)")
+                         "fixed-base-signed: the same with signed 7-bit windows (37 additions instead of 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
@@ -53,7 +53,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from ecsimd_amd import Engine, CURVES, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED6
+    from ecsimd_amd import Engine, CURVES, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -90,7 +90,7 @@ def main():
         def compute(o):
             eng.scalar_mult(curve, k, xm, ym, flags=flags, out=[o[0], o[1], o[2]])
     else:
-        alg = ALG_WINDOWED if args.workload == "fixed-base" else ALG_WINDOWED6
+        alg = ALG_WINDOWED if args.workload == "fixed-base" else ALG_WINDOWED_SIGNED
 
         def compute(o):                                     # affine (x, y); o[2] is unused
             eng.scalar_mult_base(curve, k, flags=OUT_AFFINE | alg, out=[o[0], o[1], o[2]])
@@ -126,7 +126,7 @@ def main():
         "config": {"workload": (f"scalar_mult_{args.curve} variable-base co-Z ladder (reference algorithm), "
                                 f"batch=2^{args.log2_batch} per GPU, Jacobian Montgomery out") if args.workload == "ladder" else
                                (f"scalar_mult_{args.curve} fixed-base (G), batch=2^{args.log2_batch} random scalars per GPU, "
-                                + ("4-bit window table in LDS" if args.workload == "fixed-base" else "signed 6-bit window table in LDS")
+                                + ("4-bit window table in LDS" if args.workload == "fixed-base" else "signed 7-bit window table in LDS")
                                 + " + simultaneous inversion, affine out"),
                    "element": "256-bit integers: 8 x u32 words (= 4 x u64 limbs) in VGPRs, v_mad_u64_u32 carry chains",
                    "global_batch": n * world, "per_gpu_batch": n, "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
@@ -142,9 +142,9 @@ def main():
         else:
             # what THIS algorithm needs per scalar: 64 mixed additions x 11 field mults,
             # 7 mults of the simultaneous-inversion walk and 383/32 of the shared inversion; 32 B in, 64 B out.
-            adds = 64 if args.workload == "fixed-base" else 43
+            adds = 64 if args.workload == "fixed-base" else 37
             mad32_unit, bytes_unit = int((adds * 11 + 7 + 383 / 32) * 136), 96
-            kname = ("k_base_windowed" if adds == 64 else "k_base_windowed6") + " + k_to_affine_batched"
+            kname = ("k_base_windowed" if adds == 64 else "k_base_windowed_s<7>") + " + k_to_affine_batched"
         achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")             # written from rocprofv3 --pmc passes

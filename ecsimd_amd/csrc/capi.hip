@@ -44,8 +44,8 @@ void trplu(hipStream_t s, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, u
 void scalar_mult(hipStream_t s, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) { DISPATCH(scalar_mult, s, k, k_stride, x, y, ox, oy, oz, n, flags); }
 void to_affine_batched(hipStream_t s, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool in_fast) { DISPATCH(to_affine_batched, s, jx, jy, jz, x, y, n, in_fast); }
 void pack_table(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table, s, tx, ty, table); }
-void pack_table6(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table6, s, tx, ty, table); }
-void base_windowed6(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed6, s, k, table, ox, oy, oz, n); }
+void pack_table_signed(hipStream_t s, int curve, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table_signed, s, wbits, tx, ty, table); }
+void base_windowed_signed(hipStream_t s, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed_signed, s, wbits, k, table, ox, oy, oz, n); }
 void affine_add_batched(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) { DISPATCH(affine_add_batched, s, ax, ay, bx, by, rx, ry, finite, n); }
 void base_windowed(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed, s, k, table, ox, oy, oz, n); }
 #undef DISPATCH
@@ -59,7 +59,7 @@ struct ecsimd_hip_ctx {
   int cus;
   uint32_t* sink;      // 4 KiB scratch: peak-probe sink [0, 1024) and the shared scalar at word 1024-8
   uint32_t* window_table[2];   // per curve: 64 x 16 affine multiples d*16^w*G (built on first use)
-  uint32_t* window6_table[2];  // per curve: 43 x 32 affine multiples m*64^i*G, m = 1..32
+  uint32_t* window6_table[2];  // per curve: signed-window table (SIGNED_WBITS bits): m * 2^(WB i) * G, m = 1..2^(WB-1)
   uint64_t* workspace;         // grow-only scratch for the windowed path's Jacobian intermediates
   size_t workspace_bytes;
   char err[256];
@@ -110,11 +110,13 @@ int ensure_workspace(ecsimd_hip_ctx* ctx, size_t bytes) {
 }
 
 // Window tables, produced with the (parity-checked) ladder kernel itself.
-//   bits = 4: 64 x 16 entries d * 16^w * G (d = 0 unused);  bits = 6: 43 x 32 entries m * 64^i * G, m = slot + 1.
+//   bits = 4: 64 x 16 entries d * 16^w * G (d = 0 unused);  bits = 6 / 7 (signed windows): 43 x 32 / 37 x 64
+//   entries m * 2^(bits i) * G, m = slot + 1.
+constexpr int SIGNED_WBITS = 7;     // 37 additions, 151 552 B of LDS (6 -> 43 additions, 88 064 B): measured faster
 int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
   uint32_t** slot = (bits == 4) ? &ctx->window_table[curve] : &ctx->window6_table[curve];
   if (*slot) return ECSIMD_HIP_OK;
-  const int windows = (bits == 4) ? 64 : 43, per = (bits == 4) ? 16 : 32;
+  const int windows = (bits == 4) ? 64 : (256 + bits) / bits, per = (bits == 4) ? 16 : 1 << (bits - 1);
   const size_t entries = (size_t)windows * per;
   std::vector<uint64_t> host_k(entries * 4, 0);
   for (int w = 0; w < windows; ++w)
@@ -147,13 +149,14 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
     launch::scalar_mult(ctx->stream, curve, kd, 4, nullptr, nullptr, jx, jy, jz, entries, ECSIMD_HIP_OUT_AFFINE);
     launch::to_affine_batched(ctx->stream, curve, jx, jy, jz, tx, ty, entries, true);
   }
-  if (bits == 6) {   // entry (42, m = 16) = 16 * 2^252 * G = T(42, 15) + T(42, 1)
+  if (bits != 4) {   // top window, entry m = 16: 16 * 2^252 * G = T(top, 15) + T(top, 1)
     uint64_t* sx = ty + entries * 4; uint64_t* sy = sx + 4;                                  // scratch (the Jacobian area is free again)
-    const size_t e15 = ((size_t)42 * per + 14) * 4, e1 = ((size_t)42 * per + 0) * 4, e16 = ((size_t)42 * per + 15) * 4;
+    const size_t top = (size_t)(windows - 1);
+    const size_t e15 = (top * per + 14) * 4, e1 = (top * per + 0) * 4, e16 = (top * per + 15) * 4;
     launch::affine_add_batched(ctx->stream, curve, tx + e15, ty + e15, tx + e1, ty + e1, sx, sy, nullptr, 1);
     (void)hipMemcpyAsync(tx + e16, sx, 32, hipMemcpyDeviceToDevice, ctx->stream);
     (void)hipMemcpyAsync(ty + e16, sy, 32, hipMemcpyDeviceToDevice, ctx->stream);
-    launch::pack_table6(ctx->stream, curve, tx, ty, table);
+    launch::pack_table_signed(ctx->stream, curve, bits, tx, ty, table);
   } else {
     launch::pack_table(ctx->stream, curve, tx, ty, table);
   }
@@ -381,18 +384,18 @@ int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[
 int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(ox); REQUIRE_PTR(oy);
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
-  if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED6)) {
-    const bool six = (flags & ECSIMD_HIP_ALG_WINDOWED6) != 0;
+  if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED)) {
+    const bool six = (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED) != 0;      // signed windows
     // 4-bit windows over an LDS-resident table, then one simultaneous inversion: affine output only
     // (the Jacobian representative differs from the reference ladder's -- SURVEY.md 8(a) level A).
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
     if (n == 0) return ECSIMD_HIP_OK;
     (void)hipSetDevice(ctx->device);
-    int rc = ensure_window_table(ctx, curve, six ? 6 : 4);
+    int rc = ensure_window_table(ctx, curve, six ? SIGNED_WBITS : 4);
     if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 3 * n * 32);
     if (rc != ECSIMD_HIP_OK) return rc;
     uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
-    RUN(((six ? launch::base_windowed6(s, curve, k, ctx->window6_table[curve], jx, jy, jz, n)
+    RUN(((six ? launch::base_windowed_signed(s, curve, SIGNED_WBITS, k, ctx->window6_table[curve], jx, jy, jz, n)
               : launch::base_windowed(s, curve, k, ctx->window_table[curve], jx, jy, jz, n)),
          launch::to_affine_batched(s, curve, jx, jy, jz, ox, oy, n, true)));
   }
@@ -411,13 +414,13 @@ int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t
   if (ry && !aligned16(ry)) return bad(ctx, "ry is not 16-byte aligned");
   if (n == 0) return ECSIMD_HIP_OK;
   (void)hipSetDevice(ctx->device);
-  int rc = ensure_window_table(ctx, curve, 6);
+  int rc = ensure_window_table(ctx, curve, SIGNED_WBITS);
   if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 7 * n * 32);        // 3 Jacobian + 2 x 2 affine intermediates
   if (rc != ECSIMD_HIP_OK) return rc;
   uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
   uint64_t* gx = jz + 4 * n; uint64_t* gy = gx + 4 * n; uint64_t* px = gy + 4 * n; uint64_t* py = px + 4 * n;
   hipStream_t s = ctx->stream;
-  launch::base_windowed6(s, curve, u1, ctx->window6_table[curve], jx, jy, jz, n);        // u1*G
+  launch::base_windowed_signed(s, curve, SIGNED_WBITS, u1, ctx->window6_table[curve], jx, jy, jz, n);   // u1*G
   launch::to_affine_batched(s, curve, jx, jy, jz, gx, gy, n, true);
   launch::scalar_mult(s, curve, u2, 4, qx, qy, jx, jy, jz, n, ECSIMD_HIP_OUT_AFFINE);    // u2*Q (reference ladder)
   launch::to_affine_batched(s, curve, jx, jy, jz, px, py, n, true);

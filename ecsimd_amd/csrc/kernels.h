@@ -62,8 +62,9 @@ void to_affine_batched(hipStream_t, int curve, const uint64_t* jx, const uint64_
 void affine_add_batched(hipStream_t, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
 void pack_table(hipStream_t, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
 void base_windowed(hipStream_t, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
-void pack_table6(hipStream_t, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
-void base_windowed6(hipStream_t, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
+// signed windows of wbits = 6 or 7 bits
+void pack_table_signed(hipStream_t, int curve, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
+void base_windowed_signed(hipStream_t, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
 
 // per-curve pieces (one translation unit each)
 template <int C> struct point_launch {
@@ -81,10 +82,9 @@ template <int C> struct point_launch {
   static void affine_add_batched(hipStream_t, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
   static void pack_table(hipStream_t, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
   static void base_windowed(hipStream_t, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
-  static void pack_table6(hipStream_t, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
-  static void base_windowed6(hipStream_t, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
+  static void pack_table_signed(hipStream_t, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
+  static void base_windowed_signed(hipStream_t, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
 };
-constexpr size_t WINDOW6_TABLE_BYTES = 43 * 32 * 64;  // 43 signed 6-bit windows x 32 magnitudes x (x, y)
 constexpr size_t WINDOW_TABLE_BYTES = 64 * 16 * 64;   // 64 windows x 16 digits x (x, y)
 
 }  // namespace launch

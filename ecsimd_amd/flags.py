@@ -4,4 +4,4 @@ BASE_MGRY = 1
 OUT_JACOBIAN = 0
 OUT_AFFINE = 2
 ALG_WINDOWED = 4
-ALG_WINDOWED6 = 8
+ALG_WINDOWED_SIGNED = 8

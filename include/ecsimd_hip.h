@@ -60,8 +60,8 @@ enum {
                                       affine result for every k except the ladder's degenerate scalars k = n-1, 2^256-n-1,
                                       2^256-n (there the reference returns a meaningless point, this path the right one);
                                       k = 0 mod n -> (0, 0) */
-  ECSIMD_HIP_ALG_WINDOWED6 = 8     /* as ALG_WINDOWED with signed 6-bit windows: 43 mixed additions instead of 64, an 88 KB
-                                      table of m*64^i*G (m = 1..32) in LDS; same results */
+  ECSIMD_HIP_ALG_WINDOWED_SIGNED = 8 /* as ALG_WINDOWED with signed 7-bit windows: 37 mixed additions instead of 64, a 148 KiB
+                                      table of m*2^(7i)*G (m = 1..64) in LDS, negative digits negate y; same results */
 };
 
 /* ---- context, stream and memory ------------------------------------------------------- */

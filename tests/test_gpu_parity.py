@@ -303,8 +303,8 @@ def test_windowed_fixed_base_matches_the_ladder_at_affine_level(engine, oracle, 
     k[103] = from_int(2**256 - order); k[104] = from_int(2**256 - order - 1)           # ... of the ladder only
     dk = engine.to_device(k)
     wx, wy = engine.scalar_mult_base(cv, dk, flags=OUT_AFFINE | ALG_WINDOWED)
-    from ecsimd_amd import ALG_WINDOWED6
-    w6x, w6y = engine.scalar_mult_base(cv, dk, flags=OUT_AFFINE | ALG_WINDOWED6)       # signed 6-bit windows: same points
+    from ecsimd_amd import ALG_WINDOWED_SIGNED
+    w6x, w6y = engine.scalar_mult_base(cv, dk, flags=OUT_AFFINE | ALG_WINDOWED_SIGNED)       # signed 7-bit windows: same points
     assert torch.equal(w6x, wx) and torch.equal(w6y, wy)
     lx, ly = engine.scalar_mult_base(cv, dk, flags=OUT_AFFINE)                        # reference ladder + (batched) to_affine
     wxn, wyn, lxn, lyn = (engine.to_numpy(t) for t in (wx, wy, lx, ly))

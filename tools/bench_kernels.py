@@ -69,9 +69,9 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     row(f"scalar_mult_base<{nm}> windowed, affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=6, out=outj)), int((64 * 11 + 7 + 383 / 32) * 136), 96, "scalar mults")
     u1 = e.fill_random(n2, SEED, 21)
     row(f"double_scalar_mult<{nm}> u1*G + u2*Q (ECDSA-verify shape)", n2, timeit(lambda: e.double_scalar_mult(cv, u1, k, b2x, b2y), 5),
-        555968 + int((64 * 11 + 2 * (7 + 383 / 32) + 6 + 383 / 32) * 136), 160, "verifications")
+        555968 + int((37 * 11 + 2 * (7 + 383 / 32) + 6 + 383 / 32) * 136), 160, "verifications")
     del u1
-    row(f"scalar_mult_base<{nm}> signed 6-bit windows, affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 8, out=outj)), int((43 * 11 + 7 + 383 / 32) * 136), 96, "scalar mults")
+    row(f"scalar_mult_base<{nm}> signed 7-bit windows, affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 8, out=outj)), int((37 * 11 + 7 + 383 / 32) * 136), 96, "scalar mults")
     wire = e.sec1_encode(cv, b2x, b2y, True)
     row(f"sec1_decode<{nm}> compressed (decompression)", n2, timeit(lambda: e.sec1_decode(cv, wire, True)), (255 + 128 + 4) * 136, 33 + 64, "points")
     wire = e.sec1_encode(cv, b2x, b2y, False)
