@@ -112,7 +112,28 @@ ECS_DEV void fe2_store(uint64_t* __restrict__ base, size_t i, const fe2& v) {
 }
 
 // ---------------------------------------------------------------- carry-chain primitives
-// a += b over 8 words; returns the carry-out (0/1).                       add.h:11-34
+// A lane mask in an SGPR pair: where the reference keeps carries / borrows as eve::logical masks
+// (add.h:16-34), the natural gfx950 form is the carry-out of the last v_addc itself -- no VALU
+// instruction is spent turning it into data.
+typedef uint64_t lane_mask;
+
+// a += b over 8 words; returns the carry-out as a lane mask.                add.h:11-34
+ECS_DEV lane_mask add8m(fe& a, const fe& b) {
+  lane_mask c;
+  asm("v_add_co_u32 %0, vcc, %0, %9\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %10, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %2, %11, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %3, %12, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %4, %13, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %5, %14, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %6, %15, vcc\n\t"
+      "v_addc_co_u32 %7, %8, %7, %16, vcc"
+      : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(a.w[4]), "+v"(a.w[5]), "+v"(a.w[6]), "+v"(a.w[7]), "=&s"(c)
+      : "v"(b.w[0]), "v"(b.w[1]), "v"(b.w[2]), "v"(b.w[3]), "v"(b.w[4]), "v"(b.w[5]), "v"(b.w[6]), "v"(b.w[7])
+      : "vcc");
+  return c;
+}
+// the same with the carry as a 0/1 word (callers that store it or add it)
 ECS_DEV uint32_t add8(fe& a, const fe& b) {
   uint32_t c;
   asm("v_add_co_u32 %0, vcc, %0, %9\n\t"
@@ -148,53 +169,61 @@ ECS_DEV uint32_t sub8(fe& a, const fe& b) {
 }
 
 // r = (r + top*2^256 >= p) ? r - p : r, for r + top*2^256 < 2p.               sub.h:46-69
-// The borrow of the 9-word subtraction lands in an SGPR pair used as the select mask
-// (v_cndmask with an SGPR-pair mask issues at 4.1 cycles; the implicit-VCC form measured slower).
-template <int CURVE> ECS_DEV void cond_sub_p(fe& r, uint32_t top) {
+// `top` (the 257th bit) is a lane mask.  r - p over 8 words leaves the borrow in VCC; r is kept where
+// (borrow and not top) -- one scalar s_andn2_b64 instead of a ninth VALU subtraction -- and the select
+// uses that SGPR-pair mask (v_cndmask with an SGPR mask issues at 4.1 cycles; the implicit-VCC form
+// measured slower).
+template <int CURVE> ECS_DEV void cond_sub_p(fe& r, lane_mask top) {
   using K = curve_consts<CURVE>;
   fe d;
-  uint64_t keep;
+  lane_mask keep;
   if constexpr (CURVE == CURVE_P256) {
     // p's words are the inline constants -1, -1, -1, 0, 0, 0, 1, -1
-    asm("v_sub_co_u32 %0, vcc, %10, -1\n\t"
-        "v_subb_co_u32 %1, vcc, %11, -1, vcc\n\t"
-        "v_subb_co_u32 %2, vcc, %12, -1, vcc\n\t"
-        "v_subb_co_u32 %3, vcc, %13, 0, vcc\n\t"
-        "v_subb_co_u32 %4, vcc, %14, 0, vcc\n\t"
-        "v_subb_co_u32 %5, vcc, %15, 0, vcc\n\t"
-        "v_subb_co_u32 %6, vcc, %16, 1, vcc\n\t"
-        "v_subb_co_u32 %7, vcc, %17, -1, vcc\n\t"
-        "v_subb_co_u32 %8, %9, %18, 0, vcc"
-        : "=&v"(d.w[0]), "=&v"(d.w[1]), "=&v"(d.w[2]), "=&v"(d.w[3]), "=&v"(d.w[4]), "=&v"(d.w[5]), "=&v"(d.w[6]), "=&v"(d.w[7]), "=&v"(top), "=&s"(keep)
-        : "v"(r.w[0]), "v"(r.w[1]), "v"(r.w[2]), "v"(r.w[3]), "v"(r.w[4]), "v"(r.w[5]), "v"(r.w[6]), "v"(r.w[7]), "v"(top)
-        : "vcc");
+    asm("v_sub_co_u32 %0, vcc, %9, -1\n\t"
+        "v_subb_co_u32 %1, vcc, %10, -1, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %11, -1, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %12, 0, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %13, 0, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %14, 0, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %15, 1, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %16, -1, vcc\n\t"
+        "s_andn2_b64 %8, vcc, %17"
+        : "=&v"(d.w[0]), "=&v"(d.w[1]), "=&v"(d.w[2]), "=&v"(d.w[3]), "=&v"(d.w[4]), "=&v"(d.w[5]), "=&v"(d.w[6]), "=&v"(d.w[7]), "=&s"(keep)
+        : "v"(r.w[0]), "v"(r.w[1]), "v"(r.w[2]), "v"(r.w[3]), "v"(r.w[4]), "v"(r.w[5]), "v"(r.w[6]), "v"(r.w[7]), "s"(top)
+        : "vcc", "scc");
   } else {
     // secp256k1: words 2..7 are -1; words 0, 1 come in VGPRs (an SGPR source next to the VCC carry-in
     // would exceed gfx9's one-scalar-operand constant-bus limit)
     const uint32_t p0 = K::P[0], p1 = K::P[1];
-    asm("v_sub_co_u32 %0, vcc, %10, %19\n\t"
-        "v_subb_co_u32 %1, vcc, %11, %20, vcc\n\t"
-        "v_subb_co_u32 %2, vcc, %12, -1, vcc\n\t"
-        "v_subb_co_u32 %3, vcc, %13, -1, vcc\n\t"
-        "v_subb_co_u32 %4, vcc, %14, -1, vcc\n\t"
-        "v_subb_co_u32 %5, vcc, %15, -1, vcc\n\t"
-        "v_subb_co_u32 %6, vcc, %16, -1, vcc\n\t"
-        "v_subb_co_u32 %7, vcc, %17, -1, vcc\n\t"
-        "v_subb_co_u32 %8, %9, %18, 0, vcc"
-        : "=&v"(d.w[0]), "=&v"(d.w[1]), "=&v"(d.w[2]), "=&v"(d.w[3]), "=&v"(d.w[4]), "=&v"(d.w[5]), "=&v"(d.w[6]), "=&v"(d.w[7]), "=&v"(top), "=&s"(keep)
-        : "v"(r.w[0]), "v"(r.w[1]), "v"(r.w[2]), "v"(r.w[3]), "v"(r.w[4]), "v"(r.w[5]), "v"(r.w[6]), "v"(r.w[7]), "v"(top), "v"(p0), "v"(p1)
-        : "vcc");
+    asm("v_sub_co_u32 %0, vcc, %9, %18\n\t"
+        "v_subb_co_u32 %1, vcc, %10, %19, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %11, -1, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %12, -1, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %13, -1, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %14, -1, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %15, -1, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %16, -1, vcc\n\t"
+        "s_andn2_b64 %8, vcc, %17"
+        : "=&v"(d.w[0]), "=&v"(d.w[1]), "=&v"(d.w[2]), "=&v"(d.w[3]), "=&v"(d.w[4]), "=&v"(d.w[5]), "=&v"(d.w[6]), "=&v"(d.w[7]), "=&s"(keep)
+        : "v"(r.w[0]), "v"(r.w[1]), "v"(r.w[2]), "v"(r.w[3]), "v"(r.w[4]), "v"(r.w[5]), "v"(r.w[6]), "v"(r.w[7]), "s"(top), "v"(p0), "v"(p1)
+        : "vcc", "scc");
   }
-  // keep (borrow of the 257-bit subtraction) set  <=>  value < p  <=>  keep r
+  // keep set  <=>  value < p  <=>  keep r
 #pragma unroll
   for (int i = 0; i < 8; ++i)
     asm("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r.w[i]) : "v"(d.w[i]), "s"(keep));
+}
+// lane mask of (v != 0)
+ECS_DEV lane_mask mask_nonzero(uint32_t v) {
+  lane_mask m;
+  asm("v_cmp_ne_u32_e64 %0, %1, 0" : "=s"(m) : "v"(v));
+  return m;
 }
 
 // ---------------------------------------------------------------- modular linear ops
 // (a + b) mod p                                                            modular.h:10-15
 template <int CURVE> ECS_DEV fe fe_add(fe a, const fe& b) {
-  uint32_t c = add8(a, b);
+  const lane_mask c = add8m(a, b);
   cond_sub_p<CURVE>(a, c);
   return a;
 }
@@ -234,7 +263,8 @@ template <int CURVE> ECS_DEV fe fe_sub(fe a, const fe& b) {
 // 2a mod p                                                                 modular.h:17-22
 template <int CURVE> ECS_DEV fe fe_dbl(const fe& a) {
   fe s;
-  uint32_t c = a.w[7] >> 31;
+  lane_mask c;                                                         // bit 255 of a = the carry out of the shift
+  asm("v_cmp_gt_i32_e64 %0, 0, %1" : "=s"(c) : "v"(a.w[7]));
 #pragma unroll
   for (int i = 7; i > 0; --i) s.w[i] = __builtin_amdgcn_alignbit(a.w[i], a.w[i - 1], 31);   // (a[i]:a[i-1]) >> 31
   s.w[0] = a.w[0] << 1;
@@ -340,7 +370,7 @@ ECS_DEV fe2 sqr8(const fe& a) {
 #pragma unroll
   for (int i = 14; i > 0; --i) c[i] = __builtin_amdgcn_alignbit(c[i], c[i - 1], 31);
   // c[0] stays 0.  Add the diagonal squares d_i = a_i^2 at word 2i: two 32-bit carry chains
-  // (words 1..7, then 8..15); the carry between them is folded into d_4 (a_4^2 + 1 < 2^64).
+  // (words 1..7, then 8..15); the carry between them travels as an SGPR lane mask.
   uint64_t d[8];
 #pragma unroll
   for (int i = 0; i < 4; ++i) d[i] = mul_wide(a.w[i], a.w[i]);
@@ -348,25 +378,22 @@ ECS_DEV fe2 sqr8(const fe& a) {
   uint32_t dh[8], dl[8];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { dl[i] = (uint32_t)d[i]; dh[i] = (uint32_t)(d[i] >> 32); }
-  uint32_t cy;
+  lane_mask cy;                             // carry from word 7 into word 8, kept as a lane mask
   asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
       "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
       "v_addc_co_u32 %2, vcc, %2, %10, vcc\n\t"
       "v_addc_co_u32 %3, vcc, %3, %11, vcc\n\t"
       "v_addc_co_u32 %4, vcc, %4, %12, vcc\n\t"
       "v_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"
-      "v_addc_co_u32 %6, vcc, %6, %14, vcc\n\t"
-      "v_addc_co_u32 %7, vcc, 0, 0, vcc"
-      : "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "=v"(cy)
+      "v_addc_co_u32 %6, %7, %6, %14, vcc"
+      : "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "=&s"(cy)
       : "v"(dh[0]), "v"(dl[1]), "v"(dh[1]), "v"(dl[2]), "v"(dh[2]), "v"(dl[3]), "v"(dh[3])
       : "vcc");
-  d[4] = (uint64_t)cy;
-  mac_nocarry(d[4], a.w[4], a.w[4]);
 #pragma unroll
-  for (int i = 5; i < 8; ++i) d[i] = mul_wide(a.w[i], a.w[i]);
+  for (int i = 4; i < 8; ++i) d[i] = mul_wide(a.w[i], a.w[i]);
 #pragma unroll
   for (int i = 4; i < 8; ++i) { dl[i] = (uint32_t)d[i]; dh[i] = (uint32_t)(d[i] >> 32); }
-  asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
+  asm("v_addc_co_u32 %0, vcc, %0, %8, %16\n\t"        // carry-in: the lane mask of the first chain
       "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
       "v_addc_co_u32 %2, vcc, %2, %10, vcc\n\t"
       "v_addc_co_u32 %3, vcc, %3, %11, vcc\n\t"
@@ -375,7 +402,7 @@ ECS_DEV fe2 sqr8(const fe& a) {
       "v_addc_co_u32 %6, vcc, %6, %14, vcc\n\t"
       "v_addc_co_u32 %7, vcc, %7, %15, vcc"
       : "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15])
-      : "v"(dl[4]), "v"(dh[4]), "v"(dl[5]), "v"(dh[5]), "v"(dl[6]), "v"(dh[6]), "v"(dl[7]), "v"(dh[7])
+      : "v"(dl[4]), "v"(dh[4]), "v"(dl[5]), "v"(dh[5]), "v"(dl[6]), "v"(dh[6]), "v"(dl[7]), "v"(dh[7]), "s"(cy)
       : "vcc");
 #pragma unroll
   for (int i = 1; i < 16; ++i) t.w[i] = c[i];
@@ -390,9 +417,9 @@ ECS_DEV fe2 sqr8(const fe& a) {
 // P-256: p = -1 mod 2^96, so m' = 1 (mgry_mul.h:37 gives mprime = 1) and q = the low 64 bits
 // themselves.  q*p = q*2^256 - q*2^224 + q*2^192 + q*2^96 - q: no multiplies.  Four 64-bit
 // rounds; in each, with M = q*(2^64 - 2^32 + 1) (the p[3] limb 0xffffffff00000001 times q):
-//   t[o+3..o+4] += q,  t[o+6..o+9] += M,  carry out -> word o+10 (folded into the next round's M).
+//   t[o+3..o+4] += q,  t[o+6..o+9] += M,  carry out -> word o+10 (an SGPR lane mask, the carry-in of the next round's M).
 ECS_DEV fe mgry_reduce_p256(fe2& t) {
-  uint32_t cin = 0;
+  lane_mask cin = 0;                       // carry out of a round's chain, consumed as carry-IN by the next
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int o = 2 * r;
@@ -402,19 +429,18 @@ ECS_DEV fe mgry_reduce_p256(fe2& t) {
         "v_subb_co_u32 %1, vcc, %3, %4, vcc\n\t"    // M2 = q0 - q1 - b
         "v_subb_co_u32 %2, vcc, %4, 0, vcc"         // M3 = q1 - b
         : "=&v"(m1), "=&v"(m2), "=&v"(m3) : "v"(q0), "v"(q1) : "vcc");
-    if (r > 0)
-      asm("v_add_co_u32 %0, vcc, %0, %2\n\t"
+    if (r > 0)                                       // M += cin * 2^64 (the previous chain's carry-out, weight of word o+8)
+      asm("v_addc_co_u32 %0, vcc, 0, %0, %2\n\t"
           "v_addc_co_u32 %1, vcc, 0, %1, vcc"
-          : "+v"(m2), "+v"(m3) : "v"(cin) : "vcc");
+          : "+v"(m2), "+v"(m3) : "s"(cin) : "vcc");
     asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
         "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
         "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
         "v_addc_co_u32 %3, vcc, %3, %8, vcc\n\t"
         "v_addc_co_u32 %4, vcc, %4, %10, vcc\n\t"
         "v_addc_co_u32 %5, vcc, %5, %11, vcc\n\t"
-        "v_addc_co_u32 %6, vcc, %6, %12, vcc\n\t"
-        "v_addc_co_u32 %7, vcc, 0, 0, vcc"
-        : "+v"(t.w[o + 3]), "+v"(t.w[o + 4]), "+v"(t.w[o + 5]), "+v"(t.w[o + 6]), "+v"(t.w[o + 7]), "+v"(t.w[o + 8]), "+v"(t.w[o + 9]), "=v"(cin)
+        "v_addc_co_u32 %6, %7, %6, %12, vcc"          // carry-out of the chain goes straight to an SGPR pair
+        : "+v"(t.w[o + 3]), "+v"(t.w[o + 4]), "+v"(t.w[o + 5]), "+v"(t.w[o + 6]), "+v"(t.w[o + 7]), "+v"(t.w[o + 8]), "+v"(t.w[o + 9]), "=&s"(cin)
         : "v"(q0), "v"(q1), "v"(m1), "v"(m2), "v"(m3)
         : "vcc");
   }
@@ -453,7 +479,7 @@ template <int CURVE> ECS_DEV fe mgry_reduce_generic(fe2& t) {
   fe res;
 #pragma unroll
   for (int i = 0; i < 8; ++i) res.w[i] = t.w[8 + i];
-  cond_sub_p<CURVE>(res, top);
+  cond_sub_p<CURVE>(res, mask_nonzero(top));
   return res;
 }
 
@@ -491,7 +517,8 @@ ECS_DEV fe reduce_secp256k1_classical(fe2& t) {
   const uint64_t m0 = mul_wide(s8, K);
   uint64_t m1 = (uint64_t)(uint32_t)(m0 >> 32);
   mac_nocarry(m1, s9, K);
-  uint32_t f0 = (uint32_t)m0, f1 = (uint32_t)m1, f2 = (uint32_t)(m1 >> 32), top;
+  uint32_t f0 = (uint32_t)m0, f1 = (uint32_t)m1, f2 = (uint32_t)(m1 >> 32);
+  lane_mask top;
   asm("v_add_co_u32 %1, vcc, %1, %12\n\t"          // f1 += s8
       "v_addc_co_u32 %2, vcc, %2, %13, vcc\n\t"    // f2 += s9 + carry
       "v_add_co_u32 %3, vcc, %3, %0\n\t"           // A0 += f0
@@ -501,9 +528,8 @@ ECS_DEV fe reduce_secp256k1_classical(fe2& t) {
       "v_addc_co_u32 %7, vcc, 0, %7, vcc\n\t"
       "v_addc_co_u32 %8, vcc, 0, %8, vcc\n\t"
       "v_addc_co_u32 %9, vcc, 0, %9, vcc\n\t"
-      "v_addc_co_u32 %10, vcc, 0, %10, vcc\n\t"
-      "v_addc_co_u32 %11, vcc, 0, 0, vcc"
-      : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(A.w[0]), "+v"(A.w[1]), "+v"(A.w[2]), "+v"(A.w[3]), "+v"(A.w[4]), "+v"(A.w[5]), "+v"(A.w[6]), "+v"(A.w[7]), "=v"(top)
+      "v_addc_co_u32 %10, %11, 0, %10, vcc"
+      : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(A.w[0]), "+v"(A.w[1]), "+v"(A.w[2]), "+v"(A.w[3]), "+v"(A.w[4]), "+v"(A.w[5]), "+v"(A.w[6]), "+v"(A.w[7]), "=&s"(top)
       : "v"(s8), "v"(s9)
       : "vcc");
   cond_sub_p<CURVE_SECP256K1_CLASSICAL>(A, top);
