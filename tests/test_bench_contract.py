@@ -1,0 +1,35 @@
+"""CPU suite: the committed bench lines carry every field the driver's contract names, and the numbers in
+them are internally consistent (achieved = value x algorithmic work; frac = achieved / peak)."""
+import glob
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_n1_*.json")))
+
+
+@pytest.mark.parametrize("path", LINES, ids=[os.path.relpath(p, ROOT) for p in LINES])
+def test_bench_line_contract(path):
+    d = json.load(open(path))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in d, key
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["global_batch"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    per_launch = d["config"]["per_gpu_batch"] / (r["kernel_ms"] * 1e-3) * r["algorithmic_mad32_per_unit"] / 1e12
+    assert abs(per_launch - r["achieved"]) / r["achieved"] < 1e-6
+    if "cpu_baseline" in d:
+        c = d["cpu_baseline"]
+        for key in ("value", "unit", "cores", "kind", "sample"):
+            assert key in c, key
+        assert c["kind"] in ("reference", "port") and c["differences_all_explained_by_reference_square_defect"] is True
+
+
+def test_there_is_a_headline_line():
+    assert any("ladder" in p and "secp" not in p for p in LINES)
