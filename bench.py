@@ -71,6 +71,12 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     curve = CURVES[args.curve]
+    import ecsimd_amd
+    if not os.path.exists(ecsimd_amd.lib_path()) and local_rank == 0:
+        import __graft_entry__
+        __graft_entry__.build()         # built artefacts normally travel with the snapshot
+    if world > 1:
+        dist.barrier()
     eng = Engine(local_rank)            # raises if the HIP library / a gfx950 device is missing: no fallback
     n = 1 << args.log2_batch
     first = rank * n                    # this rank's slice of the global synthetic streams
