@@ -1,4 +1,6 @@
-// scratch: bisect the sqr8 mismatch (cross sum / doubling / diagonal chains) against host big-int
+// Standalone check of sqr8 (cross sum / doubling / diagonal chains) and of ecsimd_hip_square against host
+// big-int arithmetic on carry-heavy operands.  This is the program that showed the HIP squaring to be exact
+// and the REFERENCE's square() to drop a carry.  Build: see the first lines of main().
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -13,4 +13,4 @@ for line in sys.stdin:
     if m and cur is not None: cur[m.group(1).strip()] = int(m.group(2))
     if "error" in line: print(line.rstrip())
 for r in rows:
-    print(f"{r['name'][:70]:70s} vgpr={r.get('VGPRs',-1):3d} agpr={r.get('AGPRs',0):3d} sgpr={r.get('SGPRs',-1):3d} scratch={r.get('ScratchSize',0):4d} occ={r.get('Occupancy',-1)} spill={r.get('VGPRs Spill',0)}")
+    print(f"{r['name'][:70]:70s} vgpr={r.get('VGPRs',-1):3d} agpr={r.get('AGPRs',0):3d} sgpr={r.get('TotalSGPRs',-1):3d} scratch={r.get('ScratchSize',0):4d} occ={r.get('Occupancy',-1)} spill={r.get('VGPRs Spill',0)}")
