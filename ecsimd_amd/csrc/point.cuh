@@ -109,6 +109,26 @@ template <int C> ECS_DEV jpoint add_z2_1(const fe& X1, const fe& Y1, const fe& Z
   return R;
 }
 
+// Mixed addition with 8M + 3S and only 7 linear operations (Hankerson-Menezes-Vanstone, Alg. 3.22) for the
+// windowed fixed-base kernels: there the Jacobian representative is free (affine-level parity), and the
+// linear operations -- canonical, ~20 VALU instructions each -- are what ADD_Z2_1's 15 of them cost.
+// Z3 = Z1 * H (ADD_Z2_1 returns 2 * Z1 * H): a different representative of the same point.
+template <int C> ECS_DEV jpoint madd_hmv(const fe& X1, const fe& Y1, const fe& Z1, const fe& x2, const fe& y2) {
+  const fe Z1Z1 = fe_sqr<C>(Z1);
+  const fe U2 = fe_mul<C>(x2, Z1Z1);
+  const fe S2 = fe_mul<C>(y2, fe_mul<C>(Z1Z1, Z1));
+  const fe H = fe_sub<C>(U2, X1);
+  const fe r = fe_sub<C>(S2, Y1);
+  const fe HH = fe_sqr<C>(H);
+  const fe HHH = fe_mul<C>(H, HH);
+  const fe V = fe_mul<C>(X1, HH);
+  jpoint R;
+  R.z = fe_mul<C>(Z1, H);
+  R.x = fe_sub<C>(fe_sub<C>(fe_sqr<C>(r), HHH), fe_dbl<C>(V));
+  R.y = fe_sub<C>(fe_mul<C>(r, fe_sub<C>(V, R.x)), fe_mul<C>(Y1, HHH));
+  return R;
+}
+
 // a^(p-2) and a^((p+1)/4): exponents as compile-time word arrays (gfp.h:79-87).
 template <int C> struct curve_exps;
 template <> struct curve_exps<CURVE_P256> {
