@@ -133,6 +133,41 @@ ECS_DEV lane_mask add8m(fe& a, const fe& b) {
       : "vcc");
   return c;
 }
+// r = a + b (three-operand form: when a stays live the compiler needs no register copies)
+ECS_DEV lane_mask add8m3(fe& r, const fe& a, const fe& b) {
+  lane_mask c;
+  asm("v_add_co_u32 %0, vcc, %9, %17\n\t"
+      "v_addc_co_u32 %1, vcc, %10, %18, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %11, %19, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %12, %20, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %13, %21, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %14, %22, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %15, %23, vcc\n\t"
+      "v_addc_co_u32 %7, %8, %16, %24, vcc"
+      : "=&v"(r.w[0]), "=&v"(r.w[1]), "=&v"(r.w[2]), "=&v"(r.w[3]), "=&v"(r.w[4]), "=&v"(r.w[5]), "=&v"(r.w[6]), "=&v"(r.w[7]), "=&s"(c)
+      : "v"(a.w[0]), "v"(a.w[1]), "v"(a.w[2]), "v"(a.w[3]), "v"(a.w[4]), "v"(a.w[5]), "v"(a.w[6]), "v"(a.w[7]),
+        "v"(b.w[0]), "v"(b.w[1]), "v"(b.w[2]), "v"(b.w[3]), "v"(b.w[4]), "v"(b.w[5]), "v"(b.w[6]), "v"(b.w[7])
+      : "vcc");
+  return c;
+}
+// r = a - b, borrow returned as an all-ones / all-zeros word (three-operand form)
+ECS_DEV uint32_t sub8_3(fe& r, const fe& a, const fe& b) {
+  uint32_t m;
+  asm("v_sub_co_u32 %0, vcc, %9, %17\n\t"
+      "v_subb_co_u32 %1, vcc, %10, %18, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %11, %19, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %12, %20, vcc\n\t"
+      "v_subb_co_u32 %4, vcc, %13, %21, vcc\n\t"
+      "v_subb_co_u32 %5, vcc, %14, %22, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %15, %23, vcc\n\t"
+      "v_subb_co_u32 %7, vcc, %16, %24, vcc\n\t"
+      "v_subb_co_u32 %8, vcc, 0, 0, vcc"
+      : "=&v"(r.w[0]), "=&v"(r.w[1]), "=&v"(r.w[2]), "=&v"(r.w[3]), "=&v"(r.w[4]), "=&v"(r.w[5]), "=&v"(r.w[6]), "=&v"(r.w[7]), "=&v"(m)
+      : "v"(a.w[0]), "v"(a.w[1]), "v"(a.w[2]), "v"(a.w[3]), "v"(a.w[4]), "v"(a.w[5]), "v"(a.w[6]), "v"(a.w[7]),
+        "v"(b.w[0]), "v"(b.w[1]), "v"(b.w[2]), "v"(b.w[3]), "v"(b.w[4]), "v"(b.w[5]), "v"(b.w[6]), "v"(b.w[7])
+      : "vcc");
+  return m;
+}
 // the same with the carry as a 0/1 word (callers that store it or add it)
 ECS_DEV uint32_t add8(fe& a, const fe& b) {
   uint32_t c;
@@ -222,14 +257,16 @@ ECS_DEV lane_mask mask_nonzero(uint32_t v) {
 
 // ---------------------------------------------------------------- modular linear ops
 // (a + b) mod p                                                            modular.h:10-15
-template <int CURVE> ECS_DEV fe fe_add(fe a, const fe& b) {
-  const lane_mask c = add8m(a, b);
+template <int CURVE> ECS_DEV fe fe_add(const fe& x, const fe& b) {
+  fe a;
+  const lane_mask c = add8m3(a, x, b);
   cond_sub_p<CURVE>(a, c);
   return a;
 }
 // (a - b) mod p: subtract, then add (p & borrow-mask).                     modular.h:24-41
-template <int CURVE> ECS_DEV fe fe_sub(fe a, const fe& b) {
-  uint32_t m = sub8(a, b);
+template <int CURVE> ECS_DEV fe fe_sub(const fe& x, const fe& b) {
+  fe a;
+  uint32_t m = sub8_3(a, x, b);
   if constexpr (CURVE == CURVE_P256) {
     uint32_t m1 = m & 1u;   // p & mask = {m, m, m, 0, 0, 0, m&1, m}
     asm("v_add_co_u32 %0, vcc, %0, %8\n\t"

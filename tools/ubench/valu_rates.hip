@@ -93,6 +93,23 @@ KERNEL_BEGIN(k_addc_chain8)   asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" 
 KERNEL_BEGIN(k_add_dep1)      asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[0]) : "v"(b)); KERNEL_END
 KERNEL64_BEGIN(k_fma64_dep1)  asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a[0]) : "v"(b64)); KERNEL64_END
 
+// register-move forms for the Comba column shift, and the cost of the s_nop the compiler puts between
+// dependent inline-asm statements (gfx950 dst-forwarding hazard workaround)
+KERNEL64_BEGIN(k_pk_mov)      asm volatile("v_pk_mov_b32 %0, %0, %1 op_sel:[1,0]" : "+v"(a[i]) : "v"(b64)); KERNEL64_END
+KERNEL64_BEGIN(k_mov_b64)     asm volatile("v_mov_b64 %0, %1" : "+v"(a[i]) : "v"(b64)); KERNEL64_END
+KERNEL64_BEGIN(k_comba4_sep)  if (i < 4) { uint32_t ex = c;
+    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "+v"(a[i]), "+v"(ex) : "v"(b), "v"(c) : "vcc");
+    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "+v"(a[i]), "+v"(ex) : "v"(b), "v"(c) : "vcc");
+    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "+v"(a[i]), "+v"(ex) : "v"(b), "v"(c) : "vcc");
+    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "+v"(a[i]), "+v"(ex) : "v"(b), "v"(c) : "vcc");
+    a[i] ^= ex; } KERNEL64_END
+KERNEL64_BEGIN(k_comba4_one)  if (i < 4) { uint32_t ex = c;
+    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+                 "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+                 "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+                 "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "+v"(a[i]), "+v"(ex) : "v"(b), "v"(c) : "vcc");
+    a[i] ^= ex; } KERNEL64_END
+
 typedef void (*kern_t)(uint32_t*, uint32_t);
 struct Entry { const char* name; kern_t k; int insts_per_slot; };
 
@@ -118,6 +135,8 @@ int main(int argc, char** argv) {
     {"v_sub_u32", k_sub_u32, 1}, {"v_cmp_lt_u32", k_cmp_only, 1}, {"v_pk_add_u16", k_pk_add_u16, 1},
     {"mad_u64 dep-chain x1", k_mad_dep1, 1}, {"mad_u64 dep-chain x2", k_mad_dep2, 1}, {"mad_u64 dep-chain x4", k_mad_dep4, 1},
     {"mad+addc dep x1", k_comba_dep1, 2}, {"addc dep x1", k_addc_dep1, 1}, {"addc chain(8 regs)", k_addc_chain8, 1}, {"v_add_u32 dep x1", k_add_dep1, 1}, {"v_fma_f64 dep x1", k_fma64_dep1, 1},
+    {"v_pk_mov_b32", k_pk_mov, 1}, {"v_mov_b64", k_mov_b64, 1},
+    {"4x(mad+addc) 4 asm /4", k_comba4_sep, 2}, {"4x(mad+addc) 1 asm /4", k_comba4_one, 2},
   };
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   const int wps_list[] = {1, 2, 4, 8};   // waves per SIMD
