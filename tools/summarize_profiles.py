@@ -4,14 +4,14 @@ import collections, csv, glob, json, os, re, shutil, sys
 
 
 def newest(pattern):
-    """gpurun merges every call's files into gpurun_out/: keep the highest-numbered (latest) run per directory."""
+    """gpurun merges every call's files into gpurun_out/: keep the most recently written run per directory
+    (the numeric prefix is a process id, not an order)."""
     best = {}
     for f in glob.glob(pattern):
-        m = re.match(r"(\d+)_", os.path.basename(f))
         key = os.path.dirname(f)
-        if m and (key not in best or int(m.group(1)) > best[key][0]):
-            best[key] = (int(m.group(1)), f)
-    return sorted(v[1] for v in best.values())
+        if key not in best or os.path.getmtime(f) > os.path.getmtime(best[key]):
+            best[key] = f
+    return sorted(best.values())
 
 
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
