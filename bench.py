@@ -19,7 +19,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  peak = the dependency-free v_mad_u64_u32 stream measured live on the same GPU.
   cpu_baseline : the REAL reference (oracle/_ref, eve/AVX2) -- or the C port if that library did
                  not travel -- timed on the host cores on a bounded sample of the same workload,
-                 and compared bit-for-bit with the GPU result on that sample.
+                 and compared bit-for-bit with the GPU result on that sample.  Its sub-object
+                 competitor_openssl is the reference's competitor benchmark (benchs/p256_ref.cpp:55-91,
+                 libcrypto's EC_POINT_mul) on the same cores, with 8 192 of the GPU's results checked
+                 against libcrypto at the affine level.
 """
 import argparse
 import json
@@ -169,6 +172,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             if args.workload == "ladder":
                 result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, runner.last_result(), args.cpu_seconds)
+                comp = competitor_openssl(eng, curve, k, bx, by, runner.last_result())
+                if comp is not None:
+                    result["cpu_baseline"]["competitor_openssl"] = comp
             else:
                 result["cpu_baseline"] = cpu_baseline_fixed_base(eng, curve, k, runner.last_result(), args.cpu_seconds)
         print(json.dumps(result), flush=True)
@@ -207,6 +213,35 @@ def cpu_baseline_fixed_base(eng, curve, k, gpu_out, target_s):
                       f"{dt:.1f} s wall, {cores} threads (to_affine single-threaded)",
             "lanes_compared": int(m), "lanes_differing_from_gpu": int(len(bad)),
             "differences_all_explained_by_reference_square_defect": bool(explained)}
+
+
+def competitor_openssl(eng, curve, k, bx, by, gpu_out, seconds=3.0, check_lanes=8192):
+    """Part of the cpu_baseline leg: the reference's competitor benchmark (benchs/p256_ref.cpp:55-91, OpenSSL's
+    EC_POINT_mul) on the host cores, run as a child process, plus an affine-level comparison of a sample of
+    the GPU's results with libcrypto -- a check that depends on neither the reference nor the restatement.
+    Returns None where the OpenSSL headers were not available to build oracle/ossl_check.c."""
+    import subprocess
+    import numpy as np
+    from oracle import loader
+    here = os.path.dirname(os.path.abspath(__file__))
+    if not loader.openssl_available():
+        subprocess.run(["make", "-s", "-C", os.path.join(here, "oracle"), "ossl"], check=False)
+        if not loader.openssl_available():
+            return None
+    cores = usable_cores()
+    try:
+        out = subprocess.run([sys.executable, os.path.join(here, "oracle", "ossl_bench.py"), "--curve", str(curve), "--procs", str(cores),
+                              "--seconds", str(seconds)], capture_output=True, text=True, timeout=120, check=True)
+        res = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:                                  # a reported side figure: never fail the bench line over it
+        return {"error": repr(e)[:200]}
+    m = min(check_lanes, k.shape[0])
+    ax, ay = eng.to_affine(curve, [t[:m].contiguous() for t in gpu_out])
+    vx, vy, inf = loader.OpenSSLCheck().scalar_mult(curve, eng.to_numpy(k[:m]), eng.to_numpy(bx[:m]), eng.to_numpy(by[:m]), threads=cores)
+    diff = (eng.to_numpy(ax) != vx).any(axis=1) | (eng.to_numpy(ay) != vy).any(axis=1) | (inf != 0)
+    res["lanes_compared_with_gpu"] = int(m)
+    res["lanes_differing_from_gpu"] = int(np.count_nonzero(diff))
+    return res
 
 
 def usable_cores():

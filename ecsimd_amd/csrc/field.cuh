@@ -350,30 +350,71 @@ ECS_DEV uint64_t mul_wide(uint32_t a, uint32_t b) {
   return r;
 }
 
+// One Comba column in ONE asm statement: acc += sum_i a[i]*b[i], ex = the number of carries out of the
+// 64-bit accumulator.  (The compiler separates dependent asm statements by an s_nop on gfx950; a statement per
+// partial product paid 64 of them per multiply.)
+#define ECS_MAC0(A, B) "v_mad_u64_u32 %0, vcc, %" #A ", %" #B ", %0\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc\n\t"
+#define ECS_MAC(A, B)  "v_mad_u64_u32 %0, vcc, %" #A ", %" #B ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+template <int N> ECS_DEV void mac_col(uint64_t& acc, uint32_t& ex, const uint32_t (&a)[N], const uint32_t (&b)[N]) {
+  static_assert(N >= 1 && N <= 8, "column length");
+  if constexpr (N == 1)
+    asm(ECS_MAC0(2, 3) : "+v"(acc), "=&v"(ex) : "v"(a[0]), "v"(b[0]) : "vcc");
+  else if constexpr (N == 2)
+    asm(ECS_MAC0(2, 4) ECS_MAC(3, 5) : "+v"(acc), "=&v"(ex) : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]) : "vcc");
+  else if constexpr (N == 3)
+    asm(ECS_MAC0(2, 5) ECS_MAC(3, 6) ECS_MAC(4, 7) : "+v"(acc), "=&v"(ex)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]) : "vcc");
+  else if constexpr (N == 4)
+    asm(ECS_MAC0(2, 6) ECS_MAC(3, 7) ECS_MAC(4, 8) ECS_MAC(5, 9) : "+v"(acc), "=&v"(ex)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]) : "vcc");
+  else if constexpr (N == 5)
+    asm(ECS_MAC0(2, 7) ECS_MAC(3, 8) ECS_MAC(4, 9) ECS_MAC(5, 10) ECS_MAC(6, 11) : "+v"(acc), "=&v"(ex)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]) : "vcc");
+  else if constexpr (N == 6)
+    asm(ECS_MAC0(2, 8) ECS_MAC(3, 9) ECS_MAC(4, 10) ECS_MAC(5, 11) ECS_MAC(6, 12) ECS_MAC(7, 13) : "+v"(acc), "=&v"(ex)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]),
+          "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]) : "vcc");
+  else if constexpr (N == 7)
+    asm(ECS_MAC0(2, 9) ECS_MAC(3, 10) ECS_MAC(4, 11) ECS_MAC(5, 12) ECS_MAC(6, 13) ECS_MAC(7, 14) ECS_MAC(8, 15) : "+v"(acc), "=&v"(ex)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]),
+          "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]) : "vcc");
+  else
+    asm(ECS_MAC0(2, 10) ECS_MAC(3, 11) ECS_MAC(4, 12) ECS_MAC(5, 13) ECS_MAC(6, 14) ECS_MAC(7, 15) ECS_MAC(8, 16) ECS_MAC(9, 17) : "+v"(acc), "=&v"(ex)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+          "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]) : "vcc");
+}
+// column k of a*b: the products a[i]*b[k-i], lo <= i <= hi
+template <int K> ECS_DEV void mul_col(uint64_t& acc, uint32_t& ex, const fe& a, const fe& b) {
+  constexpr int lo = K > 7 ? K - 7 : 0, hi = K < 7 ? K : 7, N = hi - lo + 1;
+  uint32_t x[N], y[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { x[i] = a.w[lo + i]; y[i] = b.w[K - lo - i]; }
+  mac_col<N>(acc, ex, x, y);
+}
+
 ECS_DEV fe2 mul8x8(const fe& a, const fe& b) {
   fe2 t;
   uint64_t acc = mul_wide(a.w[0], b.w[0]);
   t.w[0] = (uint32_t)acc;
   acc >>= 32;
-  uint32_t ex = 0;
-#pragma unroll
-  for (int k = 1; k < 15; ++k) {
-    bool first = true;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int j = k - i;
-      if (j < 0 || j > 7) continue;
-      if (k == 1 && first) mac_nocarry(acc, a.w[i], b.w[j]);        // a*b + (< 2^32) cannot overflow
-      else if (k == 14) mac_nocarry(acc, a.w[i], b.w[j]);           // top column: total < 2^512
-      else if (first || (k == 1)) mac_first(acc, ex, a.w[i], b.w[j]);
-      else mac(acc, ex, a.w[i], b.w[j]);
-      first = false;
-    }
-    t.w[k] = (uint32_t)acc;
-    acc = (acc >> 32) | ((uint64_t)ex << 32);
-  }
-  t.w[15] = (uint32_t)acc;
+  uint32_t ex;
+#define ECS_COL(K) mul_col<K>(acc, ex, a, b); t.w[K] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)ex << 32);
+  ECS_COL(1) ECS_COL(2) ECS_COL(3) ECS_COL(4) ECS_COL(5) ECS_COL(6) ECS_COL(7)
+  ECS_COL(8) ECS_COL(9) ECS_COL(10) ECS_COL(11) ECS_COL(12) ECS_COL(13)
+#undef ECS_COL
+  mac_nocarry(acc, a.w[7], b.w[7]);                                 // top column: total < 2^512
+  t.w[14] = (uint32_t)acc;
+  t.w[15] = (uint32_t)(acc >> 32);
   return t;
+}
+
+// column k of the cross products of a^2: a[i]*a[k-i] for i < k-i <= 7
+template <int K> ECS_DEV void sqr_col(uint64_t& acc, uint32_t& ex, const fe& a) {
+  constexpr int lo = K > 7 ? K - 7 : 0, hi = (K - 1) / 2, N = hi - lo + 1;
+  uint32_t x[N], y[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { x[i] = a.w[lo + i]; y[i] = a.w[K - lo - i]; }
+  mac_col<N>(acc, ex, x, y);
 }
 
 // Squaring: 28 cross products, doubled as a whole, plus the 8 diagonal squares.  mul.h:160-221
@@ -382,25 +423,15 @@ ECS_DEV fe2 sqr8(const fe& a) {
   // cross = sum_{i<j} a_i a_j 2^(32(i+j)), columns 1..13
   uint32_t c[16];
   c[0] = 0;
-  uint64_t acc = 0;
-  uint32_t ex = 0;
-#pragma unroll
-  for (int k = 1; k < 14; ++k) {
-    bool first = true;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int j = k - i;
-      if (j <= i || j > 7) continue;
-      if (k == 1) acc = mul_wide(a.w[i], a.w[j]);
-      else if (k == 2 && first) mac_nocarry(acc, a.w[i], a.w[j]);
-      else if (first) mac_first(acc, ex, a.w[i], a.w[j]);
-      else mac(acc, ex, a.w[i], a.w[j]);
-      first = false;
-    }
-    c[k] = (uint32_t)acc;
-    if (k == 1 || k == 2) { acc >>= 32; ex = 0; }
-    else acc = (acc >> 32) | ((uint64_t)ex << 32);
-  }
+  uint64_t acc = mul_wide(a.w[0], a.w[1]);
+  uint32_t ex;
+  c[1] = (uint32_t)acc; acc >>= 32;
+  mac_nocarry(acc, a.w[0], a.w[2]);                                  // a*b + (< 2^32) cannot overflow
+  c[2] = (uint32_t)acc; acc >>= 32;
+#define ECS_SQCOL(K) sqr_col<K>(acc, ex, a); c[K] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)ex << 32);
+  ECS_SQCOL(3) ECS_SQCOL(4) ECS_SQCOL(5) ECS_SQCOL(6) ECS_SQCOL(7) ECS_SQCOL(8)
+  ECS_SQCOL(9) ECS_SQCOL(10) ECS_SQCOL(11) ECS_SQCOL(12) ECS_SQCOL(13)
+#undef ECS_SQCOL
   c[14] = (uint32_t)acc;            // cross < 2^479: word 14 is the top word
   // double: (c << 1), 16 words
   c[15] = c[14] >> 31;

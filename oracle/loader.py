@@ -1,6 +1,8 @@
 """ctypes front-ends for the two parity checkers.  TEST INFRASTRUCTURE ONLY.
 
 * ``Oracle``      -> oracle/libecsimd_oracle.so  (C restatement, ecsimd_oracle.c)
+* ``OpenSSLCheck`` -> oracle/libecsimd_ossl.so   (libcrypto; independent level-A cross-check and the
+                     reference's competitor benchmark, ossl_check.c)
 * ``Reference``   -> oracle/_ref/libecsimd_ref.so (the real aguinet/ecsimd headers behind ref_driver.cpp;
                      present only where oracle/Makefile could build it, i.e. the build container, and
                      shipped to the GPU box as a prebuilt artefact)
@@ -263,6 +265,59 @@ class Reference(_Lib):
         r = [np.empty_like(x) for _ in range(3)]
         assert self._f("scalar_mult_1s")(C.c_int(curve), _p(k1), _p(x), _p(y), _p(r[0]), _p(r[1]), _p(r[2]), C.c_size_t(len(x))) == 0
         return tuple(r)
+
+
+class OpenSSLCheck:
+    """oracle/libecsimd_ossl.so (ossl_check.c): P-256 / secp256k1 point multiplication through OpenSSL's
+    libcrypto -- an implementation independent of both the reference and the restatement; affine classical
+    coordinates in and out, ``inf`` flags the point at infinity."""
+    path = os.path.join(HERE, "libecsimd_ossl.so")
+
+    def __init__(self):
+        if not os.path.exists(self.path):
+            raise FileNotFoundError(self.path)
+        self.lib = C.CDLL(self.path)
+        self.lib.ossl_time_scalar_mult.restype = C.c_double
+        self.lib.ossl_version.restype = C.c_char_p
+
+    def version(self) -> str:
+        return self.lib.ossl_version().decode()
+
+    def _out(self, n):
+        return np.empty((n, 4), dtype=np.uint64), np.empty((n, 4), dtype=np.uint64), np.zeros(n, dtype=np.uint8)
+
+    def scalar_mult(self, curve, k, x, y, threads=1):
+        k, x, y = _arr(k), _arr(x), _arr(y)
+        ox, oy, inf = self._out(len(k))
+        rc = self.lib.ossl_scalar_mult(C.c_int(curve), _p(k), _p(x), _p(y), _p(ox), _p(oy), _p8(inf), C.c_size_t(len(k)), C.c_int(threads))
+        assert rc == 0, rc
+        return ox, oy, inf
+
+    def scalar_mult_base(self, curve, k, threads=1):
+        k = _arr(k)
+        ox, oy, inf = self._out(len(k))
+        rc = self.lib.ossl_scalar_mult_base(C.c_int(curve), _p(k), _p(ox), _p(oy), _p8(inf), C.c_size_t(len(k)), C.c_int(threads))
+        assert rc == 0, rc
+        return ox, oy, inf
+
+    def double_scalar_mult(self, curve, u1, u2, qx, qy, threads=1):
+        u1, u2, qx, qy = _arr(u1), _arr(u2), _arr(qx), _arr(qy)
+        ox, oy, inf = self._out(len(u1))
+        rc = self.lib.ossl_double_scalar_mult(C.c_int(curve), _p(u1), _p(u2), _p(qx), _p(qy), _p(ox), _p(oy), _p8(inf),
+                                              C.c_size_t(len(u1)), C.c_int(threads))
+        assert rc == 0, rc
+        return ox, oy, inf
+
+    def time_scalar_mult(self, curve, k, x, y, threads=1) -> float:
+        """Seconds for len(k) variable-base multiplications on `threads` threads (benchs/p256_ref.cpp:55-91)."""
+        k, x, y = _arr(k), _arr(x), _arr(y)
+        t = self.lib.ossl_time_scalar_mult(C.c_int(curve), _p(k), _p(x), _p(y), C.c_size_t(len(k)), C.c_int(threads))
+        assert t > 0, t
+        return float(t)
+
+
+def openssl_available() -> bool:
+    return os.path.exists(OpenSSLCheck.path)
 
 
 def reference_available() -> bool:

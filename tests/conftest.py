@@ -43,6 +43,18 @@ def reference():
 
 
 @pytest.fixture(scope="session")
+def openssl():
+    """OpenSSL's libcrypto behind oracle/ossl_check.c: an implementation independent of the reference and of
+    the restatement (level-A cross-check).  Skipped where the headers are missing."""
+    import subprocess
+    from oracle import loader
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ossl"], check=True)
+    if not loader.openssl_available():
+        pytest.skip("OpenSSL development headers not installed")
+    return loader.OpenSSLCheck()
+
+
+@pytest.fixture(scope="session")
 def engine():
     """The product: HIP kernels through the C ABI.  No fallback: fails if the library or GPU is missing."""
     import torch
