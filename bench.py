@@ -45,8 +45,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2-batch", type=int, default=22, help="scalar mults per GPU per step = 2^this")
     ap.add_argument("--curve", default="p256", choices=["p256", "secp256k1"])
-    ap.add_argument("--workload", default="ladder", choices=["ladder", "fixed-base", "fixed-base-signed"],
+    ap.add_argument("--workload", default="ladder", choices=["ladder", "windowed", "fixed-base", "fixed-base-signed"],
                     help="ladder: scalar_mult_p256 variable base, the reference's co-Z ladder, Jacobian out (headline, BASELINE configs[3] shape per GPU); "
+                         "windowed: variable base with per-element {1..8}P tables and signed 4-bit windows, affine out (ALG_WINDOWED; affine-level parity); "
                          "fixed-base: k*G with the 4-bit-window LDS table + simultaneous inversion, affine out (BASELINE configs[2]); "
                          "fixed-base-signed: the same with signed 7-bit windows (37 additions instead of 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -98,6 +99,10 @@ def main():
     if args.workload == "ladder":
         def compute(o):
             eng.scalar_mult(curve, k, xm, ym, flags=flags, out=[o[0], o[1], o[2]])
+    elif args.workload == "windowed":
+        def compute(o):                                     # affine (x, y); o[2] is unused
+            eng.scalar_mult(curve, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED, out=[o[0], o[1], o[2]])
+        compute([eng.empty(n) for _ in range(3)])           # sizes the context workspace (1 184 B per element)
     else:
         alg = ALG_WINDOWED if args.workload == "fixed-base" else ALG_WINDOWED_SIGNED
 
@@ -134,6 +139,8 @@ def main():
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": (f"scalar_mult_{args.curve} variable-base co-Z ladder (reference algorithm), "
                                 f"batch=2^{args.log2_batch} per GPU, Jacobian Montgomery out") if args.workload == "ladder" else
+                               (f"scalar_mult_{args.curve} variable-base, per-element window tables {{1..8}}P + signed 4-bit windows + simultaneous "
+                                f"inversion, batch=2^{args.log2_batch} per GPU, affine out") if args.workload == "windowed" else
                                (f"scalar_mult_{args.curve} fixed-base (G), batch=2^{args.log2_batch} random scalars per GPU, "
                                 + ("4-bit window table in LDS" if args.workload == "fixed-base" else "signed 7-bit window table in LDS")
                                 + " + simultaneous inversion, affine out"),
@@ -148,6 +155,13 @@ def main():
         peak = mads / (ms * 1e-3) / 1e12
         if args.workload == "ladder":
             mad32_unit, bytes_unit, kname = MAD32_PER_SCALAR_MULT, ALGO_BYTES_PER_SCALAR_MULT, "k_scalar_mult"
+        elif args.workload == "windowed":
+            # what THIS algorithm needs per scalar: table = 4 doublings + 3 mixed additions, its
+            # inversion 7 x (7 + 383/32), 63 windows x (4 doublings + 1 mixed addition), the final inversion walk;
+            # a doubling is 4M + 4S (P-256) / 3M + 4S (secp256k1), a mixed addition 8M + 3S; 96 B in, 64 B out.
+            dbl = 8 if args.curve == "p256" else 7
+            fm = (4 * dbl + 3 * 11) + 7 * (7 + 383 / 32) + 63 * (4 * dbl + 11) + (7 + 383 / 32)
+            mad32_unit, bytes_unit, kname = int(fm * 136), 160, "k_varwin_mult + k_varwin_multiples + k_varwin_to_table + k_to_affine_batched"
         else:
             # what THIS algorithm needs per scalar: 64 mixed additions x 11 field mults,
             # 7 mults of the simultaneous-inversion walk and 383/32 of the shared inversion; 32 B in, 64 B out.
@@ -159,7 +173,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")             # written from rocprofv3 --pmc passes
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{'k_scalar_mult' if args.workload == 'ladder' else 'fixed_base'}_{args.curve}_2^{args.log2_batch}")
+                traffic = json.load(open(tpath)).get(f"{ {'ladder': 'k_scalar_mult', 'windowed': 'varwin'}.get(args.workload, 'fixed_base') }_{args.curve}_2^{args.log2_batch}")
             except Exception:
                 traffic = None
         result["roofline"] = {
@@ -170,7 +184,9 @@ def main():
             "peak_source": "ecsimd_hip_peak_mad32: dependency-free v_mad_u64_u32 stream, 8 waves/SIMD, same GPU, same run",
         }
         if world == 1 and not args.no_cpu_baseline:
-            if args.workload == "ladder":
+            if args.workload == "windowed":
+                result["cpu_baseline"] = cpu_baseline_fixed_base(eng, curve, k, runner.last_result(), args.cpu_seconds, base=(bx, by))
+            elif args.workload == "ladder":
                 result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, runner.last_result(), args.cpu_seconds)
                 comp = competitor_openssl(eng, curve, k, bx, by, runner.last_result())
                 if comp is not None:
@@ -185,10 +201,11 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline_fixed_base(eng, curve, k, gpu_out, target_s):
-    """Config 3 on the CPU: the reference has ONE way to compute k*G -- scalar_mult(k, WJG) followed by
-    to_affine() (exactly what its benchmark times, benchs/curve_group.cpp:23-35).  Compared with the GPU's
-    windowed result at the affine level; k = 0 / -1 mod n (degenerate in the ladder) are skipped."""
+def cpu_baseline_fixed_base(eng, curve, k, gpu_out, target_s, base=None):
+    """Affine-output workloads on the CPU: the reference has ONE way to compute k*P -- scalar_mult(k, P) followed
+    by to_affine() (exactly what its benchmark times, benchs/curve_group.cpp:23-35; P = G for config 3, `base` =
+    the per-element points for the windowed variable-base workload).  Compared with the GPU's windowed result at
+    the affine level."""
     import numpy as np
     from oracle import loader
     cores = usable_cores()
@@ -196,10 +213,12 @@ def cpu_baseline_fixed_base(eng, curve, k, gpu_out, target_s):
     c = impl.constants(curve)
     m0 = 256 * cores
     kn = eng.to_numpy(k[:m0])
-    gx, gy = np.tile(c["gx"], (m0, 1)), np.tile(c["gy"], (m0, 1))
+    points = (lambda m_: (np.tile(c["gx"], (m_, 1)), np.tile(c["gy"], (m_, 1)))) if base is None else \
+             (lambda m_: (eng.to_numpy(base[0][:m_]), eng.to_numpy(base[1][:m_])))
+    gx, gy = points(m0)
     t = time.perf_counter(); impl.to_affine(curve, impl.scalar_mult(curve, kn, gx, gy, threads=cores)); dt = time.perf_counter() - t
     m = int(min(k.shape[0], max(m0, (target_s / dt) * m0))); m -= m % 4
-    kn = eng.to_numpy(k[:m]); gx, gy = np.tile(c["gx"], (m, 1)), np.tile(c["gy"], (m, 1))
+    kn = eng.to_numpy(k[:m]); gx, gy = points(m)
     t = time.perf_counter(); J = impl.scalar_mult(curve, kn, gx, gy, threads=cores); ax, ay = impl.to_affine(curve, J); dt = time.perf_counter() - t
     gx_, gy_ = eng.to_numpy(gpu_out[0][:m]), eng.to_numpy(gpu_out[1][:m])
     bad = np.nonzero((gx_ != ax).any(axis=1) | (gy_ != ay).any(axis=1))[0]
@@ -209,7 +228,7 @@ def cpu_baseline_fixed_base(eng, curve, k, gpu_out, target_s):
         ea = ex.to_affine(curve, ex.scalar_mult(curve, kn[bad], gx[bad], gy[bad], threads=min(cores, len(bad))))
         explained = np.array_equal(ea[0], gx_[bad]) and np.array_equal(ea[1], gy_[bad])
     return {"value": m / dt, "unit": "scalar_mults/s", "cores": cores, "kind": kind,
-            "sample": f"first {m} scalars of the GPU batch through scalar_mult(k, G) + to_affine (the reference's only fixed-base path), "
+            "sample": f"first {m} scalars of the GPU batch through scalar_mult(k, {'G' if base is None else 'P'}) + to_affine (the reference's only path to affine k*P), "
                       f"{dt:.1f} s wall, {cores} threads (to_affine single-threaded)",
             "lanes_compared": int(m), "lanes_differing_from_gpu": int(len(bad)),
             "differences_all_explained_by_reference_square_defect": bool(explained)}

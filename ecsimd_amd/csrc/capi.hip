@@ -434,24 +434,29 @@ int ecsimd_hip_affine_add(ecsimd_hip_ctx* ctx, int curve, const uint64_t* ax, co
   if (overlaps(rx, ax) || overlaps(rx, ay) || overlaps(rx, bx) || overlaps(rx, by)) return bad(ctx, "rx must not alias an input (it is the inversion scratch)");
   RUN(launch::affine_add_batched(s, curve, ax, ay, bx, by, rx, ry, finite, n)); }
 
-// u1[i]*G + u2[i]*Q[i]: windowed fixed-base product + ladder product + one batched affine addition.
+// u1[i]*G + u2[i]*Q[i]: windowed fixed-base product + windowed variable-base product + one batched affine
+// addition, in chunks of VARWIN_CHUNK elements.
 int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                                   uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(u1); REQUIRE_PTR(u2); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(rx);
   if (ry && !aligned16(ry)) return bad(ctx, "ry is not 16-byte aligned");
   if (n == 0) return ECSIMD_HIP_OK;
   (void)hipSetDevice(ctx->device);
+  const size_t chunk = n < VARWIN_CHUNK ? n : VARWIN_CHUNK;
   int rc = ensure_window_table(ctx, curve, SIGNED_WBITS);
-  if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 7 * n * 32);        // 3 Jacobian + 2 x 2 affine intermediates
+  if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 7 * chunk * 32 + launch::varwin_scratch_bytes(chunk));   // 3 Jacobian + 2 x 2 affine + tables
   if (rc != ECSIMD_HIP_OK) return rc;
-  uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
-  uint64_t* gx = jz + 4 * n; uint64_t* gy = gx + 4 * n; uint64_t* px = gy + 4 * n; uint64_t* py = px + 4 * n;
+  uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * chunk; uint64_t* jz = jy + 4 * chunk;
+  uint64_t* gx = jz + 4 * chunk; uint64_t* gy = gx + 4 * chunk; uint64_t* px = gy + 4 * chunk; uint64_t* py = px + 4 * chunk;
+  uint64_t* scratch = py + 4 * chunk;
   hipStream_t s = ctx->stream;
-  launch::base_windowed_signed(s, curve, SIGNED_WBITS, u1, ctx->window6_table[curve], jx, jy, jz, n);   // u1*G
-  launch::to_affine_batched(s, curve, jx, jy, jz, gx, gy, n, true);
-  launch::scalar_mult(s, curve, u2, 4, qx, qy, jx, jy, jz, n, ECSIMD_HIP_OUT_AFFINE);    // u2*Q (reference ladder)
-  launch::to_affine_batched(s, curve, jx, jy, jz, px, py, n, true);
-  launch::affine_add_batched(s, curve, gx, gy, px, py, rx, ry, finite, n);
+  for (size_t first = 0; first < n; first += chunk) {
+    const size_t m = (n - first) < chunk ? (n - first) : chunk;
+    launch::base_windowed_signed(s, curve, SIGNED_WBITS, u1 + 4 * first, ctx->window6_table[curve], jx, jy, jz, m);   // u1*G
+    launch::to_affine_batched(s, curve, jx, jy, jz, gx, gy, m, true);
+    launch::varwin_scalar_mult(s, curve, u2 + 4 * first, qx + 4 * first, qy + 4 * first, ECSIMD_HIP_BASE_CLASSICAL, scratch, px, py, m);   // u2*Q
+    launch::affine_add_batched(s, curve, gx, gy, px, py, rx + 4 * first, ry ? ry + 4 * first : nullptr, finite ? finite + first : nullptr, m);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "double_scalar_mult launch"); }
 

@@ -55,11 +55,15 @@ enum {
   ECSIMD_HIP_BASE_MGRY = 1,        /* base point already Montgomery form (what scalar_mult_p256 receives) */
   ECSIMD_HIP_OUT_JACOBIAN = 0,     /* out = (X, Y, Z) Montgomery form, as curve_group::scalar_mult returns */
   ECSIMD_HIP_OUT_AFFINE = 2,       /* out = to_affine(): (x, y) classical; oz may be NULL */
-  ECSIMD_HIP_ALG_WINDOWED = 4,     /* scalar_mult_base + OUT_AFFINE only: 4-bit windows over an LDS-resident table of
-                                      d*16^w*G and one simultaneous inversion instead of the reference's ladder.  Same
-                                      affine result for every k except the ladder's degenerate scalars k = n-1, 2^256-n-1,
-                                      2^256-n (there the reference returns a meaningless point, this path the right one);
-                                      k = 0 mod n -> (0, 0) */
+  ECSIMD_HIP_ALG_WINDOWED = 4,     /* with OUT_AFFINE only.  scalar_mult_base: 4-bit windows over an LDS-resident table of
+                                      d*16^w*G and one simultaneous inversion instead of the reference's ladder.
+                                      scalar_mult / double_scalar_mult (variable base): a per-element table {1..8}P in
+                                      device memory, signed 4-bit windows (4 doublings + 1 mixed addition per window,
+                                      ~2 900 field multiplications against the ladder's 4 064), 1 184 B of context
+                                      workspace per element, at most 2^22 elements at a time.  Same affine result as
+                                      the ladder for every k except the ladder's degenerate scalars k = n-1, 2^256-n-1,
+                                      2^256-n (there the reference returns a meaningless point, these paths the right
+                                      one); k = 0 mod n -> (0, 0) */
   ECSIMD_HIP_ALG_WINDOWED_SIGNED = 8 /* as ALG_WINDOWED with signed 7-bit windows: 37 mixed additions instead of 64, a 148 KiB
                                       table of m*2^(7i)*G (m = 1..64) in LDS, negative digits negate y; same results */
 };
@@ -159,7 +163,8 @@ int ecsimd_hip_add_z2_1(ecsimd_hip_ctx*, int curve, const uint64_t* ax, const ui
 int ecsimd_hip_trplu(ecsimd_hip_ctx*, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
 
 /* curve_group.h:189-218 scalar_mult (per-element scalar k[i], per-element base point (x[i], y[i])):
- * the co-Z Joye double-add ladder of the reference, any 256-bit k.  flags = BASE_* | OUT_*. */
+ * the co-Z Joye double-add ladder of the reference, any 256-bit k.  flags = BASE_* | OUT_*, optionally
+ * OUT_AFFINE | ALG_WINDOWED for the faster windowed algorithm (affine-level parity, see the flag). */
 int ecsimd_hip_scalar_mult(ecsimd_hip_ctx*, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y,
                            uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
 /* curve_group.h:221-251 scalar_mult_1s: ONE scalar (host pointer) for all points. */
@@ -174,8 +179,8 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx*, int curve, const uint64_t* k, u
 int ecsimd_hip_affine_add(ecsimd_hip_ctx*, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by,
                           uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
 /* double_scalar_mult: R[i] = u1[i]*G + u2[i]*Q[i], affine classical (the ECDSA-verification shape; pass
- * ry = NULL for x only).  u1*G uses the windowed fixed-base kernel, u2*Q the reference ladder, whose
- * degenerate scalars (u2 = n-1, 2^256-n-1, 2^256-n; u2 = 0 mod n gives infinity) behave as in scalar_mult. */
+ * ry = NULL for x only).  u1*G uses the windowed fixed-base kernel, u2*Q the windowed variable-base kernels
+ * (ALG_WINDOWED): correct for every 256-bit u1, u2; 1 408 B of context workspace per element, 2^22 at a time. */
 int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx*, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                                   uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
 /* lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P) -- P-256, base in Montgomery form with

@@ -324,6 +324,44 @@ def test_windowed_fixed_base_matches_the_ladder_at_affine_level(engine, oracle, 
 
 
 @pytest.mark.parametrize("cv", CURVES)
+def test_windowed_variable_base_matches_the_ladder_at_affine_level(engine, oracle, cv):
+    """ecsimd_hip_scalar_mult with ALG_WINDOWED: per-lane tables {1..8}P + signed 4-bit windows.
+    A different algorithm from the reference's ladder, so parity is affine-level: identical (x, y) to the ladder +
+    to_affine for every non-degenerate scalar, the big-int model on the scalars where the ladder degenerates,
+    (0, 0) for k = 0 mod n; classical and Montgomery-form base points; more lanes than one internal chunk."""
+    import torch
+    import ctypes as C
+    from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, BASE_MGRY
+    c = CURVE_PARAMS[cv]; order = c["n"]
+    edge = [0, order, 1, 2, 7, 8, 9, 15, 16, 17, 0x78, 0x80, 0x88, 2**252, 2**255, (order - 1) // 2, (order + 1) // 2, order - 2, order - 1,
+            order + 1, order + 9, 2**256 - 1, 2**256 - order, 2**256 - order - 1, int("8" * 64, 16), int("7" * 64, 16), int("9" * 64, 16),
+            int("08" * 32, 16), int("80" * 32, 16), int("f0" * 32, 16), int("0f" * 32, 16)]
+    n = (1 << 22) + 4099 if cv == P256 else (1 << 18) + 77          # P-256: crosses the 2^22-lane chunk boundary
+    k = engine.fill_random(n, SEED, 53); s = engine.fill_random(n, SEED, 54)
+    k[:len(edge)] = engine.to_device(ints_to_arr(edge))
+    bx, by = engine.scalar_mult_base(cv, s, flags=OUT_AFFINE | ALG_WINDOWED)
+    wx, wy = engine.scalar_mult(cv, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)
+    lx, ly = engine.scalar_mult(cv, k, bx, by, flags=OUT_AFFINE)                   # reference ladder + batched to_affine
+    m = len(edge)
+    assert torch.equal(wx[m:], lx[m:]) and torch.equal(wy[m:], ly[m:])
+    wxn, wyn, bxn, byn = (engine.to_numpy(t[:m]) for t in (wx, wy, bx, by))
+    for i, kv in enumerate(edge):
+        exp = ec_mul(cv, kv % order, (to_int(bxn[i]), to_int(byn[i]))) or (0, 0)
+        assert (to_int(wxn[i]), to_int(wyn[i])) == exp, hex(kv)
+    P = engine.from_affine(cv, bx[:8192].contiguous(), by[:8192].contiguous())   # Montgomery-form base point
+    mx, my = engine.scalar_mult(cv, k[:8192].contiguous(), P[0], P[1], flags=OUT_AFFINE | ALG_WINDOWED | BASE_MGRY)
+    assert torch.equal(mx, wx[:8192]) and torch.equal(my, wy[:8192])
+    ix, iy = bx[:8192].clone(), by[:8192].clone()                                # in place: outputs over the base point
+    engine.scalar_mult(cv, k[:8192].contiguous(), ix, iy, flags=OUT_AFFINE | ALG_WINDOWED, out=[ix, iy, None])
+    assert torch.equal(ix, wx[:8192]) and torch.equal(iy, wy[:8192])
+    j = 4096
+    ex, ey = oracle.to_affine(cv, oracle.scalar_mult(cv, engine.to_numpy(k[m:m + j]), engine.to_numpy(bx[m:m + j]), engine.to_numpy(by[m:m + j]), threads=THREADS))
+    assert np.array_equal(engine.to_numpy(wx[m:m + j]), ex) and np.array_equal(engine.to_numpy(wy[m:m + j]), ey)
+    p_ = lambda t: C.c_void_p(t.data_ptr())
+    assert engine.lib.ecsimd_hip_scalar_mult(engine.ctx, C.c_int(cv), p_(k), p_(bx), p_(by), p_(wx), p_(wy), p_(wx), C.c_size_t(4), C.c_int(ALG_WINDOWED)) == -1   # Jacobian out is not offered
+
+
+@pytest.mark.parametrize("cv", CURVES)
 def test_simultaneous_inversion_to_affine(engine, oracle, cv):
     """to_affine with Montgomery's trick (non-aliasing outputs) == one inversion per element (aliasing
     outputs force the per-element kernel) == the oracle; Z = 0 elements give (0, 0) and do not poison

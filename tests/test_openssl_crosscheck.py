@@ -65,8 +65,9 @@ def test_gpu_scalar_mult_agrees_with_openssl(engine, openssl, cv):
     dbx, dby = engine.to_device(bx), engine.to_device(by)
     vx, vy, inf = openssl.scalar_mult(cv, k, bx, by, threads=THREADS)
     assert not inf.any()
-    px, py = engine.scalar_mult(cv, dk, dbx, dby, flags=OUT_AFFINE)
-    assert np.array_equal(engine.to_numpy(px), vx) and np.array_equal(engine.to_numpy(py), vy)
+    for flags in (OUT_AFFINE, OUT_AFFINE | ALG_WINDOWED):                           # reference ladder; per-lane window tables
+        px, py = engine.scalar_mult(cv, dk, dbx, dby, flags=flags)
+        assert np.array_equal(engine.to_numpy(px), vx) and np.array_equal(engine.to_numpy(py), vy), flags
     wx, wy, inf = openssl.double_scalar_mult(cv, u1, k, bx, by, threads=THREADS)
     assert not inf.any()
     rx, ry, fin = engine.double_scalar_mult(cv, du1, dk, dbx, dby)
