@@ -65,11 +65,15 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     outj = [e.empty(n2) for _ in range(3)]
     row(f"scalar_mult<{nm}> ladder, Jacobian out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=1, out=outj), 5), 555968, 192, "scalar mults")
     row(f"scalar_mult<{nm}> ladder, affine out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=3, out=outj), 5), 555968 + 19 * 136, 160, "scalar mults")
+    dblm = 8 if cv == 0 else 7
+    vw = int(((4 * dblm + 33) + 7 * (7 + 383 / 32) + 63 * (4 * dblm + 11) + (7 + 383 / 32)) * 136)
+    row(f"scalar_mult<{nm}> windowed variable base (per-element tables), affine out", n2,
+        timeit(lambda: e.scalar_mult(cv, k, b2x, b2y, flags=2 | 4, out=outj), 5), vw, 160, "scalar mults")
     row(f"to_affine<{nm}> (simultaneous inversion)", n2, timeit(lambda: e.to_affine(cv, outj)), int((7 + 383 / 32) * 136), 256, "points")
     row(f"scalar_mult_base<{nm}> windowed, affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=6, out=outj)), int((64 * 11 + 7 + 383 / 32) * 136), 96, "scalar mults")
     u1 = e.fill_random(n2, SEED, 21)
     row(f"double_scalar_mult<{nm}> u1*G + u2*Q (ECDSA-verify shape)", n2, timeit(lambda: e.double_scalar_mult(cv, u1, k, b2x, b2y), 5),
-        555968 + int((37 * 11 + 2 * (7 + 383 / 32) + 6 + 383 / 32) * 136), 160, "verifications")
+        vw + int((37 * 11 + (7 + 383 / 32) + 6 + 383 / 32) * 136), 160, "verifications")
     del u1
     row(f"scalar_mult_base<{nm}> signed 7-bit windows, affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 8, out=outj)), int((37 * 11 + 7 + 383 / 32) * 136), 96, "scalar mults")
     wire = e.sec1_encode(cv, b2x, b2y, True)
