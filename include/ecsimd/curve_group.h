@@ -60,6 +60,33 @@ struct curve_group {
     WJCP r = fresh(P.size());
     hip::check(ecsimd_hip_scalar_mult_1s(hip::context(), curve_id, x.limbs.data(), px(P), py(P), px(r), py(r), pz(r), P.size(), ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN), "ecsimd_hip_scalar_mult_1s"); return r;
   }
+
+  // ---- extensions (not in the reference): affine-level entry points over the faster algorithms of the C ABI.
+  // Same points as to_affine() of the ladder's result for every scalar where the ladder is non-degenerate.
+  // k[i] * P[i], P affine classical -> affine classical.  windowed: per-element tables {1..8}P + signed 4-bit
+  // windows (ECSIMD_HIP_ALG_WINDOWED); otherwise the reference ladder followed by one simultaneous inversion.
+  static WCP scalar_mult_affine(WBN const& x, WCP const& P, bool windowed = true) {
+    WCP r{WBN::uninitialized(P.size()), WBN::uninitialized(P.size())};
+    hip::check(ecsimd_hip_scalar_mult(hip::context(), curve_id, x.data(), P.x().data(), P.y().data(), r.x().data(), r.y().data(), nullptr, P.size(),
+                                      ECSIMD_HIP_BASE_CLASSICAL | ECSIMD_HIP_OUT_AFFINE | (windowed ? ECSIMD_HIP_ALG_WINDOWED : 0)), "ecsimd_hip_scalar_mult");
+    return r;
+  }
+  // k[i] * G through the LDS-resident window tables (signed 7-bit windows), affine classical.
+  static WCP scalar_mult_base_affine(WBN const& x) {
+    WCP r{WBN::uninitialized(x.size()), WBN::uninitialized(x.size())};
+    hip::check(ecsimd_hip_scalar_mult_base(hip::context(), curve_id, x.data(), r.x().data(), r.y().data(), nullptr, x.size(),
+                                           ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_ALG_WINDOWED_SIGNED), "ecsimd_hip_scalar_mult_base");
+    return r;
+  }
+  // u1[i] * G + u2[i] * Q[i] (the ECDSA-verification shape), affine classical; finite[i] is false where the sum
+  // is the point at infinity (coordinates (0, 0)).
+  static WCP double_scalar_mult(WBN const& u1, WBN const& u2, WCP const& Q, hip::mask& finite) {
+    WCP r{WBN::uninitialized(Q.size()), WBN::uninitialized(Q.size())};
+    finite = hip::mask(Q.size());
+    hip::check(ecsimd_hip_double_scalar_mult(hip::context(), curve_id, u1.data(), u2.data(), Q.x().data(), Q.y().data(), r.x().data(), r.y().data(),
+                                             finite.data(), Q.size()), "ecsimd_hip_double_scalar_mult");
+    return r;
+  }
  private:
   static WJCP fresh(size_t n) {
     WJCP r; r.x() = gfp{WMBN{WBN::uninitialized(n)}}; r.y() = gfp{WMBN{WBN::uninitialized(n)}}; r.z() = gfp{WMBN{WBN::uninitialized(n)}}; return r;

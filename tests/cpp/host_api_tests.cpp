@@ -217,6 +217,28 @@ TEST(Batch, RuntimeLengthAndSecp256k1) {
   EXPECT_TRUE(all(five.y() == W256(n, bn_from_bytes_BE<bignum_256>("d8ac222636e5e3d6d4dba9dda6c9c426f788271bab0d6840dca87d3aa6ac62d6"_hex))));
 }
 
+// Extensions: the windowed algorithms give the ladder's affine points (both curves), and u1*G + u2*Q composes them.
+template <class K> static void windowed_paths_agree() {
+  using KG = curve_group<K>;
+  const size_t n = 777;
+  W256 k(n, [](size_t i, size_t) { bignum_256 b; b.limbs = {0x9e3779b97f4a7c15ull * (i + 3), ~i * 0x100000001b3ull, i ^ 0x8888888888888888ull, 0xfedcba9876543210ull - (i << 33)}; return b; });
+  W256 s(n, [](size_t i, size_t) { bignum_256 b; b.limbs = {i + 1, i * i, 0x0123456789abcdefull * (i + 7), 0x7000000000000000ull ^ (i << 9)}; return b; });
+  const auto P = KG::scalar_mult(s, KG::WJG(n)).to_affine();                                   // lane-distinct points (ladder)
+  EXPECT_TRUE(all(KG::scalar_mult_base_affine(s) == P));
+  const auto ladder = KG::scalar_mult_affine(k, P, false);
+  EXPECT_TRUE(all(ladder == KG::scalar_mult(k, wide_jacobian_curve_point<K>::from_affine(P)).to_affine()));
+  EXPECT_TRUE(all(KG::scalar_mult_affine(k, P) == ladder));
+  hip::mask fin;
+  const auto sum = KG::double_scalar_mult(W256(n, bignum_256::from(0)), k, P, fin);             // 0*G + k*P
+  EXPECT_TRUE(all(fin)); EXPECT_TRUE(all(sum == ladder));
+  const auto sum2 = KG::double_scalar_mult(s, W256(n, bignum_256::from(1)), P, fin);            // s*G + P = 2P
+  EXPECT_TRUE(all(fin)); EXPECT_TRUE(all(sum2 == KG::scalar_mult_affine(W256(n, bignum_256::from(2)), P)));
+}
+TEST(Batch, WindowedPathsAgreeWithTheLadder) {
+  windowed_paths_agree<curve_nist_p256>();
+  windowed_paths_agree<curve_secp256k1>();
+}
+
 // utility.h:45-51 wide_mask_bit and the device wire formats (beyond the reference's tests)
 TEST(Batch, MaskBitAndWireFormats) {
   using K = curve_nist_p256; using KG = curve_group<K>;
