@@ -117,23 +117,8 @@ ECS_DEV void fe2_store(uint64_t* __restrict__ base, size_t i, const fe2& v) {
 // instruction is spent turning it into data.
 typedef uint64_t lane_mask;
 
-// a += b over 8 words; returns the carry-out as a lane mask.                add.h:11-34
-ECS_DEV lane_mask add8m(fe& a, const fe& b) {
-  lane_mask c;
-  asm("v_add_co_u32 %0, vcc, %0, %9\n\t"
-      "v_addc_co_u32 %1, vcc, %1, %10, vcc\n\t"
-      "v_addc_co_u32 %2, vcc, %2, %11, vcc\n\t"
-      "v_addc_co_u32 %3, vcc, %3, %12, vcc\n\t"
-      "v_addc_co_u32 %4, vcc, %4, %13, vcc\n\t"
-      "v_addc_co_u32 %5, vcc, %5, %14, vcc\n\t"
-      "v_addc_co_u32 %6, vcc, %6, %15, vcc\n\t"
-      "v_addc_co_u32 %7, %8, %7, %16, vcc"
-      : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(a.w[4]), "+v"(a.w[5]), "+v"(a.w[6]), "+v"(a.w[7]), "=&s"(c)
-      : "v"(b.w[0]), "v"(b.w[1]), "v"(b.w[2]), "v"(b.w[3]), "v"(b.w[4]), "v"(b.w[5]), "v"(b.w[6]), "v"(b.w[7])
-      : "vcc");
-  return c;
-}
-// r = a + b (three-operand form: when a stays live the compiler needs no register copies)
+// r = a + b over 8 words; returns the carry-out as a lane mask.             add.h:11-34
+// (three-operand form: when a stays live the compiler needs no register copies)
 ECS_DEV lane_mask add8m3(fe& r, const fe& a, const fe& b) {
   lane_mask c;
   asm("v_add_co_u32 %0, vcc, %9, %17\n\t"
@@ -331,16 +316,6 @@ template <int CURVE> ECS_DEV fe fe_neg(const fe& a) {
 // Product scanning (Comba) on 32-bit words with a 96-bit column accumulator: each partial
 // product is one v_mad_u64_u32 (64-bit accumulate, carry-out in VCC) + one v_addc_co_u32 into
 // the third accumulator word.  Replaces mul.h:115-158 (64 vpmuludq + digit renormalisation).
-ECS_DEV void mac(uint64_t& acc, uint32_t& ex, uint32_t a, uint32_t b) {
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
-      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
-      : "+v"(acc), "+v"(ex) : "v"(a), "v"(b) : "vcc");
-}
-ECS_DEV void mac_first(uint64_t& acc, uint32_t& ex, uint32_t a, uint32_t b) {   // ex = carry (ex was 0)
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
-      "v_addc_co_u32 %1, vcc, 0, 0, vcc"
-      : "+v"(acc), "=v"(ex) : "v"(a), "v"(b) : "vcc");
-}
 ECS_DEV void mac_nocarry(uint64_t& acc, uint32_t a, uint32_t b) {                // sum provably < 2^64
   asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
 }
