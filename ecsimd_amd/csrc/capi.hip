@@ -274,6 +274,13 @@ int ecsimd_hip_memcpy_d2h(ecsimd_hip_ctx* ctx, void* dst, const void* src, size_
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "hipMemcpy d2h");
 }
+int ecsimd_hip_memcpy_d2d(ecsimd_hip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  REQUIRE_CTX(); (void)hipSetDevice(ctx->device);
+  if (bytes == 0) return ECSIMD_HIP_OK;
+  if (!dst || !src) return bad(ctx, "memcpy_d2d: null pointer");
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "hipMemcpy d2d");
+}
 
 int ecsimd_hip_get_constant(int curve, int which, uint64_t out[4]) {
   if (!out || which < 0 || which > 11) return ECSIMD_HIP_ERR_BAD_ARG;

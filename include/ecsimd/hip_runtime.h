@@ -10,6 +10,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -41,16 +42,41 @@ inline void check(int rc, const char* what) {
 }
 inline void sync() { check(ecsimd_hip_sync(context()), "ecsimd_hip_sync"); }
 
+// Freed device blocks are kept for reuse by size (hipMalloc / hipFree synchronise and cost ~0.1 ms each, more than an
+// element-wise kernel over a million elements).  Reuse is safe without events: every kernel and copy of this
+// API runs on the context's one stream, so a block's next user is ordered after its last.  At most `cap` bytes
+// are parked; beyond that blocks go back to the driver.
+class block_pool {
+ public:
+  static block_pool& instance() { static block_pool p; return p; }
+  void* take(size_t bytes) {
+    auto it = parked_.find(bytes);
+    if (it != parked_.end()) { void* p = it->second; parked_.erase(it); held_ -= bytes; return p; }
+    void* p = nullptr;
+    check(ecsimd_hip_malloc(context(), &p, bytes), "ecsimd_hip_malloc");
+    return p;
+  }
+  void give(void* p, size_t bytes) {
+    if (held_ + bytes > cap) { ecsimd_hip_free(context(), p); return; }
+    parked_.emplace(bytes, p); held_ += bytes;
+  }
+  ~block_pool() { for (auto& kv : parked_) ecsimd_hip_free(context(), kv.second); }
+ private:
+  block_pool() { (void)context(); }                    // the context outlives the pool (constructed first)
+  static constexpr size_t cap = (size_t)8 << 30;
+  std::multimap<size_t, void*> parked_;
+  size_t held_ = 0;
+};
+
 // Device array of 64-bit words, shared between copies of a wide value (values are immutable once
 // produced, like registers; in-place updates clone first -- see wide_bignum::unshare()).
 class buffer {
  public:
   buffer() = default;
   explicit buffer(size_t words) : words_(words) {
-    void* p = nullptr;
-    check(ecsimd_hip_malloc(context(), &p, words * sizeof(uint64_t)), "ecsimd_hip_malloc");
-    ecsimd_hip_ctx* ctx = context();
-    mem_ = std::shared_ptr<uint64_t>(static_cast<uint64_t*>(p), [ctx](uint64_t* q) { ecsimd_hip_free(ctx, q); });
+    const size_t bytes = (words ? words : 2) * sizeof(uint64_t);
+    void* p = block_pool::instance().take(bytes);
+    mem_ = std::shared_ptr<uint64_t>(static_cast<uint64_t*>(p), [bytes](uint64_t* q) { block_pool::instance().give(q, bytes); });
   }
   uint64_t* data() const { return mem_.get(); }
   size_t words() const { return words_; }
@@ -59,8 +85,7 @@ class buffer {
   void download(uint64_t* dst) const { check(ecsimd_hip_memcpy_d2h(context(), dst, mem_.get(), words_ * 8), "d2h"); }
   buffer clone() const {
     buffer b(words_);
-    std::vector<uint64_t> tmp(words_);
-    download(tmp.data()); b.upload(tmp.data());
+    check(ecsimd_hip_memcpy_d2d(context(), b.mem_.get(), mem_.get(), words_ * 8), "d2d");
     return b;
   }
  private:
@@ -73,10 +98,9 @@ class mask {
  public:
   mask() = default;
   explicit mask(size_t n) : n_(n) {
-    void* p = nullptr;
-    check(ecsimd_hip_malloc(context(), &p, n ? n : 1), "ecsimd_hip_malloc");
-    ecsimd_hip_ctx* ctx = context();
-    mem_ = std::shared_ptr<uint8_t>(static_cast<uint8_t*>(p), [ctx](uint8_t* q) { ecsimd_hip_free(ctx, q); });
+    const size_t bytes = (n + 15) / 16 * 16 + 16;
+    void* p = block_pool::instance().take(bytes);
+    mem_ = std::shared_ptr<uint8_t>(static_cast<uint8_t*>(p), [bytes](uint8_t* q) { block_pool::instance().give(q, bytes); });
   }
   mask(std::initializer_list<bool> v) : mask(v.size()) {
     std::vector<uint8_t> h; for (bool b : v) h.push_back(b ? 1 : 0);

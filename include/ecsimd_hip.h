@@ -83,6 +83,9 @@ int ecsimd_hip_malloc(ecsimd_hip_ctx* ctx, void** dptr, size_t bytes);
 int ecsimd_hip_free(ecsimd_hip_ctx* ctx, void* dptr);
 int ecsimd_hip_memcpy_h2d(ecsimd_hip_ctx* ctx, void* dst, const void* src, size_t bytes);
 int ecsimd_hip_memcpy_d2h(ecsimd_hip_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* device -> device on the context's stream (asynchronous, ordered with the kernels); what a by-value copy of a
+ * reference `wide` (bignum.h:38-102: registers, copied freely) costs here when an in-out parameter is updated. */
+int ecsimd_hip_memcpy_d2d(ecsimd_hip_ctx* ctx, void* dst, const void* src, size_t bytes);
 /* Curve constants as the engine uses them (host memory, 4 x u64 each):
  * which = 0 p, 1 a, 2 b, 3 Gx, 4 Gy, 5 R mod p, 6 R^2 mod p, 7 -R mod p, 8 a*R, 9 b*R, 10 p-2, 11 (p+1)/4
  * (mgry_csts.h:15-24, curve_group.h:31-32, gfp.h:79-87). */

@@ -31,6 +31,33 @@ def build_binary():
     return OUT
 
 
+BENCH_SRC = os.path.join(ROOT, "benchs", "host_benchs.cpp")
+BENCH_OUT = os.path.join(ROOT, "build", "tests", "host_benchs")
+
+
+def build_benchs():
+    """The reference's benchs/curve_group.cpp and benchs/ops.cpp, re-hosted on the C++ host API."""
+    build_binary()                                      # makes sure the library exists
+    libdir = os.path.join(ROOT, "ecsimd_amd")
+    if not os.path.exists(BENCH_OUT) or os.path.getmtime(BENCH_OUT) < max(os.path.getmtime(BENCH_SRC), os.path.getmtime(OUT)):
+        subprocess.run(["g++", "-std=c++20", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), BENCH_SRC, "-o", BENCH_OUT,
+                        "-L", libdir, "-lecsimd_hip", "-Wl,-rpath," + libdir], check=True)
+    return BENCH_OUT
+
+
+def test_rehosted_benchs_compile():
+    assert os.path.exists(build_benchs())
+
+
+@pytest.mark.gpu
+def test_rehosted_benchs_run():
+    r = subprocess.run([build_benchs(), "14", "2"], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for name in ("scalar_mult_p256 + to_affine", "scalar_mult_p256_1s + to_affine", "add_256", "mul_256", "sqr_256", "mgry_sqr_256", "mgry_reduce_512"):
+        assert name in r.stdout, name
+
+
 def test_headers_compile_and_link_with_gxx():
     build_binary()
     assert os.path.exists(OUT)
