@@ -48,7 +48,7 @@ void pack_table_signed(hipStream_t s, int curve, int wbits, const uint64_t* tx, 
 void base_windowed_signed(hipStream_t s, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed_signed, s, wbits, k, table, ox, oy, oz, n); }
 void affine_add_batched(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) { DISPATCH(affine_add_batched, s, ax, ay, bx, by, rx, ry, finite, n); }
 void base_windowed(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed, s, k, table, ox, oy, oz, n); }
-void varwin_scalar_mult(hipStream_t s, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y, int flags, uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n) { DISPATCH(varwin_scalar_mult, s, k, x, y, flags, scratch, ox, oy, n); }
+void varwin_scalar_mult(hipStream_t s, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, int flags, uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n) { DISPATCH(varwin_scalar_mult, s, k, k_stride, x, y, flags, scratch, ox, oy, n); }
 #undef DISPATCH
 } }
 
@@ -193,7 +193,7 @@ int run_ladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, 
 // Variable-base windowed multiplication in chunks of VARWIN_CHUNK lanes (1 184 B of scratch per lane: the
 // per-lane tables live in HBM).  `reserve` bytes at the start of the workspace stay untouched (double_scalar_mult).
 constexpr size_t VARWIN_CHUNK = (size_t)1 << 22;
-int run_varwin(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y,
+int run_varwin(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y,
                uint64_t* ox, uint64_t* oy, size_t n, int flags, size_t reserve) {
   if (n == 0) return ECSIMD_HIP_OK;
   hipError_t e = hipSetDevice(ctx->device);
@@ -204,7 +204,7 @@ int run_varwin(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, const uint64_t
   uint64_t* scratch = ctx->workspace + reserve / 8;
   for (size_t first = 0; first < n; first += chunk) {
     const size_t m = (n - first) < chunk ? (n - first) : chunk;
-    launch::varwin_scalar_mult(ctx->stream, curve, k + 4 * first, x + 4 * first, y + 4 * first, flags, scratch, ox + 4 * first, oy + 4 * first, m);
+    launch::varwin_scalar_mult(ctx->stream, curve, k + (size_t)k_stride * first, k_stride, x + 4 * first, y + 4 * first, flags, scratch, ox + 4 * first, oy + 4 * first, m);
   }
   e = hipGetLastError();
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult (windowed) launch");
@@ -403,7 +403,7 @@ int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, co
     // per-lane window tables {1..8}P in HBM + signed 4-bit windows (k_varwin.inc): a different algorithm from
     // the reference ladder, so affine output only (SURVEY.md 8(a) level A)
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
-    return run_varwin(ctx, curve, k, x, y, ox, oy, n, flags, 0);
+    return run_varwin(ctx, curve, k, 4, x, y, ox, oy, n, flags, 0);
   }
   return run_ladder(ctx, curve, k, 4, x, y, ox, oy, oz, n, flags); }
 int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[4], const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
@@ -414,6 +414,10 @@ int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[
   if (n == 0) return ECSIMD_HIP_OK;
   (void)hipSetDevice(ctx->device);
   store_words(ctx->stream, w, kdev);
+  if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED)) {
+    if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
+    return run_varwin(ctx, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, n, flags, 0);
+  }
   return run_ladder(ctx, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, oz, n, flags); }
 int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(ox); REQUIRE_PTR(oy);
@@ -461,7 +465,7 @@ int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t
     const size_t m = (n - first) < chunk ? (n - first) : chunk;
     launch::base_windowed_signed(s, curve, SIGNED_WBITS, u1 + 4 * first, ctx->window6_table[curve], jx, jy, jz, m);   // u1*G
     launch::to_affine_batched(s, curve, jx, jy, jz, gx, gy, m, true);
-    launch::varwin_scalar_mult(s, curve, u2 + 4 * first, qx + 4 * first, qy + 4 * first, ECSIMD_HIP_BASE_CLASSICAL, scratch, px, py, m);   // u2*Q
+    launch::varwin_scalar_mult(s, curve, u2 + 4 * first, 4, qx + 4 * first, qy + 4 * first, ECSIMD_HIP_BASE_CLASSICAL, scratch, px, py, m);   // u2*Q
     launch::affine_add_batched(s, curve, gx, gy, px, py, rx + 4 * first, ry ? ry + 4 * first : nullptr, finite ? finite + first : nullptr, m);
   }
   hipError_t e = hipGetLastError();

@@ -170,7 +170,7 @@ int ecsimd_hip_trplu(ecsimd_hip_ctx*, int curve, uint64_t* px, uint64_t* py, uin
  * OUT_AFFINE | ALG_WINDOWED for the faster windowed algorithm (affine-level parity, see the flag). */
 int ecsimd_hip_scalar_mult(ecsimd_hip_ctx*, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y,
                            uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
-/* curve_group.h:221-251 scalar_mult_1s: ONE scalar (host pointer) for all points. */
+/* curve_group.h:221-251 scalar_mult_1s: ONE scalar (host pointer) for all points; flags as for scalar_mult. */
 int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx*, int curve, const uint64_t k1[4], const uint64_t* x, const uint64_t* y,
                               uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
 /* curve_group.h:35-41 WJG + scalar_mult: k[i] * G (base = the curve generator). */

@@ -354,6 +354,10 @@ def test_windowed_variable_base_matches_the_ladder_at_affine_level(engine, oracl
     ix, iy = bx[:8192].clone(), by[:8192].clone()                                # in place: outputs over the base point
     engine.scalar_mult(cv, k[:8192].contiguous(), ix, iy, flags=OUT_AFFINE | ALG_WINDOWED, out=[ix, iy, None])
     assert torch.equal(ix, wx[:8192]) and torch.equal(iy, wy[:8192])
+    k1 = engine.to_numpy(k[m + 5])                                               # one scalar for every lane (scalar_mult_1s)
+    sx, sy = engine.scalar_mult_1s(cv, k1, bx[:8192].contiguous(), by[:8192].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED)
+    tx, ty = engine.scalar_mult_1s(cv, k1, bx[:8192].contiguous(), by[:8192].contiguous(), flags=OUT_AFFINE)
+    assert torch.equal(sx, tx) and torch.equal(sy, ty)
     j = 4096
     ex, ey = oracle.to_affine(cv, oracle.scalar_mult(cv, engine.to_numpy(k[m:m + j]), engine.to_numpy(bx[m:m + j]), engine.to_numpy(by[m:m + j]), threads=THREADS))
     assert np.array_equal(engine.to_numpy(wx[m:m + j]), ex) and np.array_equal(engine.to_numpy(wy[m:m + j]), ey)
