@@ -102,7 +102,7 @@ def main():
     elif args.workload == "windowed":
         def compute(o):                                     # affine (x, y); o[2] is unused
             eng.scalar_mult(curve, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED, out=[o[0], o[1], o[2]])
-        compute([eng.empty(n) for _ in range(3)])           # sizes the context workspace (1 184 B per element)
+        compute([eng.empty(n) for _ in range(3)])           # sizes the context workspace (1 408 B per element)
     else:
         alg = ALG_WINDOWED if args.workload == "fixed-base" else ALG_WINDOWED_SIGNED
 

@@ -190,7 +190,7 @@ int run_ladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, 
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult launch");
 }
 
-// Variable-base windowed multiplication in chunks of VARWIN_CHUNK lanes (1 184 B of scratch per lane: the
+// Variable-base windowed multiplication in chunks of VARWIN_CHUNK lanes (1 408 B of scratch per lane: the
 // per-lane tables live in HBM).  `reserve` bytes at the start of the workspace stay untouched (double_scalar_mult).
 constexpr size_t VARWIN_CHUNK = (size_t)1 << 22;
 int run_varwin(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y,

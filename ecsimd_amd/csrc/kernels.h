@@ -70,7 +70,7 @@ void base_windowed_signed(hipStream_t, int curve, int wbits, const uint64_t* k, 
 // scratch: varwin_scratch_bytes(n) bytes, 32-byte aligned; k_stride, x, y as for scalar_mult (flags: ECSIMD_HIP_BASE_*).
 void varwin_scalar_mult(hipStream_t, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, int flags,
                         uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n);
-inline size_t varwin_scratch_bytes(size_t n) { return n * (7 * 3 * 32 + 8 * 64); }
+inline size_t varwin_scratch_bytes(size_t n) { return n * (7 * 4 * 32 + 8 * 64); }
 
 // per-curve pieces (one translation unit each)
 template <int C> struct point_launch {

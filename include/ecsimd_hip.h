@@ -59,7 +59,7 @@ enum {
                                       d*16^w*G and one simultaneous inversion instead of the reference's ladder.
                                       scalar_mult / double_scalar_mult (variable base): a per-element table {1..8}P in
                                       device memory, signed 4-bit windows (4 doublings + 1 mixed addition per window,
-                                      ~2 900 field multiplications against the ladder's 4 064), 1 184 B of context
+                                      ~2 900 field multiplications against the ladder's 4 064), 1 408 B of context
                                       workspace per element, at most 2^22 elements at a time.  Same affine result as
                                       the ladder for every k except the ladder's degenerate scalars k = n-1, 2^256-n-1,
                                       2^256-n (there the reference returns a meaningless point, these paths the right
@@ -183,7 +183,7 @@ int ecsimd_hip_affine_add(ecsimd_hip_ctx*, int curve, const uint64_t* ax, const 
                           uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
 /* double_scalar_mult: R[i] = u1[i]*G + u2[i]*Q[i], affine classical (the ECDSA-verification shape; pass
  * ry = NULL for x only).  u1*G uses the windowed fixed-base kernel, u2*Q the windowed variable-base kernels
- * (ALG_WINDOWED): correct for every 256-bit u1, u2; 1 408 B of context workspace per element, 2^22 at a time. */
+ * (ALG_WINDOWED): correct for every 256-bit u1, u2; 1 632 B of context workspace per element, 2^22 at a time. */
 int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx*, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                                   uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
 /* lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P) -- P-256, base in Montgomery form with
