@@ -57,6 +57,7 @@ struct ecsimd_hip_ctx {
   int device;
   hipStream_t own_stream;
   hipStream_t stream;
+  hipEvent_t handoff;  // orders a newly selected stream after the work already enqueued on the previous one
   int cus;
   uint32_t* sink;      // 4 KiB scratch: peak-probe sink [0, 1024) and the shared scalar at word 1024-8
   uint32_t* window_table[2];   // per curve: 64 x 16 affine multiples d*16^w*G (built on first use)
@@ -229,7 +230,8 @@ int ecsimd_hip_init(int device, ecsimd_hip_ctx** out) {
   ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->window6_table[0] = ctx->window6_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ECSIMD_HIP_ERR_HIP; }
   ctx->stream = ctx->own_stream;
-  if (hipMalloc(&ctx->sink, 4096) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ECSIMD_HIP_ERR_HIP; }
+  if (hipEventCreateWithFlags(&ctx->handoff, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ECSIMD_HIP_ERR_HIP; }
+  if (hipMalloc(&ctx->sink, 4096) != hipSuccess) { (void)hipEventDestroy(ctx->handoff); (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ECSIMD_HIP_ERR_HIP; }
   *out = ctx;
   return ECSIMD_HIP_OK;
 }
@@ -239,12 +241,25 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->sink);
   (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->workspace);
+  (void)hipEventDestroy(ctx->handoff);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return ECSIMD_HIP_OK;
 }
-int ecsimd_hip_set_stream(ecsimd_hip_ctx* ctx, void* s) { REQUIRE_CTX(); ctx->stream = (hipStream_t)s; return ECSIMD_HIP_OK; }
-int ecsimd_hip_use_own_stream(ecsimd_hip_ctx* ctx) { REQUIRE_CTX(); ctx->stream = ctx->own_stream; return ECSIMD_HIP_OK; }
+// The context's scratch (workspace, the shared-scalar slot, the lazily built tables) is ordered by its stream.
+// Selecting another stream therefore makes that stream wait for what this context already enqueued on the
+// previous one (an event, no host synchronisation); re-selecting the current stream costs nothing.
+static int switch_stream(ecsimd_hip_ctx* ctx, hipStream_t next) {
+  if (next == ctx->stream) return ECSIMD_HIP_OK;
+  (void)hipSetDevice(ctx->device);
+  hipError_t e = hipEventRecord(ctx->handoff, ctx->stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(next, ctx->handoff, 0);
+  if (e != hipSuccess) return fail(ctx, e, "stream hand-off");
+  ctx->stream = next;
+  return ECSIMD_HIP_OK;
+}
+int ecsimd_hip_set_stream(ecsimd_hip_ctx* ctx, void* s) { REQUIRE_CTX(); return switch_stream(ctx, (hipStream_t)s); }
+int ecsimd_hip_use_own_stream(ecsimd_hip_ctx* ctx) { REQUIRE_CTX(); return switch_stream(ctx, ctx->own_stream); }
 int ecsimd_hip_sync(ecsimd_hip_ctx* ctx) {
   REQUIRE_CTX();
   hipError_t e = hipStreamSynchronize(ctx->stream);

@@ -72,7 +72,9 @@ enum {
 int ecsimd_hip_init(int device, ecsimd_hip_ctx** ctx);
 int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream).  NULL is HIP's default (null)
- * stream -- which is what torch's default stream is -- not "none". */
+ * stream -- which is what torch's default stream is -- not "none".  The context's scratch memory is ordered
+ * by its stream: switching makes the new stream wait (by event, no host synchronisation) for the work this
+ * context enqueued on the previous one, which must still exist at that moment. */
 int ecsimd_hip_set_stream(ecsimd_hip_ctx* ctx, void* hip_stream);
 /* Go back to the non-blocking stream the context created in ecsimd_hip_init (the default). */
 int ecsimd_hip_use_own_stream(ecsimd_hip_ctx* ctx);

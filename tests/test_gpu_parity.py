@@ -432,6 +432,28 @@ def test_affine_add_and_double_scalar_mult(engine, oracle, cv):
             assert tfn[i] == 1 and (to_int(txn[i]), to_int(tyn[i])) == e_, i
 
 
+def test_switching_streams_keeps_the_context_scratch_ordered(engine):
+    """Two workspace-using calls back to back on two torch streams: the second must not start on the shared
+    scratch (per-element tables, Jacobian intermediates) before the first has finished with it."""
+    import torch
+    from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED
+    n = 1 << 19
+    ka, kb = engine.fill_random(n, SEED, 61), engine.fill_random(n, SEED, 62)
+    bx, by = engine.scalar_mult_base(P256, engine.fill_random(n, SEED, 63), flags=OUT_AFFINE | ALG_WINDOWED)
+    ea = engine.scalar_mult(P256, ka, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)
+    eb = engine.scalar_mult(P256, kb, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(sa):
+            ga = engine.scalar_mult(P256, ka, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)
+        with torch.cuda.stream(sb):
+            gb = engine.scalar_mult(P256, kb, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)
+        torch.cuda.synchronize()
+        assert torch.equal(ga[0], ea[0]) and torch.equal(ga[1], ea[1])
+        assert torch.equal(gb[0], eb[0]) and torch.equal(gb[1], eb[1])
+
+
 def test_scalar_mult_p256_entry_point(engine, oracle):
     """lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P), P Jacobian Montgomery with Z = mgry(1)."""
     n = 1024; c = CURVE_PARAMS[P256]
