@@ -66,7 +66,7 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     row(f"scalar_mult<{nm}> ladder, Jacobian out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=1, out=outj), 5), 555968, 192, "scalar mults")
     row(f"scalar_mult<{nm}> ladder, affine out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=3, out=outj), 5), 555968 + 19 * 136, 160, "scalar mults")
     dblm = 8 if cv == 0 else 7
-    vw = int(((4 * dblm + 33) + 7 * (7 + 383 / 32) + 63 * (4 * dblm + 11) + (7 + 383 / 32)) * 136)
+    vw = int(((4 * dblm + 33) + 7 * (7 + 383 / 224) + 63 * (4 * dblm + 11) + (7 + 383 / 32)) * 136)
     row(f"scalar_mult<{nm}> windowed variable base (per-element tables), affine out", n2,
         timeit(lambda: e.scalar_mult(cv, k, b2x, b2y, flags=2 | 4, out=outj), 5), vw, 160, "scalar mults")
     row(f"to_affine<{nm}> (simultaneous inversion)", n2, timeit(lambda: e.to_affine(cv, outj)), int((7 + 383 / 32) * 136), 256, "points")
