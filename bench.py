@@ -157,16 +157,17 @@ def main():
             mad32_unit, bytes_unit, kname = MAD32_PER_SCALAR_MULT, ALGO_BYTES_PER_SCALAR_MULT, "k_scalar_mult"
         elif args.workload == "windowed":
             # what THIS algorithm needs per scalar: table = 4 doublings + 3 mixed additions, its
-            # inversion 7 x (7 + 383/224) (224 points share one inversion at 2^22), 63 windows x (4 doublings + 1 mixed addition), the final inversion walk;
+            # inversion 7 x (7 + 267/224) (224 points share one inversion at 2^22), 63 windows x (4 doublings + 1 mixed addition), the final inversion walk;
             # a doubling is 4M + 4S (P-256) / 3M + 4S (secp256k1), a mixed addition 8M + 3S; 96 B in, 64 B out.
             dbl = 8 if args.curve == "p256" else 7
-            fm = (4 * dbl + 3 * 11) + 7 * (7 + 383 / 224) + 63 * (4 * dbl + 11) + (7 + 383 / 32)
+            inv = 267 if args.curve == "p256" else 270                  # addition-chain inversion (point.cuh fe_inverse)
+            fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / 224) + 63 * (4 * dbl + 11) + (7 + inv / 32)
             mad32_unit, bytes_unit, kname = int(fm * 136), 160, "k_varwin_mult + k_varwin_multiples + k_varwin_to_table + k_to_affine_batched"
         else:
             # what THIS algorithm needs per scalar: 64 mixed additions x 11 field mults,
-            # 7 mults of the simultaneous-inversion walk and 383/32 of the shared inversion; 32 B in, 64 B out.
+            # 7 mults of the simultaneous-inversion walk and 267/32 (secp256k1: 270/32) of the shared inversion; 32 B in, 64 B out.
             adds = 64 if args.workload == "fixed-base" else 37
-            mad32_unit, bytes_unit = int((adds * 11 + 7 + 383 / 32) * 136), 96
+            mad32_unit, bytes_unit = int((adds * 11 + 7 + (267 if args.curve == "p256" else 270) / 32) * 136), 96
             kname = ("k_base_windowed" if adds == 64 else "k_base_windowed_s<7>") + " + k_to_affine_batched"
         achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
         traffic = None

@@ -48,7 +48,7 @@ template <int C> __global__ void __launch_bounds__(BLOCK) k_sqrt(const uint64_t*
   GID; const fe x = fe_load(a, i);
   constexpr int CI = curve_domain<C>::fast;
   const fe xf = to_fast<C>(x);
-  const fe s = fe_pow<CI>(xf, curve_exps<CI>::P_SQRT);              // gfp.h:46-54
+  const fe s = fe_sqrt_candidate<CI>(xf);              // gfp.h:46-54
   fe_store(out, i, from_fast<C>(s)); if (ok) ok[i] = (uint8_t)fe_eq(fe_sqr<CI>(s), xf);
 }
 }  // namespace

@@ -103,7 +103,7 @@ template <int C, int REC> __global__ void __launch_bounds__(BLOCK) k_sec1_decode
     yv = load_be32(rec + 33);
     good = good && prefix == 0x04 && below_p<C>(yv) && fe_eq(fe_sqr<CI>(classical_to_fast<C>(yv)), rhs);
   } else {
-    const fe s = fe_pow<CI>(rhs, curve_exps<CI>::P_SQRT);              // p = 3 mod 4 (gfp.h:84)
+    const fe s = fe_sqrt_candidate<CI>(rhs);              // p = 3 mod 4 (gfp.h:84)
     good = good && (prefix == 0x02 || prefix == 0x03) && fe_eq(fe_sqr<CI>(s), rhs);
     yv = fast_to_classical<C>(s);
     const fe neg = fe_neg<C>(yv);                                       // p - y (0 stays 0)

@@ -142,7 +142,64 @@ template <> struct curve_exps<CURVE_SECP256K1> {
 
 template <> struct curve_exps<CURVE_SECP256K1_CLASSICAL> : curve_exps<CURVE_SECP256K1> {};
 
-template <int C> ECS_DEV fe fe_inverse(const fe& a) { return fe_pow<C>(a, curve_exps<C>::P_M2); }     // gfp.h:42-44
+// secp256k1: p - 2 = [223 ones][0][22 ones][0000][1][0][11][0][1];  (p + 1)/4 = [223 ones][0][22 ones][0000][11][00]
+template <int C, bool SQRT> ECS_DEV fe secp256k1_pow_chain(const fe& x);
+// a^(2^n): n successive squarings (a loop, not unrolled: the chains below run up to 128 of them)
+template <int C> ECS_DEV fe fe_sqr_n(fe a, int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) a = fe_sqr<C>(a);
+  return a;
+}
+// gfp.h:42-44 inverse() = a^(p-2) and gfp.h:46-54 sqrt() = a^((p+1)/4).  The reference raises to the power with
+// square-and-multiply over the exponent's bits (mgry_ops.h:44-86: 255 S + 128 M for P-256, 255 S + 249 M for
+// secp256k1); the power of a canonical residue does not depend on how the exponent is walked, so fixed addition
+// chains over the runs of ones give the same bits with 255 S + 12 M (P-256), 255 S + 15 M and 253 S + 13 M
+// (secp256k1, the chain libsecp256k1 documents).  Exponents checked against p - 2 and (p + 1)/4 symbolically.
+template <int C> ECS_DEV fe fe_inverse(const fe& x) {
+  if constexpr (C == CURVE_P256) {
+    // p - 2 = [32 ones][31 zeros][1][96 zeros][94 ones][0][1]
+    const fe x2 = fe_mul<C>(fe_sqr<C>(x), x);
+    const fe x3 = fe_mul<C>(fe_sqr<C>(x2), x);
+    const fe x6 = fe_mul<C>(fe_sqr_n<C>(x3, 3), x3);
+    const fe x12 = fe_mul<C>(fe_sqr_n<C>(x6, 6), x6);
+    const fe x15 = fe_mul<C>(fe_sqr_n<C>(x12, 3), x3);
+    const fe x30 = fe_mul<C>(fe_sqr_n<C>(x15, 15), x15);
+    const fe x32 = fe_mul<C>(fe_sqr_n<C>(x30, 2), x2);
+    fe t = fe_mul<C>(fe_sqr_n<C>(x32, 32), x);
+    t = fe_mul<C>(fe_sqr_n<C>(t, 128), x32);
+    t = fe_mul<C>(fe_sqr_n<C>(t, 32), x32);
+    t = fe_mul<C>(fe_sqr_n<C>(t, 30), x30);
+    return fe_mul<C>(fe_sqr_n<C>(t, 2), x);
+  } else {
+    return secp256k1_pow_chain<C, false>(x);
+  }
+}
+template <int C, bool SQRT> ECS_DEV fe secp256k1_pow_chain(const fe& x) {
+  const fe x2 = fe_mul<C>(fe_sqr<C>(x), x);
+  const fe x3 = fe_mul<C>(fe_sqr<C>(x2), x);
+  const fe x6 = fe_mul<C>(fe_sqr_n<C>(x3, 3), x3);
+  const fe x9 = fe_mul<C>(fe_sqr_n<C>(x6, 3), x3);
+  const fe x11 = fe_mul<C>(fe_sqr_n<C>(x9, 2), x2);
+  const fe x22 = fe_mul<C>(fe_sqr_n<C>(x11, 11), x11);
+  const fe x44 = fe_mul<C>(fe_sqr_n<C>(x22, 22), x22);
+  const fe x88 = fe_mul<C>(fe_sqr_n<C>(x44, 44), x44);
+  const fe x176 = fe_mul<C>(fe_sqr_n<C>(x88, 88), x88);
+  const fe x220 = fe_mul<C>(fe_sqr_n<C>(x176, 44), x44);
+  const fe x223 = fe_mul<C>(fe_sqr_n<C>(x220, 3), x3);
+  fe t = fe_mul<C>(fe_sqr_n<C>(x223, 23), x22);
+  if constexpr (SQRT) {
+    t = fe_mul<C>(fe_sqr_n<C>(t, 6), x2);
+    return fe_sqr_n<C>(t, 2);
+  } else {
+    t = fe_mul<C>(fe_sqr_n<C>(t, 5), x);
+    t = fe_mul<C>(fe_sqr_n<C>(t, 3), x2);
+    return fe_mul<C>(fe_sqr_n<C>(t, 2), x);
+  }
+}
+template <int C> ECS_DEV fe fe_sqrt_candidate(const fe& x) {        // a^((p+1)/4): a square root if there is one (p = 3 mod 4)
+  if constexpr (C == CURVE_P256) return fe_pow<C>(x, curve_exps<C>::P_SQRT);     // 253 S + 33 M: few set bits already
+  else return secp256k1_pow_chain<C, true>(x);
+}
 
 // API domain (Montgomery form) <-> the domain the multiplication-heavy code runs in
 // (curve_domain<C>::fast: Montgomery for P-256, classical for secp256k1 -- field.cuh).

@@ -42,6 +42,8 @@ row("to_bytes_be (HBM-bound codec)", n, timeit(lambda: e.to_bytes_be(a)), 0, 64,
 row("from_bytes_be", n, timeit(lambda: e.from_bytes_be(by)), 0, 64, "elements")
 for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     row(f"mod_add<{nm}>", n, timeit(lambda: e.mod_add(cv, a, b)), 0, 96, "elements")
+    inv_m = (255 + 12) if cv == 0 else (255 + 15)
+    row(f"gfp_inverse<{nm}> (addition chain, {inv_m} field mults)", n, timeit(lambda: e.gfp_inverse(cv, a)), inv_m * 136, 64, "elements")
     row(f"mgry_mul<{nm}> element-wise", n, timeit(lambda: e.mgry_mul(cv, a, b)), 136, 96, "field mults")
     row(f"mgry_sqr<{nm}> element-wise", n, timeit(lambda: e.mgry_sqr(cv, a)), 136, 64, "field mults")
 del by
@@ -66,18 +68,18 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     row(f"scalar_mult<{nm}> ladder, Jacobian out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=1, out=outj), 5), 555968, 192, "scalar mults")
     row(f"scalar_mult<{nm}> ladder, affine out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=3, out=outj), 5), 555968 + 19 * 136, 160, "scalar mults")
     dblm = 8 if cv == 0 else 7
-    vw = int(((4 * dblm + 33) + 7 * (7 + 383 / 224) + 63 * (4 * dblm + 11) + (7 + 383 / 32)) * 136)
+    vw = int(((4 * dblm + 33) + 7 * (7 + inv_m / 224) + 63 * (4 * dblm + 11) + (7 + inv_m / 32)) * 136)
     row(f"scalar_mult<{nm}> windowed variable base (per-element tables), affine out", n2,
         timeit(lambda: e.scalar_mult(cv, k, b2x, b2y, flags=2 | 4, out=outj), 5), vw, 160, "scalar mults")
-    row(f"to_affine<{nm}> (simultaneous inversion)", n2, timeit(lambda: e.to_affine(cv, outj)), int((7 + 383 / 32) * 136), 256, "points")
-    row(f"scalar_mult_base<{nm}> windowed, affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=6, out=outj)), int((64 * 11 + 7 + 383 / 32) * 136), 96, "scalar mults")
+    row(f"to_affine<{nm}> (simultaneous inversion)", n2, timeit(lambda: e.to_affine(cv, outj)), int((7 + inv_m / 32) * 136), 256, "points")
+    row(f"scalar_mult_base<{nm}> windowed, affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=6, out=outj)), int((64 * 11 + 7 + inv_m / 32) * 136), 96, "scalar mults")
     u1 = e.fill_random(n2, SEED, 21)
     row(f"double_scalar_mult<{nm}> u1*G + u2*Q (ECDSA-verify shape)", n2, timeit(lambda: e.double_scalar_mult(cv, u1, k, b2x, b2y), 5),
-        vw + int((37 * 11 + (7 + 383 / 32) + 6 + 383 / 32) * 136), 160, "verifications")
+        vw + int((37 * 11 + (7 + inv_m / 32) + 6 + inv_m / 32) * 136), 160, "verifications")
     del u1
-    row(f"scalar_mult_base<{nm}> signed 7-bit windows, affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 8, out=outj)), int((37 * 11 + 7 + 383 / 32) * 136), 96, "scalar mults")
+    row(f"scalar_mult_base<{nm}> signed 7-bit windows, affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 8, out=outj)), int((37 * 11 + 7 + inv_m / 32) * 136), 96, "scalar mults")
     wire = e.sec1_encode(cv, b2x, b2y, True)
-    row(f"sec1_decode<{nm}> compressed (decompression)", n2, timeit(lambda: e.sec1_decode(cv, wire, True)), (255 + 128 + 4) * 136, 33 + 64, "points")
+    row(f"sec1_decode<{nm}> compressed (decompression)", n2, timeit(lambda: e.sec1_decode(cv, wire, True)), ((253 + 33 + 4) if cv == 0 else (253 + 13 + 4)) * 136, 33 + 64, "points")
     wire = e.sec1_encode(cv, b2x, b2y, False)
     row(f"sec1_decode<{nm}> uncompressed (validation)", n2, timeit(lambda: e.sec1_decode(cv, wire, False)), 4 * 136, 65 + 64, "points")
     del k, s2, b2x, b2y, P2, outj, wire
