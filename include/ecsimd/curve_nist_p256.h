@@ -1,18 +1,20 @@
-// ecsimd/curve_nist_p256.h -- NIST P-256 (SP 800-186), same shape as the reference (curve_nist_p256.h:14-32).
+// ecsimd/curve_nist_p256.h -- NIST P-256 / secp256r1 (FIPS 186-5, SP 800-186 3.2.1.3): y^2 = x^3 - 3x + b over GF(p).
+// Member names follow the reference's curve struct (curve_nist_p256.h:14-32): bn_type, P, A, B, Gx, Gy, each
+// with a ::value.  The numbers are checked at run time against the engine's own table (ecsimd_hip_get_constant)
+// by tests/cpp/host_api_tests.cpp (Curves.ConstantsMatchTheEngine), and the engine's table against the reference's
+// by tests/test_gpu_parity.py::test_constants_match_the_oracle.
 #ifndef ECSIMD_CURVE_NIST_P256_H
 #define ECSIMD_CURVE_NIST_P256_H
 #include <ecsimd/curve.h>
-#include <ecsimd/literals.h>
-#include <ecsimd/serialization.h>
 
 namespace ecsimd {
 struct curve_nist_p256 {
   using bn_type = bignum_256;
-  struct P  { static constexpr auto value = bn_from_bytes_BE<bn_type>(literals::operator""_hex<"ffffffff00000001000000000000000000000000ffffffffffffffffffffffff">()); };
-  struct A  { static constexpr auto value = bn_from_bytes_BE<bn_type>(literals::operator""_hex<"ffffffff00000001000000000000000000000000fffffffffffffffffffffffc">()); };
-  struct B  { static constexpr auto value = bn_from_bytes_BE<bn_type>(literals::operator""_hex<"5ac635d8aa3a93e7b3ebbd55769886bc651d06b0cc53b0f63bce3c3e27d2604b">()); };
-  struct Gx { static constexpr auto value = bn_from_bytes_BE<bn_type>(literals::operator""_hex<"6b17d1f2e12c4247f8bce6e563a440f277037d812deb33a0f4a13945d898c296">()); };
-  struct Gy { static constexpr auto value = bn_from_bytes_BE<bn_type>(literals::operator""_hex<"4fe342e2fe1a7f9b8ee7eb4a7c0f9e162bce33576b315ececbb6406837bf51f5">()); };
+  using P  = detail::p256_prime;                                        // 2^256 - 2^224 + 2^192 + 2^96 - 1
+  using A  = bn256_constant<0xffffffff00000001ull, 0x0000000000000000ull, 0x00000000ffffffffull, 0xfffffffffffffffcull>;   // p - 3
+  using B  = bn256_constant<0x5ac635d8aa3a93e7ull, 0xb3ebbd55769886bcull, 0x651d06b0cc53b0f6ull, 0x3bce3c3e27d2604bull>;
+  using Gx = bn256_constant<0x6b17d1f2e12c4247ull, 0xf8bce6e563a440f2ull, 0x77037d812deb33a0ull, 0xf4a13945d898c296ull>;
+  using Gy = bn256_constant<0x4fe342e2fe1a7f9bull, 0x8ee7eb4a7c0f9e16ull, 0x2bce33576b315eceull, 0xcbb6406837bf51f5ull>;
 };
 static_assert(hip_curve_id<curve_nist_p256::P>() == ECSIMD_HIP_P256);
 }  // namespace ecsimd

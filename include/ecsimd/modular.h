@@ -23,11 +23,11 @@ template <class BN> wide_bignum<BN> mod_add(wide_bignum<BN> const& a, wide_bignu
 template <class BN> wide_bignum<BN> mod_sub(wide_bignum<BN> const& a, wide_bignum<BN> const& b, wide_bignum<BN> const& p);
 template <class BN> wide_bignum<BN> mod_shift_left_one(wide_bignum<BN> const& a, wide_bignum<BN> const& p);
 namespace detail {
-struct p256_tag { static constexpr bignum_256 value = P256_PRIME; };
-struct k256_tag { static constexpr bignum_256 value = SECP256K1_PRIME; };
+using p256_tag = p256_prime;
+using k256_tag = secp256k1_prime;
 inline int curve_of_modulus(bignum_256 const& p) {
-  if (p == P256_PRIME) return ECSIMD_HIP_P256;
-  if (p == SECP256K1_PRIME) return ECSIMD_HIP_SECP256K1;
+  if (p == p256_prime::value) return ECSIMD_HIP_P256;
+  if (p == secp256k1_prime::value) return ECSIMD_HIP_SECP256K1;
   throw hip::error("ecsimd: modulus has no HIP kernel (P-256 and secp256k1 only)");
 }
 }  // namespace detail

@@ -156,6 +156,32 @@ const auto G3x = "5ecbe4d1a6330a44c8f7ef951d4bf165e6c6b721efada985fb41661bc6e7fd
 const auto G5x = "51590b7a515140d2d784c85608668fdfef8c82fd1f5be52421554a0dc3d033ed"_hex, G5y = "e0c17da8904a727d8ae1bf36bf8a79260d012f00d4d80888d1d0bb44fda16da4"_hex;
 template <class WJ, class A> bool affine_is(WJ const& J, A const& x, A const& y) { const auto p = J.to_affine(); return all(p.x() == splat<W256>(x)) && all(p.y() == splat<W256>(y)); }
 }
+// per-lane decompression and membership (beyond the reference's all-or-nothing from_x), both curves
+template <class K> static void lanes_membership() {
+  using KG = curve_group<K>; using WCP = wide_curve_point<K>;
+  const size_t n = 64;
+  W256 s(n, [](size_t i, size_t) { bignum_256 b; b.limbs = {i * 0x9e3779b97f4a7c15ull + 11, i, 5, 0x1000000000000000ull + i}; return b; });
+  const auto P = KG::scalar_mult(s, KG::WJG(n)).to_affine();                       // points on the curve
+  EXPECT_TRUE(all(P.on_curve()));
+  hip::mask valid;
+  const auto Q = WCP::from_x_lanes(P.x(), valid);
+  EXPECT_TRUE(all(valid)); EXPECT_TRUE(all(Q.on_curve()));
+  EXPECT_TRUE(all(Q.x() == P.x()));
+  auto bad = P.y().host(); bad[3].limbs[0] ^= 1; bad[40].limbs[2] ^= 0x10;          // two lanes leave the curve
+  const auto flags = WCP{P.x(), W256(bad)}.on_curve().host();
+  for (size_t i = 0; i < n; ++i) EXPECT_TRUE((flags[i] != 0) == (i != 3 && i != 40));
+  W256 xs(n, [](size_t i, size_t) { bignum_256 b; b.limbs = {i + 1, 0, 0, 0}; return b; });   // small x: about half are abscissae
+  const auto R = WCP::from_x_lanes(xs, valid);
+  const auto v = valid.host(); const auto on = R.on_curve().host();
+  size_t good = 0;
+  for (size_t i = 0; i < n; ++i) { good += v[i] != 0; EXPECT_TRUE((v[i] != 0) == (on[i] != 0)); }
+  EXPECT_TRUE(good > n / 4 && good < 3 * n / 4);
+}
+TEST(CurvePoint, PerLaneDecompressionAndMembership) {
+  lanes_membership<curve_nist_p256>();
+  lanes_membership<curve_secp256k1>();
+}
+
 TEST(CurveGroup, DBLU) {                                                                      // :38-52
   auto G = CG::WJG();
   const auto D = CG::DBLU(G);
@@ -215,6 +241,24 @@ TEST(Batch, RuntimeLengthAndSecp256k1) {
   const auto five = KG::scalar_mult(W256(n, bignum_256::from(5)), KG::WJG(n)).to_affine();   // 5G on secp256k1
   EXPECT_TRUE(all(five.x() == W256(n, bn_from_bytes_BE<bignum_256>("2f8bde4d1a07209355b4a7250a5c5128e88b84bddc619ab7cba8d569b240efe4"_hex))));
   EXPECT_TRUE(all(five.y() == W256(n, bn_from_bytes_BE<bignum_256>("d8ac222636e5e3d6d4dba9dda6c9c426f788271bab0d6840dca87d3aa6ac62d6"_hex))));
+}
+
+// The curve structs' constants equal the engine's own table (ecsimd_hip_get_constant: 0 p, 1 a, 2 b, 3 Gx, 4 Gy) and
+// the hexadecimal literals of the standards documents.
+template <class K> static void constants_match_engine() {
+  using M = mgry_constants<typename K::P>;
+  EXPECT_TRUE(K::P::value == M::get(0)); EXPECT_TRUE(K::A::value == M::get(1)); EXPECT_TRUE(K::B::value == M::get(2));
+  EXPECT_TRUE(K::Gx::value == M::get(3)); EXPECT_TRUE(K::Gy::value == M::get(4));
+}
+TEST(Curves, ConstantsMatchTheEngine) {
+  constants_match_engine<curve_nist_p256>();
+  constants_match_engine<curve_secp256k1>();
+  EXPECT_TRUE(curve_nist_p256::P::value == bn_from_bytes_BE<bignum_256>("ffffffff00000001000000000000000000000000ffffffffffffffffffffffff"_hex));
+  EXPECT_TRUE(curve_nist_p256::B::value == bn_from_bytes_BE<bignum_256>("5ac635d8aa3a93e7b3ebbd55769886bc651d06b0cc53b0f63bce3c3e27d2604b"_hex));
+  EXPECT_TRUE(curve_nist_p256::Gx::value == bn_from_bytes_BE<bignum_256>("6b17d1f2e12c4247f8bce6e563a440f277037d812deb33a0f4a13945d898c296"_hex));
+  EXPECT_TRUE(curve_nist_p256::Gy::value == bn_from_bytes_BE<bignum_256>("4fe342e2fe1a7f9b8ee7eb4a7c0f9e162bce33576b315ececbb6406837bf51f5"_hex));
+  EXPECT_TRUE(curve_secp256k1::Gx::value == bn_from_bytes_BE<bignum_256>("79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798"_hex));
+  EXPECT_TRUE(curve_secp256k1::Gy::value == bn_from_bytes_BE<bignum_256>("483ada7726a3c4655da4fbfc0e1108a8fd17b448a68554199c47d08ffb10d4b8"_hex));
 }
 
 // Extensions: the windowed algorithms give the ladder's affine points (both curves), and u1*G + u2*Q composes them.
