@@ -1,8 +1,8 @@
 // ecsimd/curve_nist_p256.h -- NIST P-256 / secp256r1 (FIPS 186-5, SP 800-186 3.2.1.3): y^2 = x^3 - 3x + b over GF(p).
 // Member names follow the reference's curve struct (curve_nist_p256.h:14-32): bn_type, P, A, B, Gx, Gy, each
 // with a ::value.  The numbers are checked at run time against the engine's own table (ecsimd_hip_get_constant)
-// by tests/cpp/host_api_tests.cpp (Curves.ConstantsMatchTheEngine), and the engine's table against the reference's
-// by tests/test_gpu_parity.py::test_constants_match_the_oracle.
+// by tests/cpp/host_api_tests.cpp (Curves.ConstantsMatchTheEngine); the engine's table is compared with the
+// reference's constants in tests/test_gpu_parity.py.
 #ifndef ECSIMD_CURVE_NIST_P256_H
 #define ECSIMD_CURVE_NIST_P256_H
 #include <ecsimd/curve.h>
