@@ -140,7 +140,7 @@ def main():
         "config": {"workload": (f"scalar_mult_{args.curve} variable-base co-Z ladder (reference algorithm), "
                                 f"batch=2^{args.log2_batch} per GPU, Jacobian Montgomery out") if args.workload == "ladder" else
                                (f"scalar_mult_{args.curve} variable-base, per-element window tables {{1..8}}P + signed 4-bit windows + simultaneous "
-                                f"inversion, batch=2^{args.log2_batch} per GPU, affine out") if args.workload == "windowed" else
+                                f"inversion{' + GLV split k = k1 + k2*lambda' if args.curve == 'secp256k1' else ''}, batch=2^{args.log2_batch} per GPU, affine out") if args.workload == "windowed" else
                                (f"scalar_mult_{args.curve} fixed-base (G), batch=2^{args.log2_batch} random scalars per GPU, "
                                 + ("4-bit window table in LDS" if args.workload == "fixed-base" else "signed 7-bit window table in LDS")
                                 + " + simultaneous inversion, affine out"),
@@ -162,6 +162,8 @@ def main():
             dbl = 8 if args.curve == "p256" else 7
             inv = 267 if args.curve == "p256" else 270                  # addition-chain inversion (point.cuh fe_inverse)
             fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / 224) + 63 * (4 * dbl + 11) + (7 + inv / 32)
+            if args.curve == "secp256k1":     # GLV split: 32 windows x (4 doublings + 2 mixed additions + beta) + the top window's two additions
+                fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / 224) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + (7 + inv / 32)
             mad32_unit, bytes_unit, kname = int(fm * 136), 160, "k_varwin_mult + k_varwin_multiples + k_varwin_to_table + k_to_affine_batched"
         else:
             # what THIS algorithm needs per scalar: 64 mixed additions x 11 field mults,

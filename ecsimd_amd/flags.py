@@ -5,3 +5,4 @@ OUT_JACOBIAN = 0
 OUT_AFFINE = 2
 ALG_WINDOWED = 4
 ALG_WINDOWED_SIGNED = 8
+ALG_NO_ENDOMORPHISM = 16

@@ -354,6 +354,9 @@ def test_windowed_variable_base_matches_the_ladder_at_affine_level(engine, oracl
     ix, iy = bx[:8192].clone(), by[:8192].clone()                                # in place: outputs over the base point
     engine.scalar_mult(cv, k[:8192].contiguous(), ix, iy, flags=OUT_AFFINE | ALG_WINDOWED, out=[ix, iy, None])
     assert torch.equal(ix, wx[:8192]) and torch.equal(iy, wy[:8192])
+    from ecsimd_amd import ALG_NO_ENDOMORPHISM                                   # secp256k1: GLV split by default, the plain loop on request
+    qx, qy = engine.scalar_mult(cv, k[:1 << 17].contiguous(), bx[:1 << 17].contiguous(), by[:1 << 17].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED | ALG_NO_ENDOMORPHISM)
+    assert torch.equal(qx, wx[:1 << 17]) and torch.equal(qy, wy[:1 << 17])
     k1 = engine.to_numpy(k[m + 5])                                               # one scalar for every lane (scalar_mult_1s)
     sx, sy = engine.scalar_mult_1s(cv, k1, bx[:8192].contiguous(), by[:8192].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED)
     tx, ty = engine.scalar_mult_1s(cv, k1, bx[:8192].contiguous(), by[:8192].contiguous(), flags=OUT_AFFINE)

@@ -69,6 +69,8 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     row(f"scalar_mult<{nm}> ladder, affine out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=3, out=outj), 5), 555968 + 19 * 136, 160, "scalar mults")
     dblm = 8 if cv == 0 else 7
     vw = int(((4 * dblm + 33) + 7 * (7 + inv_m / 224) + 63 * (4 * dblm + 11) + (7 + inv_m / 32)) * 136)
+    if cv == 1:                                      # secp256k1: GLV split (k_varwin.inc)
+        vw = int(((4 * dblm + 33) + 7 * (7 + inv_m / 224) + 32 * (4 * dblm + 23) + 23 + (7 + inv_m / 32)) * 136)
     row(f"scalar_mult<{nm}> windowed variable base (per-element tables), affine out", n2,
         timeit(lambda: e.scalar_mult(cv, k, b2x, b2y, flags=2 | 4, out=outj), 5), vw, 160, "scalar mults")
     row(f"to_affine<{nm}> (simultaneous inversion)", n2, timeit(lambda: e.to_affine(cv, outj)), int((7 + inv_m / 32) * 136), 256, "points")

@@ -31,6 +31,8 @@ for cv in (P256, SECP256K1):
     P = e.from_affine(cv, bx, by)                                   # Montgomery-form base
     mx, my = e.scalar_mult(cv, dk, P[0], P[1], flags=OUT_AFFINE | ALG_WINDOWED | BASE_MGRY)
     good &= torch.equal(mx, wx) and torch.equal(my, wy)
+    px, py = e.scalar_mult(cv, dk, bx, by, flags=OUT_AFFINE | ALG_WINDOWED | 16)      # ALG_NO_ENDOMORPHISM: the plain loop
+    good &= torch.equal(px, wx) and torch.equal(py, wy)
     print("varwin parity", cv, "OK" if good else "FAIL"); ok &= good
 if not ok:
     sys.exit(1)
