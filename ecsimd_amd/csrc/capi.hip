@@ -48,6 +48,7 @@ void pack_table_signed(hipStream_t s, int curve, int wbits, const uint64_t* tx, 
 void base_windowed_signed(hipStream_t s, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed_signed, s, wbits, k, table, ox, oy, oz, n); }
 void affine_add_batched(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) { DISPATCH(affine_add_batched, s, ax, ay, bx, by, rx, ry, finite, n); }
 void base_windowed(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed, s, k, table, ox, oy, oz, n); }
+void add_mixed_complete(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH(add_mixed_complete, s, ax, ay, az, bx, by, rx, ry, rz, n); }
 void varwin_scalar_mult(hipStream_t s, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, int flags, uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n) { DISPATCH(varwin_scalar_mult, s, k, k_stride, x, y, flags, scratch, ox, oy, n); }
 #undef DISPATCH
 } }
@@ -408,6 +409,9 @@ int ecsimd_hip_zdau(ecsimd_hip_ctx* ctx, int curve, const uint64_t* px, const ui
 int ecsimd_hip_add_z2_1(ecsimd_hip_ctx* ctx, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(ax); REQUIRE_PTR(ay); REQUIRE_PTR(az); REQUIRE_PTR(bx); REQUIRE_PTR(by); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
   RUN(launch::add_z2_1(s, curve, ax, ay, az, bx, by, rx, ry, rz, n)); }
+int ecsimd_hip_add_mixed_complete(ecsimd_hip_ctx* ctx, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(ax); REQUIRE_PTR(ay); REQUIRE_PTR(az); REQUIRE_PTR(bx); REQUIRE_PTR(by); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
+  RUN(launch::add_mixed_complete(s, curve, ax, ay, az, bx, by, rx, ry, rz, n)); }
 int ecsimd_hip_trplu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz); RUN(launch::trplu(s, curve, px, py, pz, rx, ry, rz, n)); }
 

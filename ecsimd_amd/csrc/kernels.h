@@ -70,6 +70,9 @@ void base_windowed_signed(hipStream_t, int curve, int wbits, const uint64_t* k, 
 // scratch: varwin_scratch_bytes(n) bytes, 32-byte aligned; k_stride, x, y as for scalar_mult (flags: ECSIMD_HIP_BASE_*).
 void varwin_scalar_mult(hipStream_t, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, int flags,
                         uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n);
+// complete mixed addition (A Jacobian, Z = 0 is infinity; B Montgomery-form affine, (0, 0) is infinity)
+void add_mixed_complete(hipStream_t, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by,
+                        uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
 inline size_t varwin_scratch_bytes(size_t n) { return n * (7 * 4 * 32 + 8 * 64); }
 
 // per-curve pieces (one translation unit each)
@@ -91,6 +94,7 @@ template <int C> struct point_launch {
   static void pack_table_signed(hipStream_t, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
   static void base_windowed_signed(hipStream_t, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
   // k_varwin_<curve>.hip
+  static void add_mixed_complete(hipStream_t, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
   static void varwin_scalar_mult(hipStream_t, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, int flags, uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n);
 };
 constexpr size_t WINDOW_TABLE_BYTES = 64 * 16 * 64;   // 64 windows x 16 digits x (x, y)

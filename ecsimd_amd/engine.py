@@ -252,6 +252,10 @@ class Engine:
         n = p[0].shape[0]; r = [self.empty(n) for _ in range(3)]
         self._call("zdau", C.c_int(curve), *[self._ptr(t) for t in p], *[self._ptr(t) for t in q], *[self._ptr(t) for t in r], C.c_size_t(n)); return tuple(r)
 
+    def add_mixed_complete(self, curve, a, bxy):
+        n = a[0].shape[0]; r = [self.empty(n) for _ in range(3)]
+        self._call("add_mixed_complete", C.c_int(curve), *[self._ptr(t) for t in a], *[self._ptr(t) for t in bxy], *[self._ptr(t) for t in r], C.c_size_t(n)); return tuple(r)
+
     def add_z2_1(self, curve, a, bxy):
         n = a[0].shape[0]; r = [self.empty(n) for _ in range(3)]
         self._call("add_z2_1", C.c_int(curve), *[self._ptr(t) for t in a], *[self._ptr(t) for t in bxy], *[self._ptr(t) for t in r], C.c_size_t(n)); return tuple(r)

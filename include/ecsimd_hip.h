@@ -166,6 +166,10 @@ int ecsimd_hip_zaddu(ecsimd_hip_ctx*, int curve, uint64_t* px, uint64_t* py, uin
 int ecsimd_hip_zdau(ecsimd_hip_ctx*, int curve, const uint64_t* px, const uint64_t* py, const uint64_t* pz, uint64_t* qx, uint64_t* qy, uint64_t* qz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
 /* curve_group.h:155-179 ADD_Z2_1: r = A + B with B = (bx, by) Montgomery-form affine (Z2 = mgry(1)). */
 int ecsimd_hip_add_z2_1(ecsimd_hip_ctx*, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
+/* Extension: the complete form of the mixed addition -- r = A + B for every input: A = infinity (Z = 0), B = infinity
+ * ((0, 0)), A = B (tangent), A = -B (r = infinity: Z = 0).  Same conventions as add_z2_1 (B Montgomery-form affine);
+ * r is a representative of the same point as ADD_Z2_1's where that formula is defined (Z3 = Z1*H instead of 2*Z1*H). */
+int ecsimd_hip_add_mixed_complete(ecsimd_hip_ctx*, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
 /* curve_group.h:183-186 TRPLU: r = 3P, P rewritten in place with r's Z.  P.z must be mgry(1). */
 int ecsimd_hip_trplu(ecsimd_hip_ctx*, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
 
