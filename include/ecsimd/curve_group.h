@@ -71,6 +71,11 @@ struct curve_group {
                                       ECSIMD_HIP_BASE_CLASSICAL | ECSIMD_HIP_OUT_AFFINE | (windowed ? ECSIMD_HIP_ALG_WINDOWED : 0)), "ecsimd_hip_scalar_mult");
     return r;
   }
+  // A + B for every input, unlike ADD_Z2_1: A = B, A = -B (Z = 0 comes back), A at infinity (Z = 0); B.z must be mgry(1).
+  static WJCP add_mixed_complete(WJCP const& A, WJCP const& B) {
+    WJCP r = fresh(A.size());
+    hip::check(ecsimd_hip_add_mixed_complete(hip::context(), curve_id, px(A), py(A), pz(A), px(B), py(B), px(r), py(r), pz(r), A.size()), "ecsimd_hip_add_mixed_complete"); return r;
+  }
   // k[i] * G through the LDS-resident window tables (signed 7-bit windows), affine classical.
   static WCP scalar_mult_base_affine(WBN const& x) {
     WCP r{WBN::uninitialized(x.size()), WBN::uninitialized(x.size())};

@@ -272,6 +272,11 @@ template <class K> static void windowed_paths_agree() {
   const auto ladder = KG::scalar_mult_affine(k, P, false);
   EXPECT_TRUE(all(ladder == KG::scalar_mult(k, wide_jacobian_curve_point<K>::from_affine(P)).to_affine()));
   EXPECT_TRUE(all(KG::scalar_mult_affine(k, P) == ladder));
+  const auto JP = wide_jacobian_curve_point<K>::from_affine(P);
+  const auto J = KG::scalar_mult(k, JP);                                                       // k*P, Z != 1
+  EXPECT_TRUE(all(KG::add_mixed_complete(J, JP).to_affine() == KG::ADD_Z2_1(J, JP).to_affine()));
+  auto twoP = JP; const auto D = KG::DBLU(twoP);                                               // D = 2P
+  EXPECT_TRUE(all(KG::add_mixed_complete(JP, JP).to_affine() == D.to_affine()));              // the tangent case ADD_Z2_1 cannot do
   hip::mask fin;
   const auto sum = KG::double_scalar_mult(W256(n, bignum_256::from(0)), k, P, fin);             // 0*G + k*P
   EXPECT_TRUE(all(fin)); EXPECT_TRUE(all(sum == ladder));
