@@ -334,6 +334,29 @@ int ecsimd_hip_sub_if_above(ecsimd_hip_ctx* ctx, const uint64_t* a, const uint64
 int ecsimd_hip_cmp_lt(ecsimd_hip_ctx* ctx, const uint64_t* a, const uint64_t* b, uint8_t* flag, size_t n) {
   REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); if (!flag && n) return bad(ctx, "flag is null");
   RUN(launch::sub(s, a, b, nullptr, flag, n)); }
+int ecsimd_hip_cmp_eq(ecsimd_hip_ctx* ctx, const uint64_t* a, const uint64_t* b, int limbs, uint8_t* flag, size_t n) {
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); if (!flag && n) return bad(ctx, "flag is null");
+  if (limbs < 1 || limbs > 8) return bad(ctx, "limbs must be 1..8");
+  RUN(launch::cmp_eq(s, a, b, limbs, flag, n)); }
+int ecsimd_hip_mask_op(ecsimd_hip_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+  REQUIRE_CTX(); if (op < ECSIMD_HIP_MASK_NOT || op > ECSIMD_HIP_MASK_EQ) return bad(ctx, "unknown mask operation");
+  if (n && (!a || !out || (op != ECSIMD_HIP_MASK_NOT && !b))) return bad(ctx, "mask pointer is null");
+  RUN(launch::mask_op(s, op, a, b, out, n)); }
+int ecsimd_hip_mask_count(ecsimd_hip_ctx* ctx, const uint8_t* a, size_t n, size_t* count) {
+  REQUIRE_CTX(); if (!count) return bad(ctx, "count is null");
+  *count = 0;
+  if (n == 0) return ECSIMD_HIP_OK;
+  if (!a) return bad(ctx, "mask pointer is null");
+  (void)hipSetDevice(ctx->device);
+  unsigned long long* slot = reinterpret_cast<unsigned long long*>(ctx->sink + 1024 - 16);     // 8-byte slot next to the shared scalar
+  hipError_t e = hipMemsetAsync(slot, 0, sizeof *slot, ctx->stream);
+  if (e == hipSuccess) { launch::mask_count(ctx->stream, a, n, slot); e = hipGetLastError(); }
+  unsigned long long host = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&host, slot, sizeof host, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "mask_count");
+  *count = (size_t)host;
+  return ECSIMD_HIP_OK; }
 int ecsimd_hip_shift_left_one(ecsimd_hip_ctx* ctx, const uint64_t* a, uint64_t* out, uint8_t* carry, size_t n) {
   REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::shift_left_one(s, a, out, carry, n)); }
 int ecsimd_hip_mul(ecsimd_hip_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out8, size_t n) {

@@ -39,6 +39,27 @@ __global__ void __launch_bounds__(BLOCK) k_swap_if(const uint8_t* mask, uint64_t
   fe_cswap(0u - (uint32_t)(mask[i] != 0), x, y); fe_store(a, i, x); fe_store(b, i, y);
 }
 
+// lane-wise equality of `limbs`-limb elements (4 or 8), lane-mask logic and the count behind all() / any():
+// the reference gets these from eve's logical<wide> (bignum.h:136-137, eve::all / eve::any in its tests).
+__global__ void __launch_bounds__(BLOCK) k_cmp_eq(const uint64_t* a, const uint64_t* b, int limbs, uint8_t* flag, size_t n) {
+  GID; const int stride = limbs <= 4 ? 4 : 8;          // narrower values (the 128- and 192-bit types of the reference's unit tests)
+  const uint64_t* x = a + (size_t)stride * i;          // travel in the low limbs of a 256-bit element
+  const uint64_t* y = b + (size_t)stride * i;
+  uint64_t d = 0;
+  for (int j = 0; j < limbs; ++j) d |= x[j] ^ y[j];
+  flag[i] = (uint8_t)(d == 0ull);
+}
+__global__ void __launch_bounds__(BLOCK) k_mask_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+  GID; const bool x = a[i] != 0, y = b ? b[i] != 0 : false;
+  out[i] = (uint8_t)(op == 0 ? !x : op == 1 ? (x && y) : op == 2 ? (x || y) : (x == y));
+}
+__global__ void __launch_bounds__(BLOCK) k_mask_count(const uint8_t* a, size_t n, unsigned long long* count) {
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const bool set = i < n && a[i] != 0;
+  const unsigned long long lanes = __builtin_amdgcn_ballot_w64(set);
+  if ((threadIdx.x & 63) == 0 && lanes) atomicAdd(count, (unsigned long long)__builtin_popcountll(lanes));
+}
+
 // word w of element i of stream s = splitmix64(seed ^ (s << 56) ^ (4 i + w))
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
   z += 0x9e3779b97f4a7c15ull;
@@ -87,6 +108,9 @@ void shift_left_one(hipStream_t s, const uint64_t* a, uint64_t* out, uint8_t* ca
 void mul(hipStream_t s, const uint64_t* a, const uint64_t* b, uint64_t* out8, size_t n) { GO(k_mul, a, b, out8, n); }
 void square(hipStream_t s, const uint64_t* a, uint64_t* out8, size_t n) { GO(k_square, a, out8, n); }
 void swap_if(hipStream_t s, const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n) { GO(k_swap_if, mask, a, b, n); }
+void cmp_eq(hipStream_t s, const uint64_t* a, const uint64_t* b, int limbs, uint8_t* flag, size_t n) { GO(k_cmp_eq, a, b, limbs, flag, n); }
+void mask_op(hipStream_t s, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) { GO(k_mask_op, op, a, b, out, n); }
+void mask_count(hipStream_t s, const uint8_t* a, size_t n, unsigned long long* count) { GO(k_mask_count, a, n, count); }
 void fill_random(hipStream_t s, uint64_t* out, size_t n, uint64_t seed, uint64_t stream, uint64_t first, int clear_top) { GO(k_fill_random, out, n, seed, stream, first, clear_top); }
 void peak_mad32(hipStream_t s, int blocks, uint32_t* sink, int iters, uint32_t seed) {
   hipLaunchKernelGGL(k_peak_mad32, dim3(blocks), dim3(BLOCK), 0, s, sink, iters, seed);

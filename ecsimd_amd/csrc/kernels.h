@@ -21,6 +21,9 @@ void shift_left_one(hipStream_t, const uint64_t* a, uint64_t* out, uint8_t* carr
 void mul(hipStream_t, const uint64_t* a, const uint64_t* b, uint64_t* out8, size_t n);
 void square(hipStream_t, const uint64_t* a, uint64_t* out8, size_t n);
 void swap_if(hipStream_t, const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n);
+void cmp_eq(hipStream_t, const uint64_t* a, const uint64_t* b, int limbs, uint8_t* flag, size_t n);
+void mask_op(hipStream_t, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);     // 0 not, 1 and, 2 or, 3 equal
+void mask_count(hipStream_t, const uint8_t* a, size_t n, unsigned long long* count);
 void fill_random(hipStream_t, uint64_t* out, size_t n, uint64_t seed, uint64_t stream, uint64_t first, int clear_top);
 void peak_mad32(hipStream_t, int blocks, uint32_t* sink, int iters, uint32_t seed);
 constexpr int PEAK_MADS_PER_LANE_PER_ITER = 64;

@@ -146,6 +146,18 @@ class Engine:
         n = a.shape[0]; out = self.empty(n)
         self._call("sub_if_above", self._ptr(a), self._ptr(p), self._ptr(out), C.c_size_t(n)); return out
 
+    def cmp_eq(self, a, b):
+        n = a.shape[0]; f = self.flags(n)
+        self._call("cmp_eq", self._ptr(a, a.shape[1]), self._ptr(b, b.shape[1]), C.c_int(a.shape[1]), self._ptr(f, 0), C.c_size_t(n)); return f
+
+    def mask_op(self, op, a, b=None):
+        n = a.shape[0]; f = self.flags(n)
+        self._call("mask_op", C.c_int(op), self._ptr(a, 0), self._ptr(b, 0), self._ptr(f, 0), C.c_size_t(n)); return f
+
+    def mask_count(self, a):
+        c = C.c_size_t(0)
+        self._call("mask_count", self._ptr(a, 0), C.c_size_t(a.shape[0]), C.byref(c)); return int(c.value)
+
     def cmp_lt(self, a, b):
         n = a.shape[0]; f = self.flags(n)
         self._call("cmp_lt", self._ptr(a), self._ptr(b), self._ptr(f, 0), C.c_size_t(n)); return f

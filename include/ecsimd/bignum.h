@@ -98,10 +98,9 @@ template <class WBN> using wbn_zext_t = wide_bignum<bignum<bn_limb_t<WBN>, bn_nl
 
 // lane-wise equality of two wides (the reference gets it from eve's product-type ==)
 template <class BN> hip::mask operator==(wide_bignum<BN> const& a, wide_bignum<BN> const& b) {
-  auto x = a.host(), y = b.host(); std::vector<uint8_t> h(x.size());
-  hip::mask m(x.size());
-  for (size_t i = 0; i < x.size(); ++i) h[i] = x[i] == y[i];
-  if (!h.empty()) hip::check(ecsimd_hip_memcpy_h2d(hip::context(), m.data(), h.data(), h.size()), "h2d");
+  if (a.size() != b.size()) throw hip::error("ecsimd: comparing batches of different length");
+  hip::mask m(a.size());
+  hip::check(ecsimd_hip_cmp_eq(hip::context(), a.data(), b.data(), (int)wide_bignum<BN>::nlimbs, m.data(), a.size()), "ecsimd_hip_cmp_eq");
   return m;
 }
 template <class BN> hip::mask operator!=(wide_bignum<BN> const& a, wide_bignum<BN> const& b) { return !(a == b); }

@@ -118,18 +118,20 @@ class mask {
     return h;
   }
   bool get(size_t i) const { return host().at(i) != 0; }
-  mask operator!() const { auto h = host(); mask m(n_); for (auto& b : h) b = !b; check(ecsimd_hip_memcpy_h2d(context(), m.mem_.get(), h.data(), n_), "h2d"); return m; }
-  friend mask operator==(mask const& a, mask const& b) {
-    auto x = a.host(), y = b.host(); mask m(a.n_);
-    for (size_t i = 0; i < x.size(); ++i) x[i] = (x[i] != 0) == (y[i] != 0);
-    check(ecsimd_hip_memcpy_h2d(context(), m.mem_.get(), x.data(), x.size()), "h2d"); return m;
+  size_t count() const {                                 // lanes set (one reduction kernel + an 8-byte read-back)
+    size_t c = 0; check(ecsimd_hip_mask_count(context(), mem_.get(), n_, &c), "ecsimd_hip_mask_count"); return c;
   }
-  friend mask operator&&(mask const& a, mask const& b) {
-    auto x = a.host(), y = b.host(); mask m(a.n_);
-    for (size_t i = 0; i < x.size(); ++i) x[i] = x[i] && y[i];
-    check(ecsimd_hip_memcpy_h2d(context(), m.mem_.get(), x.data(), x.size()), "h2d"); return m;
-  }
+  mask operator!() const { return combine(ECSIMD_HIP_MASK_NOT, *this, *this); }
+  friend mask operator==(mask const& a, mask const& b) { return combine(ECSIMD_HIP_MASK_EQ, a, b); }
+  friend mask operator&&(mask const& a, mask const& b) { return combine(ECSIMD_HIP_MASK_AND, a, b); }
+  friend mask operator||(mask const& a, mask const& b) { return combine(ECSIMD_HIP_MASK_OR, a, b); }
  private:
+  static mask combine(int op, mask const& a, mask const& b) {
+    if (a.n_ != b.n_) throw error("ecsimd: lane masks of different length");
+    mask m(a.n_);
+    check(ecsimd_hip_mask_op(context(), op, a.mem_.get(), b.mem_.get(), m.mem_.get(), a.n_), "ecsimd_hip_mask_op");
+    return m;
+  }
   std::shared_ptr<uint8_t> mem_;
   size_t n_ = 0;
 };
@@ -137,8 +139,8 @@ class mask {
 }  // namespace hip
 
 // eve::all / eve::any / eve::none over a lane mask (the reference's tests use exactly these).
-inline bool all(hip::mask const& m) { for (auto b : m.host()) if (!b) return false; return true; }
-inline bool any(hip::mask const& m) { for (auto b : m.host()) if (b) return true; return false; }
+inline bool all(hip::mask const& m) { return m.count() == m.size(); }
+inline bool any(hip::mask const& m) { return m.count() != 0; }
 inline bool none(hip::mask const& m) { return !any(m); }
 
 }  // namespace ecsimd

@@ -102,6 +102,14 @@ int ecsimd_hip_add(ecsimd_hip_ctx*, const uint64_t* a, const uint64_t* b, uint64
 int ecsimd_hip_sub(ecsimd_hip_ctx*, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* borrow, size_t n);
 /* sub.h:46-75  sub_if_above: out = a >= p ? a - p : a (p is per element, like the reference's wide p) */
 int ecsimd_hip_sub_if_above(ecsimd_hip_ctx*, const uint64_t* a, const uint64_t* p, uint64_t* out, size_t n);
+/* Lane masks on the device (the reference's eve::logical<wide>, bignum.h:136-137, with eve::all / eve::any):
+ * cmp_eq: flag[i] = (a[i] == b[i]) over the low `limbs` (1..8) limbs of each element (element stride 4 limbs,
+ * 8 for limbs > 4: a 128-bit value occupies the low half of a 256-bit element); mask_op: NOT (b ignored), AND, OR, EQ of
+ * 0/1 byte masks; mask_count: number of non-zero flags (synchronises the stream: all = count == n, any = count > 0). */
+enum { ECSIMD_HIP_MASK_NOT = 0, ECSIMD_HIP_MASK_AND = 1, ECSIMD_HIP_MASK_OR = 2, ECSIMD_HIP_MASK_EQ = 3 };
+int ecsimd_hip_cmp_eq(ecsimd_hip_ctx*, const uint64_t* a, const uint64_t* b, int limbs, uint8_t* flag, size_t n);
+int ecsimd_hip_mask_op(ecsimd_hip_ctx*, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
+int ecsimd_hip_mask_count(ecsimd_hip_ctx*, const uint8_t* a, size_t n, size_t* count);
 /* cmp.h:11-13  cmp_lt: flag[i] = a < b */
 int ecsimd_hip_cmp_lt(ecsimd_hip_ctx*, const uint64_t* a, const uint64_t* b, uint8_t* flag, size_t n);
 /* shift.h:13-32  shift_left_one: out = a << 1 mod 2^256, carry[i] = bit 255 of a */

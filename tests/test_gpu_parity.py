@@ -216,6 +216,29 @@ def test_cmp_and_swap(engine, oracle):
     assert np.array_equal(engine.to_numpy(da), np.where(m[:, None], b, a)) and np.array_equal(engine.to_numpy(db), np.where(m[:, None], a, b))
 
 
+def test_lane_masks_on_the_device(engine):
+    """cmp_eq (4- and 8-limb elements), mask NOT / AND / OR / EQ and the count behind all() / any()."""
+    import torch
+    n = 100_003
+    a = fill_random_np(n, SEED, 81); b = a.copy()
+    diff = np.arange(0, n, 7); b[diff, 3] ^= np.uint64(1 << 63)                    # differ in the top bit of the top limb
+    b[5, 0] ^= np.uint64(1)
+    eq = engine.cmp_eq(engine.to_device(a), engine.to_device(b))
+    exp = (a == b).all(axis=1)
+    assert np.array_equal(engine.to_numpy(eq) != 0, exp)
+    a8 = np.concatenate([a, a[::-1]], axis=1); b8 = np.concatenate([b, a[::-1]], axis=1)
+    eq8 = engine.cmp_eq(engine.to_device(a8), engine.to_device(b8))
+    assert torch.equal(eq8, eq)
+    lt = engine.cmp_lt(engine.to_device(a), engine.to_device(b))
+    ltn = engine.to_numpy(lt) != 0
+    for op, fn in ((0, lambda x, y: ~x), (1, np.logical_and), (2, np.logical_or), (3, lambda x, y: x == y)):
+        got = engine.mask_op(op, eq, None if op == 0 else lt)
+        assert np.array_equal(engine.to_numpy(got) != 0, fn(exp, ltn)), op
+    assert engine.mask_count(eq) == int(exp.sum())
+    assert engine.mask_count(engine.flags(n)) == 0 and engine.mask_count(engine.mask_op(0, engine.flags(n))) == n
+    assert engine.mask_count(engine.flags(0)) == 0
+
+
 def _lane_distinct_points(gpu, cv, n, stream=2):
     """P_i = s_i * G, affine classical, from the synthetic generator."""
     s = fill_random_np(n, SEED, stream)
