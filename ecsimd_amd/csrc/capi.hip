@@ -253,6 +253,12 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
 static int switch_stream(ecsimd_hip_ctx* ctx, hipStream_t next) {
   if (next == ctx->stream) return ECSIMD_HIP_OK;
   (void)hipSetDevice(ctx->device);
+  // A stream under graph capture can neither wait for an outside event nor lend one: there the caller
+  // brackets the capture itself (synchronise before capturing, as graph users do for every library).
+  hipStreamCaptureStatus from = hipStreamCaptureStatusNone, to = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(ctx->stream, &from); (void)hipStreamIsCapturing(next, &to);
+  (void)hipGetLastError();
+  if (from != hipStreamCaptureStatusNone || to != hipStreamCaptureStatusNone) { ctx->stream = next; return ECSIMD_HIP_OK; }
   hipError_t e = hipEventRecord(ctx->handoff, ctx->stream);
   if (e == hipSuccess) e = hipStreamWaitEvent(next, ctx->handoff, 0);
   if (e != hipSuccess) return fail(ctx, e, "stream hand-off");

@@ -76,7 +76,9 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream).  NULL is HIP's default (null)
  * stream -- which is what torch's default stream is -- not "none".  The context's scratch memory is ordered
  * by its stream: switching makes the new stream wait (by event, no host synchronisation) for the work this
- * context enqueued on the previous one, which must still exist at that moment. */
+ * context enqueued on the previous one, which must still exist at that moment.  Streams under hipGraph capture are
+ * selected without that hand-off; every compute entry point is capturable once its first call has sized the
+ * context workspace and built its tables (those steps allocate and synchronise). */
 int ecsimd_hip_set_stream(ecsimd_hip_ctx* ctx, void* hip_stream);
 /* Go back to the non-blocking stream the context created in ecsimd_hip_init (the default). */
 int ecsimd_hip_use_own_stream(ecsimd_hip_ctx* ctx);

@@ -514,6 +514,40 @@ def test_complete_mixed_addition(engine, cv):
     assert torch.equal(zx[600:], rx[600:]) and torch.equal(zy[600:], ry[600:])
 
 
+def test_entry_points_replay_from_a_hip_graph(engine):
+    """Capture the ladder, the windowed variable-base path and u1*G + u2*Q into one graph (after a warm-up call that
+    sizes the workspace and builds the tables), change the inputs in place, replay: same results as eager calls."""
+    import torch
+    from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED
+    n = 1 << 16
+    k = engine.fill_random(n, SEED, 91); s = engine.fill_random(n, SEED, 92)
+    bx, by = engine.scalar_mult_base(P256, s, flags=OUT_AFFINE | ALG_WINDOWED)
+    J = [engine.empty(n) for _ in range(3)]; W = [engine.empty(n) for _ in range(2)]; D = None
+
+    def run():
+        engine.scalar_mult(P256, k, bx, by, out=J)
+        engine.scalar_mult(P256, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED, out=W + [None])
+        return engine.double_scalar_mult(P256, s, k, bx, by)
+    run(); torch.cuda.synchronize()                                   # warm-up: workspace, tables
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            D = run()
+    torch.cuda.synchronize()
+    k.copy_(engine.fill_random(n, SEED, 93))                          # new scalars, same buffers
+    g.replay(); torch.cuda.synchronize()
+    gj = [t.clone() for t in J]; gw = [t.clone() for t in W]; gd = [t.clone() for t in D]
+    ej = engine.scalar_mult(P256, k, bx, by)
+    ew = engine.scalar_mult(P256, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)
+    ed = engine.double_scalar_mult(P256, s, k, bx, by)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(gj, ej))
+    assert all(torch.equal(a, b) for a, b in zip(gw, ew))
+    assert all(torch.equal(a, b) for a, b in zip(gd, ed))
+
+
 def test_scalar_mult_p256_entry_point(engine, oracle):
     """lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P), P Jacobian Montgomery with Z = mgry(1)."""
     n = 1024; c = CURVE_PARAMS[P256]
