@@ -359,6 +359,12 @@ def test_windowed_variable_base_matches_the_ladder_at_affine_level(engine, oracl
     edge = [0, order, 1, 2, 7, 8, 9, 15, 16, 17, 0x78, 0x80, 0x88, 2**252, 2**255, (order - 1) // 2, (order + 1) // 2, order - 2, order - 1,
             order + 1, order + 9, 2**256 - 1, 2**256 - order, 2**256 - order - 1, int("8" * 64, 16), int("7" * 64, 16), int("9" * 64, 16),
             int("08" * 32, 16), int("80" * 32, 16), int("f0" * 32, 16), int("0f" * 32, 16)]
+    # scalars around the GLV lattice of secp256k1 (lambda, the basis vectors, their neighbours): the split's corner cases
+    lam = 0x5363ad4cc05c30e0a5261c028812645a122e22ea20816678df02967c1b23bd72
+    a1, mb1, a2 = 0x3086d221a7d46bcde86c90e49284eb15, 0xe4437ed6010e88286f547fa90abfe4c3, 0x114ca50f7a8e2f3f657c1108d9d44cfd8
+    edge += [lam, lam + 1, lam - 1, (2 * lam) % order, order - lam, (lam * lam) % order, a1, a1 + 1, a1 - 1, mb1, mb1 + 8, a2, a2 - 8, (a1 * lam) % order,
+             (mb1 * lam) % order, (a1 + mb1 * lam) % order, (8 + 8 * lam) % order, (order - 8 - 8 * lam) % order, (1 << 128) - 1, 1 << 128, ((1 << 128) * lam) % order,
+             (((1 << 128) - 1) * (lam + 1)) % order, (0x88888888888888888888888888888888 * (lam + 1)) % order]
     n = (1 << 22) + 4099 if cv == P256 else (1 << 18) + 77          # P-256: crosses the 2^22-lane chunk boundary
     k = engine.fill_random(n, SEED, 53); s = engine.fill_random(n, SEED, 54)
     k[:len(edge)] = engine.to_device(ints_to_arr(edge))
