@@ -45,11 +45,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2-batch", type=int, default=22, help="scalar mults per GPU per step = 2^this")
     ap.add_argument("--curve", default="p256", choices=["p256", "secp256k1"])
-    ap.add_argument("--workload", default="ladder", choices=["ladder", "windowed", "fixed-base", "fixed-base-signed"],
+    ap.add_argument("--workload", default="ladder", choices=["ladder", "windowed", "fixed-base", "fixed-base-signed", "fixed-base-big"],
                     help="ladder: scalar_mult_p256 variable base, the reference's co-Z ladder, Jacobian out (headline, BASELINE configs[3] shape per GPU); "
                          "windowed: variable base with per-element {1..8}P tables and signed 4-bit windows, affine out (ALG_WINDOWED; affine-level parity); "
                          "fixed-base: k*G with the 4-bit-window LDS table + simultaneous inversion, affine out (BASELINE configs[2]); "
-                         "fixed-base-signed: the same with signed 7-bit windows (37 additions instead of 64)")
+                         "fixed-base-signed: the same with signed 7-bit windows (37 additions instead of 64); "
+                         "fixed-base-big: signed 16-bit windows over a 35.7 MB table in device memory (17 additions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
@@ -57,7 +58,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from ecsimd_amd import Engine, CURVES, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED
+    from ecsimd_amd import Engine, CURVES, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -104,7 +105,7 @@ def main():
             eng.scalar_mult(curve, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED, out=[o[0], o[1], o[2]])
         compute([eng.empty(n) for _ in range(3)])           # sizes the context workspace (1 408 B per element)
     else:
-        alg = ALG_WINDOWED if args.workload == "fixed-base" else ALG_WINDOWED_SIGNED
+        alg = {"fixed-base": ALG_WINDOWED, "fixed-base-signed": ALG_WINDOWED_SIGNED, "fixed-base-big": ALG_WINDOWED_BIG}[args.workload]
 
         def compute(o):                                     # affine (x, y); o[2] is unused
             eng.scalar_mult_base(curve, k, flags=OUT_AFFINE | alg, out=[o[0], o[1], o[2]])
@@ -142,7 +143,8 @@ def main():
                                (f"scalar_mult_{args.curve} variable-base, per-element window tables {{1..8}}P + signed 4-bit windows + simultaneous "
                                 f"inversion{' + GLV split k = k1 + k2*lambda' if args.curve == 'secp256k1' else ''}, batch=2^{args.log2_batch} per GPU, affine out") if args.workload == "windowed" else
                                (f"scalar_mult_{args.curve} fixed-base (G), batch=2^{args.log2_batch} random scalars per GPU, "
-                                + ("4-bit window table in LDS" if args.workload == "fixed-base" else "signed 7-bit window table in LDS")
+                                + {"fixed-base": "4-bit window table in LDS", "fixed-base-signed": "signed 7-bit window table in LDS",
+                                   "fixed-base-big": "signed 16-bit window table (35.7 MB) in device memory"}.get(args.workload, "")
                                 + " + simultaneous inversion, affine out"),
                    "element": "256-bit integers: 8 x u32 words (= 4 x u64 limbs) in VGPRs, v_mad_u64_u32 carry chains",
                    "global_batch": n * world, "per_gpu_batch": n, "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
@@ -168,15 +170,15 @@ def main():
         else:
             # what THIS algorithm needs per scalar: 64 mixed additions x 11 field mults,
             # 7 mults of the simultaneous-inversion walk and 267/32 (secp256k1: 270/32) of the shared inversion; 32 B in, 64 B out.
-            adds = 64 if args.workload == "fixed-base" else 37
+            adds = {"fixed-base": 64, "fixed-base-signed": 37, "fixed-base-big": 17}[args.workload]
             mad32_unit, bytes_unit = int((adds * 11 + 7 + (267 if args.curve == "p256" else 270) / 32) * 136), 96
-            kname = ("k_base_windowed" if adds == 64 else "k_base_windowed_s<7>") + " + k_to_affine_batched"
+            kname = {64: "k_base_windowed", 37: "k_base_windowed_s<7>", 17: "k_base_windowed_g"}[adds] + " + k_to_affine_batched"
         achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")             # written from rocprofv3 --pmc passes
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{ {'ladder': 'k_scalar_mult', 'windowed': 'varwin'}.get(args.workload, 'fixed_base') }_{args.curve}_2^{args.log2_batch}")
+                traffic = json.load(open(tpath)).get(f"{ {'ladder': 'k_scalar_mult', 'windowed': 'varwin', 'fixed-base-big': 'fixed_base_big'}.get(args.workload, 'fixed_base') }_{args.curve}_2^{args.log2_batch}")
             except Exception:
                 traffic = None
         result["roofline"] = {

@@ -48,6 +48,8 @@ void pack_table_signed(hipStream_t s, int curve, int wbits, const uint64_t* tx, 
 void base_windowed_signed(hipStream_t s, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed_signed, s, wbits, k, table, ox, oy, oz, n); }
 void affine_add_batched(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) { DISPATCH(affine_add_batched, s, ax, ay, bx, by, rx, ry, finite, n); }
 void base_windowed(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed, s, k, table, ox, oy, oz, n); }
+void pack_table_big(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table_big, s, tx, ty, table); }
+void base_windowed_big(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed_big, s, k, table, ox, oy, oz, n); }
 void add_mixed_complete(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH(add_mixed_complete, s, ax, ay, az, bx, by, rx, ry, rz, n); }
 void varwin_scalar_mult(hipStream_t s, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, int flags, uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n) { DISPATCH(varwin_scalar_mult, s, k, k_stride, x, y, flags, scratch, ox, oy, n); }
 #undef DISPATCH
@@ -63,6 +65,7 @@ struct ecsimd_hip_ctx {
   uint32_t* sink;      // 4 KiB scratch: peak-probe sink [0, 1024) and the shared scalar at word 1024-8
   uint32_t* window_table[2];   // per curve: 64 x 16 affine multiples d*16^w*G (built on first use)
   uint32_t* window6_table[2];  // per curve: signed-window table (SIGNED_WBITS bits): m * 2^(WB i) * G, m = 1..2^(WB-1)
+  uint32_t* window16_table[2]; // per curve: signed 16-bit windows, 17 x 32 768 entries (35.7 MB, device memory)
   uint64_t* workspace;         // grow-only scratch for the windowed path's Jacobian intermediates
   size_t workspace_bytes;
   char err[256];
@@ -117,7 +120,7 @@ int ensure_workspace(ecsimd_hip_ctx* ctx, size_t bytes) {
 //   entries m * 2^(bits i) * G, m = slot + 1.
 constexpr int SIGNED_WBITS = 7;     // 37 additions, 151 552 B of LDS (6 -> 43 additions, 88 064 B): measured faster
 int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
-  uint32_t** slot = (bits == 4) ? &ctx->window_table[curve] : &ctx->window6_table[curve];
+  uint32_t** slot = (bits == 4) ? &ctx->window_table[curve] : (bits == launch::BIG_WINDOW_BITS) ? &ctx->window16_table[curve] : &ctx->window6_table[curve];
   if (*slot) return ECSIMD_HIP_OK;
   const int windows = (bits == 4) ? 64 : (256 + bits) / bits, per = (bits == 4) ? 16 : 1 << (bits - 1);
   const size_t entries = (size_t)windows * per;
@@ -128,6 +131,7 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
       const int pos = bits * w;                                                         // entry = m * 2^pos * G
       uint64_t* e = &host_k[((size_t)w * per + d) * 4];
       const int limb = pos / 64, off = pos % 64;
+      if (limb >= 4) continue;                                                          // 16-bit windows: the carry window, m * 2^256 (filled below)
       const unsigned __int128 v = (unsigned __int128)mult << off;
       e[limb] = (uint64_t)v;
       if (limb + 1 < 4) e[limb + 1] = (uint64_t)(v >> 64);
@@ -152,7 +156,14 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
     launch::scalar_mult(ctx->stream, curve, kd, 4, nullptr, nullptr, jx, jy, jz, entries, ECSIMD_HIP_OUT_AFFINE);
     launch::to_affine_batched(ctx->stream, curve, jx, jy, jz, tx, ty, entries, true);
   }
-  if (bits != 4) {   // top window, entry m = 16: 16 * 2^252 * G = T(top, 15) + T(top, 1)
+  if (bits == launch::BIG_WINDOW_BITS) {   // carry window, entry m = 1: 2^256 * G = 2 * (2^15 * 2^240 * G), the last entry of window 15 doubled
+    uint64_t* sx = ty + entries * 4; uint64_t* sy = sx + 4;
+    const size_t src = ((size_t)15 * per + (per - 1)) * 4, dst = ((size_t)16 * per) * 4;
+    launch::affine_add_batched(ctx->stream, curve, tx + src, ty + src, tx + src, ty + src, sx, sy, nullptr, 1);
+    (void)hipMemcpyAsync(tx + dst, sx, 32, hipMemcpyDeviceToDevice, ctx->stream);
+    (void)hipMemcpyAsync(ty + dst, sy, 32, hipMemcpyDeviceToDevice, ctx->stream);
+    launch::pack_table_big(ctx->stream, curve, tx, ty, table);
+  } else if (bits != 4) {   // top window, entry m = 16: 16 * 2^252 * G = T(top, 15) + T(top, 1)
     uint64_t* sx = ty + entries * 4; uint64_t* sy = sx + 4;                                  // scratch (the Jacobian area is free again)
     const size_t top = (size_t)(windows - 1);
     const size_t e15 = (top * per + 14) * 4, e1 = (top * per + 0) * 4, e16 = (top * per + 15) * 4;
@@ -228,7 +239,7 @@ int ecsimd_hip_init(int device, ecsimd_hip_ctx** out) {
   ecsimd_hip_ctx* ctx = new (std::nothrow) ecsimd_hip_ctx();
   if (!ctx) return ECSIMD_HIP_ERR_HIP;
   ctx->device = device; ctx->cus = prop.multiProcessorCount; ctx->err[0] = 0; ctx->sink = nullptr;
-  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->window6_table[0] = ctx->window6_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0;
+  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->window6_table[0] = ctx->window6_table[1] = nullptr; ctx->window16_table[0] = ctx->window16_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ECSIMD_HIP_ERR_HIP; }
   ctx->stream = ctx->own_stream;
   if (hipEventCreateWithFlags(&ctx->handoff, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ECSIMD_HIP_ERR_HIP; }
@@ -241,7 +252,7 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->sink);
-  (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->workspace);
+  (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->window16_table[0]); (void)hipFree(ctx->window16_table[1]); (void)hipFree(ctx->workspace);
   (void)hipEventDestroy(ctx->handoff);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -470,19 +481,21 @@ int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[
 int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(ox); REQUIRE_PTR(oy);
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
-  if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED)) {
-    const bool six = (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED) != 0;      // signed windows
-    // 4-bit windows over an LDS-resident table, then one simultaneous inversion: affine output only
+  if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG)) {
+    const bool big = (flags & ECSIMD_HIP_ALG_WINDOWED_BIG) != 0;         // signed 16-bit windows, table in device memory
+    const bool six = (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED) != 0;      // signed 7-bit windows, table in LDS
+    // windows over a precomputed table, then one simultaneous inversion: affine output only
     // (the Jacobian representative differs from the reference ladder's -- SURVEY.md 8(a) level A).
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
     if (n == 0) return ECSIMD_HIP_OK;
     (void)hipSetDevice(ctx->device);
-    int rc = ensure_window_table(ctx, curve, six ? SIGNED_WBITS : 4);
+    int rc = ensure_window_table(ctx, curve, big ? launch::BIG_WINDOW_BITS : six ? SIGNED_WBITS : 4);
     if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 3 * n * 32);
     if (rc != ECSIMD_HIP_OK) return rc;
     uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
-    RUN(((six ? launch::base_windowed_signed(s, curve, SIGNED_WBITS, k, ctx->window6_table[curve], jx, jy, jz, n)
-              : launch::base_windowed(s, curve, k, ctx->window_table[curve], jx, jy, jz, n)),
+    RUN(((big ? launch::base_windowed_big(s, curve, k, ctx->window16_table[curve], jx, jy, jz, n)
+          : six ? launch::base_windowed_signed(s, curve, SIGNED_WBITS, k, ctx->window6_table[curve], jx, jy, jz, n)
+                : launch::base_windowed(s, curve, k, ctx->window_table[curve], jx, jy, jz, n)),
          launch::to_affine_batched(s, curve, jx, jy, jz, ox, oy, n, true)));
   }
   return run_ladder(ctx, curve, k, 4, nullptr, nullptr, ox, oy, oz, n, flags); }
@@ -502,7 +515,7 @@ int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t
   if (n == 0) return ECSIMD_HIP_OK;
   (void)hipSetDevice(ctx->device);
   const size_t chunk = n < VARWIN_CHUNK ? n : VARWIN_CHUNK;
-  int rc = ensure_window_table(ctx, curve, SIGNED_WBITS);
+  int rc = ensure_window_table(ctx, curve, launch::BIG_WINDOW_BITS);
   if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 7 * chunk * 32 + launch::varwin_scratch_bytes(chunk));   // 3 Jacobian + 2 x 2 affine + tables
   if (rc != ECSIMD_HIP_OK) return rc;
   uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * chunk; uint64_t* jz = jy + 4 * chunk;
@@ -511,7 +524,7 @@ int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t
   hipStream_t s = ctx->stream;
   for (size_t first = 0; first < n; first += chunk) {
     const size_t m = (n - first) < chunk ? (n - first) : chunk;
-    launch::base_windowed_signed(s, curve, SIGNED_WBITS, u1 + 4 * first, ctx->window6_table[curve], jx, jy, jz, m);   // u1*G
+    launch::base_windowed_big(s, curve, u1 + 4 * first, ctx->window16_table[curve], jx, jy, jz, m);   // u1*G
     launch::to_affine_batched(s, curve, jx, jy, jz, gx, gy, m, true);
     launch::varwin_scalar_mult(s, curve, u2 + 4 * first, 4, qx + 4 * first, qy + 4 * first, ECSIMD_HIP_BASE_CLASSICAL, scratch, px, py, m);   // u2*Q
     launch::affine_add_batched(s, curve, gx, gy, px, py, rx + 4 * first, ry ? ry + 4 * first : nullptr, finite ? finite + first : nullptr, m);

@@ -78,6 +78,11 @@ void add_mixed_complete(hipStream_t, int curve, const uint64_t* ax, const uint64
                         uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
 inline size_t varwin_scratch_bytes(size_t n) { return n * (7 * 4 * 32 + 8 * 64); }
 
+// signed 16-bit windows over a 35.7 MB table in device memory (17 windows x 32 768 entries)
+void pack_table_big(hipStream_t, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
+void base_windowed_big(hipStream_t, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
+constexpr int BIG_WINDOW_BITS = 16;
+
 // per-curve pieces (one translation unit each)
 template <int C> struct point_launch {
   static void from_affine(hipStream_t, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
@@ -96,6 +101,8 @@ template <int C> struct point_launch {
   static void base_windowed(hipStream_t, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
   static void pack_table_signed(hipStream_t, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
   static void base_windowed_signed(hipStream_t, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
+  static void pack_table_big(hipStream_t, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
+  static void base_windowed_big(hipStream_t, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
   // k_varwin_<curve>.hip
   static void add_mixed_complete(hipStream_t, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
   static void varwin_scalar_mult(hipStream_t, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, int flags, uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n);

@@ -76,11 +76,11 @@ struct curve_group {
     WJCP r = fresh(A.size());
     hip::check(ecsimd_hip_add_mixed_complete(hip::context(), curve_id, px(A), py(A), pz(A), px(B), py(B), px(r), py(r), pz(r), A.size()), "ecsimd_hip_add_mixed_complete"); return r;
   }
-  // k[i] * G through the LDS-resident window tables (signed 7-bit windows), affine classical.
+  // k[i] * G through the signed 16-bit window table in device memory (17 mixed additions), affine classical.
   static WCP scalar_mult_base_affine(WBN const& x) {
     WCP r{WBN::uninitialized(x.size()), WBN::uninitialized(x.size())};
     hip::check(ecsimd_hip_scalar_mult_base(hip::context(), curve_id, x.data(), r.x().data(), r.y().data(), nullptr, x.size(),
-                                           ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_ALG_WINDOWED_SIGNED), "ecsimd_hip_scalar_mult_base");
+                                           ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_ALG_WINDOWED_BIG), "ecsimd_hip_scalar_mult_base");
     return r;
   }
   // u1[i] * G + u2[i] * Q[i] (the ECDSA-verification shape), affine classical; finite[i] is false where the sum

@@ -51,7 +51,7 @@ def test_openssl_flags_infinity_and_rejects_points_off_the_curve(openssl):
 def test_gpu_scalar_mult_agrees_with_openssl(engine, openssl, cv):
     """Variable base (the reference ladder + batched to_affine), fixed base (both window kernels) and
     u1*G + u2*Q on the HIP path against libcrypto, 4 096 lane-distinct inputs each."""
-    from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED
+    from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG
     n = 4096
     k = fill_random_np(n, SEED, 43); s = fill_random_np(n, SEED, 44); u1 = fill_random_np(n, SEED, 45)
     order = CURVE_PARAMS[cv]["n"]
@@ -59,7 +59,7 @@ def test_gpu_scalar_mult_agrees_with_openssl(engine, openssl, cv):
     dk, ds, du1 = engine.to_device(k), engine.to_device(s), engine.to_device(u1)
     bx, by, inf = openssl.scalar_mult_base(cv, s, threads=THREADS)
     assert not inf.any()
-    for flags in (OUT_AFFINE, OUT_AFFINE | ALG_WINDOWED, OUT_AFFINE | ALG_WINDOWED_SIGNED):
+    for flags in (OUT_AFFINE, OUT_AFFINE | ALG_WINDOWED, OUT_AFFINE | ALG_WINDOWED_SIGNED, OUT_AFFINE | ALG_WINDOWED_BIG):
         gx_, gy_ = engine.scalar_mult_base(cv, ds, flags=flags)
         assert np.array_equal(engine.to_numpy(gx_), bx) and np.array_equal(engine.to_numpy(gy_), by), flags
     dbx, dby = engine.to_device(bx), engine.to_device(by)

@@ -17,6 +17,7 @@ def newest(pattern):
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 traffic = {}
 for tag, kern_filter, label in (("ladder", ["k_scalar_mult"], "k_scalar_mult_p256_2^22"), ("fixed", ["k_base_windowed", "k_to_affine_batched"], "fixed_base_p256_2^22"),
+                               ("fixedbig", ["k_base_windowed_g", "k_to_affine_batched"], "fixed_base_big_p256_2^22"),
                                ("varwin", ["k_varwin_mult", "k_varwin_multiples", "k_varwin_to_table", "k_to_affine_batched"], "varwin_p256_2^22")):
     src = f"gpurun_out/prof_{rnd}_{tag}"
     if not os.path.isdir(src):
@@ -25,7 +26,7 @@ for tag, kern_filter, label in (("ladder", ["k_scalar_mult"], "k_scalar_mult_p25
     for f in newest(f"{src}/stats/runc/*_kernel_stats.csv"):
         shutil.copy(f, f"profiles/{rnd}/{tag}/kernel_stats.csv")
     out = {"_about": f"rocprofv3 --pmc passes (tools/profile.sh {rnd}_{tag}) for bench.py --steps 2 --warmup 0 --no-cpu-baseline"
-                     + {"fixed": " --workload fixed-base", "varwin": " --workload windowed"}.get(tag, "") + " on MI355X; per launch, last 2^22-lane dispatch of each kernel", "kernels": {}}
+                     + {"fixed": " --workload fixed-base", "fixedbig": " --workload fixed-base-big", "varwin": " --workload windowed"}.get(tag, "") + " on MI355X; per launch, last 2^22-lane dispatch of each kernel", "kernels": {}}
     for d in newest(f"{src}/pmc_*/runc/*_counter_collection.csv"):
         for r in csv.DictReader(open(d)):
             for kf in kern_filter:
@@ -45,5 +46,5 @@ for tag, kern_filter, label in (("ladder", ["k_scalar_mult"], "k_scalar_mult_p25
     traffic[label] = tot
     json.dump(out, open(f"profiles/{rnd}/{tag}/pmc_summary.json", "w"), indent=1)
     print(tag, {k: (round(v["valu_wave_instructions_per_wave"]), v["vgpr_count"]) for k, v in out["kernels"].items()}, "hbm bytes/step", tot)
-traffic["_source"] = f"profiles/{rnd}/{{ladder,fixed,varwin}}/pmc_summary.json (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, per bench step)"
+traffic["_source"] = f"profiles/{rnd}/{{ladder,fixed,fixedbig,varwin}}/pmc_summary.json (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, per bench step)"
 json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
