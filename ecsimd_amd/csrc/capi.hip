@@ -65,7 +65,7 @@ struct ecsimd_hip_ctx {
   uint32_t* sink;      // 4 KiB scratch: peak-probe sink [0, 1024) and the shared scalar at word 1024-8
   uint32_t* window_table[2];   // per curve: 64 x 16 affine multiples d*16^w*G (built on first use)
   uint32_t* window6_table[2];  // per curve: signed-window table (SIGNED_WBITS bits): m * 2^(WB i) * G, m = 1..2^(WB-1)
-  uint32_t* window16_table[2]; // per curve: signed 16-bit windows, 17 x 32 768 entries (35.7 MB, device memory)
+  uint32_t* window16_table[2]; // per curve: signed BIG_WINDOW_BITS-bit windows in device memory (20 bits: 13 x 524 288 entries, 436 MB)
   uint64_t* workspace;         // grow-only scratch for the windowed path's Jacobian intermediates
   size_t workspace_bytes;
   char err[256];
@@ -136,10 +136,10 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
       e[limb] = (uint64_t)v;
       if (limb + 1 < 4) e[limb + 1] = (uint64_t)(v >> 64);
       else if ((uint64_t)(v >> 64) != 0) {
-        // m * 2^pos >= 2^256: only the top signed window, where 15 + carry = 16 asks for 2^256 * G.  That
+        // m * 2^pos >= 2^256: only the top signed window, where the top digit + carry asks for 2^256 * G.  That
         // point cannot come from the ladder: k = 2^256 mod n is one of its degenerate scalars (the Joye
         // ladder keeps R0 + R1 = 2^i * P, so at i = 256 it meets n * P = infinity; the reference's ladder
-        // fails there too).  The slot is filled below as T(15) + T(1) with the affine-addition kernel.
+        // fails there too).  The slot is filled below by doubling 2^255 * G with the affine-addition kernel.
         for (int l = 0; l < 4; ++l) e[l] = 0;
       }
     }
@@ -156,21 +156,17 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
     launch::scalar_mult(ctx->stream, curve, kd, 4, nullptr, nullptr, jx, jy, jz, entries, ECSIMD_HIP_OUT_AFFINE);
     launch::to_affine_batched(ctx->stream, curve, jx, jy, jz, tx, ty, entries, true);
   }
-  if (bits == launch::BIG_WINDOW_BITS) {   // carry window, entry m = 1: 2^256 * G = 2 * (2^15 * 2^240 * G), the last entry of window 15 doubled
-    uint64_t* sx = ty + entries * 4; uint64_t* sy = sx + 4;
-    const size_t src = ((size_t)15 * per + (per - 1)) * 4, dst = ((size_t)16 * per) * 4;
+  if (bits != 4) {
+    // The one reachable entry with m * 2^pos = 2^256 (top digit + carry): the ladder cannot produce 2^256 * G (a degenerate
+    // scalar, see above), so it is the entry holding 2^255 * G doubled by the affine-addition kernel.
+    uint64_t* sx = ty + entries * 4; uint64_t* sy = sx + 4;                                  // scratch (the Jacobian area is free again)
+    const size_t src = ((size_t)(255 / bits) * per + ((size_t)1 << (255 % bits)) - 1) * 4;
+    const size_t dst = ((size_t)(256 / bits) * per + ((size_t)1 << (256 % bits)) - 1) * 4;
     launch::affine_add_batched(ctx->stream, curve, tx + src, ty + src, tx + src, ty + src, sx, sy, nullptr, 1);
     (void)hipMemcpyAsync(tx + dst, sx, 32, hipMemcpyDeviceToDevice, ctx->stream);
     (void)hipMemcpyAsync(ty + dst, sy, 32, hipMemcpyDeviceToDevice, ctx->stream);
-    launch::pack_table_big(ctx->stream, curve, tx, ty, table);
-  } else if (bits != 4) {   // top window, entry m = 16: 16 * 2^252 * G = T(top, 15) + T(top, 1)
-    uint64_t* sx = ty + entries * 4; uint64_t* sy = sx + 4;                                  // scratch (the Jacobian area is free again)
-    const size_t top = (size_t)(windows - 1);
-    const size_t e15 = (top * per + 14) * 4, e1 = (top * per + 0) * 4, e16 = (top * per + 15) * 4;
-    launch::affine_add_batched(ctx->stream, curve, tx + e15, ty + e15, tx + e1, ty + e1, sx, sy, nullptr, 1);
-    (void)hipMemcpyAsync(tx + e16, sx, 32, hipMemcpyDeviceToDevice, ctx->stream);
-    (void)hipMemcpyAsync(ty + e16, sy, 32, hipMemcpyDeviceToDevice, ctx->stream);
-    launch::pack_table_signed(ctx->stream, curve, bits, tx, ty, table);
+    if (bits == launch::BIG_WINDOW_BITS) launch::pack_table_big(ctx->stream, curve, tx, ty, table);
+    else launch::pack_table_signed(ctx->stream, curve, bits, tx, ty, table);
   } else {
     launch::pack_table(ctx->stream, curve, tx, ty, table);
   }
@@ -482,7 +478,7 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* 
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(ox); REQUIRE_PTR(oy);
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG)) {
-    const bool big = (flags & ECSIMD_HIP_ALG_WINDOWED_BIG) != 0;         // signed 16-bit windows, table in device memory
+    const bool big = (flags & ECSIMD_HIP_ALG_WINDOWED_BIG) != 0;         // signed 20-bit windows, table in device memory
     const bool six = (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED) != 0;      // signed 7-bit windows, table in LDS
     // windows over a precomputed table, then one simultaneous inversion: affine output only
     // (the Jacobian representative differs from the reference ladder's -- SURVEY.md 8(a) level A).

@@ -78,10 +78,14 @@ void add_mixed_complete(hipStream_t, int curve, const uint64_t* ax, const uint64
                         uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
 inline size_t varwin_scratch_bytes(size_t n) { return n * (7 * 4 * 32 + 8 * 64); }
 
-// signed 16-bit windows over a 35.7 MB table in device memory (17 windows x 32 768 entries)
+// signed BIG_WINDOW_BITS-bit windows over a table in device memory (20 bits: 13 windows x 524 288 entries x 64 B = 436 MB)
 void pack_table_big(hipStream_t, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
 void base_windowed_big(hipStream_t, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
-constexpr int BIG_WINDOW_BITS = 16;
+#ifndef ECS_BIG_WINDOW_BITS
+#define ECS_BIG_WINDOW_BITS 20   // measured on one MI355X, P-256 / secp256k1 M/s: 16 bits 904 / 883 (36 MB), 18 bits 995 / 965 (126 MB),
+                                 // 20 bits 1 075 / 1 090 (436 MB, built in 0.23 s), 22 bits 1 124 / 1 146 (1.6 GB, 0.8 s)
+#endif
+constexpr int BIG_WINDOW_BITS = ECS_BIG_WINDOW_BITS;
 
 // per-curve pieces (one translation unit each)
 template <int C> struct point_launch {

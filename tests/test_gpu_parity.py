@@ -319,7 +319,8 @@ def test_windowed_fixed_base_matches_the_ladder_at_affine_level(engine, oracle, 
     from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED
     c = CURVE_PARAMS[cv]; order = c["n"]
     edge = [1, 2, 3, 15, 16, 17, 255, 256, 2**64 - 1, 2**64, 2**128 + 1, 2**252, 15 * 2**252, order - 2, order + 1, order + 2, 2**256 - 1,
-            0x7fff, 0x8000, 0x8001, 0xffff, 0x10000, 0x18000, int("8000" * 16, 16), int("7fff" * 16, 16), int("8001" * 16, 16),   # 16-bit window boundaries
+            0x7fff, 0x8000, 0x8001, 0xffff, 0x10000, 0x18000, int("8000" * 16, 16), int("7fff" * 16, 16), int("8001" * 16, 16),   # 16-bit window boundaries (an earlier table width)
+            0x7ffff, 0x80000, 0x80001, 0xfffff, 0x100000, 0x180000, int("80000" * 12, 16), int("7ffff" * 12, 16), int("80001" * 12, 16),   # 20-bit window boundaries
             int("f0" * 32, 16), int("0f" * 32, 16), int("10" * 32, 16), 2**255, 0x1000000000000000000000000000000000000000000000000000000000000000]
     n = (1 << 18) + 77                                      # ragged, and large enough for several elements per lane in the inversion
     k = fill_random_np(n, SEED, 5); k[:len(edge)] = ints_to_arr(edge)
@@ -331,7 +332,7 @@ def test_windowed_fixed_base_matches_the_ladder_at_affine_level(engine, oracle, 
     w6x, w6y = engine.scalar_mult_base(cv, dk, flags=OUT_AFFINE | ALG_WINDOWED_SIGNED)       # signed 7-bit windows: same points
     assert torch.equal(w6x, wx) and torch.equal(w6y, wy)
     from ecsimd_amd import ALG_WINDOWED_BIG
-    wbx, wby = engine.scalar_mult_base(cv, dk, flags=OUT_AFFINE | ALG_WINDOWED_BIG)          # signed 16-bit windows, table in device memory
+    wbx, wby = engine.scalar_mult_base(cv, dk, flags=OUT_AFFINE | ALG_WINDOWED_BIG)          # signed 20-bit windows, table in device memory
     assert torch.equal(wbx, wx) and torch.equal(wby, wy)
     lx, ly = engine.scalar_mult_base(cv, dk, flags=OUT_AFFINE)                        # reference ladder + (batched) to_affine
     wxn, wyn, lxn, lyn = (engine.to_numpy(t) for t in (wx, wy, lx, ly))
