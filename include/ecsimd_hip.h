@@ -64,13 +64,13 @@ enum {
                                       the ladder for every k except the ladder's degenerate scalars k = n-1, 2^256-n-1,
                                       2^256-n (there the reference returns a meaningless point, these paths the right
                                       one); k = 0 mod n -> (0, 0) */
-  ECSIMD_HIP_ALG_WINDOWED_BIG = 32, /* scalar_mult_base + OUT_AFFINE: signed 20-bit windows over a 436 MB table of m*2^(20i)*G
-                                      (m = 1..2^19, 13 windows) in device memory, built on first use (0.23 s per curve):
-                                      13 mixed additions per scalar; same results */
+  ECSIMD_HIP_ALG_WINDOWED_SIGNED = 8, /* as ALG_WINDOWED with signed 7-bit windows: 37 mixed additions instead of 64, a 148 KiB
+                                      table of m*2^(7i)*G (m = 1..64) in LDS, negative digits negate y; same results */
   ECSIMD_HIP_ALG_NO_ENDOMORPHISM = 16, /* secp256k1 + ALG_WINDOWED on a variable base splits k = k1 + k2*lambda (GLV) and runs
                                       half as many windows; this flag keeps the plain 63-window loop (same results) */
-  ECSIMD_HIP_ALG_WINDOWED_SIGNED = 8 /* as ALG_WINDOWED with signed 7-bit windows: 37 mixed additions instead of 64, a 148 KiB
-                                      table of m*2^(7i)*G (m = 1..64) in LDS, negative digits negate y; same results */
+  ECSIMD_HIP_ALG_WINDOWED_BIG = 32 /* scalar_mult_base + OUT_AFFINE: signed 20-bit windows over a 436 MB table of m*2^(20i)*G
+                                      (m = 1..2^19, 13 windows) in device memory, built on first use (0.23 s per curve):
+                                      13 mixed additions per scalar; same results */
 };
 
 /* ---- context, stream and memory ------------------------------------------------------- */
