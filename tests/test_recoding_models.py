@@ -1,0 +1,93 @@
+"""CPU suite: integer models of the scalar recodings the windowed kernels use (ecsimd_amd/csrc/k_affine.inc,
+k_varwin.inc).  Each model restates the kernel's digit logic in Python and checks the identity it relies on --
+sum of digits x weights == the scalar (mod n where the kernel reduces), digit ranges, table sizes -- on edge
+patterns and random scalars.  The kernels themselves are checked on the GPU against the ladder, the oracle and
+OpenSSL; these tests pin the arithmetic the kernels were written from."""
+import random
+
+import pytest
+
+from helpers import CURVE_PARAMS, P256, SECP256K1
+
+M256 = (1 << 256) - 1
+EDGE = [0, 1, 2, 7, 8, 9, 15, 16, 0x7f, 0x80, 0x7fff, 0x8000, 0x7ffff, 0x80000, 0x80001, (1 << 128) - 1, 1 << 128, 1 << 255, M256,
+        int("8" * 64, 16), int("7" * 64, 16), int("f" * 64, 16), int("80000" * 12, 16), int("7ffff" * 12, 16)]
+
+
+def scalars(seed, count=2000):
+    rng = random.Random(seed)
+    return EDGE + [rng.getrandbits(256) for _ in range(count)]
+
+
+@pytest.mark.parametrize("bits", [6, 7, 16, 18, 20, 22])
+def test_signed_window_recoding_of_the_fixed_base_kernels(bits):
+    """k_base_windowed_s / k_base_windowed_g: u = chunk + carry; u > 2^(b-1) -> digit u - 2^b and carry 1.
+    (256 + b) // b windows absorb the final carry; |digit| <= 2^(b-1) = the table's entries per window."""
+    windows, half, full = (256 + bits) // bits, 1 << (bits - 1), 1 << bits
+    for k in scalars(bits):
+        carry, total = 0, 0
+        for w in range(windows):
+            u = ((k >> (bits * w)) & (full - 1)) + carry
+            carry = 1 if u > half else 0
+            d = u - full if carry else u
+            assert -half <= d <= half
+            if bits * w >= 256 - bits and bits * w + bits > 256 and d:                 # the top window never needs more than 2^256 / 2^pos
+                assert abs(d) << (bits * w) <= 1 << 256
+            total += d << (bits * w)
+        assert carry == 0 and total == k
+
+
+@pytest.mark.parametrize("cv", [P256, SECP256K1])
+def test_offset_recoding_of_the_variable_base_kernel(cv):
+    """k_varwin_mult: k <- k mod n, k <- min(k, n - k) (sign flips the result), k + 0x0888...8; digit j < 63 is
+    nibble - 8 in [-8, 7], the top nibble is an unsigned digit in [0, 8]; no carry out of 256 bits."""
+    n = CURVE_PARAMS[cv]["n"]
+    off = int("0" + "8" * 63, 16)
+    for k in scalars(cv + 100) + [n - 1, n, n + 1, (n - 1) // 2, (n + 1) // 2, 2 * n - (1 << 256) if 2 * n > (1 << 256) else 5]:
+        k &= M256
+        r = k - n if k >= n else k                                                  # one conditional subtraction: k < 2^256 < 2n
+        assert 0 <= r < n
+        flip = (n - r) < r
+        a = n - r if flip else r
+        assert a <= (n - 1) // 2 or r == 0
+        u = a + off
+        assert u < 1 << 256
+        digits = [((u >> (4 * j)) & 15) - 8 for j in range(63)] + [u >> 252]
+        assert all(-8 <= d <= 7 for d in digits[:63]) and 0 <= digits[63] <= 8
+        val = sum(d << (4 * j) for j, d in enumerate(digits))
+        assert val == a and ((-val if flip else val) - k) % n == 0
+        prefix = 0                                                                  # no mixed addition meets R = +-T (k_varwin.inc header)
+        for j in range(63, -1, -1):
+            if prefix and digits[j]:
+                assert (16 * prefix - digits[j]) % n and (16 * prefix + digits[j]) % n
+            prefix = 16 * prefix + digits[j]
+
+
+def test_glv_split_of_secp256k1():
+    """k_varwin_mult_glv: c_i = round(k g_i / 2^384); k1 = k - c1 a1 - c2 a2, k2 = c1 (-b1) - c2 b2 in 256-bit two's
+    complement; |k1|, |k2| < 2^128; 33 nibbles after adding 0x888...8 (32 nibbles) with a top digit of 0 or 1."""
+    n = CURVE_PARAMS[SECP256K1]["n"]; p = CURVE_PARAMS[SECP256K1]["p"]
+    lam = 0x5363ad4cc05c30e0a5261c028812645a122e22ea20816678df02967c1b23bd72
+    beta = 0x7ae96a2b657c07106e64479eac3434e99cf0497512f58995c1396c28719501ee
+    g1 = 0x3086d221a7d46bcde86c90e49284eb153daa8a1471e8ca7fe893209a45dbb031
+    g2 = 0xe4437ed6010e88286f547fa90abfe4c4221208ac9df506c61571b4ae8ac47f71
+    a1, mb1, a2 = 0x3086d221a7d46bcde86c90e49284eb15, 0xe4437ed6010e88286f547fa90abfe4c3, 0x114ca50f7a8e2f3f657c1108d9d44cfd8
+    assert pow(lam, 3, n) == 1 and lam != 1 and pow(beta, 3, p) == 1 and beta != 1
+    assert (a1 - mb1 * lam) % n == 0 and (a2 + a1 * lam) % n == 0                  # the lattice basis (a1, b1), (a2, b2 = a1)
+    off = int("8" * 32, 16)
+
+    def signed256(v):
+        v &= M256
+        return v - (1 << 256) if v >> 255 else v
+    for k in scalars(7, 5000) + [lam, lam + 1, n - lam, a1, mb1, a2, (a1 * lam) % n, n - 1]:
+        k = (k & M256) % n
+        c1 = ((k * g1) >> 384) + (((k * g1) >> 383) & 1)
+        c2 = ((k * g2) >> 384) + (((k * g2) >> 383) & 1)
+        assert c1 < 1 << 128 and c2 < 1 << 128
+        k1 = signed256(k - ((c1 * a1) & M256) - ((c2 * a2) & M256))
+        k2 = signed256(((c1 * mb1) & M256) - ((c2 * a1) & M256))
+        assert (k1 + k2 * lam - k) % n == 0 and abs(k1) < 1 << 128 and abs(k2) < 1 << 128
+        for v in (abs(k1), abs(k2)):
+            u = v + off
+            digits = [((u >> (4 * j)) & 15) - 8 for j in range(32)] + [u >> 128]
+            assert digits[32] in (0, 1) and sum(d << (4 * j) for j, d in enumerate(digits)) == v
