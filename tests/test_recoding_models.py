@@ -87,7 +87,20 @@ def test_glv_split_of_secp256k1():
         k1 = signed256(k - ((c1 * a1) & M256) - ((c2 * a2) & M256))
         k2 = signed256(((c1 * mb1) & M256) - ((c2 * a1) & M256))
         assert (k1 + k2 * lam - k) % n == 0 and abs(k1) < 1 << 128 and abs(k2) < 1 << 128
+        both = []
         for v in (abs(k1), abs(k2)):
             u = v + off
             digits = [((u >> (4 * j)) & 15) - 8 for j in range(32)] + [u >> 128]
             assert digits[32] in (0, 1) and sum(d << (4 * j) for j, d in enumerate(digits)) == v
+            both.append(digits)
+        # the window loop never adds a point to itself or to its opposite (add_checked's branches stay cold)
+        s1, s2 = (-1 if k1 < 0 else 1), (-1 if k2 < 0 else 1)
+        acc = 0                                                                     # discrete log of R
+        for j in range(32, -1, -1):
+            acc = (16 * acc) % n if j != 32 else 0
+            for t in (s1 * both[0][j], s2 * both[1][j] * lam):
+                t %= n
+                if t and acc:
+                    assert (acc - t) % n and (acc + t) % n
+                acc = (acc + t) % n
+        assert acc == k % n
