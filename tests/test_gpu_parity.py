@@ -469,6 +469,20 @@ def test_affine_add_and_double_scalar_mult(engine, oracle, cv):
             assert tfn[i] == 1 and (to_int(txn[i]), to_int(tyn[i])) == e_, i
 
 
+def test_double_scalar_mult_across_the_chunk_boundary(engine):
+    """More elements than one internal chunk (2^22): the composite equals its three parts computed separately."""
+    import torch
+    from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_BIG
+    n = (1 << 22) + 777
+    u1 = engine.fill_random(n, SEED, 95); u2 = engine.fill_random(n, SEED, 96)
+    qx, qy = engine.scalar_mult_base(P256, engine.fill_random(n, SEED, 97), flags=OUT_AFFINE | ALG_WINDOWED_BIG)
+    rx, ry, fin = engine.double_scalar_mult(P256, u1, u2, qx, qy)
+    g = engine.scalar_mult_base(P256, u1, flags=OUT_AFFINE | ALG_WINDOWED_BIG)
+    p_ = engine.scalar_mult(P256, u2, qx, qy, flags=OUT_AFFINE | ALG_WINDOWED)
+    sx, sy, sf = engine.affine_add(P256, g, p_)
+    assert torch.equal(rx, sx) and torch.equal(ry, sy) and torch.equal(fin, sf) and bool(fin.all())
+
+
 def test_switching_streams_keeps_the_context_scratch_ordered(engine):
     """Two workspace-using calls back to back on two torch streams: the second must not start on the shared
     scratch (per-element tables, Jacobian intermediates) before the first has finished with it."""
