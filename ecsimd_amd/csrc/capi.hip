@@ -46,6 +46,7 @@ void to_affine_batched(hipStream_t s, int curve, const uint64_t* jx, const uint6
 void pack_table(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table, s, tx, ty, table); }
 void pack_table_signed(hipStream_t s, int curve, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table_signed, s, wbits, tx, ty, table); }
 void base_windowed_signed(hipStream_t s, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed_signed, s, wbits, k, table, ox, oy, oz, n); }
+void inverse_batched(hipStream_t s, int curve, const uint64_t* a, uint64_t* out, size_t n) { DISPATCH(inverse_batched, s, a, out, n); }
 void affine_add_batched(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) { DISPATCH(affine_add_batched, s, ax, ay, bx, by, rx, ry, finite, n); }
 void base_windowed(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed, s, k, table, ox, oy, oz, n); }
 void pack_table_big(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table_big, s, tx, ty, table); }
@@ -416,7 +417,10 @@ int ecsimd_hip_mgry_pow(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const
   launch::words8 e; for (int i = 0; i < 4; ++i) { e.w[2 * i] = (uint32_t)exponent[i]; e.w[2 * i + 1] = (uint32_t)(exponent[i] >> 32); }
   RUN(launch::mgry_pow(s, curve, a, e, out, n)); }
 int ecsimd_hip_gfp_inverse(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, curve, launch::F_INVERSE, a, out, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out);
+  // one inversion per ~64 elements (Montgomery's trick, out[] as scratch) unless the call is in place
+  if (overlaps(out, a)) RUN(launch::field_unop(s, curve, launch::F_INVERSE, a, out, n));
+  RUN(launch::inverse_batched(s, curve, a, out, n)); }
 int ecsimd_hip_gfp_opposite(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, curve, launch::F_OPPOSITE, a, out, n)); }
 int ecsimd_hip_gfp_sqrt(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n) {

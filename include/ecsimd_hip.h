@@ -159,7 +159,9 @@ int ecsimd_hip_mgry_to_classical(ecsimd_hip_ctx*, int curve, const uint64_t* a, 
 /* mgry_ops.h:44-86 mgry_pow: out = a^e (Montgomery), e = ONE public exponent (host pointer, 4 x u64) */
 int ecsimd_hip_mgry_pow(ecsimd_hip_ctx*, int curve, const uint64_t* a, const uint64_t exponent[4], uint64_t* out, size_t n);
 /* gfp.h:42-44 inverse, :60-64 opposite, :46-54 sqrt.  sqrt reports validity PER ELEMENT in ok[]
- * (the reference collapses a wide to all-or-nothing; the C++ header reproduces that on top). */
+ * (the reference collapses a wide to all-or-nothing; the C++ header reproduces that on top).  inverse shares one
+ * inversion among ~64 elements (Montgomery's trick) when out and a are different buffers; out == a runs one
+ * addition chain per element; 0 maps to 0 either way. */
 int ecsimd_hip_gfp_inverse(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t* out, size_t n);
 int ecsimd_hip_gfp_opposite(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t* out, size_t n);
 int ecsimd_hip_gfp_sqrt(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n);

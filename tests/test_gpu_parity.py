@@ -216,6 +216,30 @@ def test_cmp_and_swap(engine, oracle):
     assert np.array_equal(engine.to_numpy(da), np.where(m[:, None], b, a)) and np.array_equal(engine.to_numpy(db), np.where(m[:, None], a, b))
 
 
+@pytest.mark.parametrize("cv", CURVES)
+def test_batched_inversion(engine, oracle, cv):
+    """gfp_inverse: Montgomery's simultaneous inversion when out != a, one addition chain per element in place; both equal
+    the oracle's a^(p-2), zeros map to zero and do not disturb their neighbours; ragged sizes around the per-lane batching."""
+    import torch
+    import ctypes as C
+    for n in (1, 63, 64, 65, (1 << 17) + 3, (1 << 20) + 77):
+        a = fill_random_np(n, SEED, 85, clear_top_bits=1)
+        for i in (0, n // 2, n - 1):
+            a[i] = 0
+        am = engine.mgry_from_classical(cv, engine.to_device(a))
+        inv = engine.gfp_inverse(cv, am)
+        inplace = am.clone()
+        assert engine.lib.ecsimd_hip_gfp_inverse(engine.ctx, C.c_int(cv), C.c_void_p(inplace.data_ptr()), C.c_void_p(inplace.data_ptr()), C.c_size_t(n)) == 0
+        assert torch.equal(inv, inplace)
+        idx = np.unique(np.concatenate([np.arange(min(n, 128)), np.arange(max(0, n - 128), n), np.array([n // 2])]))
+        exp = oracle.gfp_inverse(cv, engine.to_numpy(am)[idx])
+        assert np.array_equal(engine.to_numpy(inv)[idx], exp)
+        prod = engine.mgry_mul(cv, inv, am)                                       # a * a^-1 = 1 (Montgomery form) except where a = 0
+        one = engine.to_numpy(engine.mgry_from_classical(cv, engine.to_device(ints_to_arr([1]))))[0]
+        pn = engine.to_numpy(prod); zero = (a == 0).all(axis=1)
+        assert (pn[~zero] == one).all() and (pn[zero] == 0).all()
+
+
 def test_lane_masks_on_the_device(engine):
     """cmp_eq (4- and 8-limb elements), mask NOT / AND / OR / EQ and the count behind all() / any()."""
     import torch
