@@ -140,7 +140,7 @@ def main():
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": (f"scalar_mult_{args.curve} variable-base co-Z ladder (reference algorithm), "
                                 f"batch=2^{args.log2_batch} per GPU, Jacobian Montgomery out") if args.workload == "ladder" else
-                               (f"scalar_mult_{args.curve} variable-base, per-element window tables {{1..8}}P + signed 4-bit windows + simultaneous "
+                               (f"scalar_mult_{args.curve} variable-base, per-element window tables (8 multiples of P) + signed 4-bit windows + simultaneous "
                                 f"inversion{' + GLV split k = k1 + k2*lambda' if args.curve == 'secp256k1' else ''}, batch=2^{args.log2_batch} per GPU, affine out") if args.workload == "windowed" else
                                (f"scalar_mult_{args.curve} fixed-base (G), batch=2^{args.log2_batch} random scalars per GPU, "
                                 + {"fixed-base": "4-bit window table in LDS", "fixed-base-signed": "signed 7-bit window table in LDS",
@@ -158,14 +158,15 @@ def main():
         if args.workload == "ladder":
             mad32_unit, bytes_unit, kname = MAD32_PER_SCALAR_MULT, ALGO_BYTES_PER_SCALAR_MULT, "k_scalar_mult"
         elif args.workload == "windowed":
-            # what THIS algorithm needs per scalar: table = 4 doublings + 3 mixed additions, its
-            # inversion 7 x (7 + 267/224) (224 points share one inversion at 2^22), 63 windows x (4 doublings + 1 mixed addition), the final inversion walk;
-            # a doubling is 4M + 4S (P-256) / 3M + 4S (secp256k1), a mixed addition 8M + 3S; 96 B in, 64 B out.
+            # what THIS algorithm needs per scalar.  P-256: table {1,3,..,15}P = DBLU + 7 co-Z additions
+            # (6 + 7 x 7), its inversion 7 x (7 + 267/224) (224 points share one inversion at 2^22), 63 windows x (3 doublings
+            # + one fused double-add of 13M + 5S), the final inversion walk; a doubling is 4M + 4S (P-256) / 3M + 4S
+            # (secp256k1), a mixed addition 8M + 3S; 96 B in, 64 B out.
             dbl = 8 if args.curve == "p256" else 7
             inv = 267 if args.curve == "p256" else 270                  # addition-chain inversion (point.cuh fe_inverse)
-            fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / 224) + 63 * (4 * dbl + 11) + (7 + inv / 32)
+            fm = (6 + 7 * 7) + 7 * (7 + inv / 224) + 63 * (3 * dbl + 18) + (7 + inv / 32)
             if args.curve == "secp256k1":     # GLV split: 32 windows x (4 doublings + 2 mixed additions + beta) + the top window's two additions
-                fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / 224) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + (7 + inv / 32)
+                fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / 224) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + (7 + inv / 32)   # table {1..8}P
             mad32_unit, bytes_unit, kname = int(fm * 136), 160, "k_varwin_mult + k_varwin_multiples + k_varwin_to_table + k_to_affine_batched"
         else:
             # what THIS algorithm needs per scalar: 64 mixed additions x 11 field mults,

@@ -63,6 +63,35 @@ def test_offset_recoding_of_the_variable_base_kernel(cv):
             prefix = 16 * prefix + digits[j]
 
 
+@pytest.mark.parametrize("cv", [P256, SECP256K1])
+def test_odd_digit_recoding_of_the_variable_base_kernel(cv):
+    """k_varwin_mult_odd: k <- k mod n; the odd one of k and n - k (n is odd); digit i < 63 = (nibble_i | 1) - 16 when the
+    nibble above is even, nibble_i | 1 otherwise; the top digit = top nibble | 1.  Sixty-four odd digits, |d| <= 15,
+    magnitude m at table slot (m - 1) / 2; no addition inside the loop meets R = +-T or the point at infinity."""
+    n = CURVE_PARAMS[cv]["n"]
+    for k in scalars(cv + 300) + [n - 1, n, n + 1, n - 2, (n - 1) // 2, (n + 1) // 2, 1, 2, 3]:
+        k &= M256
+        r = k - n if k >= n else k
+        if r == 0:
+            continue                                                                # the kernel returns infinity by flag
+        flip = r % 2 == 0
+        a = n - r if flip else r
+        assert a % 2 == 1 and 0 < a < n
+        nibs = [(a >> (4 * j)) & 15 for j in range(64)]
+        digits = [(nibs[j] | 1) - (0 if nibs[j + 1] & 1 else 16) for j in range(63)] + [nibs[63] | 1]
+        assert all(d % 2 and -15 <= d <= 15 for d in digits) and digits[63] > 0
+        assert all(0 <= (abs(d) - 1) // 2 <= 7 for d in digits)
+        val = sum(d << (4 * j) for j, d in enumerate(digits))
+        assert val == a and ((-val if flip else val) - k) % n == 0
+        acc = digits[63]                                                            # discrete log of R: 16 R + d P as 2 (8 R) + d P
+        for j in range(62, -1, -1):
+            eight = 8 * acc
+            assert eight % n and (eight - digits[j]) % n and (eight + digits[j]) % n      # R + T: neither equal nor opposite
+            assert (2 * eight + digits[j]) % n and (eight + digits[j] + eight) % n          # (R + T) + R: not opposite; never equal (T != 0)
+            acc = 16 * acc + digits[j]
+        assert acc == a
+
+
 def test_glv_split_of_secp256k1():
     """k_varwin_mult_glv: c_i = round(k g_i / 2^384); k1 = k - c1 a1 - c2 a2, k2 = c1 (-b1) - c2 b2 in 256-bit two's
     complement; |k1|, |k2| < 2^128; 33 nibbles after adding 0x888...8 (32 nibbles) with a top digit of 0 or 1."""

@@ -68,7 +68,7 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     row(f"scalar_mult<{nm}> ladder, Jacobian out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=1, out=outj), 5), 555968, 192, "scalar mults")
     row(f"scalar_mult<{nm}> ladder, affine out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=3, out=outj), 5), 555968 + 19 * 136, 160, "scalar mults")
     dblm = 8 if cv == 0 else 7
-    vw = int(((4 * dblm + 33) + 7 * (7 + inv_m / 224) + 63 * (4 * dblm + 11) + (7 + inv_m / 32)) * 136)
+    vw = int((55 + 7 * (7 + inv_m / 224) + 63 * (3 * dblm + 18) + (7 + inv_m / 32)) * 136)          # odd digits, fused double-add
     if cv == 1:                                      # secp256k1: GLV split (k_varwin.inc)
         vw = int(((4 * dblm + 33) + 7 * (7 + inv_m / 224) + 32 * (4 * dblm + 23) + 23 + (7 + inv_m / 32)) * 136)
     row(f"scalar_mult<{nm}> windowed variable base (per-element tables), affine out", n2,

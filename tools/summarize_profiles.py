@@ -18,7 +18,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 traffic = {}
 for tag, kern_filter, label in (("ladder", ["k_scalar_mult"], "k_scalar_mult_p256_2^22"), ("fixed", ["k_base_windowed", "k_to_affine_batched"], "fixed_base_p256_2^22"),
                                ("fixedbig", ["k_base_windowed_g", "k_to_affine_batched"], "fixed_base_big_p256_2^22"),
-                               ("varwin", ["k_varwin_mult", "k_varwin_multiples", "k_varwin_to_table", "k_to_affine_batched"], "varwin_p256_2^22")):
+                               ("varwin", ["k_varwin_mult_odd", "k_varwin_odd_multiples", "k_varwin_to_table", "k_to_affine_batched"], "varwin_p256_2^22")):
     src = f"gpurun_out/prof_{rnd}_{tag}"
     if not os.path.isdir(src):
         continue
