@@ -57,10 +57,11 @@ enum {
   ECSIMD_HIP_OUT_AFFINE = 2,       /* out = to_affine(): (x, y) classical; oz may be NULL */
   ECSIMD_HIP_ALG_WINDOWED = 4,     /* with OUT_AFFINE only.  scalar_mult_base: 4-bit windows over an LDS-resident table of
                                       d*16^w*G and one simultaneous inversion instead of the reference's ladder.
-                                      scalar_mult / double_scalar_mult (variable base): a per-element table {1..8}P in
-                                      device memory, signed 4-bit windows (4 doublings + 1 mixed addition per window,
-                                      ~2 900 field multiplications against the ladder's 4 064), 1 408 B of context
-                                      workspace per element, at most 2^22 elements at a time.  Same affine result as
+                                      scalar_mult / double_scalar_mult (variable base): a per-element table of 8 multiples
+                                      of P in device memory and signed 4-bit windows (odd digits, 3 doublings + one fused
+                                      double-add per window: ~2 770 field multiplications against the ladder's 4 064;
+                                      secp256k1 splits k = k1 + k2*lambda first), 1 408 B of context workspace per
+                                      element, at most 2^22 elements at a time.  Same affine result as
                                       the ladder for every k except the ladder's degenerate scalars k = n-1, 2^256-n-1,
                                       2^256-n (there the reference returns a meaningless point, these paths the right
                                       one); k = 0 mod n -> (0, 0) */
