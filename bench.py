@@ -50,7 +50,7 @@ def main():
                          "windowed: variable base with per-element {1..8}P tables and signed 4-bit windows, affine out (ALG_WINDOWED; affine-level parity); "
                          "fixed-base: k*G with the 4-bit-window LDS table + simultaneous inversion, affine out (BASELINE configs[2]); "
                          "fixed-base-signed: the same with signed 7-bit windows (37 additions instead of 64); "
-                         "fixed-base-big: signed 20-bit windows over a 436 MB table in device memory (13 additions)")
+                         "fixed-base-big: 20-bit windows (odd digits) over a 436 MB table in device memory (12 additions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
@@ -144,7 +144,7 @@ def main():
                                 f"inversion{' + GLV split k = k1 + k2*lambda' if args.curve == 'secp256k1' else ''}, batch=2^{args.log2_batch} per GPU, affine out") if args.workload == "windowed" else
                                (f"scalar_mult_{args.curve} fixed-base (G), batch=2^{args.log2_batch} random scalars per GPU, "
                                 + {"fixed-base": "4-bit window table in LDS", "fixed-base-signed": "signed 7-bit window table in LDS",
-                                   "fixed-base-big": "signed 20-bit window table (436 MB) in device memory"}.get(args.workload, "")
+                                   "fixed-base-big": "20-bit window table of odd multiples (436 MB) in device memory"}.get(args.workload, "")
                                 + " + simultaneous inversion, affine out"),
                    "element": "256-bit integers: 8 x u32 words (= 4 x u64 limbs) in VGPRs, v_mad_u64_u32 carry chains",
                    "global_batch": n * world, "per_gpu_batch": n, "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
@@ -171,9 +171,9 @@ def main():
         else:
             # what THIS algorithm needs per scalar: 64 mixed additions x 11 field mults,
             # 7 mults of the simultaneous-inversion walk and 267/32 (secp256k1: 270/32) of the shared inversion; 32 B in, 64 B out.
-            adds = {"fixed-base": 64, "fixed-base-signed": 37, "fixed-base-big": 13}[args.workload]
+            adds = {"fixed-base": 64, "fixed-base-signed": 37, "fixed-base-big": 12}[args.workload]
             mad32_unit, bytes_unit = int((adds * 11 + 7 + (267 if args.curve == "p256" else 270) / 32) * 136), 96
-            kname = {64: "k_base_windowed", 37: "k_base_windowed_s<7>", 13: "k_base_windowed_g"}[adds] + " + k_to_affine_batched"
+            kname = {64: "k_base_windowed", 37: "k_base_windowed_s<7>", 12: "k_base_windowed_g"}[adds] + " + k_to_affine_batched"
         achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")             # written from rocprofv3 --pmc passes

@@ -123,12 +123,13 @@ constexpr int SIGNED_WBITS = 7;     // 37 additions, 151 552 B of LDS (6 -> 43 a
 int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
   uint32_t** slot = (bits == 4) ? &ctx->window_table[curve] : (bits == launch::BIG_WINDOW_BITS) ? &ctx->window16_table[curve] : &ctx->window6_table[curve];
   if (*slot) return ECSIMD_HIP_OK;
-  const int windows = (bits == 4) ? 64 : (256 + bits) / bits, per = (bits == 4) ? 16 : 1 << (bits - 1);
+  const bool big = (bits == launch::BIG_WINDOW_BITS);        // odd multiples (2d + 1) * 2^(bits w) * G, ceil(256 / bits) windows, no carry window
+  const int windows = (bits == 4) ? 64 : big ? (256 + bits - 1) / bits : (256 + bits) / bits, per = (bits == 4) ? 16 : 1 << (bits - 1);
   const size_t entries = (size_t)windows * per;
   std::vector<uint64_t> host_k(entries * 4, 0);
   for (int w = 0; w < windows; ++w)
     for (int d = 0; d < per; ++d) {
-      const unsigned mult = (bits == 4) ? (unsigned)d : (unsigned)d + 1u;             // multiplier m
+      const unsigned mult = (bits == 4) ? (unsigned)d : big ? 2u * (unsigned)d + 1u : (unsigned)d + 1u;   // multiplier m
       const int pos = bits * w;                                                         // entry = m * 2^pos * G
       uint64_t* e = &host_k[((size_t)w * per + d) * 4];
       const int limb = pos / 64, off = pos % 64;
@@ -157,7 +158,9 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
     launch::scalar_mult(ctx->stream, curve, kd, 4, nullptr, nullptr, jx, jy, jz, entries, ECSIMD_HIP_OUT_AFFINE);
     launch::to_affine_batched(ctx->stream, curve, jx, jy, jz, tx, ty, entries, true);
   }
-  if (bits != 4) {
+  if (big) {
+    launch::pack_table_big(ctx->stream, curve, tx, ty, table);           // odd digits: no carry, no 2^256 * G entry
+  } else if (bits != 4) {
     // The one reachable entry with m * 2^pos = 2^256 (top digit + carry): the ladder cannot produce 2^256 * G (a degenerate
     // scalar, see above), so it is the entry holding 2^255 * G doubled by the affine-addition kernel.
     uint64_t* sx = ty + entries * 4; uint64_t* sy = sx + 4;                                  // scratch (the Jacobian area is free again)
@@ -166,8 +169,7 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
     launch::affine_add_batched(ctx->stream, curve, tx + src, ty + src, tx + src, ty + src, sx, sy, nullptr, 1);
     (void)hipMemcpyAsync(tx + dst, sx, 32, hipMemcpyDeviceToDevice, ctx->stream);
     (void)hipMemcpyAsync(ty + dst, sy, 32, hipMemcpyDeviceToDevice, ctx->stream);
-    if (bits == launch::BIG_WINDOW_BITS) launch::pack_table_big(ctx->stream, curve, tx, ty, table);
-    else launch::pack_table_signed(ctx->stream, curve, bits, tx, ty, table);
+    launch::pack_table_signed(ctx->stream, curve, bits, tx, ty, table);
   } else {
     launch::pack_table(ctx->stream, curve, tx, ty, table);
   }

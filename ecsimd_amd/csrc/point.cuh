@@ -129,6 +129,15 @@ template <int C> ECS_DEV jpoint madd_hmv(const fe& X1, const fe& Y1, const fe& Z
   return R;
 }
 
+// group order n (curve_nist_p256.h has no order: the reference never reduces scalars; SEC 2 values)
+template <int CURVE> struct curve_order;
+template <> struct curve_order<CURVE_P256> {
+  static constexpr uint32_t N[8] = {0xfc632551u, 0xf3b9cac2u, 0xa7179e84u, 0xbce6faadu, 0xffffffffu, 0xffffffffu, 0x00000000u, 0xffffffffu};
+};
+template <> struct curve_order<CURVE_SECP256K1> {
+  static constexpr uint32_t N[8] = {0xd0364141u, 0xbfd25e8cu, 0xaf48a03bu, 0xbaaedce6u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+};
+
 // a^(p-2) and a^((p+1)/4): exponents as compile-time word arrays (gfp.h:79-87).
 template <int C> struct curve_exps;
 template <> struct curve_exps<CURVE_P256> {

@@ -76,7 +76,7 @@ struct curve_group {
     WJCP r = fresh(A.size());
     hip::check(ecsimd_hip_add_mixed_complete(hip::context(), curve_id, px(A), py(A), pz(A), px(B), py(B), px(r), py(r), pz(r), A.size()), "ecsimd_hip_add_mixed_complete"); return r;
   }
-  // k[i] * G through the signed 20-bit window table in device memory (13 mixed additions), affine classical.
+  // k[i] * G through the 20-bit window table of odd multiples in device memory (12 mixed additions), affine classical.
   static WCP scalar_mult_base_affine(WBN const& x) {
     WCP r{WBN::uninitialized(x.size()), WBN::uninitialized(x.size())};
     hip::check(ecsimd_hip_scalar_mult_base(hip::context(), curve_id, x.data(), r.x().data(), r.y().data(), nullptr, x.size(),

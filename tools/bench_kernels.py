@@ -77,9 +77,9 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     row(f"scalar_mult_base<{nm}> windowed, affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=6, out=outj)), int((64 * 11 + 7 + inv_m / 32) * 136), 96, "scalar mults")
     u1 = e.fill_random(n2, SEED, 21)
     row(f"double_scalar_mult<{nm}> u1*G + u2*Q (ECDSA-verify shape)", n2, timeit(lambda: e.double_scalar_mult(cv, u1, k, b2x, b2y), 5),
-        vw + int((13 * 11 + (7 + inv_m / 32) + 6 + inv_m / 32) * 136), 160, "verifications")
+        vw + int((12 * 11 + (7 + inv_m / 32) + 6 + inv_m / 32) * 136), 160, "verifications")
     del u1
-    row(f"scalar_mult_base<{nm}> signed 20-bit windows (table in device memory), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 32, out=outj)), int((13 * 11 + 7 + inv_m / 32) * 136), 96, "scalar mults")
+    row(f"scalar_mult_base<{nm}> 20-bit windows, odd digits (table in device memory), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 32, out=outj)), int((12 * 11 + 7 + inv_m / 32) * 136), 96, "scalar mults")
     row(f"scalar_mult_base<{nm}> signed 7-bit windows, affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 8, out=outj)), int((37 * 11 + 7 + inv_m / 32) * 136), 96, "scalar mults")
     wire = e.sec1_encode(cv, b2x, b2y, True)
     row(f"sec1_decode<{nm}> compressed (decompression)", n2, timeit(lambda: e.sec1_decode(cv, wire, True)), ((253 + 33 + 4) if cv == 0 else (253 + 13 + 4)) * 136, 33 + 64, "points")
