@@ -190,15 +190,22 @@ def main():
             "peak_source": "ecsimd_hip_peak_mad32: dependency-free v_mad_u64_u32 stream, 8 waves/SIMD, same GPU, same run",
         }
         if world == 1 and not args.no_cpu_baseline:
-            if args.workload == "windowed":
-                result["cpu_baseline"] = cpu_baseline_fixed_base(eng, curve, k, runner.last_result(), args.cpu_seconds, base=(bx, by))
-            elif args.workload == "ladder":
-                result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, runner.last_result(), args.cpu_seconds)
-                comp = competitor_openssl(eng, curve, k, bx, by, runner.last_result())
-                if comp is not None:
-                    result["cpu_baseline"]["competitor_openssl"] = comp
-            else:
-                result["cpu_baseline"] = cpu_baseline_fixed_base(eng, curve, k, runner.last_result(), args.cpu_seconds)
+            # The baseline is a reported side figure: a checker that cannot load (e.g. the prebuilt reference on a host
+            # without AVX2) must not cost the run its line.  A parity DISAGREEMENT is not swallowed: it is in the
+            # object (lanes_differing_from_gpu, differences_all_explained_by_reference_square_defect).
+            try:
+                if args.workload == "windowed":
+                    result["cpu_baseline"] = cpu_baseline_fixed_base(eng, curve, k, runner.last_result(), args.cpu_seconds, base=(bx, by))
+                elif args.workload == "ladder":
+                    result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, runner.last_result(), args.cpu_seconds)
+                    comp = competitor_openssl(eng, curve, k, bx, by, runner.last_result())
+                    if comp is not None:
+                        result["cpu_baseline"]["competitor_openssl"] = comp
+                else:
+                    result["cpu_baseline"] = cpu_baseline_fixed_base(eng, curve, k, runner.last_result(), args.cpu_seconds)
+            except Exception as exc:            # noqa: BLE001
+                result["cpu_baseline"] = {"value": None, "unit": "scalar_mults/s", "cores": usable_cores(), "kind": "unavailable",
+                                          "sample": "the CPU checkers could not run here", "error": repr(exc)[:300]}
         print(json.dumps(result), flush=True)
     if world > 1 or force_dist:
         if force_dist and rank == 0:
