@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--curve", default="p256", choices=["p256", "secp256k1"])
     ap.add_argument("--workload", default="ladder", choices=["ladder", "windowed", "fixed-base", "fixed-base-signed", "fixed-base-big"],
                     help="ladder: scalar_mult_p256 variable base, the reference's co-Z ladder, Jacobian out (headline, BASELINE configs[3] shape per GPU); "
-                         "windowed: variable base with per-element {1..8}P tables and signed 4-bit windows, affine out (ALG_WINDOWED; affine-level parity); "
+                         "windowed: variable base with per-element tables of 8 multiples of P and signed 4-bit windows, affine out (ALG_WINDOWED; affine-level parity); "
                          "fixed-base: k*G with the 4-bit-window LDS table + simultaneous inversion, affine out (BASELINE configs[2]); "
                          "fixed-base-signed: the same with signed 7-bit windows (37 additions instead of 64); "
                          "fixed-base-big: 20-bit windows (odd digits) over a 436 MB table in device memory (12 additions)")
@@ -167,7 +167,8 @@ def main():
             fm = (6 + 7 * 7) + 7 * (7 + inv / 224) + 63 * (3 * dbl + 18) + (7 + inv / 32)
             if args.curve == "secp256k1":     # GLV split: 32 windows x (4 doublings + 2 mixed additions + beta) + the top window's two additions
                 fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / 224) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + (7 + inv / 32)   # table {1..8}P
-            mad32_unit, bytes_unit, kname = int(fm * 136), 160, "k_varwin_mult + k_varwin_multiples + k_varwin_to_table + k_to_affine_batched"
+            mad32_unit, bytes_unit = int(fm * 136), 160
+            kname = ("k_varwin_mult_odd + k_varwin_odd_multiples" if args.curve == "p256" else "k_varwin_mult_glv + k_varwin_multiples") + " + k_varwin_to_table + k_to_affine_batched"
         else:
             # what THIS algorithm needs per scalar: 64 mixed additions x 11 field mults,
             # 7 mults of the simultaneous-inversion walk and 267/32 (secp256k1: 270/32) of the shared inversion; 32 B in, 64 B out.

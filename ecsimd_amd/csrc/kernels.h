@@ -70,7 +70,7 @@ void base_windowed(hipStream_t, int curve, const uint64_t* k, const uint32_t* ta
 void pack_table_signed(hipStream_t, int curve, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
 void base_windowed_signed(hipStream_t, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
 
-// k_varwin_<curve>.hip: variable-base multiplication with per-lane window tables {1..8}P (affine out, classical).
+// k_varwin_<curve>.hip: variable-base multiplication with per-lane window tables of 8 multiples of P (affine out, classical).
 // scratch: varwin_scratch_bytes(n) bytes, 32-byte aligned; k_stride, x, y as for scalar_mult (flags: ECSIMD_HIP_BASE_*).
 void varwin_scalar_mult(hipStream_t, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, int flags,
                         uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n);

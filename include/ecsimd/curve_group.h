@@ -63,7 +63,7 @@ struct curve_group {
 
   // ---- extensions (not in the reference): affine-level entry points over the faster algorithms of the C ABI.
   // Same points as to_affine() of the ladder's result for every scalar where the ladder is non-degenerate.
-  // k[i] * P[i], P affine classical -> affine classical.  windowed: per-element tables {1..8}P + signed 4-bit
+  // k[i] * P[i], P affine classical -> affine classical.  windowed: per-element tables of 8 multiples of P + signed 4-bit
   // windows (ECSIMD_HIP_ALG_WINDOWED); otherwise the reference ladder followed by one simultaneous inversion.
   static WCP scalar_mult_affine(WBN const& x, WCP const& P, bool windowed = true) {
     WCP r{WBN::uninitialized(P.size()), WBN::uninitialized(P.size())};

@@ -68,7 +68,7 @@ enum {
   ECSIMD_HIP_ALG_WINDOWED_SIGNED = 8, /* as ALG_WINDOWED with signed 7-bit windows: 37 mixed additions instead of 64, a 148 KiB
                                       table of m*2^(7i)*G (m = 1..64) in LDS, negative digits negate y; same results */
   ECSIMD_HIP_ALG_NO_ENDOMORPHISM = 16, /* secp256k1 + ALG_WINDOWED on a variable base splits k = k1 + k2*lambda (GLV) and runs
-                                      half as many windows; this flag keeps the plain 63-window loop (same results) */
+                                      half as many windows; this flag keeps the plain odd-digit loop of 63 windows (same results) */
   ECSIMD_HIP_ALG_WINDOWED_BIG = 32 /* scalar_mult_base + OUT_AFFINE: 20-bit windows with odd digits over a 436 MB table of the odd
                                       multiples (2d+1)*2^(20i)*G (13 windows x 2^19 entries) in device memory, built on first
                                       use (0.23 s per curve): 12 mixed additions per scalar; same results */

@@ -65,32 +65,6 @@ def test_odd_digit_recoding_of_the_device_memory_table_kernel(cv, bits):
 
 
 @pytest.mark.parametrize("cv", [P256, SECP256K1])
-def test_offset_recoding_of_the_variable_base_kernel(cv):
-    """k_varwin_mult: k <- k mod n, k <- min(k, n - k) (sign flips the result), k + 0x0888...8; digit j < 63 is
-    nibble - 8 in [-8, 7], the top nibble is an unsigned digit in [0, 8]; no carry out of 256 bits."""
-    n = CURVE_PARAMS[cv]["n"]
-    off = int("0" + "8" * 63, 16)
-    for k in scalars(cv + 100) + [n - 1, n, n + 1, (n - 1) // 2, (n + 1) // 2, 2 * n - (1 << 256) if 2 * n > (1 << 256) else 5]:
-        k &= M256
-        r = k - n if k >= n else k                                                  # one conditional subtraction: k < 2^256 < 2n
-        assert 0 <= r < n
-        flip = (n - r) < r
-        a = n - r if flip else r
-        assert a <= (n - 1) // 2 or r == 0
-        u = a + off
-        assert u < 1 << 256
-        digits = [((u >> (4 * j)) & 15) - 8 for j in range(63)] + [u >> 252]
-        assert all(-8 <= d <= 7 for d in digits[:63]) and 0 <= digits[63] <= 8
-        val = sum(d << (4 * j) for j, d in enumerate(digits))
-        assert val == a and ((-val if flip else val) - k) % n == 0
-        prefix = 0                                                                  # no mixed addition meets R = +-T (k_varwin.inc header)
-        for j in range(63, -1, -1):
-            if prefix and digits[j]:
-                assert (16 * prefix - digits[j]) % n and (16 * prefix + digits[j]) % n
-            prefix = 16 * prefix + digits[j]
-
-
-@pytest.mark.parametrize("cv", [P256, SECP256K1])
 def test_odd_digit_recoding_of_the_variable_base_kernel(cv):
     """k_varwin_mult_odd: k <- k mod n; the odd one of k and n - k (n is odd); digit i < 63 = (nibble_i | 1) - 16 when the
     nibble above is even, nibble_i | 1 otherwise; the top digit = top nibble | 1.  Sixty-four odd digits, |d| <= 15,
