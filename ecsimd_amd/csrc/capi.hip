@@ -126,7 +126,9 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
   const bool big = (bits == launch::BIG_WINDOW_BITS);        // odd multiples (2d + 1) * 2^(bits w) * G, ceil(256 / bits) windows, no carry window
   const int windows = (bits == 4) ? 64 : big ? (256 + bits - 1) / bits : (256 + bits) / bits, per = (bits == 4) ? 16 : 1 << (bits - 1);
   const size_t entries = (size_t)windows * per;
-  std::vector<uint64_t> host_k(entries * 4, 0);
+  std::vector<uint64_t> host_k;
+  try { host_k.assign(entries * 4, 0); }                       // up to 218 MB of host memory (20-bit windows): nothing may throw across the C ABI
+  catch (...) { return bad(ctx, "window table: out of host memory"); }
   for (int w = 0; w < windows; ++w)
     for (int d = 0; d < per; ++d) {
       const unsigned mult = (bits == 4) ? (unsigned)d : big ? 2u * (unsigned)d + 1u : (unsigned)d + 1u;   // multiplier m
