@@ -47,6 +47,7 @@ void pack_table(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty
 void pack_table_signed(hipStream_t s, int curve, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table_signed, s, wbits, tx, ty, table); }
 void base_windowed_signed(hipStream_t s, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed_signed, s, wbits, k, table, ox, oy, oz, n); }
 void inverse_batched(hipStream_t s, int curve, const uint64_t* a, uint64_t* out, size_t n) { DISPATCH(inverse_batched, s, a, out, n); }
+void x_mod_n_equals(hipStream_t s, int curve, const uint64_t* x, const uint8_t* finite, const uint64_t* r, uint8_t* ok, size_t n) { DISPATCH(x_mod_n_equals, s, x, finite, r, ok, n); }
 void affine_add_batched(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) { DISPATCH(affine_add_batched, s, ax, ay, bx, by, rx, ry, finite, n); }
 void base_windowed(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed, s, k, table, ox, oy, oz, n); }
 void pack_table_big(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table_big, s, tx, ty, table); }
@@ -535,6 +536,27 @@ int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "double_scalar_mult launch"); }
+
+// ECDSA's acceptance test on top of double_scalar_mult: ok[i] = (u1*G + u2*Q is finite) && (its x mod n == r[i]).
+int ecsimd_hip_ecdsa_verify_rx(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
+                               const uint64_t* r, uint8_t* ok, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(u1); REQUIRE_PTR(u2); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(r);
+  if (!ok && n) return bad(ctx, "ok is null");
+  if (n == 0) return ECSIMD_HIP_OK;
+  (void)hipSetDevice(ctx->device);
+  // x coordinates and the finite flags of the sums live behind double_scalar_mult's own workspace use
+  const size_t chunk = n < VARWIN_CHUNK ? n : VARWIN_CHUNK;
+  const size_t front = 7 * chunk * 32 + launch::varwin_scratch_bytes(chunk);
+  int rc = ensure_window_table(ctx, curve, launch::BIG_WINDOW_BITS);      // first: building it may re-allocate the workspace
+  if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, front + n * 32 + ((n + 15) / 16) * 16);
+  if (rc != ECSIMD_HIP_OK) return rc;
+  uint64_t* rx = ctx->workspace + front / 8;
+  uint8_t* fin = reinterpret_cast<uint8_t*>(rx + 4 * n);
+  rc = ecsimd_hip_double_scalar_mult(ctx, curve, u1, u2, qx, qy, rx, nullptr, fin, n);
+  if (rc != ECSIMD_HIP_OK) return rc;
+  launch::x_mod_n_equals(ctx->stream, curve, rx, fin, r, ok, n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "ecdsa_verify_rx launch"); }
 
 int ecsimd_hip_scalar_mult_p256(ecsimd_hip_ctx* ctx, const uint64_t* k, const uint64_t* xm, const uint64_t* ym, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) {
   return ecsimd_hip_scalar_mult(ctx, ECSIMD_HIP_P256, k, xm, ym, ox, oy, oz, n, ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN); }

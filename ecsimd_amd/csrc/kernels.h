@@ -63,6 +63,7 @@ void scalar_mult(hipStream_t, int curve, const uint64_t* k, int k_stride, const 
 // 4-bit-window table packer and the fixed-base windowed multiplication (Jacobian out, fast domain).
 void to_affine_batched(hipStream_t, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool in_fast_domain);
 void inverse_batched(hipStream_t, int curve, const uint64_t* a, uint64_t* out, size_t n);     // out must not alias a
+void x_mod_n_equals(hipStream_t, int curve, const uint64_t* x, const uint8_t* finite, const uint64_t* r, uint8_t* ok, size_t n);
 void affine_add_batched(hipStream_t, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
 void pack_table(hipStream_t, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
 void base_windowed(hipStream_t, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
@@ -102,6 +103,7 @@ template <int C> struct point_launch {
   // k_affine_<curve>.hip
   static void to_affine_batched(hipStream_t, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool in_fast_domain);
   static void inverse_batched(hipStream_t, const uint64_t* a, uint64_t* out, size_t n);
+  static void x_mod_n_equals(hipStream_t, const uint64_t* x, const uint8_t* finite, const uint64_t* r, uint8_t* ok, size_t n);
   static void affine_add_batched(hipStream_t, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
   static void pack_table(hipStream_t, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
   static void base_windowed(hipStream_t, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);

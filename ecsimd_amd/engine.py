@@ -300,6 +300,11 @@ class Engine:
         self._call("double_scalar_mult", C.c_int(curve), self._ptr(u1), self._ptr(u2), self._ptr(qx), self._ptr(qy), self._ptr(rx), self._ptr(ry), self._ptr(fin, 0), C.c_size_t(n))
         return rx, ry, fin
 
+    def ecdsa_verify_rx(self, curve, u1, u2, qx, qy, r):
+        n = u1.shape[0]; ok = self.flags(n)
+        self._call("ecdsa_verify_rx", C.c_int(curve), self._ptr(u1), self._ptr(u2), self._ptr(qx), self._ptr(qy), self._ptr(r), self._ptr(ok, 0), C.c_size_t(n))
+        return ok
+
     def scalar_mult_p256(self, k, xm, ym, out=None):
         n = k.shape[0]
         r = out if out is not None else [self.empty(n) for _ in range(3)]

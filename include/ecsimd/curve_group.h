@@ -92,6 +92,12 @@ struct curve_group {
                                              finite.data(), Q.size()), "ecsimd_hip_double_scalar_mult");
     return r;
   }
+  // ECDSA's acceptance test for precomputed u1 = e/s, u2 = r/s (mod n): lane i is set iff u1*G + u2*Q is finite and its x mod n == r.
+  static hip::mask ecdsa_verify_rx(WBN const& u1, WBN const& u2, WCP const& Q, WBN const& r) {
+    hip::mask ok(Q.size());
+    hip::check(ecsimd_hip_ecdsa_verify_rx(hip::context(), curve_id, u1.data(), u2.data(), Q.x().data(), Q.y().data(), r.data(), ok.data(), Q.size()), "ecsimd_hip_ecdsa_verify_rx");
+    return ok;
+  }
  private:
   static WJCP fresh(size_t n) {
     WJCP r; r.x() = gfp{WMBN{WBN::uninitialized(n)}}; r.y() = gfp{WMBN{WBN::uninitialized(n)}}; r.z() = gfp{WMBN{WBN::uninitialized(n)}}; return r;

@@ -210,6 +210,11 @@ int ecsimd_hip_affine_add(ecsimd_hip_ctx*, int curve, const uint64_t* ax, const 
  * (ALG_WINDOWED): correct for every 256-bit u1, u2; 1 632 B of context workspace per element, 2^22 at a time. */
 int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx*, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                                   uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
+/* The acceptance test of an ECDSA verification for precomputed u1 = e/s, u2 = r/s (mod n; computing them is the caller's:
+ * this library has no arithmetic modulo the group order): ok[i] = 1 iff u1[i]*G + u2[i]*Q[i] is a finite point whose
+ * x coordinate, reduced mod n, equals r[i].  Same workspace as double_scalar_mult plus 33 B per element. */
+int ecsimd_hip_ecdsa_verify_rx(ecsimd_hip_ctx*, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
+                               const uint64_t* r, uint8_t* ok, size_t n);
 /* lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P) -- P-256, base in Montgomery form with
  * Z = mgry(1), Jacobian Montgomery output. */
 int ecsimd_hip_scalar_mult_p256(ecsimd_hip_ctx*, const uint64_t* k, const uint64_t* xm, const uint64_t* ym,

@@ -493,6 +493,33 @@ def test_affine_add_and_double_scalar_mult(engine, oracle, cv):
             assert tfn[i] == 1 and (to_int(txn[i]), to_int(tyn[i])) == e_, i
 
 
+@pytest.mark.parametrize("cv", CURVES)
+def test_ecdsa_acceptance_test(engine, openssl, cv):
+    """ecdsa_verify_rx on real signatures: d random, Q = d*G, k random, r = (k*G).x mod n, s = (e + r d)/k, u1 = e/s,
+    u2 = r/s (host big-int arithmetic mod n; the points from OpenSSL).  Valid ones pass; a changed r, e or Q fails."""
+    c = CURVE_PARAMS[cv]; order = c["n"]
+    n = 2048
+    rng = np.random.default_rng(12345 + cv)
+    rand = lambda: [int.from_bytes(rng.bytes(32), "big") % (order - 1) + 1 for _ in range(n)]
+    d, kk, e_ = rand(), rand(), rand()
+    qx, qy, _ = openssl.scalar_mult_base(cv, ints_to_arr(d), threads=THREADS)
+    kx, _, _ = openssl.scalar_mult_base(cv, ints_to_arr(kk), threads=THREADS)
+    r = [to_int(v) % order for v in kx]
+    s_ = [(e_[i] + r[i] * d[i]) * pow(kk[i], -1, order) % order for i in range(n)]
+    good = [i for i in range(n) if r[i] and s_[i]]
+    w = [pow(s_[i], -1, order) if s_[i] else 1 for i in range(n)]
+    u1 = [e_[i] * w[i] % order for i in range(n)]; u2 = [r[i] * w[i] % order for i in range(n)]
+    dev = lambda v: engine.to_device(ints_to_arr(v))
+    ok = engine.to_numpy(engine.ecdsa_verify_rx(cv, dev(u1), dev(u2), engine.to_device(qx), engine.to_device(qy), dev(r)))
+    assert all(ok[i] == 1 for i in good) and len(good) > n - 4
+    bad_r = [(v + 1) % order for v in r]
+    assert not engine.to_numpy(engine.ecdsa_verify_rx(cv, dev(u1), dev(u2), engine.to_device(qx), engine.to_device(qy), dev(bad_r))).any()
+    u1b = [(e_[i] + 1) * w[i] % order for i in range(n)]                               # another message
+    assert not engine.to_numpy(engine.ecdsa_verify_rx(cv, dev(u1b), dev(u2), engine.to_device(qx), engine.to_device(qy), dev(r))).any()
+    qx2 = np.roll(qx, 1, axis=0); qy2 = np.roll(qy, 1, axis=0)                         # somebody else's key
+    assert not engine.to_numpy(engine.ecdsa_verify_rx(cv, dev(u1), dev(u2), engine.to_device(qx2), engine.to_device(qy2), dev(r))).any()
+
+
 def test_double_scalar_mult_across_the_chunk_boundary(engine):
     """More elements than one internal chunk (2^22): the composite equals its three parts computed separately."""
     import torch
