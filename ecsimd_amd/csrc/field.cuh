@@ -597,7 +597,16 @@ template <int CURVE> ECS_DEV fe fe_sqr(const fe& a) {
 }
 // n*R mod p = mgry_reduce(n * (R^2 mod p))                                 mgry.h:47-50
 template <int CURVE> ECS_DEV fe fe_from_classical(const fe& n) {
-  return fe_mul<CURVE>(n, FE_CONST(CURVE, RSQ));
+  if constexpr (CURVE == CURVE_SECP256K1) {
+    // R = 2^256 = 2^32 + 977 (mod p): n*R mod p is the pseudo-Mersenne fold of n * 2^256 -- the classical reduction applied to
+    // the 512-bit value (hi = n, lo = 0).  Same canonical residue as the Montgomery route, 61 instructions instead of 373.
+    fe2 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { t.w[i] = 0; t.w[8 + i] = n.w[i]; }
+    return reduce_secp256k1_classical(t);
+  } else {
+    return fe_mul<CURVE>(n, FE_CONST(CURVE, RSQ));
+  }
 }
 // n*R^-1 mod p = mgry_reduce(zero-extended n)                              mgry.h:52-55
 template <int CURVE> ECS_DEV fe fe_to_classical(const fe& n) {
