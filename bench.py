@@ -6,12 +6,17 @@
 
 A "step" = one pass of the hot path over one batch: scalar_mult_p256(k, P) (the reference's
 exported entry point, lib/scalar_mult_p256.cpp:10-12 -> curve_group.h:189-218, the co-Z Joye
-ladder) over 2^22 lane-distinct (scalar, point) pairs PER GPU, Jacobian Montgomery output, inputs
-resident in HBM before the timed region.  Weak scaling: rank r owns global indices
-[r*2^22, (r+1)*2^22) of the synthetic streams; no collective on the data path.
-For N > 1 each step's result shard is gathered to rank 0 with ONE RCCL gather on a side stream,
-overlapped with the next step's compute (BASELINE.json north_star: "RCCL over xGMI only for the
-final gather"); the gathers are inside the timed region.
+ladder) over lane-distinct (scalar, point) pairs, Jacobian Montgomery output, inputs resident in HBM
+before the timed region.
+
+Default = BASELINE.json configs[3] verbatim: `--scaling strong --global-log2-batch 24`, i.e. 2^24 scalar
+multiplications per step, rank r of N owning the contiguous slice shard_range(2^24, r, N) of the synthetic
+streams -- 2^24 on one GPU at N = 1, 2^21 per GPU at N = 8.  `--scaling weak
+--log2-batch B` keeps 2^B per GPU instead.  No collective on the data path.  For N > 1 each step's result
+shard is gathered to rank 0 with ONE RCCL gather on a side stream, overlapped with the next step's
+compute (BASELINE.json north_star: "RCCL over xGMI only for the final gather"); the gathers are inside
+the timed region, and a second, untimed-for-`value` loop without them gives the compute-only rate
+("throughput with and without the gather"; `config.gather`).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : integer-VALU bound.  achieved = scalar-mults/s x 555 968 mad32 (SURVEY.md 8(d):
@@ -19,16 +24,20 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  peak = the dependency-free v_mad_u64_u32 stream measured live on the same GPU.
   cpu_baseline : the REAL reference (oracle/_ref, eve/AVX2) -- or the C port if that library did
                  not travel -- timed on the host cores on a bounded sample of the same workload,
-                 and compared bit-for-bit with the GPU result on that sample.  Its sub-object
-                 competitor_openssl is the reference's competitor benchmark (benchs/p256_ref.cpp:55-91,
-                 libcrypto's EC_POINT_mul) on the same cores, with 8 192 of the GPU's results checked
-                 against libcrypto at the affine level.
+                 and compared bit-for-bit with the GPU result on that sample; every lane that differs
+                 (the reference's square() defect) is re-computed by libcrypto.
+                 Its sub-object competitor_openssl is the reference's competitor benchmark
+                 (benchs/p256_ref.cpp:55-91, libcrypto's EC_POINT_mul) on the same cores, with 8 192 of
+                 the GPU's results checked against libcrypto at the affine level.
+The process exits NON-ZERO (after printing the line) when a checker disagrees with the GPU in a way the
+reference's documented defect does not explain, and on any rank's failure.
 """
 import argparse
 import json
 import os
 import sys
 import time
+import traceback
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -36,29 +45,43 @@ sys.path.insert(0, ROOT)
 MAD32_PER_SCALAR_MULT = 555968          # 4088 field mults x 136 mad32
 ALGO_BYTES_PER_SCALAR_MULT = 192        # 32 B scalar + 64 B point in, 96 B Jacobian out
 SEED = 0x5EEDEC51D0000001
+EXIT_PARITY = 3                         # a checker contradicts the GPU result
 
 
-def main():
+class CheckerUnavailable(Exception):
+    """A CPU checker library could not be loaded or built here (not a disagreement)."""
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--log2-batch", type=int, default=22, help="scalar mults per GPU per step = 2^this")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: --global-log2-batch units per step in total, split over the ranks (BASELINE configs[3]); "
+                         "weak: --log2-batch units per step on every rank")
+    ap.add_argument("--global-log2-batch", type=int, default=24, help="strong scaling: scalar mults per step over ALL GPUs = 2^this")
+    ap.add_argument("--log2-batch", type=int, default=22, help="weak scaling: scalar mults per GPU per step = 2^this")
     ap.add_argument("--curve", default="p256", choices=["p256", "secp256k1"])
-    ap.add_argument("--workload", default="ladder", choices=["ladder", "windowed", "fixed-base", "fixed-base-signed", "fixed-base-big"],
-                    help="ladder: scalar_mult_p256 variable base, the reference's co-Z ladder, Jacobian out (headline, BASELINE configs[3] shape per GPU); "
+    ap.add_argument("--workload", default="ladder", choices=["ladder", "ladder-ref-compat", "windowed", "fixed-base", "fixed-base-signed", "fixed-base-big"],
+                    help="ladder: scalar_mult_p256 variable base, the reference's co-Z ladder, Jacobian out (headline, BASELINE configs[3]); "
+                         "ladder-ref-compat: the same with ECSIMD_HIP_REF_SQUARE_COMPAT (the reference's square() as written, dropped carry included); "
                          "windowed: variable base with per-element tables of 8 multiples of P and signed 4-bit windows, affine out (ALG_WINDOWED; affine-level parity); "
                          "fixed-base: k*G with the 4-bit-window LDS table + simultaneous inversion, affine out (BASELINE configs[2]); "
                          "fixed-base-signed: the same with signed 7-bit windows (37 additions instead of 64); "
                          "fixed-base-big: 20-bit windows (odd digits) over a 436 MB table in device memory (12 additions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
     import numpy as np
     import torch
     import torch.distributed as dist
-    from ecsimd_amd import Engine, CURVES, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG
+    from ecsimd_amd import Engine, CURVES, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG, REF_SQUARE_COMPAT
+    from ecsimd_amd.shard import ShardedRunner, plan
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -71,7 +94,8 @@ def main():
     # ECSIMD_BENCH_FORCE_DIST=1 runs the process-group + gather path even with one rank (a single-GPU
     # rehearsal of the N > 1 code: RCCL init, side stream, dist.gather, barrier).
     force_dist = os.environ.get("ECSIMD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
-    if world > 1 or force_dist:
+    distributed = world > 1 or force_dist
+    if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -83,79 +107,102 @@ def main():
     if world > 1:
         dist.barrier()
     eng = Engine(local_rank)            # raises if the HIP library / a gfx950 device is missing: no fallback
-    n = 1 << args.log2_batch
-    first = rank * n                    # this rank's slice of the global synthetic streams
+    units = (1 << args.global_log2_batch) if args.scaling == "strong" else (1 << args.log2_batch)
+    first, n, total_units, rows = plan(args.scaling, units, rank, world)       # this rank's slice of the global synthetic streams
+    if n == 0:
+        raise SystemExit("the batch is smaller than the number of ranks")
 
     # ---- inputs, resident in HBM before anything is timed
     k = eng.fill_random(n, SEED, 1, first_index=first)                       # scalars: uniform 256-bit
     s = eng.fill_random(n, SEED, 2, first_index=first)                       # point seeds: P_i = s_i * G
-    bx, by = eng.scalar_mult_base(curve, s, flags=2)                          # affine classical (x, y)
+    bx, by = eng.scalar_mult_base(curve, s, flags=OUT_AFFINE | ALG_WINDOWED_BIG)   # affine classical (x, y)
     P = eng.from_affine(curve, bx, by)                                        # Montgomery form, Z = mgry(1)
     xm, ym = P[0], P[1]
     del s, P
-    flags = BASE_MGRY | OUT_JACOBIAN
-    from ecsimd_amd.shard import ShardedRunner
-    runner = ShardedRunner((3, n, 4), torch.int64, eng.tdev, world, rank, always_gather=force_dist)
+    runner = ShardedRunner((3, rows, 4), torch.int64, eng.tdev, world, rank, always_gather=force_dist)
+    view = (lambda o: [o[0][:n], o[1][:n], o[2][:n]]) if rows != n else (lambda o: [o[0], o[1], o[2]])
 
-    if args.workload == "ladder":
+    if args.workload in ("ladder", "ladder-ref-compat"):
+        flags = BASE_MGRY | OUT_JACOBIAN | (REF_SQUARE_COMPAT if args.workload == "ladder-ref-compat" else 0)
+
         def compute(o):
-            eng.scalar_mult(curve, k, xm, ym, flags=flags, out=[o[0], o[1], o[2]])
+            eng.scalar_mult(curve, k, xm, ym, flags=flags, out=view(o))
     elif args.workload == "windowed":
         def compute(o):                                     # affine (x, y); o[2] is unused
-            eng.scalar_mult(curve, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED, out=[o[0], o[1], o[2]])
-        compute([eng.empty(n) for _ in range(3)])           # sizes the context workspace (1 408 B per element)
+            eng.scalar_mult(curve, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED, out=view(o))
+        compute([eng.empty(rows) for _ in range(3)])        # sizes the context workspace (1 408 B per element)
     else:
         alg = {"fixed-base": ALG_WINDOWED, "fixed-base-signed": ALG_WINDOWED_SIGNED, "fixed-base-big": ALG_WINDOWED_BIG}[args.workload]
 
         def compute(o):                                     # affine (x, y); o[2] is unused
-            eng.scalar_mult_base(curve, k, flags=OUT_AFFINE | alg, out=[o[0], o[1], o[2]])
+            eng.scalar_mult_base(curve, k, flags=OUT_AFFINE | alg, out=view(o))
         eng.scalar_mult_base(curve, k[:1024].contiguous(), flags=OUT_AFFINE | alg)   # builds the table and the workspace
+        compute([eng.empty(rows) for _ in range(3)])
 
-    def step(i, ev0=None, ev1=None):
-        runner.step(compute, before=(ev0.record if ev0 is not None else None), after=(ev1.record if ev1 is not None else None))
+    def timed(steps, record_events):
+        """`steps` steps between two fences; wall time = max over ranks."""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if record_events else None
+        runner.fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if evs:
+                runner.step(compute, before=evs[i][0].record, after=evs[i][1].record)
+            else:
+                runner.step(compute)
+        runner.fence()
+        elapsed = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=eng.tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, ([a.elapsed_time(b) for a, b in evs] if evs else None)      # events: same stream as the launches
 
-    fence = runner.fence
+    for _ in range(args.warmup):
+        runner.step(compute)
+    elapsed, kernel_ms = timed(args.steps, True)                     # THE measurement: gathers (N > 1) inside
+    gather_ms = runner.gather_ms(args.steps) if distributed else []
+    compute_only = None
+    if distributed:                                                   # the same steps without the gather
+        runner.gather = False
+        compute_only, _ = timed(args.steps, False)
+        runner.gather = True
 
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, *evs[i])
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = [a.elapsed_time(b) for a, b in evs]                            # same stream as the launches
-    if world > 1 or force_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    total = float(n) * world * args.steps
+    total = float(total_units) * args.steps
     value = total / elapsed
+    sizes = f"2^{args.global_log2_batch} per step over {world} GPU(s) (strong scaling, BASELINE configs[3])" if args.scaling == "strong" \
+        else f"2^{args.log2_batch} per GPU per step (weak scaling)"
+    names = {
+        "ladder": f"scalar_mult_{args.curve} variable-base co-Z ladder (reference algorithm), batch {sizes}, Jacobian Montgomery out",
+        "ladder-ref-compat": f"scalar_mult_{args.curve} variable-base co-Z ladder with ECSIMD_HIP_REF_SQUARE_COMPAT (the reference's square() as written), batch {sizes}, Jacobian Montgomery out",
+        "windowed": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 multiples of P) + signed 4-bit windows + simultaneous "
+                    f"inversion{' + GLV split k = k1 + k2*lambda' if args.curve == 'secp256k1' else ''}, batch {sizes}, affine out",
+    }
+    fixed = {"fixed-base": "4-bit window table in LDS", "fixed-base-signed": "signed 7-bit window table in LDS",
+             "fixed-base-big": "20-bit window table of odd multiples (436 MB) in device memory"}
     result = {
         "metric": "P-256 scalar mults/sec (batched)" if args.curve == "p256" else "secp256k1 scalar mults/sec (batched)",
         "value": value, "unit": "scalar_mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": (f"scalar_mult_{args.curve} variable-base co-Z ladder (reference algorithm), "
-                                f"batch=2^{args.log2_batch} per GPU, Jacobian Montgomery out") if args.workload == "ladder" else
-                               (f"scalar_mult_{args.curve} variable-base, per-element window tables (8 multiples of P) + signed 4-bit windows + simultaneous "
-                                f"inversion{' + GLV split k = k1 + k2*lambda' if args.curve == 'secp256k1' else ''}, batch=2^{args.log2_batch} per GPU, affine out") if args.workload == "windowed" else
-                               (f"scalar_mult_{args.curve} fixed-base (G), batch=2^{args.log2_batch} random scalars per GPU, "
-                                + {"fixed-base": "4-bit window table in LDS", "fixed-base-signed": "signed 7-bit window table in LDS",
-                                   "fixed-base-big": "20-bit window table of odd multiples (436 MB) in device memory"}.get(args.workload, "")
-                                + " + simultaneous inversion, affine out"),
+        "config": {"workload": names.get(args.workload) or (f"scalar_mult_{args.curve} fixed-base (G), {sizes}, random scalars, "
+                                                             + fixed[args.workload] + " + simultaneous inversion, affine out"),
                    "element": "256-bit integers: 8 x u32 words (= 4 x u64 limbs) in VGPRs, v_mad_u64_u32 carry chains",
-                   "global_batch": n * world, "per_gpu_batch": n, "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
+                   "global_batch": total_units, "per_gpu_batch": n, "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
     }
+    if distributed:
+        result["config"]["gather"] = {
+            "what": "one RCCL gather of every rank's result shard to rank 0 per step, on a side stream, into one pre-sized receive buffer",
+            "bytes_per_rank_per_step": 3 * rows * 32, "ms_avg_on_the_side_stream_rank0": (float(np.mean(gather_ms)) if gather_ms else None),
+            "ms_per_step_with_gather": 1e3 * elapsed / args.steps, "ms_per_step_compute_only": 1e3 * compute_only / args.steps,
+            "value_compute_only": total / compute_only}
 
+    failures = []
     if rank == 0:
         # ---- roofline of the dominant kernel (k_scalar_mult), measured live
         avg_ms = float(np.mean(kernel_ms))
         mads, ms = eng.peak_mad32(8192, reps=5)
         peak = mads / (ms * 1e-3) / 1e12
-        if args.workload == "ladder":
+        if args.workload in ("ladder", "ladder-ref-compat"):
             mad32_unit, bytes_unit, kname = MAD32_PER_SCALAR_MULT, ALGO_BYTES_PER_SCALAR_MULT, "k_scalar_mult"
         elif args.workload == "windowed":
             # what THIS algorithm needs per scalar (DESIGN.md section 4).  P-256: table {1,3,..,15}P = DBLU + 7 co-Z additions
@@ -176,54 +223,93 @@ def main():
             mad32_unit, bytes_unit = int((adds * 11 + 7 + (267 if args.curve == "p256" else 270) / 32) * 136), 96
             kname = {64: "k_base_windowed", 37: "k_base_windowed_s<7>", 12: "k_base_windowed_g"}[adds] + " + k_to_affine_batched"
         achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")             # written from rocprofv3 --pmc passes
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"{ {'ladder': 'k_scalar_mult', 'windowed': 'varwin', 'fixed-base-big': 'fixed_base_big'}.get(args.workload, 'fixed_base') }_{args.curve}_2^{args.log2_batch}")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = committed_traffic(args, n)
         result["roofline"] = {
             "bound": "valu", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "Tmad32/s", "frac": achieved / peak,
-            "traffic": traffic, "kernel_ms": avg_ms, "algorithmic_mad32_per_unit": mad32_unit,
+            "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": avg_ms, "algorithmic_mad32_per_unit": mad32_unit,
             "hbm": {"achieved": n / (avg_ms * 1e-3) * bytes_unit / 1e9, "peak": 8000.0, "unit": "GB/s",
                     "algorithmic_bytes_per_unit": bytes_unit},
             "peak_source": "ecsimd_hip_peak_mad32: dependency-free v_mad_u64_u32 stream, 8 waves/SIMD, same GPU, same run",
         }
         if world == 1 and not args.no_cpu_baseline:
-            # The baseline is a reported side figure: a checker that cannot load (e.g. the prebuilt reference on a host
-            # without AVX2) must not cost the run its line.  A parity DISAGREEMENT is not swallowed: it is in the
-            # object (lanes_differing_from_gpu, differences_all_explained_by_reference_square_defect).
+            # The baseline is a reported side figure: a checker that cannot LOAD (e.g. the prebuilt reference on a host
+            # without AVX2) costs the run neither its line nor its exit code.  A parity DISAGREEMENT does: it is in the
+            # object and the process exits EXIT_PARITY after printing.
             try:
+                out = [t[:n] for t in runner.last_result()]
                 if args.workload == "windowed":
-                    result["cpu_baseline"] = cpu_baseline_fixed_base(eng, curve, k, runner.last_result(), args.cpu_seconds, base=(bx, by))
-                elif args.workload == "ladder":
-                    result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, runner.last_result(), args.cpu_seconds)
-                    comp = competitor_openssl(eng, curve, k, bx, by, runner.last_result())
+                    result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, base=(bx, by))
+                elif args.workload in ("ladder", "ladder-ref-compat"):
+                    result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, out, args.cpu_seconds, failures, compat=(args.workload == "ladder-ref-compat"))
+                    comp = competitor_openssl(eng, curve, k, bx, by, out, failures)
                     if comp is not None:
                         result["cpu_baseline"]["competitor_openssl"] = comp
                 else:
-                    result["cpu_baseline"] = cpu_baseline_fixed_base(eng, curve, k, runner.last_result(), args.cpu_seconds)
-            except Exception as exc:            # noqa: BLE001
+                    result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures)
+            except (CheckerUnavailable, OSError) as exc:
                 result["cpu_baseline"] = {"value": None, "unit": "scalar_mults/s", "cores": usable_cores(), "kind": "unavailable",
-                                          "sample": "the CPU checkers could not run here", "error": repr(exc)[:300]}
+                                          "sample": "the CPU checkers could not be loaded here", "error": repr(exc)[:300]}
+        if force_dist and not torch.equal(runner.gathered[0], runner.last_result()):
+            failures.append("the gathered shard differs from the computed one")
+        if failures:
+            result["parity_failures"] = failures
         print(json.dumps(result), flush=True)
-    if world > 1 or force_dist:
-        if force_dist and rank == 0:
-            assert torch.equal(runner.gathered[0], runner.last_result()), "gathered shard differs from the computed one"
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    return EXIT_PARITY if failures else 0
 
 
-def cpu_baseline_fixed_base(eng, curve, k, gpu_out, target_s, base=None):
+def committed_traffic(args, n):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), scaled to this
+    run's lanes per launch: the counters cannot be read from inside the run, so the figure is NOT measured here."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tpath):
+        return None, None
+    try:
+        table = json.load(open(tpath))
+    except ValueError:
+        return None, None
+    key = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult", "windowed": "varwin", "fixed-base-big": "fixed_base_big"}.get(args.workload, "fixed_base")
+    per22 = table.get(f"{key}_{args.curve}_2^22")
+    if per22 is None:
+        return None, None
+    return per22 * n / float(1 << 22), "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at 2^22 lanes per launch, scaled by lanes; not measured in this run"
+
+
+def load_checkers():
+    """(timed implementation, its kind).  Raises CheckerUnavailable when neither library can be had."""
+    from oracle import loader
+    try:
+        if loader.reference_available():
+            return loader.Reference(), "reference"
+        if not os.path.exists(loader.Oracle.path):
+            loader.build()
+        return loader.Oracle(), "port"
+    except OSError as exc:
+        raise CheckerUnavailable(repr(exc)) from exc
+
+
+def openssl_checker():
+    """oracle/ossl_check.c over libcrypto, or None where the OpenSSL headers are missing."""
+    import subprocess
+    from oracle import loader
+    if not loader.openssl_available():
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ossl"], check=False)
+        if not loader.openssl_available():
+            return None
+    return loader.OpenSSLCheck()
+
+
+def cpu_baseline_affine(eng, curve, k, gpu_out, target_s, failures, base=None):
     """Affine-output workloads on the CPU: the reference has ONE way to compute k*P -- scalar_mult(k, P) followed
     by to_affine() (exactly what its benchmark times, benchs/curve_group.cpp:23-35; P = G for config 3, `base` =
     the per-element points for the windowed variable-base workload).  Compared with the GPU's windowed result at
-    the affine level."""
+    the affine level; lanes that differ are settled by the exact oracle and by libcrypto."""
     import numpy as np
     from oracle import loader
     cores = usable_cores()
-    impl, kind = (loader.Reference(), "reference") if loader.reference_available() else (loader.Oracle(), "port")
+    impl, kind = load_checkers()
     c = impl.constants(curve)
     m0 = 256 * cores
     kn = eng.to_numpy(k[:m0])
@@ -236,44 +322,52 @@ def cpu_baseline_fixed_base(eng, curve, k, gpu_out, target_s, base=None):
     t = time.perf_counter(); J = impl.scalar_mult(curve, kn, gx, gy, threads=cores); ax, ay = impl.to_affine(curve, J); dt = time.perf_counter() - t
     gx_, gy_ = eng.to_numpy(gpu_out[0][:m]), eng.to_numpy(gpu_out[1][:m])
     bad = np.nonzero((gx_ != ax).any(axis=1) | (gy_ != ay).any(axis=1))[0]
-    explained = True
+    explained, by_ossl = True, None
     if len(bad):                                        # reference square() defect: the exact oracle must side with the GPU
         ex = loader.Oracle(faithful=False)
         ea = ex.to_affine(curve, ex.scalar_mult(curve, kn[bad], gx[bad], gy[bad], threads=min(cores, len(bad))))
-        explained = np.array_equal(ea[0], gx_[bad]) and np.array_equal(ea[1], gy_[bad])
+        explained = bool(np.array_equal(ea[0], gx_[bad]) and np.array_equal(ea[1], gy_[bad]))
+        ossl = openssl_checker()
+        if ossl is not None:
+            vx, vy, inf = ossl.scalar_mult(curve, kn[bad], gx[bad], gy[bad], threads=1)
+            by_ossl = int(np.count_nonzero(~((gx_[bad] != vx).any(axis=1) | (gy_[bad] != vy).any(axis=1) | (inf != 0))))
+    if not explained:
+        failures.append("cpu_baseline: a lane differs from the reference and the exact oracle does not side with the GPU")
+    if by_ossl is not None and by_ossl != len(bad):
+        failures.append("cpu_baseline: libcrypto does not confirm the GPU on a lane where it differs from the reference")
     return {"value": m / dt, "unit": "scalar_mults/s", "cores": cores, "kind": kind,
             "sample": f"first {m} scalars of the GPU batch through scalar_mult(k, {'G' if base is None else 'P'}) + to_affine (the reference's only path to affine k*P), "
                       f"{dt:.1f} s wall, {cores} threads (to_affine single-threaded)",
             "lanes_compared": int(m), "lanes_differing_from_gpu": int(len(bad)),
-            "differences_all_explained_by_reference_square_defect": bool(explained)}
+            "differences_all_explained_by_reference_square_defect": bool(explained),
+            "lanes_differing_confirmed_by_openssl": by_ossl}
 
 
-def competitor_openssl(eng, curve, k, bx, by, gpu_out, seconds=3.0, check_lanes=8192):
+def competitor_openssl(eng, curve, k, bx, by, gpu_out, failures, seconds=3.0, check_lanes=8192):
     """Part of the cpu_baseline leg: the reference's competitor benchmark (benchs/p256_ref.cpp:55-91, OpenSSL's
     EC_POINT_mul) on the host cores, run as a child process, plus an affine-level comparison of a sample of
     the GPU's results with libcrypto -- a check that depends on neither the reference nor the restatement.
     Returns None where the OpenSSL headers were not available to build oracle/ossl_check.c."""
     import subprocess
     import numpy as np
-    from oracle import loader
-    here = os.path.dirname(os.path.abspath(__file__))
-    if not loader.openssl_available():
-        subprocess.run(["make", "-s", "-C", os.path.join(here, "oracle"), "ossl"], check=False)
-        if not loader.openssl_available():
-            return None
+    ossl = openssl_checker()
+    if ossl is None:
+        return None
     cores = usable_cores()
     try:
-        out = subprocess.run([sys.executable, os.path.join(here, "oracle", "ossl_bench.py"), "--curve", str(curve), "--procs", str(cores),
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ossl_bench.py"), "--curve", str(curve), "--procs", str(cores),
                               "--seconds", str(seconds)], capture_output=True, text=True, timeout=120, check=True)
         res = json.loads(out.stdout.strip().splitlines()[-1])
-    except Exception as e:                                  # a reported side figure: never fail the bench line over it
-        return {"error": repr(e)[:200]}
+    except (subprocess.SubprocessError, ValueError, IndexError) as e:      # the TIMING is a reported side figure; the comparison below is not
+        res = {"error": repr(e)[:200]}
     m = min(check_lanes, k.shape[0])
     ax, ay = eng.to_affine(curve, [t[:m].contiguous() for t in gpu_out])
-    vx, vy, inf = loader.OpenSSLCheck().scalar_mult(curve, eng.to_numpy(k[:m]), eng.to_numpy(bx[:m]), eng.to_numpy(by[:m]), threads=cores)
+    vx, vy, inf = ossl.scalar_mult(curve, eng.to_numpy(k[:m]), eng.to_numpy(bx[:m]), eng.to_numpy(by[:m]), threads=cores)
     diff = (eng.to_numpy(ax) != vx).any(axis=1) | (eng.to_numpy(ay) != vy).any(axis=1) | (inf != 0)
     res["lanes_compared_with_gpu"] = int(m)
     res["lanes_differing_from_gpu"] = int(np.count_nonzero(diff))
+    if res["lanes_differing_from_gpu"]:
+        failures.append("competitor_openssl: libcrypto's k*P differs from the GPU's")
     return res
 
 
@@ -291,23 +385,18 @@ def usable_cores():
                 if q > 0:
                     n = min(n, max(1, q // per))
             break
-        except Exception:
+        except (OSError, ValueError, IndexError):
             continue
     return n
 
 
-def cpu_baseline(eng, curve, k, bx, by, gpu_out, target_s):
+def cpu_baseline(eng, curve, k, bx, by, gpu_out, target_s, failures, compat=False):
     """ecsimd's own CPU path (or the C port) on the host cores, bounded sample, rank 0 only; the
     sample's CPU result is also compared bit-for-bit with what the GPU produced for those elements."""
     import numpy as np
     from oracle import loader
     cores = usable_cores()
-    if loader.reference_available():
-        impl, kind = loader.Reference(), "reference"
-    else:
-        if not os.path.exists(loader.Oracle.path):
-            loader.build()
-        impl, kind = loader.Oracle(), "port"
+    impl, kind = load_checkers()
     to_np = eng.to_numpy
     # calibrate on a small sample, then size the real one for ~target_s seconds
     m0 = 256 * cores
@@ -316,15 +405,21 @@ def cpu_baseline(eng, curve, k, bx, by, gpu_out, target_s):
     m = int(min(k.shape[0], max(m0, (target_s / dt) * m0)))
     m -= m % 4
     kn, xn, yn = (to_np(t[:m]) for t in (k, bx, by))
+    if kind == "port" and compat:
+        impl = loader.Oracle(faithful=True)              # the bug-for-bug restatement stands in for the reference
     t = time.perf_counter(); ref = impl.scalar_mult(curve, kn, xn, yn, threads=cores); dt = time.perf_counter() - t
     got = [to_np(gpu_out[j][:m]) for j in range(3)]
     bad = np.nonzero((got[0] != ref[0]).any(axis=1) | (got[1] != ref[1]).any(axis=1) | (got[2] != ref[2]).any(axis=1))[0]
-    # The reference's square() drops a carry with probability ~4e-6 per random scalar mult
+    # The reference's square() drops a carry with probability ~3e-6 per random scalar mult
     # (mul.h:186-190,207; oracle/ecsimd_oracle.c bn_square; DESIGN.md "Reference defect").  Every
     # lane where the reference and the GPU differ must be such a lane: there the exact oracle has
-    # to agree with the GPU and the bug-for-bug oracle with the reference.
-    explained = True
-    if len(bad):
+    # to agree with the GPU, the bug-for-bug oracle with the reference, and libcrypto -- which shares
+    # nothing with either -- with the GPU's affine point.  With ECSIMD_HIP_REF_SQUARE_COMPAT no lane may differ.
+    explained, by_ossl = True, None
+    if len(bad) and compat:
+        explained = False
+        failures.append("cpu_baseline: the reference-compatible ladder differs from the reference")
+    elif len(bad):
         if not os.path.exists(loader.Oracle.path):
             loader.build()
         ex, fa = loader.Oracle(faithful=False), loader.Oracle(faithful=True)
@@ -332,12 +427,32 @@ def cpu_baseline(eng, curve, k, bx, by, gpu_out, target_s):
         e_ = ex.scalar_mult(curve, kn[bad], xn[bad], yn[bad], threads=min(cores, len(bad)))
         f_ = fa.scalar_mult(curve, kn[bad], xn[bad], yn[bad], threads=min(cores, len(bad)))
         explained = all(np.array_equal(u, v) for u, v in zip(e_, sub(got))) and all(np.array_equal(u, v) for u, v in zip(f_, sub(ref)))
+        if not explained:
+            failures.append("cpu_baseline: a lane differs from the reference and the two oracles do not attribute it to the square() defect")
+        ossl = openssl_checker()
+        if ossl is not None:
+            import torch
+            sel = torch.from_numpy(bad).to(gpu_out[0].device)
+            ax, ay = eng.to_affine(curve, [t[sel].contiguous() for t in gpu_out])
+            vx, vy, inf = ossl.scalar_mult(curve, kn[bad], xn[bad], yn[bad], threads=1)
+            by_ossl = int(np.count_nonzero(~((to_np(ax) != vx).any(axis=1) | (to_np(ay) != vy).any(axis=1) | (inf != 0))))
+            if by_ossl != len(bad):
+                failures.append("cpu_baseline: libcrypto does not confirm the GPU on a lane where it differs from the reference")
     return {"value": m / dt, "unit": "scalar_mults/s", "cores": cores, "kind": kind,
             "sample": f"first {m} (scalar, point) pairs of the GPU batch, {dt:.1f} s wall, {cores} threads, "
                       + ("g++ -O2 -mavx2 build of the reference headers" if kind == "reference" else "gcc -O2 C restatement"),
             "lanes_compared": int(m), "lanes_differing_from_gpu": int(len(bad)),
-            "differences_all_explained_by_reference_square_defect": bool(explained)}
+            "differences_all_explained_by_reference_square_defect": bool(explained),
+            "lanes_differing_confirmed_by_openssl": by_ossl}
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        code = main()
+    except SystemExit:
+        raise
+    except BaseException:                   # any rank's failure is the job's failure: torch.distributed.run tears the others down
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
+    sys.exit(code)

@@ -32,7 +32,11 @@ void store_words(hipStream_t s, const launch::words8& w, uint32_t* dst) {
 
 // curve dispatch for the per-curve translation units
 namespace ecsimd_hip { namespace launch {
-#define DISPATCH(fn, ...) do { if (curve == CURVE_P256) point_launch<CURVE_P256>::fn(__VA_ARGS__); else point_launch<CURVE_SECP256K1>::fn(__VA_ARGS__); } while (0)
+// DISPATCH: the kernels every instance has (k_point.inc, k_ladder.inc) -- the two API curves and their
+// ECSIMD_HIP_REF_SQUARE_COMPAT twins; DISPATCH2: the kernels of the other algorithms (k_affine.inc, k_varwin.inc), API curves only.
+#define DISPATCH(fn, ...) do { switch (curve) { case CURVE_P256: point_launch<CURVE_P256>::fn(__VA_ARGS__); break; case CURVE_SECP256K1: point_launch<CURVE_SECP256K1>::fn(__VA_ARGS__); break; \
+    case CURVE_P256_REFSQR: point_launch<CURVE_P256_REFSQR>::fn(__VA_ARGS__); break; default: point_launch<CURVE_SECP256K1_REFSQR>::fn(__VA_ARGS__); break; } } while (0)
+#define DISPATCH2(fn, ...) do { if (curve == CURVE_P256) point_launch<CURVE_P256>::fn(__VA_ARGS__); else point_launch<CURVE_SECP256K1>::fn(__VA_ARGS__); } while (0)
 void from_affine(hipStream_t s, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n) { DISPATCH(from_affine, s, x, y, jx, jy, jz, n); }
 void to_affine(hipStream_t s, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n) { DISPATCH(to_affine, s, jx, jy, jz, x, y, n); }
 void compute_y(hipStream_t s, int curve, const uint64_t* x, uint64_t* y, uint8_t* ok, size_t n) { DISPATCH(compute_y, s, x, y, ok, n); }
@@ -42,19 +46,20 @@ void zdau(hipStream_t s, int curve, const uint64_t* px, const uint64_t* py, cons
 void add_z2_1(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH(add_z2_1, s, ax, ay, az, bx, by, rx, ry, rz, n); }
 void trplu(hipStream_t s, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH(trplu, s, px, py, pz, rx, ry, rz, n); }
 void scalar_mult(hipStream_t s, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) { DISPATCH(scalar_mult, s, k, k_stride, x, y, ox, oy, oz, n, flags); }
-void to_affine_batched(hipStream_t s, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool in_fast) { DISPATCH(to_affine_batched, s, jx, jy, jz, x, y, n, in_fast); }
-void pack_table(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table, s, tx, ty, table); }
-void pack_table_signed(hipStream_t s, int curve, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table_signed, s, wbits, tx, ty, table); }
-void base_windowed_signed(hipStream_t s, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed_signed, s, wbits, k, table, ox, oy, oz, n); }
-void inverse_batched(hipStream_t s, int curve, const uint64_t* a, uint64_t* out, size_t n) { DISPATCH(inverse_batched, s, a, out, n); }
-void x_mod_n_equals(hipStream_t s, int curve, const uint64_t* x, const uint8_t* finite, const uint64_t* r, uint8_t* ok, size_t n) { DISPATCH(x_mod_n_equals, s, x, finite, r, ok, n); }
-void affine_add_batched(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) { DISPATCH(affine_add_batched, s, ax, ay, bx, by, rx, ry, finite, n); }
-void base_windowed(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed, s, k, table, ox, oy, oz, n); }
-void pack_table_big(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH(pack_table_big, s, tx, ty, table); }
-void base_windowed_big(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH(base_windowed_big, s, k, table, ox, oy, oz, n); }
-void add_mixed_complete(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH(add_mixed_complete, s, ax, ay, az, bx, by, rx, ry, rz, n); }
-void varwin_scalar_mult(hipStream_t s, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, int flags, uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n) { DISPATCH(varwin_scalar_mult, s, k, k_stride, x, y, flags, scratch, ox, oy, n); }
+void to_affine_batched(hipStream_t s, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool in_fast) { DISPATCH2(to_affine_batched, s, jx, jy, jz, x, y, n, in_fast); }
+void pack_table(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH2(pack_table, s, tx, ty, table); }
+void pack_table_signed(hipStream_t s, int curve, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH2(pack_table_signed, s, wbits, tx, ty, table); }
+void base_windowed_signed(hipStream_t s, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH2(base_windowed_signed, s, wbits, k, table, ox, oy, oz, n); }
+void inverse_batched(hipStream_t s, int curve, const uint64_t* a, uint64_t* out, size_t n) { DISPATCH2(inverse_batched, s, a, out, n); }
+void x_mod_n_equals(hipStream_t s, int curve, const uint64_t* x, const uint8_t* finite, const uint64_t* r, uint8_t* ok, size_t n) { DISPATCH2(x_mod_n_equals, s, x, finite, r, ok, n); }
+void affine_add_batched(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) { DISPATCH2(affine_add_batched, s, ax, ay, bx, by, rx, ry, finite, n); }
+void base_windowed(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH2(base_windowed, s, k, table, ox, oy, oz, n); }
+void pack_table_big(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH2(pack_table_big, s, tx, ty, table); }
+void base_windowed_big(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH2(base_windowed_big, s, k, table, ox, oy, oz, n); }
+void add_mixed_complete(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH2(add_mixed_complete, s, ax, ay, az, bx, by, rx, ry, rz, n); }
+void varwin_scalar_mult(hipStream_t s, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, int flags, uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n) { DISPATCH2(varwin_scalar_mult, s, k, k_stride, x, y, flags, scratch, ox, oy, n); }
 #undef DISPATCH
+#undef DISPATCH2
 } }
 
 // ================================================================== host side
@@ -70,6 +75,7 @@ struct ecsimd_hip_ctx {
   uint32_t* window16_table[2]; // per curve: signed BIG_WINDOW_BITS-bit windows in device memory (20 bits: 13 x 524 288 entries, 436 MB)
   uint64_t* workspace;         // grow-only scratch for the windowed path's Jacobian intermediates
   size_t workspace_bytes;
+  int ref_square;              // ecsimd_hip_set_ref_square_compat: the reference's square() as written (mul.h:160-212)
   char err[256];
 };
 
@@ -185,6 +191,14 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
 
 bool overlaps(const void* a, const void* b) { return a == b; }
 
+// The kernel instance an entry point runs: the API curve, or its reference-square twin (field.cuh) when the
+// context option or the call's ECSIMD_HIP_REF_SQUARE_COMPAT flag asks for the reference's bits.
+int instance(const ecsimd_hip_ctx* ctx, int curve, int flags = 0) {
+  return (ctx->ref_square || (flags & ECSIMD_HIP_REF_SQUARE_COMPAT)) ? curve + (CURVE_P256_REFSQR - CURVE_P256) : curve;
+}
+static_assert(CURVE_SECP256K1_REFSQR - CURVE_SECP256K1 == CURVE_P256_REFSQR - CURVE_P256, "instance() adds one offset");
+#define NO_COMPAT(what) do { if (ctx->ref_square || (flags & ECSIMD_HIP_REF_SQUARE_COMPAT)) return bad(ctx, what " is not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT form"); } while (0)
+
 // The reference ladder, then (for OUT_AFFINE) one simultaneous inversion over the whole batch.
 int run_ladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y,
                uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
@@ -196,10 +210,13 @@ int run_ladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, 
     int rc = ensure_workspace(ctx, 3 * n * 32);
     if (rc != ECSIMD_HIP_OK) return rc;
     uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
-    launch::scalar_mult(ctx->stream, curve, k, k_stride, x, y, jx, jy, jz, n, flags);
-    launch::to_affine_batched(ctx->stream, curve, jx, jy, jz, ox, oy, n, true);
+    const int cv = instance(ctx, curve, flags);
+    launch::scalar_mult(ctx->stream, cv, k, k_stride, x, y, jx, jy, jz, n, flags);
+    // reference-square instances: to_affine() per element with the reference's own power ladder (gfp.h:42-44)
+    if (cv != curve) launch::to_affine(ctx->stream, cv, jx, jy, jz, ox, oy, n);
+    else launch::to_affine_batched(ctx->stream, curve, jx, jy, jz, ox, oy, n, true);
   } else {
-    launch::scalar_mult(ctx->stream, curve, k, k_stride, x, y, ox, oy, oz, n, flags);
+    launch::scalar_mult(ctx->stream, instance(ctx, curve, flags), k, k_stride, x, y, ox, oy, oz, n, flags);
   }
   e = hipGetLastError();
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult launch");
@@ -241,7 +258,7 @@ int ecsimd_hip_init(int device, ecsimd_hip_ctx** out) {
   ecsimd_hip_ctx* ctx = new (std::nothrow) ecsimd_hip_ctx();
   if (!ctx) return ECSIMD_HIP_ERR_HIP;
   ctx->device = device; ctx->cus = prop.multiProcessorCount; ctx->err[0] = 0; ctx->sink = nullptr;
-  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->window6_table[0] = ctx->window6_table[1] = nullptr; ctx->window16_table[0] = ctx->window16_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0;
+  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->window6_table[0] = ctx->window6_table[1] = nullptr; ctx->window16_table[0] = ctx->window16_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0; ctx->ref_square = 0;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ECSIMD_HIP_ERR_HIP; }
   ctx->stream = ctx->own_stream;
   if (hipEventCreateWithFlags(&ctx->handoff, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ECSIMD_HIP_ERR_HIP; }
@@ -280,6 +297,7 @@ static int switch_stream(ecsimd_hip_ctx* ctx, hipStream_t next) {
 }
 int ecsimd_hip_set_stream(ecsimd_hip_ctx* ctx, void* s) { REQUIRE_CTX(); return switch_stream(ctx, (hipStream_t)s); }
 int ecsimd_hip_use_own_stream(ecsimd_hip_ctx* ctx) { REQUIRE_CTX(); return switch_stream(ctx, ctx->own_stream); }
+int ecsimd_hip_set_ref_square_compat(ecsimd_hip_ctx* ctx, int on) { REQUIRE_CTX(); ctx->ref_square = on ? 1 : 0; return ECSIMD_HIP_OK; }
 int ecsimd_hip_sync(ecsimd_hip_ctx* ctx) {
   REQUIRE_CTX();
   hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -381,7 +399,7 @@ int ecsimd_hip_shift_left_one(ecsimd_hip_ctx* ctx, const uint64_t* a, uint64_t* 
 int ecsimd_hip_mul(ecsimd_hip_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out8, size_t n) {
   REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out8); RUN(launch::mul(s, a, b, out8, n)); }
 int ecsimd_hip_square(ecsimd_hip_ctx* ctx, const uint64_t* a, uint64_t* out8, size_t n) {
-  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(out8); RUN(launch::square(s, a, out8, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(out8); RUN(launch::square(s, a, out8, n, ctx->ref_square != 0)); }
 int ecsimd_hip_swap_if(ecsimd_hip_ctx* ctx, const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n) {
   REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); if (!mask && n) return bad(ctx, "mask is null"); RUN(launch::swap_if(s, mask, a, b, n)); }
 
@@ -400,65 +418,66 @@ int ecsimd_hip_sec1_decode(ecsimd_hip_ctx* ctx, int curve, const uint8_t* in, ui
 
 // ---- L3
 int ecsimd_hip_mod_add(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, curve, launch::F_MOD_ADD, a, b, out, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, instance(ctx, curve), launch::F_MOD_ADD, a, b, out, n)); }
 int ecsimd_hip_mod_sub(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, curve, launch::F_MOD_SUB, a, b, out, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, instance(ctx, curve), launch::F_MOD_SUB, a, b, out, n)); }
 int ecsimd_hip_mod_mul(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::mod_mul(s, curve, a, b, out, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::mod_mul(s, instance(ctx, curve), a, b, out, n)); }
 int ecsimd_hip_mod_shift_left(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, int count, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); if (count < 1) return bad(ctx, "count < 1"); RUN(launch::mod_shift_left(s, curve, a, count, out, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); if (count < 1) return bad(ctx, "count < 1"); RUN(launch::mod_shift_left(s, instance(ctx, curve), a, count, out, n)); }
 int ecsimd_hip_mgry_reduce(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a8, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a8); REQUIRE_PTR(out); RUN(launch::mgry_reduce(s, curve, a8, out, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a8); REQUIRE_PTR(out); RUN(launch::mgry_reduce(s, instance(ctx, curve), a8, out, n)); }
 int ecsimd_hip_mgry_mul(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, curve, launch::F_MGRY_MUL, a, b, out, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, instance(ctx, curve), launch::F_MGRY_MUL, a, b, out, n)); }
 int ecsimd_hip_mgry_sqr(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, curve, launch::F_MGRY_SQR, a, out, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, instance(ctx, curve), launch::F_MGRY_SQR, a, out, n)); }
 int ecsimd_hip_mgry_from_classical(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, curve, launch::F_FROM_CLASSICAL, a, out, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, instance(ctx, curve), launch::F_FROM_CLASSICAL, a, out, n)); }
 int ecsimd_hip_mgry_to_classical(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, curve, launch::F_TO_CLASSICAL, a, out, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, instance(ctx, curve), launch::F_TO_CLASSICAL, a, out, n)); }
 int ecsimd_hip_mgry_pow(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t exponent[4], uint64_t* out, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); if (!exponent) return bad(ctx, "exponent is null");
   launch::words8 e; for (int i = 0; i < 4; ++i) { e.w[2 * i] = (uint32_t)exponent[i]; e.w[2 * i + 1] = (uint32_t)(exponent[i] >> 32); }
-  RUN(launch::mgry_pow(s, curve, a, e, out, n)); }
+  RUN(launch::mgry_pow(s, instance(ctx, curve), a, e, out, n)); }
 int ecsimd_hip_gfp_inverse(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out);
   // one inversion per ~64 elements (Montgomery's trick, out[] as scratch) unless the call is in place
-  if (overlaps(out, a)) RUN(launch::field_unop(s, curve, launch::F_INVERSE, a, out, n));
+  // (the reference-square instances raise to p - 2 per element, squaring by squaring as the reference does)
+  if (overlaps(out, a) || ctx->ref_square) RUN(launch::field_unop(s, instance(ctx, curve), launch::F_INVERSE, a, out, n));
   RUN(launch::inverse_batched(s, curve, a, out, n)); }
 int ecsimd_hip_gfp_opposite(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, curve, launch::F_OPPOSITE, a, out, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, instance(ctx, curve), launch::F_OPPOSITE, a, out, n)); }
 int ecsimd_hip_gfp_sqrt(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::gfp_sqrt(s, curve, a, out, ok, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::gfp_sqrt(s, instance(ctx, curve), a, out, ok, n)); }
 
 // ---- L4/L5
 int ecsimd_hip_from_affine(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); RUN(launch::from_affine(s, curve, x, y, jx, jy, jz, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); RUN(launch::from_affine(s, instance(ctx, curve), x, y, jx, jy, jz, n)); }
 int ecsimd_hip_to_affine(ecsimd_hip_ctx* ctx, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); REQUIRE_PTR(x); REQUIRE_PTR(y);
   // Simultaneous inversion uses x[] as scratch: only when the outputs do not alias the inputs.
   const bool alias = overlaps(x, jx) || overlaps(x, jy) || overlaps(x, jz) || overlaps(y, jx) || overlaps(y, jy) || overlaps(y, jz) || overlaps(x, y);
-  if (alias) RUN(launch::to_affine(s, curve, jx, jy, jz, x, y, n));
+  if (alias || ctx->ref_square) RUN(launch::to_affine(s, instance(ctx, curve), jx, jy, jz, x, y, n));
   RUN(launch::to_affine_batched(s, curve, jx, jy, jz, x, y, n, false)); }
 int ecsimd_hip_compute_y(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, uint64_t* y, uint8_t* ok, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); RUN(launch::compute_y(s, curve, x, y, ok, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); RUN(launch::compute_y(s, instance(ctx, curve), x, y, ok, n)); }
 int ecsimd_hip_dblu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz); RUN(launch::dblu(s, curve, px, py, pz, rx, ry, rz, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz); RUN(launch::dblu(s, instance(ctx, curve), px, py, pz, rx, ry, rz, n)); }
 int ecsimd_hip_zaddu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, const uint64_t* ox, const uint64_t* oy, const uint64_t* oz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(ox); REQUIRE_PTR(oy); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
   (void)oz;   // co-Z: O.z == P.z by precondition (curve_group.h:92)
-  RUN(launch::zaddu(s, curve, px, py, pz, ox, oy, rx, ry, rz, n)); }
+  RUN(launch::zaddu(s, instance(ctx, curve), px, py, pz, ox, oy, rx, ry, rz, n)); }
 int ecsimd_hip_zdau(ecsimd_hip_ctx* ctx, int curve, const uint64_t* px, const uint64_t* py, const uint64_t* pz, uint64_t* qx, uint64_t* qy, uint64_t* qz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(qz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
-  RUN(launch::zdau(s, curve, px, py, pz, qx, qy, qz, rx, ry, rz, n)); }
+  RUN(launch::zdau(s, instance(ctx, curve), px, py, pz, qx, qy, qz, rx, ry, rz, n)); }
 int ecsimd_hip_add_z2_1(ecsimd_hip_ctx* ctx, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(ax); REQUIRE_PTR(ay); REQUIRE_PTR(az); REQUIRE_PTR(bx); REQUIRE_PTR(by); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
-  RUN(launch::add_z2_1(s, curve, ax, ay, az, bx, by, rx, ry, rz, n)); }
+  RUN(launch::add_z2_1(s, instance(ctx, curve), ax, ay, az, bx, by, rx, ry, rz, n)); }
 int ecsimd_hip_add_mixed_complete(ecsimd_hip_ctx* ctx, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(ax); REQUIRE_PTR(ay); REQUIRE_PTR(az); REQUIRE_PTR(bx); REQUIRE_PTR(by); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
   RUN(launch::add_mixed_complete(s, curve, ax, ay, az, bx, by, rx, ry, rz, n)); }
 int ecsimd_hip_trplu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz); RUN(launch::trplu(s, curve, px, py, pz, rx, ry, rz, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz); RUN(launch::trplu(s, instance(ctx, curve), px, py, pz, rx, ry, rz, n)); }
 
 int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_PTR(oy);
@@ -467,6 +486,7 @@ int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, co
     // per-lane window tables (8 multiples of P) in HBM + signed 4-bit windows (k_varwin.inc): a different algorithm from
     // the reference ladder, so affine output only (SURVEY.md 8(a) level A)
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
+    NO_COMPAT("ALG_WINDOWED");
     return run_varwin(ctx, curve, k, 4, x, y, ox, oy, n, flags, 0);
   }
   return run_ladder(ctx, curve, k, 4, x, y, ox, oy, oz, n, flags); }
@@ -480,6 +500,7 @@ int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[
   store_words(ctx->stream, w, kdev);
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED)) {
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
+    NO_COMPAT("ALG_WINDOWED");
     return run_varwin(ctx, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, n, flags, 0);
   }
   return run_ladder(ctx, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, oz, n, flags); }
@@ -492,6 +513,7 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* 
     // windows over a precomputed table, then one simultaneous inversion: affine output only
     // (the Jacobian representative differs from the reference ladder's -- SURVEY.md 8(a) level A).
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
+    NO_COMPAT("ALG_WINDOWED");
     if (n == 0) return ECSIMD_HIP_OK;
     (void)hipSetDevice(ctx->device);
     int rc = ensure_window_table(ctx, curve, big ? launch::BIG_WINDOW_BITS : six ? SIGNED_WBITS : 4);

@@ -23,7 +23,12 @@ namespace ecsimd_hip {
 // kept in the CLASSICAL domain (x instead of x*R), where p = 2^256 - 2^32 - 977 allows a
 // pseudo-Mersenne reduction.  x -> x*R is a field isomorphism, so a formula evaluated in either
 // domain yields the same element; kernels convert at their boundary and the C ABI never sees it.
-enum : int { CURVE_P256 = 0, CURVE_SECP256K1 = 1, CURVE_SECP256K1_CLASSICAL = 2 };
+//
+// CURVE_*_REFSQR (ECSIMD_HIP_REF_SQUARE_COMPAT): the same curves with the reference's square() as it is written,
+// mul.h:160-212 -- including the carry it drops at mul.h:186-190 (its own "TODO: carry?", mul.h:207).  Opt-in, for
+// callers that need the reference's bits on the ~3e-6 of scalar multiplications where square(a) != mul(a, a).
+// The dropped carry depends on the Montgomery-form digits, so these instances stay in the Montgomery domain.
+enum : int { CURVE_P256 = 0, CURVE_SECP256K1 = 1, CURVE_SECP256K1_CLASSICAL = 2, CURVE_P256_REFSQR = 3, CURVE_SECP256K1_REFSQR = 4 };
 
 struct fe { uint32_t w[8]; };                  // little-endian 32-bit words
 struct fe2 { uint32_t w[16]; };                // 512-bit product
@@ -71,8 +76,15 @@ template <> struct curve_consts<CURVE_SECP256K1_CLASSICAL> {
   static constexpr uint32_t GY[8]   = {0xfb10d4b8u, 0x9c47d08fu, 0xa6855419u, 0xfd17b448u, 0x0e1108a8u, 0x5da4fbfcu, 0x26a3c465u, 0x483ada77u};
   static constexpr uint32_t MPRIME  = 0u;                             // unused
 };
+template <> struct curve_consts<CURVE_P256_REFSQR> : curve_consts<CURVE_P256> {};
+template <> struct curve_consts<CURVE_SECP256K1_REFSQR> : curve_consts<CURVE_SECP256K1> {};
 template <int CURVE> struct curve_domain { static constexpr int fast = CURVE; };                       // domain the hot loops run in
 template <> struct curve_domain<CURVE_SECP256K1> { static constexpr int fast = CURVE_SECP256K1_CLASSICAL; };
+// which prime / which squaring an instance uses
+template <int CURVE> struct curve_prime {
+  static constexpr bool is_p256 = (CURVE == CURVE_P256 || CURVE == CURVE_P256_REFSQR);
+  static constexpr bool ref_square = (CURVE == CURVE_P256_REFSQR || CURVE == CURVE_SECP256K1_REFSQR);
+};
 
 template <int CURVE, const uint32_t (&ARR)[8]> ECS_DEV fe fe_const() {
   fe r;
@@ -189,15 +201,23 @@ ECS_DEV uint32_t sub8(fe& a, const fe& b) {
 }
 
 // r = (r + top*2^256 >= p) ? r - p : r, for r + top*2^256 < 2p.               sub.h:46-69
-// `top` (the 257th bit) is a lane mask.  r - p over 8 words leaves the borrow in VCC; r is kept where
-// (borrow and not top) -- one scalar s_andn2_b64 instead of a ninth VALU subtraction -- and the select
-// uses that SGPR-pair mask (v_cndmask with an SGPR mask issues at 4.1 cycles; the implicit-VCC form
-// measured slower).
-template <int CURVE> ECS_DEV void cond_sub_p(fe& r, lane_mask top) {
+// `top` (the 257th bit) is a lane mask.  Three forms, chosen by ECS_COND_SUB (all return the same canonical residue):
+//   0  r - p over 8 words, keep r where (borrow and not top) -- one scalar s_andn2_b64 -- and 8 v_cndmask by that
+//      SGPR-pair mask (4.3-4.9 cycles each at 2-4 waves per SIMD);
+//   1  the same subtraction, then the 8 results are MOVED over r under EXEC = the lanes that take them: v_mov_b32 issues
+//      at 2.6-3.6 cycles where v_cndmask takes a full-rate slot (profiles/r02/valu_issue_rates_gfx950.txt);
+//   2  the lanes with `top` set subtract p IN PLACE under EXEC (8 instructions, no temporaries, no selects); a lane
+//      without it needs the subtraction only when r >= p, which needs r[7] == 0xffffffff (both primes' top word) --
+//      2^-32 of the values -- so one v_cmp guards a wave-uniform branch to form 0.  Not constant-time in that 2^-32
+//      case: kept for the public-input kernels, never the ladder's default (INTEGRATION.md "timing").
+#ifndef ECS_COND_SUB
+#define ECS_COND_SUB 1
+#endif
+template <int CURVE> ECS_DEV void cond_sub_p_select(fe& r, lane_mask top) {
   using K = curve_consts<CURVE>;
   fe d;
   lane_mask keep;
-  if constexpr (CURVE == CURVE_P256) {
+  if constexpr (curve_prime<CURVE>::is_p256) {
     // p's words are the inline constants -1, -1, -1, 0, 0, 0, 1, -1
     asm("v_sub_co_u32 %0, vcc, %9, -1\n\t"
         "v_subb_co_u32 %1, vcc, %10, -1, vcc\n\t"
@@ -233,6 +253,92 @@ template <int CURVE> ECS_DEV void cond_sub_p(fe& r, lane_mask top) {
   for (int i = 0; i < 8; ++i)
     asm("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r.w[i]) : "v"(d.w[i]), "s"(keep));
 }
+// form 1: d = r - p, then r <- d under EXEC = (top or no borrow)
+template <int CURVE> ECS_DEV void cond_sub_p_move(fe& r, lane_mask top) {
+  using K = curve_consts<CURVE>;
+  fe d;
+  lane_mask save;
+#define ECS_MOVE_TAIL \
+        "s_orn2_b64 vcc, %17, vcc\n\t"                 /* take d where top or not borrow */ \
+        "s_and_saveexec_b64 %16, vcc\n\t" \
+        "v_mov_b32 %8, %0\n\tv_mov_b32 %9, %1\n\tv_mov_b32 %10, %2\n\tv_mov_b32 %11, %3\n\t" \
+        "v_mov_b32 %12, %4\n\tv_mov_b32 %13, %5\n\tv_mov_b32 %14, %6\n\tv_mov_b32 %15, %7\n\t" \
+        "s_mov_b64 exec, %16"
+#define ECS_MOVE_OUTS "=&v"(d.w[0]), "=&v"(d.w[1]), "=&v"(d.w[2]), "=&v"(d.w[3]), "=&v"(d.w[4]), "=&v"(d.w[5]), "=&v"(d.w[6]), "=&v"(d.w[7]), \
+        "+v"(r.w[0]), "+v"(r.w[1]), "+v"(r.w[2]), "+v"(r.w[3]), "+v"(r.w[4]), "+v"(r.w[5]), "+v"(r.w[6]), "+v"(r.w[7]), "=&s"(save)
+  if constexpr (curve_prime<CURVE>::is_p256) {
+    asm("v_sub_co_u32 %0, vcc, %8, -1\n\t"
+        "v_subb_co_u32 %1, vcc, %9, -1, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %10, -1, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %11, 0, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %12, 0, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %13, 0, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %14, 1, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %15, -1, vcc\n\t"
+        ECS_MOVE_TAIL
+        : ECS_MOVE_OUTS : "s"(top) : "vcc", "scc");
+  } else {
+    const uint32_t p0 = K::P[0], p1 = K::P[1];
+    asm("v_sub_co_u32 %0, vcc, %8, %18\n\t"
+        "v_subb_co_u32 %1, vcc, %9, %19, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %10, -1, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %11, -1, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %12, -1, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %13, -1, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %14, -1, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %15, -1, vcc\n\t"
+        ECS_MOVE_TAIL
+        : ECS_MOVE_OUTS : "s"(top), "v"(p0), "v"(p1) : "vcc", "scc");
+  }
+#undef ECS_MOVE_TAIL
+#undef ECS_MOVE_OUTS
+}
+// form 2: in place under EXEC = top, then the 2^-32 guard
+template <int CURVE> ECS_DEV void cond_sub_p_guard(fe& r, lane_mask top) {
+  using K = curve_consts<CURVE>;
+  lane_mask save, maybe;
+  if constexpr (curve_prime<CURVE>::is_p256) {
+    asm("s_and_saveexec_b64 %8, %10\n\t"
+        "v_sub_co_u32 %0, vcc, %0, -1\n\t"
+        "v_subb_co_u32 %1, vcc, %1, -1, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %2, -1, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %3, 0, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %4, 0, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %5, 0, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %6, 1, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %7, -1, vcc\n\t"
+        "s_mov_b64 exec, %8\n\t"
+        "v_cmp_eq_u32_e64 %9, %7, -1"
+        : "+v"(r.w[0]), "+v"(r.w[1]), "+v"(r.w[2]), "+v"(r.w[3]), "+v"(r.w[4]), "+v"(r.w[5]), "+v"(r.w[6]), "+v"(r.w[7]), "=&s"(save), "=&s"(maybe)
+        : "s"(top) : "vcc", "scc");
+  } else {
+    const uint32_t p0 = K::P[0], p1 = K::P[1];
+    asm("s_and_saveexec_b64 %8, %10\n\t"
+        "v_sub_co_u32 %0, vcc, %0, %11\n\t"
+        "v_subb_co_u32 %1, vcc, %1, %12, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %2, -1, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %3, -1, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %4, -1, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %5, -1, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %6, -1, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %7, -1, vcc\n\t"
+        "s_mov_b64 exec, %8\n\t"
+        "v_cmp_eq_u32_e64 %9, %7, -1"
+        : "+v"(r.w[0]), "+v"(r.w[1]), "+v"(r.w[2]), "+v"(r.w[3]), "+v"(r.w[4]), "+v"(r.w[5]), "+v"(r.w[6]), "+v"(r.w[7]), "=&s"(save), "=&s"(maybe)
+        : "s"(top), "v"(p0), "v"(p1) : "vcc", "scc");
+  }
+  // A lane that subtracted is below p now (its r[7] may still read 0xffffffff: the full form leaves it alone).
+  if (__builtin_expect(maybe != 0, 0)) cond_sub_p_select<CURVE>(r, 0);
+}
+template <int CURVE> ECS_DEV void cond_sub_p(fe& r, lane_mask top) {
+#if ECS_COND_SUB == 2
+  cond_sub_p_guard<CURVE>(r, top);
+#elif ECS_COND_SUB == 1
+  cond_sub_p_move<CURVE>(r, top);
+#else
+  cond_sub_p_select<CURVE>(r, top);
+#endif
+}
 // lane mask of (v != 0)
 ECS_DEV lane_mask mask_nonzero(uint32_t v) {
   lane_mask m;
@@ -248,38 +354,55 @@ template <int CURVE> ECS_DEV fe fe_add(const fe& x, const fe& b) {
   cond_sub_p<CURVE>(a, c);
   return a;
 }
-// (a - b) mod p: subtract, then add (p & borrow-mask).                     modular.h:24-41
+// (a - b) mod p: subtract, then add p where the subtraction borrowed.        modular.h:24-41
+// The add-back runs under EXEC = the borrow mask with p's words as inline constants: no mask word is ever built
+// (16 VALU instructions + 2 scalar ones; the masked-operand form took 18).
 template <int CURVE> ECS_DEV fe fe_sub(const fe& x, const fe& b) {
   fe a;
-  uint32_t m = sub8_3(a, x, b);
-  if constexpr (CURVE == CURVE_P256) {
-    uint32_t m1 = m & 1u;   // p & mask = {m, m, m, 0, 0, 0, m&1, m}
-    asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
-        "v_addc_co_u32 %1, vcc, %1, %8, vcc\n\t"
-        "v_addc_co_u32 %2, vcc, %2, %8, vcc\n\t"
+  lane_mask save;
+#define ECS_SUB_HEAD \
+      "v_sub_co_u32 %0, vcc, %9, %17\n\t" \
+      "v_subb_co_u32 %1, vcc, %10, %18, vcc\n\t" \
+      "v_subb_co_u32 %2, vcc, %11, %19, vcc\n\t" \
+      "v_subb_co_u32 %3, vcc, %12, %20, vcc\n\t" \
+      "v_subb_co_u32 %4, vcc, %13, %21, vcc\n\t" \
+      "v_subb_co_u32 %5, vcc, %14, %22, vcc\n\t" \
+      "v_subb_co_u32 %6, vcc, %15, %23, vcc\n\t" \
+      "v_subb_co_u32 %7, vcc, %16, %24, vcc\n\t" \
+      "s_and_saveexec_b64 %8, vcc\n\t"
+#define ECS_SUB_OPS \
+      : "=&v"(a.w[0]), "=&v"(a.w[1]), "=&v"(a.w[2]), "=&v"(a.w[3]), "=&v"(a.w[4]), "=&v"(a.w[5]), "=&v"(a.w[6]), "=&v"(a.w[7]), "=&s"(save) \
+      : "v"(x.w[0]), "v"(x.w[1]), "v"(x.w[2]), "v"(x.w[3]), "v"(x.w[4]), "v"(x.w[5]), "v"(x.w[6]), "v"(x.w[7]), \
+        "v"(b.w[0]), "v"(b.w[1]), "v"(b.w[2]), "v"(b.w[3]), "v"(b.w[4]), "v"(b.w[5]), "v"(b.w[6]), "v"(b.w[7])
+  if constexpr (curve_prime<CURVE>::is_p256) {
+    asm(ECS_SUB_HEAD
+        "v_add_co_u32 %0, vcc, -1, %0\n\t"
+        "v_addc_co_u32 %1, vcc, -1, %1, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, -1, %2, vcc\n\t"
         "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
         "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
         "v_addc_co_u32 %5, vcc, 0, %5, vcc\n\t"
-        "v_addc_co_u32 %6, vcc, %6, %9, vcc\n\t"
-        "v_addc_co_u32 %7, vcc, %7, %8, vcc"
-        : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(a.w[4]), "+v"(a.w[5]), "+v"(a.w[6]), "+v"(a.w[7])
-        : "v"(m), "v"(m1)
-        : "vcc");
+        "v_addc_co_u32 %6, vcc, 1, %6, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, -1, %7, vcc\n\t"
+        "s_mov_b64 exec, %8"
+        ECS_SUB_OPS : "vcc", "scc");
   } else {
     using K = curve_consts<CURVE>;
-    uint32_t m0 = m & K::P[0], m1 = m & K::P[1];   // p & mask = {m&p0, m&p1, m, m, m, m, m, m}
-    asm("v_add_co_u32 %0, vcc, %0, %9\n\t"
-        "v_addc_co_u32 %1, vcc, %1, %10, vcc\n\t"
-        "v_addc_co_u32 %2, vcc, %2, %8, vcc\n\t"
-        "v_addc_co_u32 %3, vcc, %3, %8, vcc\n\t"
-        "v_addc_co_u32 %4, vcc, %4, %8, vcc\n\t"
-        "v_addc_co_u32 %5, vcc, %5, %8, vcc\n\t"
-        "v_addc_co_u32 %6, vcc, %6, %8, vcc\n\t"
-        "v_addc_co_u32 %7, vcc, %7, %8, vcc"
-        : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(a.w[4]), "+v"(a.w[5]), "+v"(a.w[6]), "+v"(a.w[7])
-        : "v"(m), "v"(m0), "v"(m1)
-        : "vcc");
+    const uint32_t p0 = K::P[0], p1 = K::P[1];     // p = {p0, p1, -1, -1, -1, -1, -1, -1}
+    asm(ECS_SUB_HEAD
+        "v_add_co_u32 %0, vcc, %0, %25\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %26, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, -1, %2, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, -1, %3, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, -1, %4, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, -1, %5, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, -1, %6, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, -1, %7, vcc\n\t"
+        "s_mov_b64 exec, %8"
+        ECS_SUB_OPS, "v"(p0), "v"(p1) : "vcc", "scc");
   }
+#undef ECS_SUB_HEAD
+#undef ECS_SUB_OPS
   return a;
 }
 // 2a mod p                                                                 modular.h:17-22
@@ -452,6 +575,43 @@ ECS_DEV fe2 sqr8(const fe& a) {
   return t;
 }
 
+// The reference's square() AS WRITTEN (mul.h:160-212 square_u32_zext between zext_u32x64 and trunc_u64x32): operand
+// scanning on 32-bit digits held in 64-bit lanes, the cross products doubled one by one.  At mul.h:186-190 the sum
+// 2*a_i*a_j + ret + prevs[0] can exceed 2^64 and the lane wraps (the reference's "TODO: carry?", mul.h:207); the
+// digits are truncated to 32 bits at the end (mul.h:100-107).  uint64_t arithmetic wraps exactly like the AVX2
+// lanes do, so this returns the reference's bits on every input -- including the ones where they are not a^2.
+// Only the ECSIMD_HIP_REF_SQUARE_COMPAT instances use it (curve_prime<C>::ref_square); it is ~3x sqr8's cost.
+ECS_DEV fe2 sqr8_ref(const fe& a) {
+  uint64_t ret[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ret[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint64_t t = (uint64_t)a.w[i] * a.w[i];
+    t += ret[2 * i];
+    ret[2 * i] = t & 0xffffffffu;
+    uint64_t prevs0 = t >> 32, prevs1 = 0;
+#pragma unroll
+    for (int j = i + 1; j < 8; ++j) {
+      uint64_t u = (uint64_t)a.w[i] * a.w[j];
+      const uint64_t carry = u >> 63;
+      u <<= 1;
+      u += ret[i + j];
+      u += prevs0;                         // may wrap: the reference's dropped carry
+      ret[i + j] = u & 0xffffffffu;
+      prevs0 = prevs1;
+      prevs0 += u >> 32;
+      prevs1 = carry;
+    }
+    ret[i + 8] += prevs0;                  // mul.h:207
+    if (i + 9 < 16) ret[i + 9] = prevs1;
+  }
+  fe2 r;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r.w[i] = (uint32_t)ret[i];
+  return r;
+}
+
 // ---------------------------------------------------------------- Montgomery reduction
 // T * 2^-256 mod p, canonical.  Same value as mgry_mul.h:84-121 (8 rounds of 32-bit digits + one
 // conditional subtract); the word size and the use of the primes' special form differ, the
@@ -462,31 +622,64 @@ ECS_DEV fe2 sqr8(const fe& a) {
 // rounds; in each, with M = q*(2^64 - 2^32 + 1) (the p[3] limb 0xffffffff00000001 times q):
 //   t[o+3..o+4] += q,  t[o+6..o+9] += M,  carry out -> word o+10 (an SGPR lane mask, the carry-in of the next round's M).
 ECS_DEV fe mgry_reduce_p256(fe2& t) {
-  lane_mask cin = 0;                       // carry out of a round's chain, consumed as carry-IN by the next
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int o = 2 * r;
-    const uint32_t q0 = t.w[o], q1 = t.w[o + 1];
-    uint32_t m1, m2, m3;
-    asm("v_sub_co_u32 %0, vcc, %4, %3\n\t"          // M1 = q1 - q0
-        "v_subb_co_u32 %1, vcc, %3, %4, vcc\n\t"    // M2 = q0 - q1 - b
-        "v_subb_co_u32 %2, vcc, %4, 0, vcc"         // M3 = q1 - b
-        : "=&v"(m1), "=&v"(m2), "=&v"(m3) : "v"(q0), "v"(q1) : "vcc");
-    if (r > 0)                                       // M += cin * 2^64 (the previous chain's carry-out, weight of word o+8)
-      asm("v_addc_co_u32 %0, vcc, 0, %0, %2\n\t"
-          "v_addc_co_u32 %1, vcc, 0, %1, vcc"
-          : "+v"(m2), "+v"(m3) : "s"(cin) : "vcc");
-    asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
-        "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
-        "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
-        "v_addc_co_u32 %3, vcc, %3, %8, vcc\n\t"
-        "v_addc_co_u32 %4, vcc, %4, %10, vcc\n\t"
-        "v_addc_co_u32 %5, vcc, %5, %11, vcc\n\t"
-        "v_addc_co_u32 %6, %7, %6, %12, vcc"          // carry-out of the chain goes straight to an SGPR pair
-        : "+v"(t.w[o + 3]), "+v"(t.w[o + 4]), "+v"(t.w[o + 5]), "+v"(t.w[o + 6]), "+v"(t.w[o + 7]), "+v"(t.w[o + 8]), "+v"(t.w[o + 9]), "=&s"(cin)
-        : "v"(q0), "v"(q1), "v"(m1), "v"(m2), "v"(m3)
-        : "vcc");
-  }
+  // The four rounds are ONE asm statement: the compiler puts an s_nop between an inline-asm statement and a following
+  // instruction that reads a register it wrote (gfx950 forwarding-hazard workaround it cannot rule out for asm), and the
+  // statement-per-chain form paid 12 of them per reduction.  %0..%12 = t[3..15], %13..%15 = M1..M3, %16 = the chain
+  // carry (an SGPR pair: each round's carry-out is the next round's carry-in, the last one is the 257th bit),
+  // %17..%19 = t[0..2].
+  lane_mask cin;
+  uint32_t m1, m2, m3;
+  asm(
+      "v_sub_co_u32 %13, vcc, %18, %17\n\t"
+      "v_subb_co_u32 %14, vcc, %17, %18, vcc\n\t"
+      "v_subb_co_u32 %15, vcc, %18, 0, vcc\n\t"
+      "v_add_co_u32 %0, vcc, %0, %17\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %18, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %3, %17, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %4, %13, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %5, %14, vcc\n\t"
+      "v_addc_co_u32 %6, %16, %6, %15, vcc\n\t"
+      "v_sub_co_u32 %13, vcc, %0, %19\n\t"
+      "v_subb_co_u32 %14, vcc, %19, %0, vcc\n\t"
+      "v_subb_co_u32 %15, vcc, %0, 0, vcc\n\t"
+      "v_addc_co_u32 %14, vcc, 0, %14, %16\n\t"
+      "v_addc_co_u32 %15, vcc, 0, %15, vcc\n\t"
+      "v_add_co_u32 %2, vcc, %2, %19\n\t"
+      "v_addc_co_u32 %3, vcc, %3, %0, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %5, %19, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %6, %13, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, %7, %14, vcc\n\t"
+      "v_addc_co_u32 %8, %16, %8, %15, vcc\n\t"
+      "v_sub_co_u32 %13, vcc, %2, %1\n\t"
+      "v_subb_co_u32 %14, vcc, %1, %2, vcc\n\t"
+      "v_subb_co_u32 %15, vcc, %2, 0, vcc\n\t"
+      "v_addc_co_u32 %14, vcc, 0, %14, %16\n\t"
+      "v_addc_co_u32 %15, vcc, 0, %15, vcc\n\t"
+      "v_add_co_u32 %4, vcc, %4, %1\n\t"
+      "v_addc_co_u32 %5, vcc, %5, %2, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, %7, %1, vcc\n\t"
+      "v_addc_co_u32 %8, vcc, %8, %13, vcc\n\t"
+      "v_addc_co_u32 %9, vcc, %9, %14, vcc\n\t"
+      "v_addc_co_u32 %10, %16, %10, %15, vcc\n\t"
+      "v_sub_co_u32 %13, vcc, %4, %3\n\t"
+      "v_subb_co_u32 %14, vcc, %3, %4, vcc\n\t"
+      "v_subb_co_u32 %15, vcc, %4, 0, vcc\n\t"
+      "v_addc_co_u32 %14, vcc, 0, %14, %16\n\t"
+      "v_addc_co_u32 %15, vcc, 0, %15, vcc\n\t"
+      "v_add_co_u32 %6, vcc, %6, %3\n\t"
+      "v_addc_co_u32 %7, vcc, %7, %4, vcc\n\t"
+      "v_addc_co_u32 %8, vcc, 0, %8, vcc\n\t"
+      "v_addc_co_u32 %9, vcc, %9, %3, vcc\n\t"
+      "v_addc_co_u32 %10, vcc, %10, %13, vcc\n\t"
+      "v_addc_co_u32 %11, vcc, %11, %14, vcc\n\t"
+      "v_addc_co_u32 %12, %16, %12, %15, vcc"
+      : "+v"(t.w[3]), "+v"(t.w[4]), "+v"(t.w[5]), "+v"(t.w[6]), "+v"(t.w[7]), "+v"(t.w[8]), "+v"(t.w[9]), "+v"(t.w[10]),
+        "+v"(t.w[11]), "+v"(t.w[12]), "+v"(t.w[13]), "+v"(t.w[14]), "+v"(t.w[15]), "=&v"(m1), "=&v"(m2), "=&v"(m3), "=&s"(cin)
+      : "v"(t.w[0]), "v"(t.w[1]), "v"(t.w[2])
+      : "vcc");
   fe res;
 #pragma unroll
   for (int i = 0; i < 8; ++i) res.w[i] = t.w[8 + i];
@@ -580,7 +773,7 @@ ECS_DEV fe reduce_secp256k1_classical(fe2& t) {
 }
 
 template <int CURVE> ECS_DEV fe mgry_reduce(fe2& t) {
-  if constexpr (CURVE == CURVE_P256) return mgry_reduce_p256(t);
+  if constexpr (curve_prime<CURVE>::is_p256) return mgry_reduce_p256(t);
   else if constexpr (CURVE == CURVE_SECP256K1_CLASSICAL) return reduce_secp256k1_classical(t);
   else return mgry_reduce_generic<CURVE>(t);
 }
@@ -592,12 +785,13 @@ template <int CURVE> ECS_DEV fe fe_mul(const fe& a, const fe& b) {
 }
 // a*a*R^-1 mod p                                                           mgry_ops.h:37-42
 template <int CURVE> ECS_DEV fe fe_sqr(const fe& a) {
-  fe2 t = sqr8(a);
+  fe2 t;
+  if constexpr (curve_prime<CURVE>::ref_square) t = sqr8_ref(a); else t = sqr8(a);
   return mgry_reduce<CURVE>(t);
 }
 // n*R mod p = mgry_reduce(n * (R^2 mod p))                                 mgry.h:47-50
 template <int CURVE> ECS_DEV fe fe_from_classical(const fe& n) {
-  if constexpr (CURVE == CURVE_SECP256K1) {
+  if constexpr (CURVE == CURVE_SECP256K1 || CURVE == CURVE_SECP256K1_REFSQR) {
     // R = 2^256 = 2^32 + 977 (mod p): n*R mod p is the pseudo-Mersenne fold of n * 2^256 -- the classical reduction applied to
     // the 512-bit value (hi = n, lo = 0).  Same canonical residue as the Montgomery route, 61 instructions instead of 373.
     fe2 t;

@@ -31,8 +31,8 @@ __global__ void __launch_bounds__(BLOCK) k_shift_left_one(const uint64_t* a, uin
 __global__ void __launch_bounds__(BLOCK) k_mul(const uint64_t* a, const uint64_t* b, uint64_t* out8, size_t n) {
   GID; fe2_store(out8, i, mul8x8(fe_load(a, i), fe_load(b, i)));
 }
-__global__ void __launch_bounds__(BLOCK) k_square(const uint64_t* a, uint64_t* out8, size_t n) {
-  GID; fe2_store(out8, i, sqr8(fe_load(a, i)));
+template <bool REF> __global__ void __launch_bounds__(BLOCK) k_square(const uint64_t* a, uint64_t* out8, size_t n) {
+  GID; if constexpr (REF) fe2_store(out8, i, sqr8_ref(fe_load(a, i))); else fe2_store(out8, i, sqr8(fe_load(a, i)));
 }
 __global__ void __launch_bounds__(BLOCK) k_swap_if(const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n) {
   GID; fe x = fe_load(a, i), y = fe_load(b, i);
@@ -106,7 +106,7 @@ void sub(hipStream_t s, const uint64_t* a, const uint64_t* b, uint64_t* out, uin
 void sub_if_above(hipStream_t s, const uint64_t* a, const uint64_t* p, uint64_t* out, size_t n) { GO(k_sub_if_above, a, p, out, n); }
 void shift_left_one(hipStream_t s, const uint64_t* a, uint64_t* out, uint8_t* carry, size_t n) { GO(k_shift_left_one, a, out, carry, n); }
 void mul(hipStream_t s, const uint64_t* a, const uint64_t* b, uint64_t* out8, size_t n) { GO(k_mul, a, b, out8, n); }
-void square(hipStream_t s, const uint64_t* a, uint64_t* out8, size_t n) { GO(k_square, a, out8, n); }
+void square(hipStream_t s, const uint64_t* a, uint64_t* out8, size_t n, bool ref_compat) { if (ref_compat) GO(k_square<true>, a, out8, n); else GO(k_square<false>, a, out8, n); }
 void swap_if(hipStream_t s, const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n) { GO(k_swap_if, mask, a, b, n); }
 void cmp_eq(hipStream_t s, const uint64_t* a, const uint64_t* b, int limbs, uint8_t* flag, size_t n) { GO(k_cmp_eq, a, b, limbs, flag, n); }
 void mask_op(hipStream_t s, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) { GO(k_mask_op, op, a, b, out, n); }

@@ -55,8 +55,11 @@ template <int C> __global__ void __launch_bounds__(BLOCK) k_sqrt(const uint64_t*
 
 namespace launch {
 #define GO(kern, ...) hipLaunchKernelGGL(kern, grid_for(n), dim3(BLOCK), 0, s, __VA_ARGS__)
-#define BY_CURVE(kern, ...) do { if (curve == CURVE_P256) GO((kern<CURVE_P256>), __VA_ARGS__); else GO((kern<CURVE_SECP256K1>), __VA_ARGS__); } while (0)
-#define BY_CURVE_OP(kern, OP, ...) do { if (curve == CURVE_P256) GO((kern<CURVE_P256, OP>), __VA_ARGS__); else GO((kern<CURVE_SECP256K1, OP>), __VA_ARGS__); } while (0)
+// curve: the two API curves and their ECSIMD_HIP_REF_SQUARE_COMPAT instances (field.cuh)
+#define BY_CURVE(kern, ...) do { switch (curve) { case CURVE_P256: GO((kern<CURVE_P256>), __VA_ARGS__); break; case CURVE_SECP256K1: GO((kern<CURVE_SECP256K1>), __VA_ARGS__); break; \
+    case CURVE_P256_REFSQR: GO((kern<CURVE_P256_REFSQR>), __VA_ARGS__); break; default: GO((kern<CURVE_SECP256K1_REFSQR>), __VA_ARGS__); break; } } while (0)
+#define BY_CURVE_OP(kern, OP, ...) do { switch (curve) { case CURVE_P256: GO((kern<CURVE_P256, OP>), __VA_ARGS__); break; case CURVE_SECP256K1: GO((kern<CURVE_SECP256K1, OP>), __VA_ARGS__); break; \
+    case CURVE_P256_REFSQR: GO((kern<CURVE_P256_REFSQR, OP>), __VA_ARGS__); break; default: GO((kern<CURVE_SECP256K1_REFSQR, OP>), __VA_ARGS__); break; } } while (0)
 
 void field_binop(hipStream_t s, int curve, field_op op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
   switch (op) {

@@ -28,7 +28,7 @@ template <int C> ECS_DEV void dblu(fe& x, fe& y, fe& rx, fe& ry, fe& z) {
   t = fe_sub<C>(fe_sub<C>(t, B), L);
   const fe S = fe_dbl<C>(t);
   fe M = fe_add<C>(fe_dbl<C>(B), B);
-  if constexpr (C != CURVE_P256) { /* secp256k1, a = 0: M = 3B + 0 */ } else { M = fe_add<C>(M, FE_CONST(C, AM)); }
+  if constexpr (!curve_prime<C>::is_p256) { /* secp256k1, a = 0: M = 3B + 0 */ } else { M = fe_add<C>(M, FE_CONST(C, AM)); }
   rx = fe_sub<C>(fe_sqr<C>(M), fe_dbl<C>(S));
   const fe Lm8 = fe_shl<C, 3>(L);
   ry = fe_sub<C>(fe_mul<C>(M, fe_sub<C>(S, rx)), Lm8);
@@ -55,8 +55,15 @@ template <int C> ECS_DEV void zaddu(fe& x1, fe& y1, const fe& x2, const fe& y2, 
 }
 
 // curve_group.h:120-153 ZDAU: (x1,y1) <- 2*(x1,y1) + (x2,y2); (x2,y2) re-expressed with the new z.
-// 9M + 7S.
-template <int C> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe& y2, fe& z) {
+// 9M + 7S.  Same field values as the reference's DAG, with three things computed once instead of twice:
+//   * u = X3' - W1' and W1 + W2 (shared sub-expressions);
+//   * 4*X3'*C and 4*W1'*C quadruple C once;
+//   * Y3' + 2A1' (the reference's curve_group.h:146) IS (dy + W1' - X3')^2 - D' - C: the term it adds back is the
+//     one Y3' just subtracted, and both are canonical residues of the same element -- so it is taken, not recomputed.
+// `oswap` (a per-lane all-ones / all-zeros word) exchanges the two OUTPUT points: (x1,y1) and (x2,y2) are
+// (ym^2 - W12, ym*(W1 - x) - A1) and the same with yp, so swapping the outputs is swapping (ym, yp) -- one
+// field-element swap instead of two.  The ladder folds its per-bit swaps into it; the point kernel passes 0.
+template <int C> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe& y2, fe& z, uint32_t oswap = 0u) {
   const fe dx = fe_sub<C>(x1, x2);
   const fe Cp = fe_sqr<C>(dx);
   const fe W1p = fe_mul<C>(x1, Cp);
@@ -69,23 +76,24 @@ template <int C> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe& y2, fe& z) {
   const fe Cc = fe_sqr<C>(u);
   const fe A1p2 = fe_dbl<C>(A1p);
   // Y3' = (dy + (W1' - X3'))^2 - D' - C - 2A1'
-  fe Y3p = fe_sqr<C>(fe_sub<C>(dy, u));
-  Y3p = fe_sub<C>(fe_sub<C>(fe_sub<C>(Y3p, Dp), Cc), A1p2);
+  fe yp = fe_sqr<C>(fe_sub<C>(dy, u));
+  yp = fe_sub<C>(fe_sub<C>(yp, Dp), Cc);                 // = Y3' + 2A1'
+  const fe Y3p = fe_sub<C>(yp, A1p2);
   // W1 = 4*X3'*C and W2 = 4*W1'*C: quadruple C once instead of X3' and W1' (same residues)
   const fe C4 = fe_shl<C, 2>(Cc);
   const fe W1 = fe_mul<C>(X3pc, C4);
   const fe W2 = fe_mul<C>(W1p, C4);
-  const fe ym = fe_sub<C>(Y3p, A1p2);
-  const fe D = fe_sqr<C>(ym);
+  fe ym = fe_sub<C>(Y3p, A1p2);
   const fe A1 = fe_mul<C>(Y3p, fe_sub<C>(W1, W2));
   const fe W12 = fe_add<C>(W1, W2);
   // Z3 = Z * ((dx + X3' - W1')^2 - C' - C)
   fe zz = fe_sqr<C>(fe_add<C>(dx, u));
   zz = fe_sub<C>(fe_sub<C>(zz, Cp), Cc);
   z = fe_mul<C>(z, zz);
+  fe_cswap(oswap, ym, yp);
+  const fe D = fe_sqr<C>(ym);
   x1 = fe_sub<C>(D, W12);
   y1 = fe_sub<C>(fe_mul<C>(ym, fe_sub<C>(W1, x1)), A1);
-  const fe yp = fe_add<C>(Y3p, A1p2);
   const fe Dc = fe_sqr<C>(yp);
   x2 = fe_sub<C>(Dc, W12);
   y2 = fe_sub<C>(fe_mul<C>(yp, fe_sub<C>(W1, x2)), A1);
@@ -150,6 +158,8 @@ template <> struct curve_exps<CURVE_SECP256K1> {
 };
 
 template <> struct curve_exps<CURVE_SECP256K1_CLASSICAL> : curve_exps<CURVE_SECP256K1> {};
+template <> struct curve_exps<CURVE_P256_REFSQR> : curve_exps<CURVE_P256> {};
+template <> struct curve_exps<CURVE_SECP256K1_REFSQR> : curve_exps<CURVE_SECP256K1> {};
 
 // secp256k1: p - 2 = [223 ones][0][22 ones][0000][1][0][11][0][1];  (p + 1)/4 = [223 ones][0][22 ones][0000][11][00]
 template <int C, bool SQRT> ECS_DEV fe secp256k1_pow_chain(const fe& x);
@@ -165,7 +175,10 @@ template <int C> ECS_DEV fe fe_sqr_n(fe a, int n) {
 // chains over the runs of ones give the same bits with 255 S + 12 M (P-256), 255 S + 15 M and 253 S + 13 M
 // (secp256k1, the chain libsecp256k1 documents).  Exponents checked against p - 2 and (p + 1)/4 symbolically.
 template <int C> ECS_DEV fe fe_inverse(const fe& x) {
-  if constexpr (C == CURVE_P256) {
+  if constexpr (curve_prime<C>::ref_square) {
+    // reference-compatible squaring: the squarings the reference performs, in its order (mgry_ops.h:44-86)
+    return fe_pow<C>(x, curve_exps<C>::P_M2);
+  } else if constexpr (C == CURVE_P256) {
     // p - 2 = [32 ones][31 zeros][1][96 zeros][94 ones][0][1]
     const fe x2 = fe_mul<C>(fe_sqr<C>(x), x);
     const fe x3 = fe_mul<C>(fe_sqr<C>(x2), x);
@@ -206,7 +219,7 @@ template <int C, bool SQRT> ECS_DEV fe secp256k1_pow_chain(const fe& x) {
   }
 }
 template <int C> ECS_DEV fe fe_sqrt_candidate(const fe& x) {        // a^((p+1)/4): a square root if there is one (p = 3 mod 4)
-  if constexpr (C == CURVE_P256) return fe_pow<C>(x, curve_exps<C>::P_SQRT);     // 253 S + 33 M: few set bits already
+  if constexpr (C == CURVE_P256 || curve_prime<C>::ref_square) return fe_pow<C>(x, curve_exps<C>::P_SQRT);     // 253 S + 33 M: few set bits already (and the reference's own sequence)
   else return secp256k1_pow_chain<C, true>(x);
 }
 
@@ -252,28 +265,23 @@ template <int C> ECS_DEV jpoint scalar_mult_ladder(const uint32_t* __restrict__ 
   }
   uint32_t kw = kwords[0];
   const uint32_t k0 = kw;
+  // The reference runs swap(m_1), then swap(m_b); ZDAU; swap(m_b) for b = 2..255 (curve_group.h:196-211; m_b =
+  // utility.h:45-51 wide_mask_bit of bit b).  Two swaps in a row compose into one by the XOR of their masks, and the
+  // swap after a ZDAU is folded into the ZDAU's own output (zdau's `oswap`): one field-element swap per bit.
+  uint32_t cur = 0u - ((kw >> 2) & 1u);                  // m_2
   {
-    const uint32_t m = 0u - ((kw >> 1) & 1u);
-    fe_cswap(m, px, bx);
+    const uint32_t m = (0u - ((kw >> 1) & 1u)) ^ cur;    // swap(m_1) then swap(m_2)
+    fe_cswap(m, px, bx);                                 // swap.h:47-56 swap_if_same_z
     fe_cswap(m, py, by);
   }
-  // Each iteration is swap(m); ZDAU; swap(m) in the reference (curve_group.h:206-210).  The second
-  // swap of iteration i and the first of iteration i+1 compose into ONE swap with mask m_i ^ m_{i+1}
-  // (swapping twice is the identity), which halves the select work without changing any value.
-  uint32_t prev = 0;
-  for (int w = 0; w < 8; ++w) {
-    if (w > 0) kw = kwords[w];
-    for (int b = (w == 0 ? 2 : 0); b < 32; ++b) {
-      const uint32_t m = 0u - ((kw >> b) & 1u);       // utility.h:45-51 wide_mask_bit
-      const uint32_t sw = m ^ prev;
-      fe_cswap(sw, px, bx);                            // swap.h:47-56 swap_if_same_z
-      fe_cswap(sw, py, by);
-      zdau<C>(bx, by, px, py, z);                      // base = ZDAU(base, P)
-      prev = m;
-    }
+#pragma unroll 1
+  for (int b = 2; b < 256; ++b) {
+    const int nb = b + 1;
+    if ((nb & 31) == 0) kw = (nb < 256) ? kwords[nb >> 5] : 0u;       // one word per 32 bits: the scalar is not kept in VGPRs
+    const uint32_t next = 0u - ((kw >> (nb & 31)) & 1u);              // m_(b+1); 0 after the last bit: the closing swap(m_255)
+    zdau<C>(bx, by, px, py, z, cur ^ next);                           // base = ZDAU(base, P), outputs swapped by m_b ^ m_(b+1)
+    cur = next;
   }
-  fe_cswap(prev, px, bx);
-  fe_cswap(prev, py, by);
   // even k: subtract the original point once (curve_group.h:214-217)
   const fe oppy = fe_opposite<C>(ym);                    // jacobian_curve_point.h:48-54 via gfp.h:60-64
   const jpoint Psub = add_z2_1<C>(px, py, z, xm, oppy);

@@ -22,7 +22,8 @@ class EcsimdHipError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libecsimd_hip.so")
+    # ECSIMD_HIP_LIBRARY: another build of the SAME library (tools/ compares kernel variants with it); never a fallback
+    return os.environ.get("ECSIMD_HIP_LIBRARY") or os.path.join(_HERE, "libecsimd_hip.so")
 
 
 _SYMBOLS = None
@@ -68,6 +69,7 @@ class Engine:
             raise EcsimdHipError(f"ecsimd_hip_init(device={device}) failed with {rc} "
                                  "(-2 = no gfx950 device visible; the HIP path has no CPU fallback)")
         self.tdev = torch.device("cuda", self.device)
+        self._rows = set()      # batch lengths of the tensors handed to the call being assembled (see _ptr / _call)
 
     def close(self):
         if self.ctx:
@@ -88,7 +90,7 @@ class Engine:
 
     def _bind_stream(self):
         s = self.torch.cuda.current_stream(self.tdev).cuda_stream
-        self.lib.ecsimd_hip_set_stream(self.ctx, C.c_void_p(s))
+        self._check(self.lib.ecsimd_hip_set_stream(self.ctx, C.c_void_p(s)), "set_stream")
 
     def _ptr(self, t, words=4, dtype_ok=None):
         torch = self.torch
@@ -100,6 +102,7 @@ class Engine:
             assert t.dtype in (torch.int64, torch.uint64) and t.dim() == 2 and t.shape[1] == words, (t.dtype, t.shape)
         else:
             assert t.dtype == torch.uint8 and t.dim() == 1
+        self._rows.add(int(t.shape[0]))
         return C.c_void_p(t.data_ptr())
 
     def empty(self, n, words=4):
@@ -119,8 +122,17 @@ class Engine:
         return a if a.dtype == np.uint8 else a.view(np.uint64)
 
     def _call(self, name, *args):
+        # The C ABI takes ONE length for all operands (in the reference it is a compile-time property of the type): a
+        # shorter tensor would be read or written out of bounds on the device, so it is refused here.
+        rows, self._rows = self._rows, set()
+        if len(rows) > 1:
+            raise EcsimdHipError(f"{name}: operands disagree on the batch length: {sorted(rows)}")
         self._bind_stream()
         self._check(getattr(self.lib, "ecsimd_hip_" + name)(self.ctx, *args), name)
+
+    def set_ref_square_compat(self, on: bool):
+        """ecsimd_hip_set_ref_square_compat: square like the reference's square() as written (mul.h:160-212)."""
+        self._check(self.lib.ecsimd_hip_set_ref_square_compat(self.ctx, C.c_int(int(bool(on)))), "set_ref_square_compat")
 
     def sync(self):
         self._bind_stream()

@@ -69,6 +69,11 @@ enum {
                                       table of m*2^(7i)*G (m = 1..64) in LDS, negative digits negate y; same results */
   ECSIMD_HIP_ALG_NO_ENDOMORPHISM = 16, /* secp256k1 + ALG_WINDOWED on a variable base splits k = k1 + k2*lambda (GLV) and runs
                                       half as many windows; this flag keeps the plain odd-digit loop of 63 windows (same results) */
+  ECSIMD_HIP_REF_SQUARE_COMPAT = 64, /* ladder only: square with the reference's square() AS WRITTEN (mul.h:160-212), which drops a
+                                      carry at mul.h:186-190 (its "TODO: carry?", mul.h:207) on ~2e-9 of random operands -- ~3e-6 of
+                                      random scalar multiplications then differ from the exact result.  With this flag (or the
+                                      context option below) the output is the reference's bits on EVERY input, at ~0.6x the speed;
+                                      without it, it is the exact k*P (what the reference's own tests assume) */
   ECSIMD_HIP_ALG_WINDOWED_BIG = 32 /* scalar_mult_base + OUT_AFFINE: 20-bit windows with odd digits over a 436 MB table of the odd
                                       multiples (2d+1)*2^(20i)*G (13 windows x 2^19 entries) in device memory, built on first
                                       use (0.23 s per curve): 12 mixed additions per scalar; same results */
@@ -87,6 +92,12 @@ int ecsimd_hip_set_stream(ecsimd_hip_ctx* ctx, void* hip_stream);
 /* Go back to the non-blocking stream the context created in ecsimd_hip_init (the default). */
 int ecsimd_hip_use_own_stream(ecsimd_hip_ctx* ctx);
 int ecsimd_hip_sync(ecsimd_hip_ctx* ctx);
+/* Reference-square compatibility for every entry point that evaluates the reference's own expression DAG and contains a
+ * squaring (square, mgry_sqr, mgry_pow, gfp_inverse, gfp_sqrt, compute_y, to_affine, DBLU ... TRPLU, the ladder):
+ * on != 0 makes them square with mul.h:160-212 as written, dropped carry included (see ECSIMD_HIP_REF_SQUARE_COMPAT), and
+ * walk exponents bit by bit as mgry_ops.h:44-86 does, so a caller gets the compiled reference's bits on every input.
+ * Off by default.  The windowed algorithms are not the reference's and refuse to run while it is on. */
+int ecsimd_hip_set_ref_square_compat(ecsimd_hip_ctx* ctx, int on);
 const char* ecsimd_hip_last_error(const ecsimd_hip_ctx* ctx);
 const char* ecsimd_hip_version(void);
 int ecsimd_hip_malloc(ecsimd_hip_ctx* ctx, void** dptr, size_t bytes);

@@ -67,8 +67,8 @@ class EngineNP:
 
     def add_z2_1(self, cv, a, bxy): return self._ptd(self.e.add_z2_1(cv, self._pt(a), self._pt(bxy)))
 
-    def scalar_mult(self, cv, k, x, y, threads=1, mgry_in=False, affine=False):
-        flags = (1 if mgry_in else 0) | (2 if affine else 0)
+    def scalar_mult(self, cv, k, x, y, threads=1, mgry_in=False, affine=False, ref_compat=False):
+        flags = (1 if mgry_in else 0) | (2 if affine else 0) | (64 if ref_compat else 0)
         return self._ptd(self.e.scalar_mult(cv, self._up(k), self._up(x), self._up(y), flags=flags))
 
     def scalar_mult_1s(self, cv, k1, x, y): return self._ptd(self.e.scalar_mult_1s(cv, k1, self._up(x), self._up(y)))

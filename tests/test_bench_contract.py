@@ -15,7 +15,7 @@ def test_bench_line_contract(path):
     d = json.load(open(path))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert key in d, key
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["higher_is_better"] is True and d["scaling"] in ("weak", "strong") and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - d["config"]["global_batch"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
     r = d["roofline"]
@@ -29,7 +29,21 @@ def test_bench_line_contract(path):
         for key in ("value", "unit", "cores", "kind", "sample"):
             assert key in c, key
         assert c["kind"] in ("reference", "port") and c["differences_all_explained_by_reference_square_defect"] is True
+        if "lanes_differing_confirmed_by_openssl" in c and c["lanes_differing_confirmed_by_openssl"] is not None:      # round 2 on
+            assert c["lanes_differing_confirmed_by_openssl"] == c["lanes_differing_from_gpu"]
+    assert "parity_failures" not in d
 
 
 def test_there_is_a_headline_line():
     assert any("ladder" in p and "secp" not in p for p in LINES)
+
+
+def test_bench_defaults_are_config_4_verbatim():
+    """BASELINE.json configs[3]: variable base, batch 2^24 over the GPUs of the node (strong scaling)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    a = bench.parse_args([])
+    assert (a.gpus, a.scaling, a.global_log2_batch, a.workload, a.curve) == (1, "strong", 24, "ladder", "p256")
+    from ecsimd_amd.shard import plan
+    assert plan(a.scaling, 1 << a.global_log2_batch, 5, 8) == (5 << 21, 1 << 21, 1 << 24, 1 << 21)

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from ecsimd_amd.shard import ShardedRunner, shard_range  # noqa: E402
+from ecsimd_amd.shard import ShardedRunner, shard_range, plan  # noqa: E402
 
 
 def test_shard_range_partitions_exactly():
@@ -28,6 +28,62 @@ def test_shard_range_partitions_exactly():
             for (f0, c0), (f1, _) in zip(spans, spans[1:]):
                 assert f0 + c0 == f1
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_strong_and_weak_plans_cover_the_global_index_space():
+    """bench.py --scaling strong / weak: every global index is owned by exactly one rank, BASELINE configs[3]
+    (2^24 over 8) gives 2^21 per GPU, and all ranks allocate the same number of result rows (a gather moves equal pieces)."""
+    assert [plan("strong", 1 << 24, r, 8)[:2] for r in (0, 3, 7)] == [(0, 1 << 21), (3 << 21, 1 << 21), (7 << 21, 1 << 21)]
+    assert plan("strong", 1 << 24, 0, 1) == (0, 1 << 24, 1 << 24, 1 << 24)
+    for scaling, units in (("strong", 1 << 24), ("strong", 1000003), ("strong", 7), ("weak", 1 << 22), ("weak", 5)):
+        for world in (1, 2, 3, 4, 6, 8):
+            plans = [plan(scaling, units, r, world) for r in range(world)]
+            total = plans[0][2]
+            assert total == (units if scaling == "strong" else units * world) and all(p[2] == total for p in plans)
+            assert len({p[3] for p in plans}) == 1 and all(p[1] <= p[3] for p in plans)
+            owned = sorted((p[0], p[0] + p[1]) for p in plans)
+            assert owned[0][0] == 0 and owned[-1][1] == total and all(a[1] == b[0] for a, b in zip(owned, owned[1:]))
+    with pytest.raises(ValueError):
+        plan("medium", 8, 0, 1)
+
+
+def _worker_uneven(rank, world, port, total, q):
+    """Strong scaling with a total the ranks do not divide: shorter shards leave their last buffer row unused."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        first, count, tot, rows = plan("strong", total, rank, world)
+        runner = ShardedRunner((rows, 4), torch.int64, "cpu", world, rank)
+        for step in range(3):
+            def compute(out):
+                out.zero_()
+                out[:count] = (torch.arange(first, first + count, dtype=torch.int64)[:, None] * 4 + torch.arange(4)) + 1000 * step
+            runner.step(compute)
+        runner.gather = False                        # compute-only steps must not disturb what rank 0 holds
+        runner.step(lambda out: out.fill_(-1))
+        runner.fence()
+        if rank == 0:
+            assert runner.received.shape == (world, rows, 4) and runner.gathered[1].data_ptr() == runner.received[1].data_ptr()
+            q.put(torch.cat([runner.gathered[r][:plan("strong", total, r, world)[1]] for r in range(world)]).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_strong_scaling_gather_with_uneven_shards():
+    world, total = 2, 101
+    port = 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = (np.arange(total, dtype=np.int64)[:, None] * 4 + np.arange(4)) + 2000
+    assert np.array_equal(got, exp)
 
 
 def _worker(rank, world, port, n_per_rank, steps, q):

@@ -11,6 +11,7 @@ import pytest
 from helpers import (CURVE_PARAMS, CURVE_NAMES, P256, SECP256K1, SEED, hexes_to_arr, arr_to_hexes, from_int, to_int, ints_to_arr,
                      arr_to_ints, from_hex, fill_random_np, ec_mul, ec_add, jacobian_mgry_to_affine_int)
 from test_oracle import run_against_golden, structured_words
+from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG, REF_SQUARE_COMPAT, EcsimdHipError
 
 pytestmark = pytest.mark.gpu
 CURVES = [P256, SECP256K1]
@@ -749,6 +750,16 @@ def test_config3_and_5_fixed_base_2pow22(engine, oracle, cv, log2n):
     S = engine.add_z2_1(cv, J, (Gm[0], Gm[1]))
     ax, ay = engine.to_affine(cv, S); bx, by = engine.to_affine(cv, J1)
     assert torch.equal(ax, bx) and torch.equal(ay, by)
+    # BASELINE configs[2] names the 4-bit window table in LDS: that kernel and its two siblings (signed 7-bit windows in LDS,
+    # 20-bit windows over the 436 MB table in device memory) at the SAME full size, every lane against the ladder's affine
+    # result -- all 13 x 2^19 entries of the big table and all 64 x 16 / 37 x 64 of the LDS ones are in play at 2^22 scalars --
+    # and a strided sample against the oracle.
+    lx, ly = engine.to_affine(cv, J)
+    ex, ey = oracle.to_affine(cv, exp)
+    for alg in (ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG):
+        wx, wy = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | alg)
+        assert torch.equal(wx, lx) and torch.equal(wy, ly), ("windowed fixed-base kernel differs from the ladder", alg)
+        assert np.array_equal(engine.to_numpy(wx[tidx]), ex) and np.array_equal(engine.to_numpy(wy[tidx]), ey)
 
 
 def test_config4_variable_base_shard_2pow21(engine, oracle):
@@ -773,3 +784,109 @@ def test_config4_variable_base_shard_2pow21(engine, oracle):
     ax, ay = engine.to_affine(cv, tuple(t[:m].contiguous() for t in J))
     rx, ry = engine.scalar_mult(cv, engine.to_device(kinv), ax, ay, flags=2)
     assert torch.equal(rx, bx[:m]) and torch.equal(ry, by[:m])
+
+
+# ---------------------------------------------------------------- literal parity with the compiled reference
+def _carry_heavy_field_elements(cv, n, seed):
+    p = CURVE_PARAMS[cv]["p"]
+    return ints_to_arr([v % p for v in arr_to_ints(structured_words(n, seed=seed))])
+
+
+@pytest.mark.parametrize("cv", CURVES)
+def test_ref_square_compat_is_the_reference_bug_for_bug(engine, gpu, oracle, oracle_faithful, golden, cv):
+    """ECSIMD_HIP_REF_SQUARE_COMPAT / ecsimd_hip_set_ref_square_compat: square with mul.h:160-212 AS WRITTEN (the carry
+    dropped at mul.h:186-190 included).  Pinned by the vectors minted from the compiled reference
+    (ref_vectors.json "square_defect": reference_square, p256_reference_mgry_sqr) and, on carry-heavy operands where
+    the defect is frequent, by the bug-for-bug oracle (itself proven equal to the compiled reference,
+    tests/test_oracle.py::test_structured_operands_vs_live_reference) through every layer above the squaring."""
+    d = golden["square_defect"]; x = hexes_to_arr(d["a"])
+    a = structured_words(100000)
+    ar = _carry_heavy_field_elements(cv, 20000, 3); br = np.roll(ar, 5, axis=0)
+    m = 2048
+    k = fill_random_np(m, SEED, 7); k[:8, 0] &= np.uint64(~np.uint64(1))            # some even scalars: the ADD_Z2_1 tail
+    engine.set_ref_square_compat(True)
+    try:
+        assert arr_to_hexes(gpu.square(x), 8) == d["reference_square"]
+        if cv == P256:
+            assert arr_to_hexes(gpu.mgry_sqr(P256, x)) == d["p256_reference_mgry_sqr"]
+        sq = gpu.square(a)
+        assert np.array_equal(sq, oracle_faithful.square(a))
+        wrong = (sq != oracle.square(a)).any(axis=1)
+        assert 1000 < wrong.sum() < len(a)                                             # the defect is really exercised
+        got = gpu.mgry_sqr(cv, ar)
+        assert np.array_equal(got, oracle_faithful.mgry_sqr(cv, ar)) and (got != oracle.mgry_sqr(cv, ar)).any()
+        assert np.array_equal(gpu.mgry_mul(cv, ar, br), oracle.mgry_mul(cv, ar, br))   # mul() has no defect
+        e = from_int(0x1234567890abcdef_0fedcba987654321_00000000ffffffff_8000000000000001)
+        assert np.array_equal(gpu.mgry_pow(cv, ar[:m], e), oracle_faithful.mgry_pow(cv, ar[:m], e))
+        assert np.array_equal(gpu.gfp_inverse(cv, ar[:m]), oracle_faithful.gfp_inverse(cv, ar[:m]))
+        s_, ok = gpu.gfp_sqrt(cv, ar[:m]); so, oko = oracle_faithful.gfp_sqrt(cv, ar[:m])
+        assert np.array_equal(s_, so) and np.array_equal(ok, oko)
+        # the formulas are plain field arithmetic: carry-heavy (x, y) pairs need not be curve points to compare DAGs
+        P = oracle.from_affine(cv, ar[:m], br[:m])
+        (Rg, Pg), (Ro, Po) = gpu.trplu(cv, P), oracle_faithful.trplu(cv, P)
+        assert all(np.array_equal(u, v) for u, v in zip(Rg + Pg, Ro + Po))
+        (Zg, Qg), (Zo, Qo) = gpu.zdau(cv, Ro, Po), oracle_faithful.zdau(cv, Ro, Po)
+        assert all(np.array_equal(u, v) for u, v in zip(Zg + Qg, Zo + Qo))
+        assert all(np.array_equal(u, v) for u, v in zip(gpu.add_z2_1(cv, Zo, (P[0], P[1])), oracle_faithful.add_z2_1(cv, Zo, (P[0], P[1]))))
+        assert any((u != v).any() for u, v in zip(Zo + Qo, sum(oracle.zdau(cv, Ro, Po), ())))    # ... and differ from the exact DAG
+        Jf = oracle_faithful.scalar_mult(cv, k, ar[:m], br[:m], threads=THREADS)
+        Jg = gpu.scalar_mult(cv, k, ar[:m], br[:m])
+        assert all(np.array_equal(u, v) for u, v in zip(Jg, Jf))
+        assert any((u != v).any() for u, v in zip(Jf, oracle.scalar_mult(cv, k, ar[:m], br[:m], threads=THREADS)))
+        af = oracle_faithful.to_affine(cv, Jf)
+        assert all(np.array_equal(u, v) for u, v in zip(gpu.to_affine(cv, Jf), af))
+        assert all(np.array_equal(u, v) for u, v in zip(gpu.scalar_mult(cv, k, ar[:m], br[:m], affine=True), af))
+        with pytest.raises(EcsimdHipError):                      # the windowed algorithms are not the reference's DAG
+            engine.scalar_mult_base(cv, engine.to_device(k), flags=OUT_AFFINE | ALG_WINDOWED)
+    finally:
+        engine.set_ref_square_compat(False)
+    # the per-call flag does the same for the ladder, and the default stays exact
+    dk, dx, dy = (engine.to_device(v) for v in (k, ar[:m], br[:m]))
+    Jflag = engine.scalar_mult(cv, dk, dx, dy, flags=REF_SQUARE_COMPAT)
+    assert all(np.array_equal(engine.to_numpy(u), v) for u, v in zip(Jflag, Jf))
+    Jexact = engine.scalar_mult(cv, dk, dx, dy)
+    assert all(np.array_equal(engine.to_numpy(u), v) for u, v in zip(Jexact, oracle.scalar_mult(cv, k, ar[:m], br[:m], threads=THREADS)))
+    assert arr_to_hexes(gpu.square(x), 8) == d["exact_square"]
+
+
+@pytest.mark.parametrize("cv", CURVES)
+def test_ladder_vs_the_live_reference_2pow20(engine, oracle, reference, openssl, cv):
+    """2^20 random (scalar, point) pairs through the COMPILED reference (oracle/_ref, skipped where it was not built) and
+    through the HIP ladder.  With ECSIMD_HIP_REF_SQUARE_COMPAT not one lane may differ.  Without it the HIP result is the exact
+    k*P: every lane that differs from the reference must be confirmed by libcrypto -- an implementation that shares no
+    code or algorithm with either -- and by the exact oracle."""
+    import torch
+    n = 1 << 20
+    k = engine.fill_random(n, SEED, 1, first_index=5 * n); s = engine.fill_random(n, SEED, 2, first_index=5 * n)
+    bx, by = engine.scalar_mult_base(cv, s, flags=OUT_AFFINE | ALG_WINDOWED_BIG)
+    kn, bxn, byn = (engine.to_numpy(t) for t in (k, bx, by))
+    ref = reference.scalar_mult(cv, kn, bxn, byn, threads=THREADS)
+    compat = engine.scalar_mult(cv, k, bx, by, flags=REF_SQUARE_COMPAT)
+    for name, g, r in zip("XYZ", compat, ref):
+        assert np.array_equal(engine.to_numpy(g), r), f"compat ladder {name} differs from the compiled reference"
+    J = engine.scalar_mult(cv, k, bx, by)
+    got = [engine.to_numpy(t) for t in J]
+    bad = np.nonzero((got[0] != ref[0]).any(axis=1) | (got[1] != ref[1]).any(axis=1) | (got[2] != ref[2]).any(axis=1))[0]
+    assert len(bad) < 64                                           # ~3e-6 of the lanes
+    if len(bad):
+        ax, ay = engine.to_affine(cv, tuple(t[torch.from_numpy(bad).to(t.device)].contiguous() for t in J))
+        vx, vy, inf = openssl.scalar_mult(cv, kn[bad], bxn[bad], byn[bad], threads=1)
+        assert not inf.any() and np.array_equal(engine.to_numpy(ax), vx) and np.array_equal(engine.to_numpy(ay), vy), "libcrypto sides with the reference"
+        ex = oracle.scalar_mult(cv, kn[bad], bxn[bad], byn[bad], threads=1)
+        assert all(np.array_equal(g[bad], e) for g, e in zip(got, ex))
+        rx, ry = reference.to_affine(cv, tuple(v[bad] for v in ref))             # the reference's own point on those lanes is NOT k*P
+        assert ((rx != vx) | (ry != vy)).any(axis=1).all()
+    print(f"curve {cv}: {len(bad)} of {n} lanes differ from the compiled reference without the flag, 0 with it")
+
+
+def test_operands_must_agree_on_the_batch_length(engine):
+    """The C ABI takes one length for all operands; the binding refuses tensors that disagree (they would be read or
+    written out of bounds on the device)."""
+    k = engine.fill_random(64, SEED, 1); x = engine.fill_random(32, SEED, 2, clear_top_bits=1)
+    with pytest.raises(EcsimdHipError):
+        engine.scalar_mult(P256, k, x, x)
+    with pytest.raises(EcsimdHipError):
+        engine.mgry_mul(P256, k, x)
+    with pytest.raises(EcsimdHipError):
+        engine.scalar_mult(P256, x, x, x, out=[engine.empty(16) for _ in range(3)])
+    assert engine.mgry_mul(P256, x, x).shape == (32, 4)         # and the refused calls left no state behind

@@ -110,6 +110,64 @@ KERNEL64_BEGIN(k_comba4_one)  if (i < 4) { uint32_t ex = c;
                  "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "+v"(a[i]), "+v"(ex) : "v"(b), "v"(c) : "vcc");
     a[i] ^= ex; } KERNEL64_END
 
+
+// ---- round 2: forms for the conditional corrections of the modular linear ops.  Each statement below is a GROUP of 8
+// VALU instructions (plus scalar set-up) executed for i < 2, so a trip still counts 16 VALU instructions per REP.
+#define G8(op) op(0) op(1) op(2) op(3) op(4) op(5) op(6) op(7)
+#define OPS8 "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+#define SRC8 "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15])
+// 8 selects by an SGPR-pair mask (what cond_sub_p does today)
+KERNEL_BEGIN(k_g_cndmask_e64) if (i < 2) asm volatile("s_mov_b32 s20, 0x55555555\n\ts_mov_b32 s21, 0x33333333\n\t"
+    "v_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %9, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %10, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %11, s[20:21]\n\t"
+    "v_cndmask_b32_e64 %4, %4, %12, s[20:21]\n\tv_cndmask_b32_e64 %5, %5, %13, s[20:21]\n\tv_cndmask_b32_e64 %6, %6, %14, s[20:21]\n\tv_cndmask_b32_e64 %7, %7, %15, s[20:21]"
+    : OPS8 : SRC8 : "s20", "s21"); KERNEL_END
+// the mask in VCC written by a scalar instruction, 8 VOP2 selects
+KERNEL_BEGIN(k_g_cndmask_vcc_salu) if (i < 2) asm volatile("s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x33333333\n\t"
+    "v_cndmask_b32 %0, %0, %8, vcc\n\tv_cndmask_b32 %1, %1, %9, vcc\n\tv_cndmask_b32 %2, %2, %10, vcc\n\tv_cndmask_b32 %3, %3, %11, vcc\n\t"
+    "v_cndmask_b32 %4, %4, %12, vcc\n\tv_cndmask_b32 %5, %5, %13, vcc\n\tv_cndmask_b32 %6, %6, %14, vcc\n\tv_cndmask_b32 %7, %7, %15, vcc"
+    : OPS8 : SRC8 : "vcc"); KERNEL_END
+// the mask in VCC written by ONE vector compare (a 9th VALU instruction, not counted), 8 VOP2 selects
+KERNEL_BEGIN(k_g_cndmask_vcc_valu) if (i < 2) asm volatile("v_cmp_lt_u32 vcc, %0, %8\n\t"
+    "v_cndmask_b32 %0, %0, %8, vcc\n\tv_cndmask_b32 %1, %1, %9, vcc\n\tv_cndmask_b32 %2, %2, %10, vcc\n\tv_cndmask_b32 %3, %3, %11, vcc\n\t"
+    "v_cndmask_b32 %4, %4, %12, vcc\n\tv_cndmask_b32 %5, %5, %13, vcc\n\tv_cndmask_b32 %6, %6, %14, vcc\n\tv_cndmask_b32 %7, %7, %15, vcc"
+    : OPS8 : SRC8 : "vcc"); KERNEL_END
+// vector compare, scalar and-not into VCC, 8 VOP2 selects (cond_sub_p with the mask kept in VCC)
+KERNEL_BEGIN(k_g_cndmask_vcc_andn2) if (i < 2) asm volatile("s_mov_b32 s20, 0x0f0f0f0f\n\ts_mov_b32 s21, 0x00ff00ff\n\tv_cmp_lt_u32 vcc, %0, %8\n\ts_andn2_b64 vcc, vcc, s[20:21]\n\t"
+    "v_cndmask_b32 %0, %0, %8, vcc\n\tv_cndmask_b32 %1, %1, %9, vcc\n\tv_cndmask_b32 %2, %2, %10, vcc\n\tv_cndmask_b32 %3, %3, %11, vcc\n\t"
+    "v_cndmask_b32 %4, %4, %12, vcc\n\tv_cndmask_b32 %5, %5, %13, vcc\n\tv_cndmask_b32 %6, %6, %14, vcc\n\tv_cndmask_b32 %7, %7, %15, vcc"
+    : OPS8 : SRC8 : "vcc", "scc", "s20", "s21"); KERNEL_END
+// EXEC-masked moves: s_and_saveexec, 8 v_mov, restore
+KERNEL_BEGIN(k_g_mov_exec) if (i < 2) asm volatile("s_mov_b32 s20, 0x55555555\n\ts_mov_b32 s21, 0x33333333\n\ts_and_saveexec_b64 s[22:23], s[20:21]\n\t"
+    "v_mov_b32 %0, %8\n\tv_mov_b32 %1, %9\n\tv_mov_b32 %2, %10\n\tv_mov_b32 %3, %11\n\tv_mov_b32 %4, %12\n\tv_mov_b32 %5, %13\n\tv_mov_b32 %6, %14\n\tv_mov_b32 %7, %15\n\t"
+    "s_mov_b64 exec, s[22:23]"
+    : OPS8 : SRC8 : "scc", "s20", "s21", "s22", "s23"); KERNEL_END
+// EXEC-masked in-place borrow chain with inline constants (subtract p under the mask)
+KERNEL_BEGIN(k_g_subb_exec) if (i < 2) asm volatile("s_mov_b32 s20, 0x55555555\n\ts_mov_b32 s21, 0x33333333\n\ts_and_saveexec_b64 s[22:23], s[20:21]\n\t"
+    "v_sub_co_u32 %0, vcc, %0, -1\n\tv_subb_co_u32 %1, vcc, %1, -1, vcc\n\tv_subb_co_u32 %2, vcc, %2, -1, vcc\n\tv_subb_co_u32 %3, vcc, %3, 0, vcc\n\t"
+    "v_subb_co_u32 %4, vcc, %4, 0, vcc\n\tv_subb_co_u32 %5, vcc, %5, 0, vcc\n\tv_subb_co_u32 %6, vcc, %6, 1, vcc\n\tv_subb_co_u32 %7, vcc, %7, -1, vcc\n\t"
+    "s_mov_b64 exec, s[22:23]"
+    : OPS8 : : "vcc", "scc", "s20", "s21", "s22", "s23"); KERNEL_END
+// the same chain without the EXEC games (reference for the previous line)
+KERNEL_BEGIN(k_g_subb_plain) if (i < 2) asm volatile(
+    "v_sub_co_u32 %0, vcc, %0, -1\n\tv_subb_co_u32 %1, vcc, %1, -1, vcc\n\tv_subb_co_u32 %2, vcc, %2, -1, vcc\n\tv_subb_co_u32 %3, vcc, %3, 0, vcc\n\t"
+    "v_subb_co_u32 %4, vcc, %4, 0, vcc\n\tv_subb_co_u32 %5, vcc, %5, 0, vcc\n\tv_subb_co_u32 %6, vcc, %6, 1, vcc\n\tv_subb_co_u32 %7, vcc, %7, -1, vcc"
+    : OPS8 : : "vcc"); KERNEL_END
+// v_swap_b32 (a conditional swap under EXEC would be 8 of these per field element)
+KERNEL_BEGIN(k_g_swap) if (i < 2) asm volatile(
+    "v_swap_b32 %0, %8\n\tv_swap_b32 %1, %9\n\tv_swap_b32 %2, %10\n\tv_swap_b32 %3, %11\n\tv_swap_b32 %4, %12\n\tv_swap_b32 %5, %13\n\tv_swap_b32 %6, %14\n\tv_swap_b32 %7, %15"
+    : OPS8, "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])); KERNEL_END
+// carry-less add under EXEC
+KERNEL_BEGIN(k_g_add_exec) if (i < 2) asm volatile("s_mov_b32 s20, 0x55555555\n\ts_mov_b32 s21, 0x33333333\n\ts_and_saveexec_b64 s[22:23], s[20:21]\n\t"
+    "v_add_u32 %0, %0, %8\n\tv_add_u32 %1, %1, %9\n\tv_add_u32 %2, %2, %10\n\tv_add_u32 %3, %3, %11\n\tv_add_u32 %4, %4, %12\n\tv_add_u32 %5, %5, %13\n\tv_add_u32 %6, %6, %14\n\tv_add_u32 %7, %7, %15\n\t"
+    "s_mov_b64 exec, s[22:23]"
+    : OPS8 : SRC8 : "scc", "s20", "s21", "s22", "s23"); KERNEL_END
+// v_cmp_eq with an SGPR-pair destination + scalar test + never-taken branch (the rare-case guard)
+KERNEL_BEGIN(k_g_guard) if (i < 2) asm volatile(
+    "v_sub_co_u32 %0, vcc, %0, -1\n\tv_subb_co_u32 %1, vcc, %1, -1, vcc\n\tv_subb_co_u32 %2, vcc, %2, -1, vcc\n\tv_subb_co_u32 %3, vcc, %3, 0, vcc\n\t"
+    "v_subb_co_u32 %4, vcc, %4, 0, vcc\n\tv_subb_co_u32 %5, vcc, %5, 0, vcc\n\tv_subb_co_u32 %6, vcc, %6, 1, vcc\n\t"
+    "v_cmp_eq_u32_e64 s[20:21], %7, -1\n\ts_cmp_lg_u64 s[20:21], 0\n\ts_cbranch_scc0 1f\n\tv_add_u32 %7, %7, 1\n\t1:"
+    : OPS8 : : "vcc", "scc", "s20", "s21"); KERNEL_END
+
 typedef void (*kern_t)(uint32_t*, uint32_t);
 struct Entry { const char* name; kern_t k; int insts_per_slot; };
 
@@ -137,6 +195,9 @@ int main(int argc, char** argv) {
     {"mad+addc dep x1", k_comba_dep1, 2}, {"addc dep x1", k_addc_dep1, 1}, {"addc chain(8 regs)", k_addc_chain8, 1}, {"v_add_u32 dep x1", k_add_dep1, 1}, {"v_fma_f64 dep x1", k_fma64_dep1, 1},
     {"v_pk_mov_b32", k_pk_mov, 1}, {"v_mov_b64", k_mov_b64, 1},
     {"4x(mad+addc) 4 asm /4", k_comba4_sep, 2}, {"4x(mad+addc) 1 asm /4", k_comba4_one, 2},
+    {"8 cndmask e64 sgpr", k_g_cndmask_e64, 1}, {"8 cndmask vcc<-salu", k_g_cndmask_vcc_salu, 1}, {"cmp + 8 cndmask vcc", k_g_cndmask_vcc_valu, 1},
+    {"cmp,andn2,8 cndmask", k_g_cndmask_vcc_andn2, 1}, {"8 v_mov under exec", k_g_mov_exec, 1}, {"8 subb under exec", k_g_subb_exec, 1},
+    {"8 subb plain", k_g_subb_plain, 1}, {"8 v_swap_b32", k_g_swap, 1}, {"8 v_add_u32 exec", k_g_add_exec, 1}, {"7 subb+cmp+guard", k_g_guard, 1},
   };
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   const int wps_list[] = {1, 2, 4, 8};   // waves per SIMD
