@@ -402,6 +402,8 @@ int ecsimd_hip_square(ecsimd_hip_ctx* ctx, const uint64_t* a, uint64_t* out8, si
   REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(out8); RUN(launch::square(s, a, out8, n, ctx->ref_square != 0)); }
 int ecsimd_hip_swap_if(ecsimd_hip_ctx* ctx, const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n) {
   REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); if (!mask && n) return bad(ctx, "mask is null"); RUN(launch::swap_if(s, mask, a, b, n)); }
+int ecsimd_hip_if_else(ecsimd_hip_ctx* ctx, const uint8_t* mask, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); if (!mask && n) return bad(ctx, "mask is null"); RUN(launch::if_else(s, mask, a, b, out, n)); }
 
 // ---- wire formats
 int ecsimd_hip_from_bytes_be(ecsimd_hip_ctx* ctx, const uint8_t* bytes, uint64_t* out, size_t n) {

@@ -98,6 +98,10 @@ __global__ void __launch_bounds__(BLOCK) k_peak_mad32(uint32_t* sink, int iters,
 }
 }  // namespace
 
+__global__ void __launch_bounds__(BLOCK) k_if_else(const uint8_t* mask, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  GID; fe_store(out, i, fe_select(0u - (uint32_t)(mask[i] != 0), fe_load(a, i), fe_load(b, i)));      // ifelse.h:15-22
+}
+
 namespace launch {
 static_assert(PEAK_MADS_PER_LANE_PER_ITER == 4 * 16, "keep in sync with k_peak_mad32");
 #define GO(kern, ...) hipLaunchKernelGGL(kern, grid_for(n), dim3(BLOCK), 0, s, __VA_ARGS__)
@@ -108,6 +112,7 @@ void shift_left_one(hipStream_t s, const uint64_t* a, uint64_t* out, uint8_t* ca
 void mul(hipStream_t s, const uint64_t* a, const uint64_t* b, uint64_t* out8, size_t n) { GO(k_mul, a, b, out8, n); }
 void square(hipStream_t s, const uint64_t* a, uint64_t* out8, size_t n, bool ref_compat) { if (ref_compat) GO(k_square<true>, a, out8, n); else GO(k_square<false>, a, out8, n); }
 void swap_if(hipStream_t s, const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n) { GO(k_swap_if, mask, a, b, n); }
+void if_else(hipStream_t s, const uint8_t* mask, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { GO(k_if_else, mask, a, b, out, n); }
 void cmp_eq(hipStream_t s, const uint64_t* a, const uint64_t* b, int limbs, uint8_t* flag, size_t n) { GO(k_cmp_eq, a, b, limbs, flag, n); }
 void mask_op(hipStream_t s, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) { GO(k_mask_op, op, a, b, out, n); }
 void mask_count(hipStream_t s, const uint8_t* a, size_t n, unsigned long long* count) { GO(k_mask_count, a, n, count); }

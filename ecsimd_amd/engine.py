@@ -338,3 +338,82 @@ class Engine:
             if best is None or mads.value / ms.value > best[0] / best[1]:
                 best = (mads.value, ms.value)
         return best
+
+
+def shard_range_c(n_total: int, member: int, members: int):
+    """ecsimd_hip_shard_range: the C ABI's partition of a batch over a device group (pure host arithmetic)."""
+    lib = load_library()
+    first, count = C.c_size_t(0), C.c_size_t(0)
+    rc = lib.ecsimd_hip_shard_range(C.c_size_t(n_total), C.c_int(member), C.c_int(members), C.byref(first), C.byref(count))
+    if rc != 0:
+        raise EcsimdHipError(f"ecsimd_hip_shard_range({n_total}, {member}, {members}) -> {rc}")
+    return int(first.value), int(count.value)
+
+
+class DeviceGroup:
+    """ecsimd_hip_group_*: one batch over several GPUs behind the C ABI (one context per device, contiguous shards,
+    one RCCL gather to member 0).  `devices` may list a device twice (members then exchange by device copies)."""
+
+    def __init__(self, devices):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        self.lib.ecsimd_hip_group_last_error.restype = C.c_char_p
+        self.devices = [int(d) for d in devices]
+        self.g = C.c_void_p()
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        rc = self.lib.ecsimd_hip_group_init(arr, C.c_int(len(self.devices)), C.byref(self.g))
+        if rc != 0:
+            raise EcsimdHipError(f"ecsimd_hip_group_init({self.devices}) failed with {rc}")
+
+    def close(self):
+        if self.g:
+            self.lib.ecsimd_hip_group_destroy(self.g)
+            self.g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.ecsimd_hip_group_last_error(self.g)
+            raise EcsimdHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    @property
+    def size(self):
+        return int(self.lib.ecsimd_hip_group_size(self.g))
+
+    @property
+    def uses_rccl(self):
+        return bool(self.lib.ecsimd_hip_group_uses_rccl(self.g))
+
+    def scalar_mult(self, curve, k_shards, x_shards, y_shards, n, flags=0):
+        """Device-resident form: *_shards[m] = member m's slice (torch tensor on that member's device).
+        Returns (ox, oy[, oz]) on member 0's device and the gather time in ms."""
+        torch = self.torch
+        G = self.size
+        dev0 = torch.device("cuda", self.devices[0])
+        outs = [torch.empty((n, 4), dtype=torch.int64, device=dev0) for _ in range(2 if flags & 2 else 3)]
+        ptrs = lambda ts: (C.c_void_p * G)(*[C.c_void_p(t.data_ptr() if t is not None and t.numel() else 0) for t in ts])
+        for m in range(G):
+            torch.cuda.synchronize(self.devices[m])         # the inputs were produced on torch's streams
+        o = [C.c_void_p(t.data_ptr()) for t in outs] + [C.c_void_p(0)] * (3 - len(outs))
+        self._check(self.lib.ecsimd_hip_group_scalar_mult(self.g, C.c_int(curve), ptrs(k_shards), ptrs(x_shards), ptrs(y_shards),
+                                                          o[0], o[1], o[2], C.c_size_t(n), C.c_int(flags)), "group_scalar_mult")
+        ms = C.c_double(0)
+        self._check(self.lib.ecsimd_hip_group_sync(self.g, C.byref(ms)), "group_sync")
+        return tuple(outs), float(ms.value)
+
+    def scalar_mult_host(self, curve, k, x, y, flags=0):
+        """Host-array form: numpy uint64 (n, 4) arrays in, numpy arrays out."""
+        k, x, y = (np.ascontiguousarray(a, dtype=np.uint64) for a in (k, x, y))
+        n = len(k)
+        outs = [np.empty((n, 4), dtype=np.uint64) for _ in range(2 if flags & 2 else 3)]
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        o = [p(a) for a in outs] + [C.c_void_p(0)] * (3 - len(outs))
+        self._check(self.lib.ecsimd_hip_group_scalar_mult_host(self.g, C.c_int(curve), p(k), p(x), p(y), o[0], o[1], o[2], C.c_size_t(n), C.c_int(flags)),
+                    "group_scalar_mult_host")
+        return tuple(outs)

@@ -27,6 +27,10 @@ struct bignum {
   static constexpr size_t nlimbs = NLimbs;
   std::array<LimbType, NLimbs> limbs{};   // little-endian limb order, like the reference's tuple
 
+  // bignum.h:61-67 cbn() / from(): the limbs as the plain array ctbignum's big_int is (the reference bit_casts between the two)
+  using cbn_type = std::array<LimbType, NLimbs>;
+  constexpr cbn_type cbn() const { return limbs; }
+  static constexpr bignum from(cbn_type const& v) { bignum r; r.limbs = v; return r; }
   static constexpr bignum from(limb_type v0) { bignum r; r.limbs[0] = v0; return r; }
   constexpr limb_type operator[](size_t i) const { return limbs[i]; }
   constexpr limb_type& operator[](size_t i) { return limbs[i]; }

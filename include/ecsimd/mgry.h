@@ -21,6 +21,32 @@ template <class P> struct mgry_constants {            // mgry_csts.h:15-24, valu
   static bignum_256 Pm1_by_R_p() { return get(7); }
 };
 
+// mgry.h:18-26 to_mgry<P>(v): v * R mod p at COMPILE TIME (the reference divides with ctbignum; here 256 modular
+// doublings of v mod p -- the same residue).  p must exceed 2^255 (both supported primes), so v < 2^256 < 2p.
+namespace details {
+constexpr bool bn_geq(bignum_256 const& a, bignum_256 const& b) {
+  for (int i = 3; i >= 0; --i) { if (a.limbs[i] != b.limbs[i]) return a.limbs[i] > b.limbs[i]; }
+  return true;
+}
+constexpr bignum_256 bn_sub_wrap(bignum_256 const& a, bignum_256 const& b) {
+  bignum_256 r; uint64_t borrow = 0;
+  for (int i = 0; i < 4; ++i) { const uint64_t d = a.limbs[i] - b.limbs[i], d2 = d - borrow; borrow = (a.limbs[i] < b.limbs[i]) || (d < borrow); r.limbs[i] = d2; }
+  return r;
+}
+}  // namespace details
+template <class P> constexpr bignum_256 to_mgry(bignum_256 const& v) {
+  constexpr bignum_256 p = P::value;
+  static_assert(p.limbs[3] >> 63, "to_mgry: p > 2^255");
+  bignum_256 r = details::bn_geq(v, p) ? details::bn_sub_wrap(v, p) : v;
+  for (int k = 0; k < 256; ++k) {
+    const bool top = r.limbs[3] >> 63;
+    bignum_256 d; for (int i = 3; i > 0; --i) d.limbs[i] = (r.limbs[i] << 1) | (r.limbs[i - 1] >> 63);
+    d.limbs[0] = r.limbs[0] << 1;
+    r = (top || details::bn_geq(d, p)) ? details::bn_sub_wrap(d, p) : d;          // 2r < 2p: one subtraction (mod 2^256 when the top bit fell off)
+  }
+  return r;
+}
+
 template <class WBN, class P>
 struct wide_mgry_bignum {
   using wide_bignum_type = WBN;

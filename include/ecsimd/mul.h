@@ -16,7 +16,26 @@ template <class R, class BN> wide_bignum<R> take_low(hip::buffer const& raw8, si
 }
 }  // namespace detail
 
+// mul.h:63-83 zext_u32x64: the 2N 32-bit digits of every element, each in its own 64-bit limb (the layout the reference's
+// AVX2 multiplier works on), and mul.h:85-113 trunc_u64x32, its inverse (each limb's upper half is dropped, as the
+// reference's blend does).  Host-side relayouts: the device multiplier needs neither (csrc/field.cuh works on 32-bit words).
+template <class BN> auto zext_u32x64(wide_bignum<BN> const& v) {
+  static_assert(BN::nlimbs <= 4, "zext_u32x64: at most 256-bit operands");
+  using R = bignum<typename BN::limb_type, 2 * BN::nlimbs>;
+  auto h = v.host(); std::vector<R> o(h.size());
+  for (size_t i = 0; i < h.size(); ++i) for (size_t l = 0; l < BN::nlimbs; ++l) { o[i].limbs[2 * l] = h[i].limbs[l] & 0xffffffffull; o[i].limbs[2 * l + 1] = h[i].limbs[l] >> 32; }
+  return wide_bignum<R>(o);
+}
+template <class BN> auto trunc_u64x32(wide_bignum<BN> const& v) {
+  static_assert(BN::nlimbs % 2 == 0, "trunc_u64x32: an even number of limbs");
+  using R = bignum<typename BN::limb_type, BN::nlimbs / 2>;
+  auto h = v.host(); std::vector<R> o(h.size());
+  for (size_t i = 0; i < h.size(); ++i) for (size_t l = 0; l < R::nlimbs; ++l) o[i].limbs[l] = (h[i].limbs[2 * l] & 0xffffffffull) | (h[i].limbs[2 * l + 1] << 32);
+  return wide_bignum<R>(o);
+}
+
 template <class BN> auto mul(wide_bignum<BN> const& a, wide_bignum<BN> const& b) {
+  if (a.size() != b.size()) throw hip::error("ecsimd: mul over batches of different length");
   using R = bignum<typename BN::limb_type, 2 * BN::nlimbs>;
   hip::buffer out(a.size() * 8);
   hip::check(ecsimd_hip_mul(hip::context(), a.data(), b.data(), out.data(), a.size()), "ecsimd_hip_mul");

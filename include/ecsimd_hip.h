@@ -137,6 +137,8 @@ int ecsimd_hip_mul(ecsimd_hip_ctx*, const uint64_t* a, const uint64_t* b, uint64
 int ecsimd_hip_square(ecsimd_hip_ctx*, const uint64_t* a, uint64_t* out8, size_t n);
 /* swap.h:15-22  swap_if: swap a[i] and b[i] in place where mask[i] != 0 */
 int ecsimd_hip_swap_if(ecsimd_hip_ctx*, const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n);
+/* ifelse.h:15-22  if_else: out[i] = mask[i] != 0 ? a[i] : b[i] (out may alias a or b) */
+int ecsimd_hip_if_else(ecsimd_hip_ctx*, const uint8_t* mask, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 
 /* ---- wire formats on the device ------------------------------- */
 /* serialization.h:12-24 bn_from_bytes_BE / :26-48 bn_to_bytes_BE over a batch: 32 big-endian bytes per
@@ -238,6 +240,34 @@ int ecsimd_hip_fill_random(ecsimd_hip_ctx*, uint64_t* out, size_t n, uint64_t se
 /* Dependency-free v_mad_u64_u32 stream: the integer-multiply roofline denominator.  Returns the
  * number of mad32 executed in *mads; elapsed device time in *ms (HIP events on the ctx stream). */
 int ecsimd_hip_peak_mad32(ecsimd_hip_ctx*, int iters, double* mads, double* ms);
+
+/* ---- device groups: one batch over several GPUs -------------------------------
+ * The reference is single-threaded and has no collectives (nothing to cite); BASELINE.json north_star asks for
+ * batches sharded across the GPUs of a node "with RCCL over xGMI only for the final gather", host code behind this ABI.
+ * A group owns one context per listed device.  Member m of G owns the contiguous slice shard_range(n, m, G) of a
+ * batch (the first n % G members take one element more); no collective touches the data path; the result shards
+ * are gathered to member 0's device memory by one grouped ncclSend / ncclRecv exchange.  RCCL is loaded at run time
+ * (dlopen) when the group has more than one device; a device may be listed twice, in which case those members exchange
+ * by device copies (how a one-GPU machine exercises the bookkeeping).  One host thread drives a group. */
+typedef struct ecsimd_hip_group ecsimd_hip_group;
+int ecsimd_hip_shard_range(size_t n_total, int member, int members, size_t* first, size_t* count);   /* pure host arithmetic */
+int ecsimd_hip_group_init(const int* devices, int n_devices, ecsimd_hip_group** group);
+int ecsimd_hip_group_destroy(ecsimd_hip_group* group);
+int ecsimd_hip_group_size(const ecsimd_hip_group* group);
+int ecsimd_hip_group_uses_rccl(const ecsimd_hip_group* group);                 /* 1 when the gather goes through RCCL */
+ecsimd_hip_ctx* ecsimd_hip_group_context(ecsimd_hip_group* group, int member); /* e.g. to allocate on that device, set options */
+const char* ecsimd_hip_group_last_error(const ecsimd_hip_group* group);
+/* curve_group.h:189-218 over the group, device-resident: k[m], x[m], y[m] = member m's slice in ITS device memory;
+ * ox, oy, oz = n elements each in member 0's device memory (oz may be NULL with OUT_AFFINE); flags as
+ * ecsimd_hip_scalar_mult.  Asynchronous; ecsimd_hip_group_sync waits for every member and reports how long the last
+ * gather took on member 0's stream (milliseconds; NULL to skip; -1 if there was none). */
+int ecsimd_hip_group_scalar_mult(ecsimd_hip_group* group, int curve, const uint64_t* const* k, const uint64_t* const* x, const uint64_t* const* y,
+                                 uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
+int ecsimd_hip_group_sync(ecsimd_hip_group* group, double* last_gather_ms);
+/* The same with every array in HOST memory (n elements each): slices copied in, computed, gathered, copied out.
+ * Synchronous. */
+int ecsimd_hip_group_scalar_mult_host(ecsimd_hip_group* group, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y,
+                                      uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
 
 #ifdef __cplusplus
 }

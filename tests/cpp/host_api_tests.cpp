@@ -48,6 +48,30 @@ TEST(Ops128, MulSquare) {
   EXPECT_TRUE(all(square(splat<W128>("ffffffffffffffffffffffffffffffff"_hex)) == splat<W256>("fffffffffffffffffffffffffffffffe00000000000000000000000000000001"_hex)));
   EXPECT_TRUE(all(square(splat<W128>("b59edca51009bb15c309b23171c102da"_hex)) == splat<W256>("80da06968299ac8e1bc23ef95d49c1469d01bb136df7c96b75ba357dc0bc21a4"_hex)));
 }
+TEST(Ops128, ZextTruncAndLimbShifts) {
+  // tests/ops.cpp:122-127: trunc_u64x32(zext_u32x64(v)) == v
+  const auto v = splat<W128>("b59edca51009bb15c309b23171c102da"_hex);
+  const auto z = zext_u32x64(v);
+  EXPECT_TRUE(all(z == splat<W256>("00000000b59edca5000000001009bb1500000000c309b2310000000071c102da"_hex)));
+  EXPECT_TRUE(all(trunc_u64x32(z) == v));
+  const auto q = lanes<W256>("80000000800000008000000080000000ffffffffffffffff0123456789abcdef"_hex, "0000000000000000000000000000000000000000000000000000000000000001"_hex,
+                             "ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff"_hex, "00000000000000010000000000000002000000000000000300000000000000f4"_hex);
+  EXPECT_TRUE(all(trunc_u64x32(zext_u32x64(q)) == q));
+  // shift.h:53-96 (what mgry_reduce's zero-extended shifts are built from in the reference)
+  using W192 = wide_bignum<bignum<uint64_t, 3>>;
+  EXPECT_TRUE(all(limb_shift_left<4, 1>(v) == splat<W256>("0000000000000000b59edca51009bb15c309b23171c102da0000000000000000"_hex)));
+  EXPECT_TRUE(all(limb_shift_left<3, 2>(v) == splat<W192>("c309b23171c102da00000000000000000000000000000000"_hex)));       // the high limb does not fit: dropped
+  EXPECT_TRUE(all(limb_shift_left<2, 2>(v) == W128{bignum_128{}}));
+  EXPECT_TRUE(all(limb_shift_right<1>(q) == lanes<W192>("80000000800000008000000080000000ffffffffffffffff"_hex, "000000000000000000000000000000000000000000000000"_hex,
+                                                        "ffffffffffffffffffffffffffffffffffffffffffffffff"_hex, "000000000000000100000000000000020000000000000003"_hex)));
+  // utility.h:36-43 wide_uasr: arithmetic shift of one limb of every lane
+  const auto sh = wide_uasr(q, 3, 63);
+  EXPECT_TRUE(sh[0] == ~0ull && sh[1] == 0 && sh[2] == ~0ull && sh[3] == 0);
+  EXPECT_TRUE(wide_uasr(q, 0, 4)[3] == 0xfull && wide_uasr(q, 3, 4)[0] == 0xf800000008000000ull);
+  // bignum.h:61-67 cbn() / from()
+  constexpr auto one = bignum_256::from(bignum_256::cbn_type{1, 0, 0, 0});
+  static_assert(one.cbn()[0] == 1 && one == bignum_256::from(1));
+}
 TEST(Ops128, Compare) {
   const auto lo = splat<W128>("AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA"_hex), hi = splat<W128>("BAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA"_hex);
   EXPECT_TRUE(all(lo < hi)); EXPECT_TRUE(all(lo <= hi)); EXPECT_TRUE(all(lo <= lo));
@@ -98,6 +122,20 @@ TEST(Mgry, FromTo) {                                                            
     const auto a = splat<W256>(v);
     EXPECT_TRUE(all(WMBN::from_classical(a).to_classical() == a));
   }
+}
+TEST(Mgry, ConstexprToMgry) {                                                                 // mgry.h:18-26
+  using WMBN = wide_mgry_bignum<W256, K1P>;
+  constexpr auto four = bn_from_bytes_BE<bignum_256>("FFFFFFFFFFFFFFFFFFFFFF000000000000000000000000000000000000000004"_hex);
+  constexpr auto m = to_mgry<K1P>(four);                                                        // a compile-time constant, like the reference's Am / Bm
+  static_assert(to_mgry<K1P>(bignum_256::from(1)) == bn_from_bytes_BE<bignum_256>("00000000000000000000000000000000000000000000000000000001000003d1"_hex));   // R mod p
+  EXPECT_TRUE(all(WMBN::from_classical(W256{four}).wbn() == W256{m}));
+  EXPECT_TRUE(all(WMBN::R().wbn() == W256{to_mgry<K1P>(bignum_256::from(1))}));                 // mgry.h:43
+  using P256P = curve_nist_p256::P;
+  static_assert(to_mgry<P256P>(bignum_256::from(1)) == bn_from_bytes_BE<bignum_256>("00000000fffffffeffffffffffffffffffffffff000000000000000000000001"_hex));
+  EXPECT_TRUE(all(W256{to_mgry<P256P>(curve_nist_p256::Gx::value)} == curve_group<curve_nist_p256>::WJG().x().wbn()));
+  // a value >= p is reduced first
+  constexpr auto big = bn_from_bytes_BE<bignum_256>("FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF"_hex);
+  EXPECT_TRUE(all(wide_mgry_bignum<W256, K1P>::from_classical(W256{big}).wbn() == W256{to_mgry<K1P>(big)}));
 }
 TEST(Mgry, Reduce) {                                                                          // :52-76: reduce(mul(a,b)) == a*b*R^-1 == mgry_mul
   using WMBN = wide_mgry_bignum<W256, K1P>;

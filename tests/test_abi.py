@@ -74,3 +74,25 @@ def test_product_never_touches_the_oracle():
     assert not bad, bad
     nm = subprocess.run(["ldd", os.path.join(ROOT, "ecsimd_amd", "libecsimd_hip.so")], capture_output=True, text=True).stdout
     assert "oracle" not in nm and "ecsimd_ref" not in nm
+
+
+def test_group_shard_arithmetic_without_a_gpu():
+    """ecsimd_hip_shard_range (the C ABI's partition of a batch over a device group) agrees with the Python runner's
+    and covers [0, n) exactly; BASELINE configs[3]: 2^24 over 8 GPUs = 2^21 each.  No GPU call is made."""
+    import ecsimd_amd
+    from ecsimd_amd.shard import shard_range
+    assert ecsimd_amd.shard_range_c(1 << 24, 5, 8) == (5 << 21, 1 << 21)
+    for n in (0, 1, 7, 8, 9, 1000003, 1 << 22):
+        for g in (1, 2, 3, 5, 8):
+            spans = [ecsimd_amd.shard_range_c(n, m, g) for m in range(g)]
+            assert spans == [shard_range(n, m, g) for m in range(g)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+    lib = ecsimd_amd.load_library()
+    f, c = C.c_size_t(), C.c_size_t()
+    assert lib.ecsimd_hip_shard_range(C.c_size_t(8), C.c_int(2), C.c_int(2), C.byref(f), C.byref(c)) == -1      # member out of range
+    assert lib.ecsimd_hip_shard_range(C.c_size_t(8), C.c_int(0), C.c_int(0), C.byref(f), C.byref(c)) == -1
+    g = C.c_void_p()
+    assert lib.ecsimd_hip_group_init(None, C.c_int(1), C.byref(g)) == -1 and not g
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.ecsimd_hip_group_init((C.c_int * 1)(0), C.c_int(1), C.byref(g)) == -2 and not g               # no device: no fallback

@@ -825,10 +825,10 @@ def test_ref_square_compat_is_the_reference_bug_for_bug(engine, gpu, oracle, ora
         P = oracle.from_affine(cv, ar[:m], br[:m])
         (Rg, Pg), (Ro, Po) = gpu.trplu(cv, P), oracle_faithful.trplu(cv, P)
         assert all(np.array_equal(u, v) for u, v in zip(Rg + Pg, Ro + Po))
+        assert any((u != v).any() for u, v in zip(Ro + Po, sum(oracle.trplu(cv, P), ())))        # ... and differ from the exact DAG (DBLU squares x and y)
         (Zg, Qg), (Zo, Qo) = gpu.zdau(cv, Ro, Po), oracle_faithful.zdau(cv, Ro, Po)
         assert all(np.array_equal(u, v) for u, v in zip(Zg + Qg, Zo + Qo))
         assert all(np.array_equal(u, v) for u, v in zip(gpu.add_z2_1(cv, Zo, (P[0], P[1])), oracle_faithful.add_z2_1(cv, Zo, (P[0], P[1]))))
-        assert any((u != v).any() for u, v in zip(Zo + Qo, sum(oracle.zdau(cv, Ro, Po), ())))    # ... and differ from the exact DAG
         Jf = oracle_faithful.scalar_mult(cv, k, ar[:m], br[:m], threads=THREADS)
         Jg = gpu.scalar_mult(cv, k, ar[:m], br[:m])
         assert all(np.array_equal(u, v) for u, v in zip(Jg, Jf))
@@ -890,3 +890,40 @@ def test_operands_must_agree_on_the_batch_length(engine):
     with pytest.raises(EcsimdHipError):
         engine.scalar_mult(P256, x, x, x, out=[engine.empty(16) for _ in range(3)])
     assert engine.mgry_mul(P256, x, x).shape == (32, 4)         # and the refused calls left no state behind
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_device_group_behind_the_c_abi(engine, oracle, devices):
+    """ecsimd_hip_group_*: contiguous shards, one context per member, results gathered to member 0.  A one-GPU box
+    can only build groups on device 0: [0] is the 1-device group of SURVEY.md 8(e); listing the device two or three
+    times exercises the multi-member bookkeeping (uneven shards, staging, the gather into member 0's arrays) with
+    device copies where RCCL -- which refuses two ranks on one GPU -- would run on a real node."""
+    import torch
+    from ecsimd_amd import DeviceGroup, shard_range_c
+    cv = P256; n = 10007; G = len(devices)
+    grp = DeviceGroup(devices)
+    try:
+        assert grp.size == G and grp.uses_rccl is False
+        k = engine.fill_random(n, SEED, 1, first_index=77); s_ = engine.fill_random(n, SEED, 2, first_index=77)
+        bx, by = engine.scalar_mult_base(cv, s_, flags=OUT_AFFINE | ALG_WINDOWED_BIG)
+        exp = engine.scalar_mult(cv, k, bx, by)
+        spans = [shard_range_c(n, m, G) for m in range(G)]
+        cut = lambda t: [t[f:f + c].contiguous() for f, c in spans]
+        got, gather_ms = grp.scalar_mult(cv, cut(k), cut(bx), cut(by), n)
+        assert all(torch.equal(a, b) for a, b in zip(got, exp)) and gather_ms >= 0
+        (ax, ay), _ = grp.scalar_mult(cv, cut(k), cut(bx), cut(by), n, flags=OUT_AFFINE | ALG_WINDOWED)
+        ex, ey = engine.to_affine(cv, exp)
+        assert torch.equal(ax, ex) and torch.equal(ay, ey)
+        # host-array form, checked against the oracle on a sample as well
+        kn, xn, yn = (engine.to_numpy(t) for t in (k, bx, by))
+        H = grp.scalar_mult_host(cv, kn, xn, yn)
+        assert all(np.array_equal(h, engine.to_numpy(e)) for h, e in zip(H, exp))
+        idx = np.arange(0, n, 97)
+        assert all(np.array_equal(h[idx], o) for h, o in zip(H, oracle.scalar_mult(cv, kn[idx], xn[idx], yn[idx], threads=THREADS)))
+        # fewer elements than members: empty shards
+        small = grp.scalar_mult_host(cv, kn[:2], xn[:2], yn[:2])
+        assert all(np.array_equal(h, engine.to_numpy(e)[:2]) for h, e in zip(small, exp))
+        with pytest.raises(EcsimdHipError):
+            grp.scalar_mult(cv, cut(k), cut(bx), [None] * G, n)
+    finally:
+        grp.close()
