@@ -75,6 +75,8 @@ struct ecsimd_hip_ctx {
   uint32_t* window16_table[2]; // per curve: signed BIG_WINDOW_BITS-bit windows in device memory (20 bits: 13 x 524 288 entries, 436 MB)
   uint64_t* workspace;         // grow-only scratch for the windowed path's Jacobian intermediates
   size_t workspace_bytes;
+  uint8_t* valid;              // grow-only: per-lane public-key validity of double_scalar_mult / ecdsa_verify_rx
+  size_t valid_bytes;
   int ref_square;              // ecsimd_hip_set_ref_square_compat: the reference's square() as written (mul.h:160-212)
   char err[256];
 };
@@ -112,14 +114,34 @@ void words_to_limbs(const uint32_t (&w)[8], uint64_t out[4]) {
 // Grow-only device scratch, ordered by the context's stream (synchronise before switching streams with
 // ecsimd_hip_set_stream while a scratch-using call is in flight).  hipMalloc synchronises: callers that
 // capture graphs warm the path up once.
+bool capturing(ecsimd_hip_ctx* ctx) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st != hipStreamCaptureStatusNone;
+}
 int ensure_workspace(ecsimd_hip_ctx* ctx, size_t bytes) {
   if (ctx->workspace_bytes >= bytes) return ECSIMD_HIP_OK;
+  // Growing frees the old block: pointers a hipGraph captured earlier would dangle, and a capture in progress can neither
+  // synchronise nor allocate.  The caller warms the path up at its largest batch BEFORE capturing (include/ecsimd_hip.h).
+  if (capturing(ctx)) return bad(ctx, "the context workspace would have to grow during stream capture: run this call once at the largest batch size before capturing");
   hipError_t e = hipStreamSynchronize(ctx->stream);
   if (e == hipSuccess && ctx->workspace) e = hipFree(ctx->workspace);
   ctx->workspace = nullptr; ctx->workspace_bytes = 0;
   if (e == hipSuccess) e = hipMalloc(&ctx->workspace, bytes);
   if (e != hipSuccess) return fail(ctx, e, "workspace hipMalloc");
   ctx->workspace_bytes = bytes;
+  return ECSIMD_HIP_OK;
+}
+
+int ensure_valid(ecsimd_hip_ctx* ctx, size_t bytes) {
+  if (ctx->valid_bytes >= bytes) return ECSIMD_HIP_OK;
+  if (capturing(ctx)) return bad(ctx, "the validity buffer would have to grow during stream capture: run this call once at the largest batch size before capturing");
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess && ctx->valid) e = hipFree(ctx->valid);
+  ctx->valid = nullptr; ctx->valid_bytes = 0;
+  if (e == hipSuccess) e = hipMalloc(&ctx->valid, bytes);
+  if (e != hipSuccess) return fail(ctx, e, "validity buffer hipMalloc");
+  ctx->valid_bytes = bytes;
   return ECSIMD_HIP_OK;
 }
 
@@ -154,36 +176,39 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
         for (int l = 0; l < 4; ++l) e[l] = 0;
       }
     }
-  int rc = ensure_workspace(ctx, 6 * entries * 32);
-  if (rc != ECSIMD_HIP_OK) return rc;
-  uint64_t* kd = ctx->workspace; uint64_t* tx = kd + entries * 4; uint64_t* ty = tx + entries * 4;
+  // The build needs 6 x entries x 32 B of scratch (1.3 GB for the 20-bit table): a TEMPORARY block freed below, not the
+  // context's grow-only workspace -- a caller that verifies one signature must not keep 1.3 GB pinned for it.
+  if (capturing(ctx)) return bad(ctx, "a window table would have to be built during stream capture: run this call once before capturing");
+  uint64_t* kd = nullptr;
   uint32_t* table = nullptr;
-  hipError_t e = hipMalloc(&table, entries * 64);
+  hipError_t e = hipMalloc(&kd, 6 * entries * 32);
+  if (e == hipSuccess) e = hipMalloc(&table, entries * 64);
+  uint64_t* tx = kd + entries * 4; uint64_t* ty = tx + entries * 4;
   if (e == hipSuccess) e = hipMemcpyAsync(kd, host_k.data(), entries * 32, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // host_k must outlive the copy
-  if (e != hipSuccess) return fail(ctx, e, "window table setup");
-  {   // ladder (Jacobian, fast domain) into scratch, then affine classical (x, y)
+  if (e == hipSuccess) {   // ladder (Jacobian, fast domain) into scratch, then affine classical (x, y)
     uint64_t* jx = ty + entries * 4; uint64_t* jy = jx + entries * 4; uint64_t* jz = jy + entries * 4;
     launch::scalar_mult(ctx->stream, curve, kd, 4, nullptr, nullptr, jx, jy, jz, entries, ECSIMD_HIP_OUT_AFFINE);
     launch::to_affine_batched(ctx->stream, curve, jx, jy, jz, tx, ty, entries, true);
+    if (big) {
+      launch::pack_table_big(ctx->stream, curve, tx, ty, table);           // odd digits: no carry, no 2^256 * G entry
+    } else if (bits != 4) {
+      // The one reachable entry with m * 2^pos = 2^256 (top digit + carry): the ladder cannot produce 2^256 * G (a degenerate
+      // scalar, see above), so it is the entry holding 2^255 * G doubled by the affine-addition kernel.
+      uint64_t* sx = ty + entries * 4; uint64_t* sy = sx + 4;                                  // scratch (the Jacobian area is free again)
+      const size_t src = ((size_t)(255 / bits) * per + ((size_t)1 << (255 % bits)) - 1) * 4;
+      const size_t dst = ((size_t)(256 / bits) * per + ((size_t)1 << (256 % bits)) - 1) * 4;
+      launch::affine_add_batched(ctx->stream, curve, tx + src, ty + src, tx + src, ty + src, sx, sy, nullptr, 1);
+      e = hipMemcpyAsync(tx + dst, sx, 32, hipMemcpyDeviceToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(ty + dst, sy, 32, hipMemcpyDeviceToDevice, ctx->stream);
+      if (e == hipSuccess) launch::pack_table_signed(ctx->stream, curve, bits, tx, ty, table);
+    } else {
+      launch::pack_table(ctx->stream, curve, tx, ty, table);
+    }
   }
-  if (big) {
-    launch::pack_table_big(ctx->stream, curve, tx, ty, table);           // odd digits: no carry, no 2^256 * G entry
-  } else if (bits != 4) {
-    // The one reachable entry with m * 2^pos = 2^256 (top digit + carry): the ladder cannot produce 2^256 * G (a degenerate
-    // scalar, see above), so it is the entry holding 2^255 * G doubled by the affine-addition kernel.
-    uint64_t* sx = ty + entries * 4; uint64_t* sy = sx + 4;                                  // scratch (the Jacobian area is free again)
-    const size_t src = ((size_t)(255 / bits) * per + ((size_t)1 << (255 % bits)) - 1) * 4;
-    const size_t dst = ((size_t)(256 / bits) * per + ((size_t)1 << (256 % bits)) - 1) * 4;
-    launch::affine_add_batched(ctx->stream, curve, tx + src, ty + src, tx + src, ty + src, sx, sy, nullptr, 1);
-    (void)hipMemcpyAsync(tx + dst, sx, 32, hipMemcpyDeviceToDevice, ctx->stream);
-    (void)hipMemcpyAsync(ty + dst, sy, 32, hipMemcpyDeviceToDevice, ctx->stream);
-    launch::pack_table_signed(ctx->stream, curve, bits, tx, ty, table);
-  } else {
-    launch::pack_table(ctx->stream, curve, tx, ty, table);
-  }
-  e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e == hipSuccess) e = hipGetLastError();
+  (void)hipFree(kd);
   if (e != hipSuccess) { (void)hipFree(table); return fail(ctx, e, "window table build"); }
   *slot = table;
   return ECSIMD_HIP_OK;
@@ -258,7 +283,7 @@ int ecsimd_hip_init(int device, ecsimd_hip_ctx** out) {
   ecsimd_hip_ctx* ctx = new (std::nothrow) ecsimd_hip_ctx();
   if (!ctx) return ECSIMD_HIP_ERR_HIP;
   ctx->device = device; ctx->cus = prop.multiProcessorCount; ctx->err[0] = 0; ctx->sink = nullptr;
-  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->window6_table[0] = ctx->window6_table[1] = nullptr; ctx->window16_table[0] = ctx->window16_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0; ctx->ref_square = 0;
+  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->window6_table[0] = ctx->window6_table[1] = nullptr; ctx->window16_table[0] = ctx->window16_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0; ctx->ref_square = 0; ctx->valid = nullptr; ctx->valid_bytes = 0;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ECSIMD_HIP_ERR_HIP; }
   ctx->stream = ctx->own_stream;
   if (hipEventCreateWithFlags(&ctx->handoff, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ECSIMD_HIP_ERR_HIP; }
@@ -271,7 +296,7 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->sink);
-  (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->window16_table[0]); (void)hipFree(ctx->window16_table[1]); (void)hipFree(ctx->workspace);
+  (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->window16_table[0]); (void)hipFree(ctx->window16_table[1]); (void)hipFree(ctx->workspace); (void)hipFree(ctx->valid);
   (void)hipEventDestroy(ctx->handoff);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -536,49 +561,74 @@ int ecsimd_hip_affine_add(ecsimd_hip_ctx* ctx, int curve, const uint64_t* ax, co
   RUN(launch::affine_add_batched(s, curve, ax, ay, bx, by, rx, ry, finite, n)); }
 
 // u1[i]*G + u2[i]*Q[i]: windowed fixed-base product + windowed variable-base product + one batched affine
-// addition, in chunks of VARWIN_CHUNK elements.
-int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
-                                  uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(u1); REQUIRE_PTR(u2); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(rx);
-  if (ry && !aligned16(ry)) return bad(ctx, "ry is not 16-byte aligned");
-  if (n == 0) return ECSIMD_HIP_OK;
+// addition, in chunks of VARWIN_CHUNK elements.  Every Q[i] is validated first (x, y < p, on the curve; the point at
+// infinity (0, 0) fails): an invalid public key yields the point at infinity and finite[i] = 0 -- without the check
+// the window tables of such a lane would hold multiples on some other curve and the result would look like a point.
+// u1*G comes from the 20-bit window table in device memory (436 MB per curve, built on first use) once that table
+// exists or the batch is large enough to pay for building it; smaller batches take the signed 7-bit table in LDS.
+namespace {
+constexpr size_t BIG_TABLE_WORTH_IT = (size_t)1 << 16;
+int double_scalar_mult_impl(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
+                            uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n, size_t reserve_behind) {
   (void)hipSetDevice(ctx->device);
   const size_t chunk = n < VARWIN_CHUNK ? n : VARWIN_CHUNK;
-  int rc = ensure_window_table(ctx, curve, launch::BIG_WINDOW_BITS);
-  if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 7 * chunk * 32 + launch::varwin_scratch_bytes(chunk));   // 3 Jacobian + 2 x 2 affine + tables
+  const bool big = ctx->window16_table[curve] != nullptr || n >= BIG_TABLE_WORTH_IT;
+  int rc = ensure_window_table(ctx, curve, big ? launch::BIG_WINDOW_BITS : SIGNED_WBITS);
+  if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 7 * chunk * 32 + launch::varwin_scratch_bytes(chunk) + reserve_behind);   // 3 Jacobian + 2 x 2 affine + tables
+  if (rc == ECSIMD_HIP_OK) rc = ensure_valid(ctx, (n + 15) / 16 * 16);
   if (rc != ECSIMD_HIP_OK) return rc;
   uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * chunk; uint64_t* jz = jy + 4 * chunk;
   uint64_t* gx = jz + 4 * chunk; uint64_t* gy = gx + 4 * chunk; uint64_t* px = gy + 4 * chunk; uint64_t* py = px + 4 * chunk;
   uint64_t* scratch = py + 4 * chunk;
   hipStream_t s = ctx->stream;
+  launch::on_curve(s, curve, qx, qy, ctx->valid, n);
   for (size_t first = 0; first < n; first += chunk) {
     const size_t m = (n - first) < chunk ? (n - first) : chunk;
-    launch::base_windowed_big(s, curve, u1 + 4 * first, ctx->window16_table[curve], jx, jy, jz, m);   // u1*G
+    if (big) launch::base_windowed_big(s, curve, u1 + 4 * first, ctx->window16_table[curve], jx, jy, jz, m);   // u1*G
+    else launch::base_windowed_signed(s, curve, SIGNED_WBITS, u1 + 4 * first, ctx->window6_table[curve], jx, jy, jz, m);
     launch::to_affine_batched(s, curve, jx, jy, jz, gx, gy, m, true);
     launch::varwin_scalar_mult(s, curve, u2 + 4 * first, 4, qx + 4 * first, qy + 4 * first, ECSIMD_HIP_BASE_CLASSICAL, scratch, px, py, m);   // u2*Q
     launch::affine_add_batched(s, curve, gx, gy, px, py, rx + 4 * first, ry ? ry + 4 * first : nullptr, finite ? finite + first : nullptr, m);
   }
+  launch::clear_invalid(s, ctx->valid, rx, ry, finite, n);
   hipError_t e = hipGetLastError();
-  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "double_scalar_mult launch"); }
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "double_scalar_mult launch");
+}
+}  // namespace
 
-// ECDSA's acceptance test on top of double_scalar_mult: ok[i] = (u1*G + u2*Q is finite) && (its x mod n == r[i]).
+int ecsimd_hip_on_curve(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, uint8_t* ok, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); if (!ok && n) return bad(ctx, "ok is null");
+  RUN(launch::on_curve(s, curve, x, y, ok, n)); }
+
+int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
+                                  uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(u1); REQUIRE_PTR(u2); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(rx);
+  if (ry && !aligned16(ry)) return bad(ctx, "ry is not 16-byte aligned");
+  if (ctx->ref_square) return bad(ctx, "double_scalar_mult is not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT form");
+  if (n == 0) return ECSIMD_HIP_OK;
+  return double_scalar_mult_impl(ctx, curve, u1, u2, qx, qy, rx, ry, finite, n, 0); }
+
+// ECDSA's acceptance test on top of double_scalar_mult: ok[i] = Q[i] is a valid public key && u1*G + u2*Q is finite && its x mod n == r[i].
 int ecsimd_hip_ecdsa_verify_rx(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                                const uint64_t* r, uint8_t* ok, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(u1); REQUIRE_PTR(u2); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(r);
   if (!ok && n) return bad(ctx, "ok is null");
+  if (ctx->ref_square) return bad(ctx, "ecdsa_verify_rx is not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT form");
   if (n == 0) return ECSIMD_HIP_OK;
   (void)hipSetDevice(ctx->device);
   // x coordinates and the finite flags of the sums live behind double_scalar_mult's own workspace use
   const size_t chunk = n < VARWIN_CHUNK ? n : VARWIN_CHUNK;
   const size_t front = 7 * chunk * 32 + launch::varwin_scratch_bytes(chunk);
-  int rc = ensure_window_table(ctx, curve, launch::BIG_WINDOW_BITS);      // first: building it may re-allocate the workspace
-  if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, front + n * 32 + ((n + 15) / 16) * 16);
+  const size_t behind = n * 32 + ((n + 15) / 16) * 16;
+  // sizes the workspace (and builds the table) first, so that the pointers taken below stay valid
+  int rc = ensure_window_table(ctx, curve, (ctx->window16_table[curve] != nullptr || n >= BIG_TABLE_WORTH_IT) ? launch::BIG_WINDOW_BITS : SIGNED_WBITS);
+  if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, front + behind);
   if (rc != ECSIMD_HIP_OK) return rc;
   uint64_t* rx = ctx->workspace + front / 8;
   uint8_t* fin = reinterpret_cast<uint8_t*>(rx + 4 * n);
-  rc = ecsimd_hip_double_scalar_mult(ctx, curve, u1, u2, qx, qy, rx, nullptr, fin, n);
+  rc = double_scalar_mult_impl(ctx, curve, u1, u2, qx, qy, rx, nullptr, fin, n, behind);
   if (rc != ECSIMD_HIP_OK) return rc;
-  launch::x_mod_n_equals(ctx->stream, curve, rx, fin, r, ok, n);
+  launch::x_mod_n_equals(ctx->stream, curve, rx, fin, r, ok, n);       // fin is 0 for the lanes whose Q failed validation
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "ecdsa_verify_rx launch"); }
 

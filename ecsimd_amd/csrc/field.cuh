@@ -719,6 +719,62 @@ template <int CURVE> ECS_DEV fe mgry_reduce_generic(fe2& t) {
   return res;
 }
 
+// secp256k1, Montgomery domain: T * 2^-256 mod p with the prime's special form.  The reference's eight 32-bit rounds
+// (mgry_mul.h:110-116) add q_i * p * W^i, W = 2^32; with p = W^8 - c, c = W + 977, that is  + q_i W^(8+i)  - q_i c W^i:
+//     (T + Q p) / W^8  =  T_hi + Q - E,      Q = sum q_i W^i,   E = (Q c - T_lo) / W^8   (exact: Q c = T_lo mod W^8).
+// Only the low half has to be walked word by word, and each round multiplies by the 10-bit constant 977 instead of by
+// the 8 words of p: with D_i the amount still to be subtracted at word i (D_0 = 0, D_i < 2^34),
+//     s = t_i - lo(D_i)  (borrow b);   q_i = s * m' mod W   [m' = 977^-1 mod W, so lo(977 q_i) = s: word i cancels];
+//     D_(i+1) = hi(D_i) + b + hi(977 q_i) + q_i;                                    and E = D_8.
+// 6 instructions per round (2 of them multiplies) + 16 for T_hi + Q - E: 64, against 224 for the generic row-by-row
+// form -- same residue, Montgomery reduction being a function of T and p only.
+ECS_DEV fe mgry_reduce_secp256k1(fe2& t) {
+  const uint32_t MP = curve_consts<CURVE_SECP256K1>::MPRIME, K = 977u;
+  fe q; uint32_t dl, dh, sw, xh;
+  // %0..%7 = q_0..q_7, %8 = lo(D), %9 = hi(D), %10 = s, %11 = hi(977 q), %12..%19 = t_0..t_7, %20 = m', %21 = 977
+#define ECS_K1_ROUND(QI, TI) \
+      "v_sub_co_u32 %10, vcc, " TI ", %8\n\t"        /* s = t_i - lo(D), borrow in VCC */ \
+      "v_mul_lo_u32 " QI ", %10, %20\n\t"             /* q_i = s * m' */ \
+      "v_mul_hi_u32 %11, " QI ", %21\n\t"             /* hi(977 q_i) */ \
+      "v_addc_co_u32 %11, vcc, %9, %11, vcc\n\t"      /* + hi(D) + b   (< 2^11: no carry) */ \
+      "v_add_co_u32 %8, vcc, %11, " QI "\n\t"         /* lo(D') = ... + q_i */ \
+      "v_addc_co_u32 %9, vcc, 0, 0, vcc\n\t"          /* hi(D') */
+  asm("v_mov_b32 %8, 0\n\tv_mov_b32 %9, 0\n\t"
+      ECS_K1_ROUND("%0", "%12") ECS_K1_ROUND("%1", "%13") ECS_K1_ROUND("%2", "%14") ECS_K1_ROUND("%3", "%15")
+      ECS_K1_ROUND("%4", "%16") ECS_K1_ROUND("%5", "%17") ECS_K1_ROUND("%6", "%18") ECS_K1_ROUND("%7", "%19")
+      : "=&v"(q.w[0]), "=&v"(q.w[1]), "=&v"(q.w[2]), "=&v"(q.w[3]), "=&v"(q.w[4]), "=&v"(q.w[5]), "=&v"(q.w[6]), "=&v"(q.w[7]),
+        "=&v"(dl), "=&v"(dh), "=&v"(sw), "=&v"(xh)
+      : "v"(t.w[0]), "v"(t.w[1]), "v"(t.w[2]), "v"(t.w[3]), "v"(t.w[4]), "v"(t.w[5]), "v"(t.w[6]), "v"(t.w[7]), "s"(MP), "s"(K)
+      : "vcc");
+#undef ECS_K1_ROUND
+  // res = T_hi + Q - E; carry of the addition and borrow of the subtraction net out to the 257th bit (the value is in [0, 2p))
+  fe res;
+  lane_mask top;
+  asm("v_add_co_u32 %0, vcc, %9, %17\n\t"
+      "v_addc_co_u32 %1, vcc, %10, %18, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %11, %19, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %12, %20, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %13, %21, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %14, %22, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %15, %23, vcc\n\t"
+      "v_addc_co_u32 %7, %8, %16, %24, vcc\n\t"       /* carry -> %8 */
+      "v_sub_co_u32 %0, vcc, %0, %25\n\t"
+      "v_subb_co_u32 %1, vcc, %1, %26, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %2, 0, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %3, 0, vcc\n\t"
+      "v_subb_co_u32 %4, vcc, %4, 0, vcc\n\t"
+      "v_subb_co_u32 %5, vcc, %5, 0, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %6, 0, vcc\n\t"
+      "v_subb_co_u32 %7, vcc, %7, 0, vcc\n\t"
+      "s_andn2_b64 %8, %8, vcc"                        /* top = carry and not borrow */
+      : "=&v"(res.w[0]), "=&v"(res.w[1]), "=&v"(res.w[2]), "=&v"(res.w[3]), "=&v"(res.w[4]), "=&v"(res.w[5]), "=&v"(res.w[6]), "=&v"(res.w[7]), "=&s"(top)
+      : "v"(t.w[8]), "v"(t.w[9]), "v"(t.w[10]), "v"(t.w[11]), "v"(t.w[12]), "v"(t.w[13]), "v"(t.w[14]), "v"(t.w[15]),
+        "v"(q.w[0]), "v"(q.w[1]), "v"(q.w[2]), "v"(q.w[3]), "v"(q.w[4]), "v"(q.w[5]), "v"(q.w[6]), "v"(q.w[7]), "v"(dl), "v"(dh)
+      : "vcc", "scc");
+  cond_sub_p<CURVE_SECP256K1>(res, top);
+  return res;
+}
+
 // secp256k1, classical domain: T mod p with p = 2^256 - c, c = 2^32 + 977.
 //   T = H*2^256 + L  ==  L + H*c       (first fold, S < 2^289)
 //   S = h2*2^256 + S_lo == S_lo + h2*c  (second fold, h2 < 2^33, result < 2^256 + 2^67)
@@ -775,6 +831,7 @@ ECS_DEV fe reduce_secp256k1_classical(fe2& t) {
 template <int CURVE> ECS_DEV fe mgry_reduce(fe2& t) {
   if constexpr (curve_prime<CURVE>::is_p256) return mgry_reduce_p256(t);
   else if constexpr (CURVE == CURVE_SECP256K1_CLASSICAL) return reduce_secp256k1_classical(t);
+  else if constexpr (CURVE == CURVE_SECP256K1 || CURVE == CURVE_SECP256K1_REFSQR) return mgry_reduce_secp256k1(t);
   else return mgry_reduce_generic<CURVE>(t);
 }
 

@@ -113,10 +113,36 @@ template <int C, int REC> __global__ void __launch_bounds__(BLOCK) k_sec1_decode
   fe_store(x, i, xv); fe_store(y, i, yv);
   if (ok) ok[i] = (uint8_t)good;
 }
+// Public-key validation (SEC 1 section 3.2.2.1 without the subgroup step: both curves have cofactor 1): ok[i] = x, y < p and
+// y^2 = x^3 + a x + b.  (0, 0) -- this library's encoding of the point at infinity -- fails the equation (b != 0).
+template <int C> __global__ void __launch_bounds__(BLOCK) k_on_curve(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, uint8_t* __restrict__ ok, size_t n) {
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  constexpr int CI = curve_domain<C>::fast;
+  const fe xv = fe_load(x, i), yv = fe_load(y, i);
+  const fe xf = classical_to_fast<C>(xv);
+  fe rhs = fe_mul<CI>(fe_sqr<CI>(xf), xf);
+  if constexpr (C == CURVE_P256) rhs = fe_sub<CI>(fe_add<CI>(rhs, FE_CONST(CI, BM)), fe_add<CI>(fe_dbl<CI>(xf), xf));
+  else rhs = fe_add<CI>(rhs, FE_CONST(CI, BM));
+  ok[i] = (uint8_t)(below_p<C>(xv) && below_p<C>(yv) && fe_eq(fe_sqr<CI>(classical_to_fast<C>(yv)), rhs));
+}
+// lanes whose input failed validation report the point at infinity: (0, 0), finite = 0
+__global__ void __launch_bounds__(BLOCK) k_clear_invalid(const uint8_t* __restrict__ valid, uint64_t* __restrict__ rx, uint64_t* __restrict__ ry, uint8_t* __restrict__ finite, size_t n) {
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n || valid[i]) return;
+  fe z;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) z.w[j] = 0;
+  fe_store(rx, i, z); if (ry) fe_store(ry, i, z); if (finite) finite[i] = 0;
+}
 }  // namespace
 
 namespace launch {
 #define GO(kern, ...) hipLaunchKernelGGL(kern, grid_for(n), dim3(BLOCK), 0, s, __VA_ARGS__)
+void on_curve(hipStream_t s, int curve, const uint64_t* x, const uint64_t* y, uint8_t* ok, size_t n) {
+  if (curve == CURVE_P256) GO((k_on_curve<CURVE_P256>), x, y, ok, n); else GO((k_on_curve<CURVE_SECP256K1>), x, y, ok, n);
+}
+void clear_invalid(hipStream_t s, const uint8_t* valid, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) { GO(k_clear_invalid, valid, rx, ry, finite, n); }
 void bytes_be(hipStream_t s, const void* in, void* out, size_t n) { GO(k_bytes_be, static_cast<const uint4*>(in), static_cast<uint4*>(out), n); }
 void mask_bit(hipStream_t s, const uint64_t* a, int bit, uint8_t* flag, size_t n) { GO(k_mask_bit, a, bit, flag, n); }
 void sec1_encode(hipStream_t s, int curve, const uint64_t* x, const uint64_t* y, uint8_t* out, size_t n, bool compressed) {

@@ -34,6 +34,8 @@ void bytes_be(hipStream_t, const void* in, void* out, size_t n);
 void mask_bit(hipStream_t, const uint64_t* a, int bit, uint8_t* flag, size_t n);
 void sec1_encode(hipStream_t, int curve, const uint64_t* x, const uint64_t* y, uint8_t* out, size_t n, bool compressed);
 void sec1_decode(hipStream_t, int curve, const uint8_t* in, uint64_t* x, uint64_t* y, uint8_t* ok, size_t n, bool compressed);
+void on_curve(hipStream_t, int curve, const uint64_t* x, const uint64_t* y, uint8_t* ok, size_t n);                 // classical (x, y): x, y < p and on the curve
+void clear_invalid(hipStream_t, const uint8_t* valid, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);      // (0, 0) / not finite where !valid
 
 // k_field.hip
 enum field_op { F_MOD_ADD, F_MOD_SUB, F_MGRY_MUL, F_MGRY_SQR, F_FROM_CLASSICAL, F_TO_CLASSICAL, F_INVERSE, F_OPPOSITE };

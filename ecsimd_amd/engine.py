@@ -256,6 +256,10 @@ class Engine:
         n = j[0].shape[0]; x, y = self.empty(n), self.empty(n)
         self._call("to_affine", C.c_int(curve), *[self._ptr(t) for t in j], self._ptr(x), self._ptr(y), C.c_size_t(n)); return x, y
 
+    def on_curve(self, curve, x, y):
+        n = x.shape[0]; ok = self.flags(n)
+        self._call("on_curve", C.c_int(curve), self._ptr(x), self._ptr(y), self._ptr(ok, 0), C.c_size_t(n)); return ok
+
     def compute_y(self, curve, x):
         n = x.shape[0]; y = self.empty(n); ok = self.flags(n)
         self._call("compute_y", C.c_int(curve), self._ptr(x), self._ptr(y), self._ptr(ok, 0), C.c_size_t(n)); return y, ok

@@ -87,7 +87,9 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx);
  * by its stream: switching makes the new stream wait (by event, no host synchronisation) for the work this
  * context enqueued on the previous one, which must still exist at that moment.  Streams under hipGraph capture are
  * selected without that hand-off; every compute entry point is capturable once its first call has sized the
- * context workspace and built its tables (those steps allocate and synchronise). */
+ * context workspace and built its tables (those steps allocate and synchronise).  A call that would have to grow the
+ * workspace or build a table WHILE its stream is being captured returns ECSIMD_HIP_ERR_BAD_ARG instead (growing frees the
+ * old block, which an earlier capture may still point into): warm up at the largest batch size, then capture. */
 int ecsimd_hip_set_stream(ecsimd_hip_ctx* ctx, void* hip_stream);
 /* Go back to the non-blocking stream the context created in ecsimd_hip_init (the default). */
 int ecsimd_hip_use_own_stream(ecsimd_hip_ctx* ctx);
@@ -218,12 +220,19 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx*, int curve, const uint64_t* k, u
  * not alias an input). */
 int ecsimd_hip_affine_add(ecsimd_hip_ctx*, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by,
                           uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
+/* on_curve: ok[i] = x[i], y[i] < p and y^2 = x^3 + a x + b (classical coordinates) -- SEC 1 public-key validation (both
+ * curves have cofactor 1); (0, 0), this library's point at infinity, fails. */
+int ecsimd_hip_on_curve(ecsimd_hip_ctx*, int curve, const uint64_t* x, const uint64_t* y, uint8_t* ok, size_t n);
 /* double_scalar_mult: R[i] = u1[i]*G + u2[i]*Q[i], affine classical (the ECDSA-verification shape; pass
  * ry = NULL for x only).  u1*G uses the windowed fixed-base kernel, u2*Q the windowed variable-base kernels
- * (ALG_WINDOWED): correct for every 256-bit u1, u2; 1 632 B of context workspace per element, 2^22 at a time. */
+ * (ALG_WINDOWED): correct for every 256-bit u1, u2; 1 632 B of context workspace per element, 2^22 at a time.
+ * Q[i] is VALIDATED (on_curve): an invalid public key -- off the curve, a coordinate >= p, the point at infinity --
+ * gives R[i] = (0, 0) and finite[i] = 0.  The scalars here are public (signature verification): the window kernels index
+ * their tables by scalar digits and are not for secret scalars.  u1*G goes through the 436 MB table of 20-bit windows once it
+ * exists in this context or n >= 2^16 (which builds it); smaller batches use the 148 KiB table in LDS and keep nothing that size. */
 int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx*, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                                   uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
-/* The acceptance test of an ECDSA verification for precomputed u1 = e/s, u2 = r/s (mod n; computing them is the caller's:
+/* (ok[i] is also 0 when Q[i] fails the validation above.)  The acceptance test of an ECDSA verification for precomputed u1 = e/s, u2 = r/s (mod n; computing them is the caller's:
  * this library has no arithmetic modulo the group order): ok[i] = 1 iff u1[i]*G + u2[i]*Q[i] is a finite point whose
  * x coordinate, reduced mod n, equals r[i].  Same workspace as double_scalar_mult plus 33 B per element. */
 int ecsimd_hip_ecdsa_verify_rx(ecsimd_hip_ctx*, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,

@@ -60,7 +60,9 @@ TEST(Ops128, ZextTruncAndLimbShifts) {
   // shift.h:53-96 (what mgry_reduce's zero-extended shifts are built from in the reference)
   using W192 = wide_bignum<bignum<uint64_t, 3>>;
   EXPECT_TRUE(all(limb_shift_left<4, 1>(v) == splat<W256>("0000000000000000b59edca51009bb15c309b23171c102da0000000000000000"_hex)));
-  EXPECT_TRUE(all(limb_shift_left<3, 2>(v) == splat<W192>("c309b23171c102da00000000000000000000000000000000"_hex)));       // the high limb does not fit: dropped
+  EXPECT_TRUE(all(limb_shift_left<2, 1>(v) == splat<W128>("c309b23171c102da0000000000000000"_hex)));                       // the high limb does not fit: dropped
+  EXPECT_TRUE(all(limb_shift_left<3, 1>(v) == splat<W192>("b59edca51009bb15c309b23171c102da0000000000000000"_hex)));
+  EXPECT_TRUE(all(limb_shift_left<3, 2>(v) == W192{bignum<uint64_t, 3>{}}));                                               // ShiftBy >= the operand's limbs: zero (shift.h:60-62)
   EXPECT_TRUE(all(limb_shift_left<2, 2>(v) == W128{bignum_128{}}));
   EXPECT_TRUE(all(limb_shift_right<1>(q) == lanes<W192>("80000000800000008000000080000000ffffffffffffffff"_hex, "000000000000000000000000000000000000000000000000"_hex,
                                                         "ffffffffffffffffffffffffffffffffffffffffffffffff"_hex, "000000000000000100000000000000020000000000000003"_hex)));

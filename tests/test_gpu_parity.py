@@ -927,3 +927,89 @@ def test_device_group_behind_the_c_abi(engine, oracle, devices):
             grp.scalar_mult(cv, cut(k), cut(bx), [None] * G, n)
     finally:
         grp.close()
+
+
+@pytest.mark.parametrize("cv", CURVES)
+def test_invalid_public_keys_are_rejected(engine, cv):
+    """double_scalar_mult / ecdsa_verify_rx validate Q: the point at infinity (0, 0), a point off the curve and a
+    coordinate >= p give (0, 0), finite = 0, ok = 0 -- and leave their neighbours alone.  A fresh context below 2^16
+    elements takes the LDS-table route for u1*G (no 436 MB table is built for a small batch): same results."""
+    import torch
+    from ecsimd_amd import Engine
+    c = CURVE_PARAMS[cv]; p = c["p"]; n = 300
+    u1 = engine.fill_random(n, SEED, 71); u2 = engine.fill_random(n, SEED, 72)
+    qx, qy = engine.scalar_mult_base(cv, engine.fill_random(n, SEED, 73), flags=OUT_AFFINE | ALG_WINDOWED)
+    gx, gy, gfin = engine.double_scalar_mult(cv, u1, u2, qx, qy)
+    assert bool(gfin.all()) and bool(engine.on_curve(cv, qx, qy).all())
+    bx, by = engine.to_numpy(qx).copy(), engine.to_numpy(qy).copy()
+    bx[3] = 0; by[3] = 0                                             # infinity
+    by[10] = from_int((to_int(by[10]) + 1) % p)                      # off the curve
+    bx[20] = from_int(p + 1)                                         # x >= p (x = 1 mod p may well be on the curve: the range check must catch it)
+    by[30] = from_int(p - to_int(by[30]))                            # -Q: a VALID key, another point
+    bad = [3, 10, 20]
+    dqx, dqy = engine.to_device(bx), engine.to_device(by)
+    okc = engine.to_numpy(engine.on_curve(cv, dqx, dqy))
+    assert [i for i in range(n) if not okc[i]] == bad
+    rx, ry, fin = engine.double_scalar_mult(cv, u1, u2, dqx, dqy)
+    rxn, ryn, finn = engine.to_numpy(rx), engine.to_numpy(ry), engine.to_numpy(fin)
+    same = np.ones(n, dtype=bool); same[bad + [30]] = False
+    assert np.array_equal(rxn[same], engine.to_numpy(gx)[same]) and np.array_equal(ryn[same], engine.to_numpy(gy)[same]) and finn[same].all()
+    assert not finn[bad].any() and not rxn[bad].any() and not ryn[bad].any() and finn[30] == 1
+    r = engine.to_device(ints_to_arr([to_int(v) % c["n"] for v in engine.to_numpy(gx)]))            # r = x mod n of the honest sums
+    ok = engine.to_numpy(engine.ecdsa_verify_rx(cv, u1, u2, dqx, dqy, r))
+    assert ok[same].all() and not ok[bad].any() and ok[30] == 0
+    # x-only output, no finite array
+    rx2, _, _ = engine.double_scalar_mult(cv, u1, u2, dqx, dqy, x_only=True)
+    assert torch.equal(rx2, rx)
+    fresh = Engine(0)
+    try:
+        fx, fy, ffin = fresh.double_scalar_mult(cv, u1, u2, dqx, dqy)
+        torch.cuda.synchronize()
+        assert torch.equal(fx, rx) and torch.equal(fy, ry) and torch.equal(ffin, fin)
+        assert torch.equal(fresh.ecdsa_verify_rx(cv, u1, u2, dqx, dqy, r), engine.ecdsa_verify_rx(cv, u1, u2, dqx, dqy, r))
+    finally:
+        fresh.close()
+
+
+def test_workspace_growth_is_refused_during_stream_capture():
+    """Growing the context workspace frees the old block (pointers an earlier hipGraph captured would dangle) and needs a
+    synchronisation a capture cannot have: a call that would have to grow it -- or build a window table -- while its
+    stream is being captured returns an error; after a warm-up at that size the same call captures and replays."""
+    import torch
+    from ecsimd_amd import Engine
+    eng = Engine(0)
+    try:
+        n = 1 << 12
+        k = eng.fill_random(n, SEED, 81); bx, by = eng.scalar_mult_base(P256, eng.fill_random(n, SEED, 82), flags=OUT_AFFINE)
+        out = [eng.empty(n), eng.empty(n), None]
+        eager = eng.scalar_mult(P256, k, bx, by)                     # Jacobian ladder: no workspace
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+        refused = []
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for flags in (OUT_AFFINE | ALG_WINDOWED, OUT_AFFINE | ALG_WINDOWED_SIGNED):
+                    try:
+                        eng.scalar_mult_base(P256, k, flags=flags, out=out)          # needs a table + a workspace
+                    except EcsimdHipError as exc:
+                        refused.append(str(exc))
+                try:
+                    eng.scalar_mult(P256, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED, out=out)    # 1 408 B of workspace per element
+                except EcsimdHipError as exc:
+                    refused.append(str(exc))
+                J = eng.scalar_mult(P256, k, bx, by)                                  # capturable as it is
+        torch.cuda.synchronize()
+        assert len(refused) == 3 and all("capture" in m for m in refused), refused
+        g.replay(); torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(J, eager))
+        want = eng.scalar_mult(P256, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)     # warm-up sizes the workspace ...
+        torch.cuda.synchronize()
+        g2 = torch.cuda.CUDAGraph(); side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g2, stream=side):
+                eng.scalar_mult(P256, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED, out=out)     # ... and now it captures
+        g2.replay(); torch.cuda.synchronize()
+        assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1])
+    finally:
+        eng.close()
