@@ -84,7 +84,10 @@ template <int C> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe& y2, fe& z, uint32
   const fe W1 = fe_mul<C>(X3pc, C4);
   const fe W2 = fe_mul<C>(W1p, C4);
   fe ym = fe_sub<C>(Y3p, A1p2);
-  const fe A1 = fe_mul<C>(Y3p, fe_sub<C>(W1, W2));
+  // A1 = Y3' * (W1 - W2) is only ever subtracted from a product (y = ym * (W1 - x) - A1, twice): it stays an unreduced 512-bit
+  // product and each y takes ONE reduction of the difference (fe_mul_sub_product) -- except with the reference's squaring, where
+  // nothing about a squaring-free value changes but the instance is kept formula-for-formula.
+  const fe2 A1wide = mul8x8(Y3p, fe_sub<C>(W1, W2));
   const fe W12 = fe_add<C>(W1, W2);
   // Z3 = Z * ((dx + X3' - W1')^2 - C' - C)
   fe zz = fe_sqr<C>(fe_add<C>(dx, u));
@@ -93,10 +96,10 @@ template <int C> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe& y2, fe& z, uint32
   fe_cswap(oswap, ym, yp);
   const fe D = fe_sqr<C>(ym);
   x1 = fe_sub<C>(D, W12);
-  y1 = fe_sub<C>(fe_mul<C>(ym, fe_sub<C>(W1, x1)), A1);
+  y1 = fe_mul_sub_product<C>(ym, fe_sub<C>(W1, x1), A1wide);
   const fe Dc = fe_sqr<C>(yp);
   x2 = fe_sub<C>(Dc, W12);
-  y2 = fe_sub<C>(fe_mul<C>(yp, fe_sub<C>(W1, x2)), A1);
+  y2 = fe_mul_sub_product<C>(yp, fe_sub<C>(W1, x2), A1wide);
 }
 
 // curve_group.h:155-179 ADD_Z2_1: (X1,Y1,Z1) + affine (x2, y2) [Z2 = R mod p].  7M + 4S.
@@ -112,7 +115,7 @@ template <int C> ECS_DEV jpoint add_z2_1(const fe& X1, const fe& Y1, const fe& Z
   const fe V = fe_mul<C>(X1, I);
   jpoint R;
   R.x = fe_sub<C>(fe_sub<C>(fe_sqr<C>(r), J), fe_dbl<C>(V));
-  R.y = fe_sub<C>(fe_mul<C>(r, fe_sub<C>(V, R.x)), fe_mul<C>(fe_dbl<C>(Y1), J));
+  R.y = fe_mul_sub_product<C>(r, fe_sub<C>(V, R.x), mul8x8(fe_dbl<C>(Y1), J));     // r*(V - X3) - 2*Y1*J: one reduction for the difference
   R.z = fe_sub<C>(fe_sub<C>(fe_sqr<C>(fe_add<C>(Z1, H)), Z1Z1), HH);
   return R;
 }
@@ -133,7 +136,7 @@ template <int C> ECS_DEV jpoint madd_hmv(const fe& X1, const fe& Y1, const fe& Z
   jpoint R;
   R.z = fe_mul<C>(Z1, H);
   R.x = fe_sub<C>(fe_sub<C>(fe_sqr<C>(r), HHH), fe_dbl<C>(V));
-  R.y = fe_sub<C>(fe_mul<C>(r, fe_sub<C>(V, R.x)), fe_mul<C>(Y1, HHH));
+  R.y = fe_mul_sub_product<C>(r, fe_sub<C>(V, R.x), mul8x8(Y1, HHH));               // one reduction for the difference of two products
   return R;
 }
 

@@ -3,6 +3,7 @@
 // updates in place (DBLU's P, ZADDU's P, ZDAU's Q, TRPLU's P) are updated in place here too.
 #ifndef ECSIMD_CURVE_GROUP_H
 #define ECSIMD_CURVE_GROUP_H
+#include <ecsimd/device_group.h>
 #include <ecsimd/jacobian_curve_point.h>
 #include <optional>
 
@@ -97,6 +98,22 @@ struct curve_group {
     hip::mask ok(Q.size());
     hip::check(ecsimd_hip_ecdsa_verify_rx(hip::context(), curve_id, u1.data(), u2.data(), Q.x().data(), Q.y().data(), r.data(), ok.data(), Q.size()), "ecsimd_hip_ecdsa_verify_rx");
     return ok;
+  }
+  // ---- several GPUs: k[i] * P[i] for HOST arrays, sharded over a device group.  P affine classical (x, y);
+  // the result is what scalar_mult(x, from_affine(P)) returns lane by lane -- Jacobian, Montgomery form -- or, with
+  // affine_out, what .to_affine() of it returns.  Member m computes the slice device_group::shard_range(n, m, size());
+  // one gather brings the shards to the first device and the result to the host.
+  struct host_points { std::vector<BN> x, y, z; };            // z is empty for affine output
+  static host_points scalar_mult(hip::device_group& g, std::vector<BN> const& k, std::vector<BN> const& px, std::vector<BN> const& py, bool affine_out = false) {
+    if (k.size() != px.size() || k.size() != py.size()) throw hip::error("ecsimd: scalar_mult over host arrays of different length");
+    static_assert(sizeof(BN) == 32, "a 256-bit element is 4 x u64, contiguous");
+    const size_t n = k.size();
+    host_points r; r.x.resize(n); r.y.resize(n); if (!affine_out) r.z.resize(n);
+    auto w = [](std::vector<BN> const& v) { return reinterpret_cast<const uint64_t*>(v.data()); };
+    auto m = [](std::vector<BN>& v) { return v.empty() ? nullptr : reinterpret_cast<uint64_t*>(v.data()); };
+    g.check(ecsimd_hip_group_scalar_mult_host(g.handle(), curve_id, w(k), w(px), w(py), m(r.x), m(r.y), m(r.z), n,
+                                              ECSIMD_HIP_BASE_CLASSICAL | (affine_out ? ECSIMD_HIP_OUT_AFFINE : ECSIMD_HIP_OUT_JACOBIAN)), "ecsimd_hip_group_scalar_mult_host");
+    return r;
   }
  private:
   static WJCP fresh(size_t n) {

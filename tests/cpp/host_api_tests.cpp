@@ -329,6 +329,26 @@ TEST(Batch, WindowedPathsAgreeWithTheLadder) {
 }
 
 // utility.h:45-51 wide_mask_bit and the device wire formats (beyond the reference's tests)
+TEST(Batch, DeviceGroup) {                                                                    // shards over a device group, one gather
+  using CG = curve_group<curve_nist_p256>;
+  using BN = bignum_256;
+  EXPECT_TRUE((hip::device_group::shard_range(size_t(1) << 24, 5, 8) == std::pair<size_t, size_t>{size_t(5) << 21, size_t(1) << 21}));
+  const size_t n = 37;
+  std::vector<BN> k(n), s(n);
+  for (size_t i = 0; i < n; ++i) { k[i] = BN{{0x9e3779b97f4a7c15ull * (i + 1), 0xbf58476d1ce4e5b9ull ^ i, i * i + 7, 0x0123456789abcdefull + i}}; s[i] = BN::from(i + 2); }
+  const auto P = CG::scalar_mult(wide_bignum<BN>(s), CG::WJG(n)).to_affine();                  // P_i = (i + 2) * G
+  const auto J = CG::scalar_mult(wide_bignum<BN>(k), wide_jacobian_curve_point<curve_nist_p256>::from_affine(P));
+  const auto A = J.to_affine();
+  const auto hx = P.x().host(), hy = P.y().host();
+  for (auto const& devices : {std::vector<int>{0}, std::vector<int>{0, 0}, std::vector<int>{0, 0, 0, 0, 0}}) {
+    hip::device_group g(devices);
+    EXPECT_TRUE(g.size() == (int)devices.size() && !g.uses_rccl());                             // RCCL needs distinct devices: a one-GPU box has none to offer
+    const auto r = CG::scalar_mult(g, k, hx, hy);
+    EXPECT_TRUE(r.x == J.x().wbn().host() && r.y == J.y().wbn().host() && r.z == J.z().wbn().host());
+    const auto a = CG::scalar_mult(g, k, hx, hy, true);
+    EXPECT_TRUE(a.x == A.x().host() && a.y == A.y().host() && a.z.empty());
+  }
+}
 TEST(Batch, MaskBitAndWireFormats) {
   using K = curve_nist_p256; using KG = curve_group<K>;
   const auto a = lanes<W128>("00000000000000000000000000000001"_hex, "00000000000000008000000000000000"_hex, "00000000000000010000000000000000"_hex, "80000000000000000000000000000000"_hex);

@@ -1,35 +1,51 @@
 #!/usr/bin/env python3
 """Soak parity run: GPU ladder vs the REAL reference (oracle/_ref) on many seeded batches, both curves.
-Every differing lane must be explained by the reference's square() defect (exact oracle == GPU and
-faithful oracle == reference).  Usage: soak.py [lanes_per_curve_log2=22] [batches=2]"""
+
+Default ladder (exact squaring): every lane that differs from the reference must be explained by the reference's
+square() defect (exact oracle == GPU and faithful oracle == reference) AND confirmed by libcrypto, which shares no code
+or algorithm with either: OpenSSL's k*P must equal the GPU's affine point on that lane and differ from the reference's.
+With ECSIMD_HIP_REF_SQUARE_COMPAT (the second pass over the same inputs) not one lane may differ.
+Usage: soak.py [lanes_per_batch_log2=22] [batches=2]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
-from ecsimd_amd import Engine, P256, SECP256K1
+from ecsimd_amd import Engine, P256, SECP256K1, OUT_AFFINE, ALG_WINDOWED_BIG, REF_SQUARE_COMPAT
 from oracle import loader
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from bench import usable_cores
+from bench import usable_cores, openssl_checker
 log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 batches = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-e = Engine(0); ref = loader.Reference(); ex = loader.Oracle(False); fa = loader.Oracle(True)
+e = Engine(0); ref = loader.Reference(); ex = loader.Oracle(False); fa = loader.Oracle(True); ossl = openssl_checker()
 cores = usable_cores(); n = 1 << log2n
-tot = diff = unexplained = 0
+tot = diff = unexplained = confirmed = compat_diff = 0
 t0 = time.time()
 for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     for b in range(batches):
         seed = 0xC0FFEE00 + 977 * b + cv
         k = e.fill_random(n, seed, 1); s = e.fill_random(n, seed, 2)
-        bx, by = e.scalar_mult_base(cv, s, flags=6)                      # windowed path makes the base points
+        bx, by = e.scalar_mult_base(cv, s, flags=OUT_AFFINE | ALG_WINDOWED_BIG)          # a windowed path makes the base points
         J = e.scalar_mult(cv, k, bx, by)
-        kn, xn, yn = (e.to_numpy(t) for t in (k, bx, by)); g = [e.to_numpy(t) for t in J]
+        Jc = e.scalar_mult(cv, k, bx, by, flags=REF_SQUARE_COMPAT)
+        kn, xn, yn = (e.to_numpy(t) for t in (k, bx, by)); g = [e.to_numpy(t) for t in J]; gc = [e.to_numpy(t) for t in Jc]
         r = ref.scalar_mult(cv, kn, xn, yn, threads=cores)
         bad = np.nonzero((g[0] != r[0]).any(axis=1) | (g[1] != r[1]).any(axis=1) | (g[2] != r[2]).any(axis=1))[0]
-        ok = True
+        cbad = int(np.count_nonzero((gc[0] != r[0]).any(axis=1) | (gc[1] != r[1]).any(axis=1) | (gc[2] != r[2]).any(axis=1)))
+        ok, conf = True, 0
         if len(bad):
             e_ = ex.scalar_mult(cv, kn[bad], xn[bad], yn[bad], threads=min(cores, len(bad)))
             f_ = fa.scalar_mult(cv, kn[bad], xn[bad], yn[bad], threads=min(cores, len(bad)))
             ok = all(np.array_equal(u, v[bad]) for u, v in zip(e_, g)) and all(np.array_equal(u, v[bad]) for u, v in zip(f_, r))
-        tot += n; diff += len(bad); unexplained += 0 if ok else len(bad)
-        print(f"{nm} batch {b}: {n} lanes, {len(bad)} differ from the reference, explained by its square() defect: {ok}   [{time.time()-t0:.0f}s]", flush=True)
-print(f"TOTAL {tot} scalar multiplications, {diff} lanes differ ({diff/tot:.2e}), unexplained: {unexplained}")
-sys.exit(1 if unexplained else 0)
+            if ossl is not None:
+                sel = torch.from_numpy(bad).to(J[0].device)
+                ax, ay = (e.to_numpy(t) for t in e.to_affine(cv, [t[sel].contiguous() for t in J]))
+                vx, vy, inf = ossl.scalar_mult(cv, kn[bad], xn[bad], yn[bad], threads=1)
+                rx, ry = ref.to_affine(cv, [v[bad] for v in r])
+                gpu_right = ~((ax != vx).any(axis=1) | (ay != vy).any(axis=1) | (inf != 0))
+                ref_wrong = (rx != vx).any(axis=1) | (ry != vy).any(axis=1)
+                conf = int(np.count_nonzero(gpu_right & ref_wrong))
+        tot += n; diff += len(bad); unexplained += 0 if ok else len(bad); confirmed += conf; compat_diff += cbad
+        print(f"{nm} batch {b}: {n} lanes, {len(bad)} differ from the reference (explained by its square() defect: {ok}; libcrypto sides with the GPU on {conf}); "
+              f"with REF_SQUARE_COMPAT {cbad} differ   [{time.time()-t0:.0f}s]", flush=True)
+print(f"TOTAL {tot} scalar multiplications per mode: exact ladder {diff} lanes differ from the reference ({diff/tot:.2e}), unexplained {unexplained}, "
+      f"confirmed by OpenSSL {confirmed if ossl is not None else 'n/a'}; REF_SQUARE_COMPAT ladder {compat_diff} lanes differ")
+sys.exit(1 if (unexplained or compat_diff or (ossl is not None and confirmed != diff)) else 0)
