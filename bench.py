@@ -271,10 +271,13 @@ def committed_traffic(args, n):
     except ValueError:
         return None, None
     key = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult", "windowed": "varwin", "fixed-base-big": "fixed_base_big"}.get(args.workload, "fixed_base")
-    per22 = table.get(f"{key}_{args.curve}_2^22")
-    if per22 is None:
-        return None, None
-    return per22 * n / float(1 << 22), "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at 2^22 lanes per launch, scaled by lanes; not measured in this run"
+    for log2 in (24, 22):                                 # a pass at this run's own launch size first
+        per = table.get(f"{key}_{args.curve}_2^{log2}")
+        if per is not None:
+            exact = n == (1 << log2)
+            return per * n / float(1 << log2), (f"profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at 2^{log2} lanes per launch"
+                                                 + ("" if exact else ", scaled by lanes") + "; not measured in this run")
+    return None, None
 
 
 def load_checkers():

@@ -36,14 +36,17 @@ struct curve_group {
     hip::check(ecsimd_hip_dblu(hip::context(), curve_id, px(P), py(P), pz(P), px(r), py(r), pz(r), P.size()), "ecsimd_hip_dblu"); return r;
   }
   static WJCP ZADDU(WJCP& P, WJCP const& O) {                                // :91-116
+    same_length(P.size(), O.size(), "ZADDU");
     P.unshare(); WJCP r = fresh(P.size());
     hip::check(ecsimd_hip_zaddu(hip::context(), curve_id, px(P), py(P), pz(P), px(O), py(O), pz(O), px(r), py(r), pz(r), P.size()), "ecsimd_hip_zaddu"); return r;
   }
   static WJCP ZDAU(WJCP const& P, WJCP& Q) {                                 // :120-153
+    same_length(P.size(), Q.size(), "ZDAU");
     Q.unshare(); WJCP r = fresh(P.size());
     hip::check(ecsimd_hip_zdau(hip::context(), curve_id, px(P), py(P), pz(P), px(Q), py(Q), pz(Q), px(r), py(r), pz(r), P.size()), "ecsimd_hip_zdau"); return r;
   }
   static WJCP ADD_Z2_1(WJCP const& A, WJCP const& B) {                       // :155-179 (B.z must be mgry(1))
+    same_length(A.size(), B.size(), "ADD_Z2_1");
     WJCP r = fresh(A.size());
     hip::check(ecsimd_hip_add_z2_1(hip::context(), curve_id, px(A), py(A), pz(A), px(B), py(B), px(r), py(r), pz(r), A.size()), "ecsimd_hip_add_z2_1"); return r;
   }
@@ -53,6 +56,7 @@ struct curve_group {
   }
   // k[i] * P[i], P.z must be mgry(1) (:189-218).  One kernel: the whole ladder stays in registers.
   static WJCP scalar_mult(WBN const& x, WJCP P) {
+    same_length(x.size(), P.size(), "scalar_mult");
     WJCP r = fresh(P.size());
     hip::check(ecsimd_hip_scalar_mult(hip::context(), curve_id, x.data(), px(P), py(P), px(r), py(r), pz(r), P.size(), ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN), "ecsimd_hip_scalar_mult"); return r;
   }
@@ -67,6 +71,7 @@ struct curve_group {
   // k[i] * P[i], P affine classical -> affine classical.  windowed: per-element tables of 8 multiples of P + signed 4-bit
   // windows (ECSIMD_HIP_ALG_WINDOWED); otherwise the reference ladder followed by one simultaneous inversion.
   static WCP scalar_mult_affine(WBN const& x, WCP const& P, bool windowed = true) {
+    same_length(x.size(), P.size(), "scalar_mult_affine");
     WCP r{WBN::uninitialized(P.size()), WBN::uninitialized(P.size())};
     hip::check(ecsimd_hip_scalar_mult(hip::context(), curve_id, x.data(), P.x().data(), P.y().data(), r.x().data(), r.y().data(), nullptr, P.size(),
                                       ECSIMD_HIP_BASE_CLASSICAL | ECSIMD_HIP_OUT_AFFINE | (windowed ? ECSIMD_HIP_ALG_WINDOWED : 0)), "ecsimd_hip_scalar_mult");
@@ -74,6 +79,7 @@ struct curve_group {
   }
   // A + B for every input, unlike ADD_Z2_1: A = B, A = -B (Z = 0 comes back), A at infinity (Z = 0); B.z must be mgry(1).
   static WJCP add_mixed_complete(WJCP const& A, WJCP const& B) {
+    same_length(A.size(), B.size(), "add_mixed_complete");
     WJCP r = fresh(A.size());
     hip::check(ecsimd_hip_add_mixed_complete(hip::context(), curve_id, px(A), py(A), pz(A), px(B), py(B), px(r), py(r), pz(r), A.size()), "ecsimd_hip_add_mixed_complete"); return r;
   }
@@ -87,6 +93,7 @@ struct curve_group {
   // u1[i] * G + u2[i] * Q[i] (the ECDSA-verification shape), affine classical; finite[i] is false where the sum
   // is the point at infinity (coordinates (0, 0)).
   static WCP double_scalar_mult(WBN const& u1, WBN const& u2, WCP const& Q, hip::mask& finite) {
+    same_length(u1.size(), Q.size(), "double_scalar_mult"); same_length(u2.size(), Q.size(), "double_scalar_mult");
     WCP r{WBN::uninitialized(Q.size()), WBN::uninitialized(Q.size())};
     finite = hip::mask(Q.size());
     hip::check(ecsimd_hip_double_scalar_mult(hip::context(), curve_id, u1.data(), u2.data(), Q.x().data(), Q.y().data(), r.x().data(), r.y().data(),
@@ -95,6 +102,7 @@ struct curve_group {
   }
   // ECDSA's acceptance test for precomputed u1 = e/s, u2 = r/s (mod n): lane i is set iff u1*G + u2*Q is finite and its x mod n == r.
   static hip::mask ecdsa_verify_rx(WBN const& u1, WBN const& u2, WCP const& Q, WBN const& r) {
+    same_length(u1.size(), Q.size(), "ecdsa_verify_rx"); same_length(u2.size(), Q.size(), "ecdsa_verify_rx"); same_length(r.size(), Q.size(), "ecdsa_verify_rx");
     hip::mask ok(Q.size());
     hip::check(ecsimd_hip_ecdsa_verify_rx(hip::context(), curve_id, u1.data(), u2.data(), Q.x().data(), Q.y().data(), r.data(), ok.data(), Q.size()), "ecsimd_hip_ecdsa_verify_rx");
     return ok;
@@ -116,6 +124,11 @@ struct curve_group {
     return r;
   }
  private:
+  // The C ABI takes one length for all operands (in the reference it is a property of the type): a shorter batch would be
+  // read or written out of bounds on the device.
+  static void same_length(size_t a, size_t b, const char* what) {
+    if (a != b) throw hip::error(std::string("ecsimd: ") + what + " over batches of different length");
+  }
   static WJCP fresh(size_t n) {
     WJCP r; r.x() = gfp{WMBN{WBN::uninitialized(n)}}; r.y() = gfp{WMBN{WBN::uninitialized(n)}}; r.z() = gfp{WMBN{WBN::uninitialized(n)}}; return r;
   }

@@ -329,6 +329,15 @@ TEST(Batch, WindowedPathsAgreeWithTheLadder) {
 }
 
 // utility.h:45-51 wide_mask_bit and the device wire formats (beyond the reference's tests)
+TEST(Batch, OperandsMustAgreeOnTheLength) {
+  using CG = curve_group<curve_nist_p256>;
+  bool threw = false;
+  try { (void)CG::scalar_mult(W256(8, bignum_256::from(3)), CG::WJG()); } catch (hip::error const&) { threw = true; }      // 8 scalars, 4 points
+  EXPECT_TRUE(threw);
+  threw = false;
+  try { auto P = CG::WJG(4); auto O = CG::WJG(6); (void)CG::ZADDU(P, O); } catch (hip::error const&) { threw = true; }
+  EXPECT_TRUE(threw);
+}
 TEST(Batch, DeviceGroup) {                                                                    // shards over a device group, one gather
   using CG = curve_group<curve_nist_p256>;
   using BN = bignum_256;
