@@ -434,9 +434,7 @@ def cpu_baseline(eng, curve, k, bx, by, gpu_out, target_s, failures, compat=Fals
             failures.append("cpu_baseline: a lane differs from the reference and the two oracles do not attribute it to the square() defect")
         ossl = openssl_checker()
         if ossl is not None:
-            import torch
-            sel = torch.from_numpy(bad).to(gpu_out[0].device)
-            ax, ay = eng.to_affine(curve, [t[sel].contiguous() for t in gpu_out])
+            ax, ay = eng.to_affine(curve, [eng.select_rows(t, bad) for t in gpu_out])
             vx, vy, inf = ossl.scalar_mult(curve, kn[bad], xn[bad], yn[bad], threads=1)
             by_ossl = int(np.count_nonzero(~((to_np(ax) != vx).any(axis=1) | (to_np(ay) != vy).any(axis=1) | (inf != 0))))
             if by_ossl != len(bad):

@@ -116,6 +116,10 @@ class Engine:
         a = np.ascontiguousarray(arr, dtype=np.uint64)
         return self.torch.from_numpy(a.view(np.int64)).to(self.tdev)
 
+    def select_rows(self, t, rows):
+        """t[rows] for a numpy index array (contiguous result on the device)."""
+        return t[self.torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int64)).to(t.device)].contiguous()
+
     @staticmethod
     def to_numpy(t):
         a = t.detach().cpu().numpy()

@@ -47,3 +47,43 @@ def test_bench_defaults_are_config_4_verbatim():
     assert (a.gpus, a.scaling, a.global_log2_batch, a.workload, a.curve) == (1, "strong", 24, "ladder", "p256")
     from ecsimd_amd.shard import plan
     assert plan(a.scaling, 1 << a.global_log2_batch, 5, 8) == (5 << 21, 1 << 21, 1 << 24, 1 << 21)
+
+
+def test_a_wrong_gpu_result_fails_the_benchmark():
+    """a kernel regression must not print a headline and exit 0.  bench.py's cpu_baseline leg is driven here with a
+    stand-in "GPU" (numpy arrays holding the exact oracle's results): untouched it reports no failure; with ONE corrupted lane the
+    two oracles cannot attribute the difference to the reference's square() defect, libcrypto does not confirm it, the leg appends
+    to `failures`, and main() turns a non-empty `failures` into exit code EXIT_PARITY (checked on the source)."""
+    import importlib.util
+    import numpy as np
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import fill_random_np, SEED, P256
+    from oracle import loader
+    spec = importlib.util.spec_from_file_location("bench_for_test2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    ora = loader.Oracle(faithful=False)
+
+    class FakeEngine:                                   # numpy in, numpy out: what bench.py needs from an Engine on this leg
+        to_numpy = staticmethod(lambda t: t)
+        select_rows = staticmethod(lambda t, rows: t[rows])
+        to_affine = staticmethod(lambda curve, j: ora.to_affine(curve, j))
+
+    n = 256 * bench.usable_cores()
+    k = fill_random_np(n, SEED, 1); s = fill_random_np(n, SEED, 2)
+    c = ora.constants(P256)
+    bx, by = ora.to_affine(P256, ora.scalar_mult(P256, s, np.tile(c["gx"], (n, 1)), np.tile(c["gy"], (n, 1)), threads=8))
+    good = [a.copy() for a in ora.scalar_mult(P256, k, bx, by, threads=8)]
+    failures = []
+    res = bench.cpu_baseline(FakeEngine, P256, k, bx, by, good, 0.01, failures)
+    assert failures == [] and res["lanes_differing_from_gpu"] == 0 and res["differences_all_explained_by_reference_square_defect"] is True
+    bad = [a.copy() for a in good]
+    bad[0][5, 0] ^= np.uint64(1)                        # one wrong bit in one X coordinate
+    failures = []
+    res = bench.cpu_baseline(FakeEngine, P256, k, bx, by, bad, 0.01, failures)
+    assert res["lanes_differing_from_gpu"] == 1 and res["differences_all_explained_by_reference_square_defect"] is False
+    assert any("square() defect" in f for f in failures)
+    if res["lanes_differing_confirmed_by_openssl"] is not None:
+        assert res["lanes_differing_confirmed_by_openssl"] == 0 and any("libcrypto" in f for f in failures)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "return EXIT_PARITY if failures else 0" in src and "sys.exit(code)" in src and bench.EXIT_PARITY != 0

@@ -36,8 +36,7 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
             f_ = fa.scalar_mult(cv, kn[bad], xn[bad], yn[bad], threads=min(cores, len(bad)))
             ok = all(np.array_equal(u, v[bad]) for u, v in zip(e_, g)) and all(np.array_equal(u, v[bad]) for u, v in zip(f_, r))
             if ossl is not None:
-                sel = torch.from_numpy(bad).to(J[0].device)
-                ax, ay = (e.to_numpy(t) for t in e.to_affine(cv, [t[sel].contiguous() for t in J]))
+                ax, ay = (e.to_numpy(t) for t in e.to_affine(cv, [e.select_rows(t, bad) for t in J]))
                 vx, vy, inf = ossl.scalar_mult(cv, kn[bad], xn[bad], yn[bad], threads=1)
                 rx, ry = ref.to_affine(cv, [v[bad] for v in r])
                 gpu_right = ~((ax != vx).any(axis=1) | (ay != vy).any(axis=1) | (inf != 0))
