@@ -451,7 +451,7 @@ int ecsimd_hip_mod_sub(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const 
 int ecsimd_hip_mod_mul(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::mod_mul(s, instance(ctx, curve), a, b, out, n)); }
 int ecsimd_hip_mod_shift_left(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, int count, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); if (count < 1) return bad(ctx, "count < 1"); RUN(launch::mod_shift_left(s, instance(ctx, curve), a, count, out, n)); }
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); if ((count & 0xff) < 1 || (count & ~0x1ff)) return bad(ctx, "count must be 1..255, optionally | ECSIMD_HIP_SHIFT_FUSED"); RUN(launch::mod_shift_left(s, instance(ctx, curve), a, count, out, n)); }
 int ecsimd_hip_mgry_reduce(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a8, uint64_t* out, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a8); REQUIRE_PTR(out); RUN(launch::mgry_reduce(s, instance(ctx, curve), a8, out, n)); }
 int ecsimd_hip_mgry_mul(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {

@@ -416,10 +416,60 @@ template <int CURVE> ECS_DEV fe fe_dbl(const fe& a) {
   cond_sub_p<CURVE>(s, c);
   return s;
 }
-// a * 2^N mod p = N successive doublings                                   mgry_ops.h:14-22
+// 4a mod p in one pass (the reference doubles twice, mgry_ops.h:14-22: same canonical residue).  4a = q*2^256 + s with
+// q = a >> 254 in 0..3 and s the low 256 bits; 2^256 = c (mod p), c = 2^256 - p, so 4a = s + q*c, which is below 2p:
+// ONE conditional subtraction instead of two.
+//   P-256:     c = 2^224 - 2^192 - 2^96 + 1.  s + q*c = s - X + q*2^224 with X = q*2^192 + q*2^96 - q, whose words are
+//              {-q, m, m, q + m, 0, 0, q, 0} (m = all-ones iff q > 0); the + q*2^224 rides the same borrow chain as
+//              "- (-q)" in word 7, and the 257th bit comes out as (q > 0) and not the final borrow.
+//   secp256k1: c = 2^32 + 977: add {977 q, q} to the two low words; the 257th bit is the carry.
+template <int CURVE> ECS_DEV fe fe_shl2(const fe& a) {
+  fe s;
+#pragma unroll
+  for (int i = 7; i > 0; --i) s.w[i] = __builtin_amdgcn_alignbit(a.w[i], a.w[i - 1], 30);   // (a[i]:a[i-1]) >> 30
+  s.w[0] = a.w[0] << 2;
+  const uint32_t q = a.w[7] >> 30;
+  lane_mask top;
+  if constexpr (curve_prime<CURVE>::is_p256) {
+    uint32_t nq, m, x3;
+    asm("v_sub_co_u32 %8, %11, 0, %12\n\t"            /* nq = -q, %11 = (q > 0) */
+        "v_subb_co_u32 %9, vcc, 0, 0, %11\n\t"          /* m = -(q > 0) */
+        "v_add_u32 %10, %12, %9\n\t"                    /* x3 = q + m */
+        "v_sub_co_u32 %0, vcc, %0, %8\n\t"
+        "v_subb_co_u32 %1, vcc, %1, %9, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %2, %9, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %3, %10, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %4, 0, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %5, 0, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %6, %12, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %7, %8, vcc\n\t"        /* - (-q) = + q at 2^224 */
+        "s_andn2_b64 %11, %11, vcc"                     /* 257th bit = (q > 0) and not borrow */
+        : "+v"(s.w[0]), "+v"(s.w[1]), "+v"(s.w[2]), "+v"(s.w[3]), "+v"(s.w[4]), "+v"(s.w[5]), "+v"(s.w[6]), "+v"(s.w[7]),
+          "=&v"(nq), "=&v"(m), "=&v"(x3), "=&s"(top)
+        : "v"(q) : "vcc", "scc");
+  } else {
+    const uint32_t k977 = 977u;
+    uint32_t lo;
+    asm("v_mul_u32_u24 %8, %10, %11\n\t"               /* 977 q */
+        "v_add_co_u32 %0, vcc, %0, %8\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %10, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, 0, %5, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"
+        "v_addc_co_u32 %7, %9, 0, %7, vcc"
+        : "+v"(s.w[0]), "+v"(s.w[1]), "+v"(s.w[2]), "+v"(s.w[3]), "+v"(s.w[4]), "+v"(s.w[5]), "+v"(s.w[6]), "+v"(s.w[7]), "=&v"(lo), "=&s"(top)
+        : "v"(q), "v"(k977) : "vcc");
+  }
+  cond_sub_p<CURVE>(s, top);
+  return s;
+}
+// a * 2^N mod p = N successive doublings (pairs of them in one pass)         mgry_ops.h:14-22
 template <int CURVE, int N> ECS_DEV fe fe_shl(fe a) {
 #pragma unroll
-  for (int i = 0; i < N; ++i) a = fe_dbl<CURVE>(a);
+  for (int i = 0; i + 1 < N; i += 2) a = fe_shl2<CURVE>(a);
+  if constexpr (N & 1) a = fe_dbl<CURVE>(a);
   return a;
 }
 // gfp.h:60-64 opposite(): (-R) - (a - R), two modular subtractions.  Equal to fe_neg for canonical a; kept in

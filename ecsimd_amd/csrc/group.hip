@@ -72,7 +72,10 @@ int gfail(ecsimd_hip_group* g, int code, const char* what, const char* detail = 
 }
 int ensure_stage(ecsimd_hip_group* g, member& mb, size_t bytes) {
   if (mb.stage_bytes >= bytes) return ECSIMD_HIP_OK;
-  hipError_t e = hipSetDevice(mb.device);
+  // the block may still be read by this member's stream (RCCL send) or by member 0's (the device-copy gather of a shared device)
+  hipError_t e = hipSetDevice(g->m[0].device);
+  if (e == hipSuccess) e = hipStreamSynchronize(g->m[0].stream);
+  if (e == hipSuccess) e = hipSetDevice(mb.device);
   if (e == hipSuccess) e = hipStreamSynchronize(mb.stream);
   if (e == hipSuccess && mb.stage) e = hipFree(mb.stage);
   mb.stage = nullptr; mb.stage_bytes = 0;
@@ -95,10 +98,13 @@ int ecsimd_hip_shard_range(size_t n_total, int member_index, int members, size_t
 
 int ecsimd_hip_group_destroy(ecsimd_hip_group* g) {
   if (!g) return ECSIMD_HIP_ERR_BAD_ARG;
+  for (auto& mb : g->m) {                                     // every stream first: member 0's may still read another member's staging
+    if (mb.device >= 0) (void)hipSetDevice(mb.device);
+    if (mb.stream) (void)hipStreamSynchronize(mb.stream);
+  }
   for (size_t i = 0; i < g->comm.size(); ++i) if (g->comm[i]) (void)g->rccl.CommDestroy(g->comm[i]);
   for (auto& mb : g->m) {
     if (mb.device >= 0) (void)hipSetDevice(mb.device);
-    if (mb.stream) (void)hipStreamSynchronize(mb.stream);
     if (mb.ctx) (void)ecsimd_hip_destroy(mb.ctx);          // the context does not own the group's stream
     if (mb.stage) (void)hipFree(mb.stage);
     if (mb.done) (void)hipEventDestroy(mb.done);
@@ -164,6 +170,47 @@ int ecsimd_hip_group_sync(ecsimd_hip_group* g, double* last_gather_ms) {
     *last_gather_ms = (g->timed && hipEventElapsedTime(&ms, g->g0, g->g1) == hipSuccess) ? (double)ms : -1.0;
   }
   return ECSIMD_HIP_OK;
+}
+
+// What a one-GPU machine can check of the RCCL side: load the library the way ecsimd_hip_group_init does, create a ONE-rank
+// communicator on member 0's device and move `elements` 256-bit elements from one buffer to another with the very
+// calls the gather uses (grouped ncclSend + ncclRecv, ncclUint64 counts of 4 per element, member 0's stream).  Returns 0 when
+// the bytes arrived intact.  The exchange between DIFFERENT devices is what only a multi-GPU node can run.
+int ecsimd_hip_group_rccl_selftest(ecsimd_hip_group* g, size_t elements) {
+  if (!g || elements == 0) return ECSIMD_HIP_ERR_BAD_ARG;
+  member& root = g->m[0];
+  rccl_api api;
+  if (!api.load()) return gfail(g, ECSIMD_HIP_ERR_HIP, "RCCL selftest", "librccl.so could not be loaded");
+  int rc = ECSIMD_HIP_OK;
+  ncclComm_t comm = nullptr;
+  uint64_t* buf = nullptr;
+  hipError_t e = hipSetDevice(root.device);
+  if (e == hipSuccess) e = hipMalloc(&buf, 2 * elements * 32);
+  std::vector<uint64_t> h(elements * 4), back(elements * 4, 0);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = 0x9e3779b97f4a7c15ull * (i + 1);
+  if (e == hipSuccess) e = hipMemcpyAsync(buf, h.data(), elements * 32, hipMemcpyHostToDevice, root.stream);
+  if (e == hipSuccess) e = hipMemsetAsync(buf + elements * 4, 0, elements * 32, root.stream);
+  if (e != hipSuccess) rc = gfail(g, ECSIMD_HIP_ERR_HIP, "RCCL selftest setup", hipGetErrorString(e));
+  if (rc == ECSIMD_HIP_OK) {
+    const int dev = root.device;
+    ncclResult_t r = api.CommInitAll(&comm, 1, &dev);
+    if (r == ncclSuccess) r = api.GroupStart();
+    if (r == ncclSuccess) r = api.Recv(buf + elements * 4, elements * 4, ncclUint64, 0, comm, root.stream);
+    if (r == ncclSuccess) r = api.Send(buf, elements * 4, ncclUint64, 0, comm, root.stream);
+    const ncclResult_t r2 = (r == ncclSuccess) ? api.GroupEnd() : r;
+    if (r2 != ncclSuccess) rc = gfail(g, ECSIMD_HIP_ERR_HIP, "RCCL selftest", api.GetErrorString(r2));
+  }
+  if (rc == ECSIMD_HIP_OK) {
+    e = hipMemcpyAsync(back.data(), buf + elements * 4, elements * 32, hipMemcpyDeviceToHost, root.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(root.stream);
+    if (e != hipSuccess) rc = gfail(g, ECSIMD_HIP_ERR_HIP, "RCCL selftest read-back", hipGetErrorString(e));
+    else if (back != h) rc = gfail(g, ECSIMD_HIP_ERR_HIP, "RCCL selftest", "the received bytes differ from the sent ones");
+  }
+  (void)hipStreamSynchronize(root.stream);
+  if (comm) (void)api.CommDestroy(comm);
+  if (buf) (void)hipFree(buf);
+  (void)dlclose(api.lib);
+  return rc;
 }
 
 // Device-resident form.  k[m], x[m], y[m]: member m's shard (shard_range(n, m, G) elements) in ITS device memory.

@@ -35,7 +35,11 @@ template <int C> __global__ void __launch_bounds__(BLOCK) k_mod_mul(const uint64
 }
 template <int C> __global__ void __launch_bounds__(BLOCK) k_shift_left(const uint64_t* a, int count, uint64_t* out, size_t n) {
   GID; fe x = fe_load(a, i);
-  for (int k = 0; k < count; ++k) x = fe_dbl<C>(x);
+  int left = count & 0xff;
+  // ECSIMD_HIP_SHIFT_FUSED: pairs of doublings as one quadrupling (field.cuh fe_shl2, what the point formulas use on their own
+  // canonical intermediates): the same residue for a < p; for a >= p only the literal doubling chain is the reference's value
+  if (count & 0x100) for (; left >= 2; left -= 2) x = fe_shl2<C>(x);
+  for (; left > 0; --left) x = fe_dbl<C>(x);
   fe_store(out, i, x);
 }
 template <int C> __global__ void __launch_bounds__(BLOCK) k_reduce(const uint64_t* a8, uint64_t* out, size_t n) {

@@ -415,6 +415,9 @@ class DeviceGroup:
         self._check(self.lib.ecsimd_hip_group_sync(self.g, C.byref(ms)), "group_sync")
         return tuple(outs), float(ms.value)
 
+    def rccl_selftest(self, elements=1 << 16):
+        self._check(self.lib.ecsimd_hip_group_rccl_selftest(self.g, C.c_size_t(elements)), "group_rccl_selftest")
+
     def scalar_mult_host(self, curve, k, x, y, flags=0):
         """Host-array form: numpy uint64 (n, 4) arrays in, numpy arrays out."""
         k, x, y = (np.ascontiguousarray(a, dtype=np.uint64) for a in (k, x, y))

@@ -158,7 +158,11 @@ int ecsimd_hip_sec1_encode(ecsimd_hip_ctx*, int curve, const uint64_t* x, const 
 int ecsimd_hip_sec1_decode(ecsimd_hip_ctx*, int curve, const uint8_t* in, uint64_t* x, uint64_t* y, uint8_t* ok, size_t n, int compressed);
 
 /* ---- L3: GF(p) ------------------------------------------------------------------------ */
-/* modular.h:10-15 mod_add, :24-41 mod_sub, mgry_ops.h:14-22 mgry_shift_left<count> (count >= 1) */
+/* modular.h:10-15 mod_add, :24-41 mod_sub, mgry_ops.h:14-22 mgry_shift_left<count> (1 <= count <= 255).
+ * count | ECSIMD_HIP_SHIFT_FUSED runs pairs of doublings as one quadrupling with a single conditional subtraction (what the point
+ * formulas use on their own intermediates): the same canonical residue for every a < p; for a >= p only the plain form is
+ * the reference's chain of doublings. */
+enum { ECSIMD_HIP_SHIFT_FUSED = 0x100 };
 int ecsimd_hip_mod_add(ecsimd_hip_ctx*, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int ecsimd_hip_mod_sub(ecsimd_hip_ctx*, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int ecsimd_hip_mod_shift_left(ecsimd_hip_ctx*, int curve, const uint64_t* a, int count, uint64_t* out, size_t n);
@@ -273,6 +277,10 @@ const char* ecsimd_hip_group_last_error(const ecsimd_hip_group* group);
 int ecsimd_hip_group_scalar_mult(ecsimd_hip_group* group, int curve, const uint64_t* const* k, const uint64_t* const* x, const uint64_t* const* y,
                                  uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
 int ecsimd_hip_group_sync(ecsimd_hip_group* group, double* last_gather_ms);
+/* What one GPU can verify of the RCCL side: loads RCCL as group_init does, creates a one-rank communicator on member 0's
+ * device and moves `elements` 256-bit elements between two buffers with the calls the gather uses (grouped ncclSend /
+ * ncclRecv of ncclUint64, member 0's stream).  0 = the bytes arrived intact. */
+int ecsimd_hip_group_rccl_selftest(ecsimd_hip_group* group, size_t elements);
 /* The same with every array in HOST memory (n elements each): slices copied in, computed, gathered, copied out.
  * Synchronous. */
 int ecsimd_hip_group_scalar_mult_host(ecsimd_hip_group* group, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y,

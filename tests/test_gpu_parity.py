@@ -99,6 +99,14 @@ def test_field_ops_vs_oracle(gpu, oracle, cv):
         assert np.array_equal(getattr(gpu, name)(cv, a), getattr(oracle, name)(cv, a)), name
     for cnt in (1, 2, 3, 7):
         assert np.array_equal(gpu.mod_shift_left(cv, a, cnt), oracle.mod_shift_left(cv, a, cnt))
+    # the fused quadrupling the point formulas use (ECSIMD_HIP_SHIFT_FUSED): same residue for canonical operands -- the edge
+    # values above, every top-two-bit pattern, and the neighbourhoods of k*p/4 where the conditional subtraction flips
+    q4 = [(kq * p) // 4 + d for kq in (1, 2, 3) for d in (-2, -1, 0, 1, 2)] + [2**254 - 1, 2**254, 2**255 - 1, 2**255, 3 * 2**254 - 1, 3 * 2**254, p - 1, p - 2, 0, 1]
+    af = a.copy(); af[100:100 + len(q4)] = ints_to_arr([v % p for v in q4])
+    for cnt in (2, 3, 4, 7):
+        assert np.array_equal(gpu.mod_shift_left(cv, af, cnt | 0x100), oracle.mod_shift_left(cv, af, cnt)), cnt
+    sw = _carry_heavy_field_elements(cv, 20000, 9)
+    assert np.array_equal(gpu.mod_shift_left(cv, sw, 2 | 0x100), oracle.mod_shift_left(cv, sw, 2))
     t8 = rng.integers(0, 2**64, size=(n, 8), dtype=np.uint64)
     t8[:, 7] &= np.uint64(2**63 - 1)                                   # < 2^511 < p * 2^256
     t8[0] = 0; t8[1] = ints_to_arr([p * (2**256) - 1], 8)[0]; t8[2] = ints_to_arr([(p - 1) * (p - 1)], 8)[0]
@@ -925,6 +933,9 @@ def test_device_group_behind_the_c_abi(engine, oracle, devices):
         assert all(np.array_equal(h, engine.to_numpy(e)[:2]) for h, e in zip(small, exp))
         with pytest.raises(EcsimdHipError):
             grp.scalar_mult(cv, cut(k), cut(bx), [None] * G, n)
+        if G == 1:
+            # what one GPU can run of the RCCL side: dlopen, a one-rank communicator, the gather's own send / recv calls
+            grp.rccl_selftest(1 << 16)
     finally:
         grp.close()
 
