@@ -211,16 +211,18 @@ def main():
             # (secp256k1), a mixed addition 8M + 3S; 96 B in, 64 B out.
             dbl = 8 if args.curve == "p256" else 7
             inv = 267 if args.curve == "p256" else 270                  # addition-chain inversion (point.cuh fe_inverse)
-            fm = (6 + 7 * 7) + 7 * (7 + inv / 224) + 63 * (3 * dbl + 18) + (7 + inv / 32)
+            share = min(128, max(1, min(n, 1 << 22) >> 17))            # elements per shared inversion (k_affine.inc; the windowed path works in chunks of 2^22)
+            fm = (6 + 7 * 7) + 7 * (7 + inv / min(256, 7 * share)) + 63 * (3 * dbl + 18) + (7 + inv / share)
             if args.curve == "secp256k1":     # GLV split: 32 windows x (4 doublings + 2 mixed additions + beta) + the top window's two additions
-                fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / 224) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + (7 + inv / 32)   # table {1..8}P
+                fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / min(256, 7 * share)) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + (7 + inv / share)   # table {1..8}P
             mad32_unit, bytes_unit = int(fm * 136), 160
             kname = ("k_varwin_mult_odd + k_varwin_odd_multiples" if args.curve == "p256" else "k_varwin_mult_glv + k_varwin_multiples") + " + k_varwin_to_table + k_to_affine_batched"
         else:
             # what THIS algorithm needs per scalar: 64 mixed additions x 11 field mults,
-            # 7 mults of the simultaneous-inversion walk and 267/32 (secp256k1: 270/32) of the shared inversion; 32 B in, 64 B out.
+            # 7 mults of the simultaneous-inversion walk and 267/m (secp256k1: 270/m) of the inversion m = min(128, n / 2^17) points share; 32 B in, 64 B out.
             adds = {"fixed-base": 64, "fixed-base-signed": 37, "fixed-base-big": 12}[args.workload]
-            mad32_unit, bytes_unit = int((adds * 11 + 7 + (267 if args.curve == "p256" else 270) / 32) * 136), 96
+            share = min(128, max(1, n >> 17))
+            mad32_unit, bytes_unit = int((adds * 11 + 7 + (267 if args.curve == "p256" else 270) / share) * 136), 96
             kname = {64: "k_base_windowed", 37: "k_base_windowed_s<7>", 12: "k_base_windowed_g"}[adds] + " + k_to_affine_batched"
         achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
         traffic, traffic_src = committed_traffic(args, n)

@@ -32,18 +32,18 @@ struct curve_group {
   }
 
   static WJCP DBLU(WJCP& P) {                                                // :64-87
-    P.unshare(); WJCP r = fresh(P.size());
-    hip::check(ecsimd_hip_dblu(hip::context(), curve_id, px(P), py(P), pz(P), px(r), py(r), pz(r), P.size()), "ecsimd_hip_dblu"); return r;
+    P.unshare(); WJCP r = fresh_xy(P.size());                               // co-Z: r and the rewritten P share ONE Z array, written once
+    hip::check(ecsimd_hip_dblu(hip::context(), curve_id, px(P), py(P), pz(P), px(r), py(r), pz(P), P.size()), "ecsimd_hip_dblu"); r.z() = P.z(); return r;
   }
   static WJCP ZADDU(WJCP& P, WJCP const& O) {                                // :91-116
     same_length(P.size(), O.size(), "ZADDU");
-    P.unshare(); WJCP r = fresh(P.size());
-    hip::check(ecsimd_hip_zaddu(hip::context(), curve_id, px(P), py(P), pz(P), px(O), py(O), pz(O), px(r), py(r), pz(r), P.size()), "ecsimd_hip_zaddu"); return r;
+    P.unshare(); WJCP r = fresh_xy(P.size());
+    hip::check(ecsimd_hip_zaddu(hip::context(), curve_id, px(P), py(P), pz(P), px(O), py(O), pz(O), px(r), py(r), pz(P), P.size()), "ecsimd_hip_zaddu"); r.z() = P.z(); return r;
   }
   static WJCP ZDAU(WJCP const& P, WJCP& Q) {                                 // :120-153
     same_length(P.size(), Q.size(), "ZDAU");
-    Q.unshare(); WJCP r = fresh(P.size());
-    hip::check(ecsimd_hip_zdau(hip::context(), curve_id, px(P), py(P), pz(P), px(Q), py(Q), pz(Q), px(r), py(r), pz(r), P.size()), "ecsimd_hip_zdau"); return r;
+    Q.unshare(); WJCP r = fresh_xy(P.size());
+    hip::check(ecsimd_hip_zdau(hip::context(), curve_id, px(P), py(P), pz(P), px(Q), py(Q), pz(Q), px(r), py(r), pz(Q), P.size()), "ecsimd_hip_zdau"); r.z() = Q.z(); return r;
   }
   static WJCP ADD_Z2_1(WJCP const& A, WJCP const& B) {                       // :155-179 (B.z must be mgry(1))
     same_length(A.size(), B.size(), "ADD_Z2_1");
@@ -51,8 +51,8 @@ struct curve_group {
     hip::check(ecsimd_hip_add_z2_1(hip::context(), curve_id, px(A), py(A), pz(A), px(B), py(B), px(r), py(r), pz(r), A.size()), "ecsimd_hip_add_z2_1"); return r;
   }
   static WJCP TRPLU(WJCP& P) {                                               // :183-186
-    P.unshare(); WJCP r = fresh(P.size());
-    hip::check(ecsimd_hip_trplu(hip::context(), curve_id, px(P), py(P), pz(P), px(r), py(r), pz(r), P.size()), "ecsimd_hip_trplu"); return r;
+    P.unshare(); WJCP r = fresh_xy(P.size());
+    hip::check(ecsimd_hip_trplu(hip::context(), curve_id, px(P), py(P), pz(P), px(r), py(r), pz(P), P.size()), "ecsimd_hip_trplu"); r.z() = P.z(); return r;
   }
   // k[i] * P[i], P.z must be mgry(1) (:189-218).  One kernel: the whole ladder stays in registers.
   static WJCP scalar_mult(WBN const& x, WJCP P) {
@@ -128,6 +128,9 @@ struct curve_group {
   // read or written out of bounds on the device.
   static void same_length(size_t a, size_t b, const char* what) {
     if (a != b) throw hip::error(std::string("ecsimd: ") + what + " over batches of different length");
+  }
+  static WJCP fresh_xy(size_t n) {                  // z is attached by the caller (a shared co-Z array)
+    WJCP r; r.x() = gfp{WMBN{WBN::uninitialized(n)}}; r.y() = gfp{WMBN{WBN::uninitialized(n)}}; return r;
   }
   static WJCP fresh(size_t n) {
     WJCP r; r.x() = gfp{WMBN{WBN::uninitialized(n)}}; r.y() = gfp{WMBN{WBN::uninitialized(n)}}; r.z() = gfp{WMBN{WBN::uninitialized(n)}}; return r;

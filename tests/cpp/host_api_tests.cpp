@@ -245,6 +245,22 @@ TEST(CurveGroup, ZDAU) {                                                        
   EXPECT_TRUE(all(F.z().wbn() == G.z().wbn()));
   EXPECT_TRUE(affine_is(F, G5x, G5y));
 }
+TEST(CurveGroup, SharedZKeepsValueSemantics) {
+  // The co-Z formulas hand out ONE Z array for the result and the rewritten operand (written once on the device).  A later
+  // in-place update of either must not show through the other: D stays 2G over the Z it was born with.
+  auto G = CG::WJG();
+  auto D = CG::DBLU(G);                                   // D.z shares G.z
+  const auto Dz = D.z().wbn().host();
+  const auto T = CG::ZADDU(G, D);                         // rewrites G (new Z) -- D's Z must survive
+  EXPECT_TRUE(D.z().wbn().host() == Dz);
+  EXPECT_TRUE(affine_is(D, G2x, G2y) && affine_is(T, G3x, G3y));
+  auto G2 = CG::WJG();
+  auto D2 = CG::DBLU(G2);
+  const auto D2z = D2.z().wbn().host();
+  const auto F = CG::ZDAU(D2, G2);                        // rewrites G2 (shares its old Z with D2): D2 is const
+  EXPECT_TRUE(D2.z().wbn().host() == D2z && affine_is(D2, G2x, G2y) && affine_is(F, G5x, G5y));
+  EXPECT_TRUE(all(F.z().wbn() == G2.z().wbn()));
+}
 TEST(CurveGroup, Swap) {                                                                      // :96-115
   auto G = CG::WJG();
   auto D = CG::DBLU(G);

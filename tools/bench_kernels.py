@@ -43,7 +43,8 @@ row("from_bytes_be", n, timeit(lambda: e.from_bytes_be(by)), 0, 64, "elements")
 for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     row(f"mod_add<{nm}>", n, timeit(lambda: e.mod_add(cv, a, b)), 0, 96, "elements")
     inv_m = (255 + 12) if cv == 0 else (255 + 15)
-    row(f"gfp_inverse<{nm}> (simultaneous inversion, 3 + {inv_m}/64 field mults)", n, timeit(lambda: e.gfp_inverse(cv, a)), int((3 + inv_m / 64) * 136), 128, "elements")
+    share = min(128, max(1, n >> 17))                 # elements that share one inversion (k_affine.inc BATCH_INVERSION_MAX)
+    row(f"gfp_inverse<{nm}> (simultaneous inversion, 3 + {inv_m}/{share} field mults)", n, timeit(lambda: e.gfp_inverse(cv, a)), int((3 + inv_m / share) * 136), 128, "elements")
     row(f"mgry_mul<{nm}> element-wise", n, timeit(lambda: e.mgry_mul(cv, a, b)), 136, 96, "field mults")
     row(f"mgry_sqr<{nm}> element-wise", n, timeit(lambda: e.mgry_sqr(cv, a)), 136, 64, "field mults")
 del by
