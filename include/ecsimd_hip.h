@@ -194,7 +194,9 @@ int ecsimd_hip_to_affine(ecsimd_hip_ctx*, int curve, const uint64_t* jx, const u
 /* curve_group.h:43-58 compute_y for y^2 = x^3 + a x + b (classical in/out), per-element ok[] */
 int ecsimd_hip_compute_y(ecsimd_hip_ctx*, int curve, const uint64_t* x, uint64_t* y, uint8_t* ok, size_t n);
 /* curve_group.h:64-87 DBLU: r = 2P, P rewritten in place with r's Z.  P.z must be mgry(1).
- * (DBLU, ZADDU, ZDAU, TRPLU: co-Z, ONE Z for the result and the rewritten operand -- rz may be the very array pz (ZDAU: qz); it is then written once.) */
+ * (DBLU, ZADDU, ZDAU, TRPLU: co-Z, ONE Z for the result and the rewritten operand -- rz may be the very array pz (ZDAU: qz); it is then written once.)
+ * Point formulas and the ladder take CANONICAL coordinates (< p), which is what every entry point of this library returns; the element-wise
+ * field operations above additionally reproduce the reference on operands >= p (it never rejects them, tests/ops.cpp:232). */
 int ecsimd_hip_dblu(ecsimd_hip_ctx*, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
 /* curve_group.h:91-116 ZADDU: r = P + O (co-Z), P rewritten in place with r's Z. */
 int ecsimd_hip_zaddu(ecsimd_hip_ctx*, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, const uint64_t* ox, const uint64_t* oy, const uint64_t* oz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
