@@ -357,6 +357,44 @@ template <int CURVE> ECS_DEV fe fe_add(const fe& x, const fe& b) {
 // (a - b) mod p: subtract, then add p where the subtraction borrowed.        modular.h:24-41
 // The add-back runs under EXEC = the borrow mask with p's words as inline constants: no mask word is ever built
 // (16 VALU instructions + 2 scalar ones; the masked-operand form took 18).
+#ifndef ECS_SUB_EXEC
+#define ECS_SUB_EXEC 1
+#endif
+#if !ECS_SUB_EXEC
+// the masked-operand form (round 1): borrow word, p & mask, one more chain.  Kept for the A/B: 47.8-47.9 M scalar mults/s against
+// 48.5-48.6 with the EXEC form (-DECS_SUB_EXEC=0, same box, two runs each).
+template <int CURVE> ECS_DEV fe fe_sub(const fe& x, const fe& b) {
+  fe a;
+  uint32_t m = sub8_3(a, x, b);
+  if constexpr (curve_prime<CURVE>::is_p256) {
+    uint32_t m1 = m & 1u;
+    asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %8, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %8, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, 0, %5, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %9, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %7, %8, vcc"
+        : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(a.w[4]), "+v"(a.w[5]), "+v"(a.w[6]), "+v"(a.w[7])
+        : "v"(m), "v"(m1) : "vcc");
+  } else {
+    using K = curve_consts<CURVE>;
+    uint32_t m0 = m & K::P[0], m1 = m & K::P[1];
+    asm("v_add_co_u32 %0, vcc, %0, %9\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %10, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %8, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %8, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %4, %8, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %5, %8, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %8, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %7, %8, vcc"
+        : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(a.w[4]), "+v"(a.w[5]), "+v"(a.w[6]), "+v"(a.w[7])
+        : "v"(m), "v"(m0), "v"(m1) : "vcc");
+  }
+  return a;
+}
+#else
 template <int CURVE> ECS_DEV fe fe_sub(const fe& x, const fe& b) {
   fe a;
   lane_mask save;
@@ -405,6 +443,7 @@ template <int CURVE> ECS_DEV fe fe_sub(const fe& x, const fe& b) {
 #undef ECS_SUB_OPS
   return a;
 }
+#endif
 // 2a mod p                                                                 modular.h:17-22
 template <int CURVE> ECS_DEV fe fe_dbl(const fe& a) {
   fe s;
