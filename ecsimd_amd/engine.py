@@ -190,6 +190,10 @@ class Engine:
         n = a.shape[0]; out = self.empty(n, 8)
         self._call("square", self._ptr(a), self._ptr(out, 8), C.c_size_t(n)); return out
 
+    def if_else(self, mask, a, b):
+        n = a.shape[0]; out = self.empty(n)
+        self._call("if_else", self._ptr(mask, 0), self._ptr(a), self._ptr(b), self._ptr(out), C.c_size_t(n)); return out
+
     def swap_if(self, mask, a, b):
         self._call("swap_if", self._ptr(mask, 0), self._ptr(a), self._ptr(b), C.c_size_t(a.shape[0]))
 

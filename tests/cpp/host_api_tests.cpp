@@ -271,6 +271,23 @@ TEST(CurveGroup, Swap) {                                                        
   swap_if(!Z, a, b);
   EXPECT_TRUE(all(a == D)); EXPECT_TRUE(all(b == G));
 }
+TEST(CurveGroup, IfElse) {                                                                    // ifelse.h:15-49 (what scalar_mult's even-k correction uses, curve_group.h:217)
+  auto G = CG::WJG();
+  auto D = CG::DBLU(G);
+  const hip::mask m{true, false, false, true};
+  const auto S = if_else(m, G, D);                       // lanes 0, 3 from G; lanes 1, 2 from D
+  const auto Gx = G.x().wbn().host(), Dx = D.x().wbn().host(), Sx = S.x().wbn().host();
+  EXPECT_TRUE(Sx[0] == Gx[0] && Sx[1] == Dx[1] && Sx[2] == Dx[2] && Sx[3] == Gx[3]);
+  EXPECT_TRUE(all(if_else(hip::mask::filled(4, true), G, D) == G) && all(if_else(hip::mask::filled(4, false), G, D) == D));
+  const auto a = lanes<W256>("0000000000000000000000000000000000000000000000000000000000000001"_hex, "0000000000000000000000000000000000000000000000000000000000000002"_hex,
+                             "0000000000000000000000000000000000000000000000000000000000000003"_hex, "0000000000000000000000000000000000000000000000000000000000000004"_hex);
+  const auto b = splat<W256>("00000000000000000000000000000000000000000000000000000000000000ff"_hex);
+  EXPECT_TRUE(all(if_else(m, a, b) == lanes<W256>("0000000000000000000000000000000000000000000000000000000000000001"_hex, "00000000000000000000000000000000000000000000000000000000000000ff"_hex,
+                                                  "00000000000000000000000000000000000000000000000000000000000000ff"_hex, "0000000000000000000000000000000000000000000000000000000000000004"_hex)));
+  bool threw = false;
+  try { (void)if_else(hip::mask::filled(3, true), a, b); } catch (hip::error const&) { threw = true; }
+  EXPECT_TRUE(threw);
+}
 TEST(CurveGroup, ScalarMult) {                                                                // :117-173
   const auto G = CG::WJG();
   struct { std::array<uint8_t, 32> k, x, y; } cases[] = {

@@ -223,6 +223,15 @@ def test_cmp_and_swap(engine, oracle):
     engine.swap_if(mask, da, db)                                                        # tests/ops.cpp:179-208
     m = mask.cpu().numpy().astype(bool)
     assert np.array_equal(engine.to_numpy(da), np.where(m[:, None], b, a)) and np.array_equal(engine.to_numpy(db), np.where(m[:, None], a, b))
+    # ifelse.h:15-22 if_else(m, x, y) = m ? x : y, into a fresh array and in place over either operand
+    xa, xb = engine.to_device(a), engine.to_device(b)
+    assert np.array_equal(engine.to_numpy(engine.if_else(mask, xa, xb)), np.where(m[:, None], a, b))
+    import ctypes as C
+    engine._call("if_else", engine._ptr(mask, 0), engine._ptr(xa), engine._ptr(xb), engine._ptr(xa), C.c_size_t(n))       # out aliases a
+    assert np.array_equal(engine.to_numpy(xa), np.where(m[:, None], a, b))
+    xa = engine.to_device(a)
+    engine._call("if_else", engine._ptr(mask, 0), engine._ptr(xa), engine._ptr(xb), engine._ptr(xb), C.c_size_t(n))       # out aliases b
+    assert np.array_equal(engine.to_numpy(xb), np.where(m[:, None], a, b))
 
 
 @pytest.mark.parametrize("cv", CURVES)

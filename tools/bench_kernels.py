@@ -83,7 +83,7 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     row(f"scalar_mult_base<{nm}> 20-bit windows, odd digits (table in device memory), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 32, out=outj)), int((12 * 11 + 7 + inv_m / 32) * 136), 96, "scalar mults")
     row(f"scalar_mult_base<{nm}> signed 7-bit windows, affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 8, out=outj)), int((37 * 11 + 7 + inv_m / 32) * 136), 96, "scalar mults")
     wire = e.sec1_encode(cv, b2x, b2y, True)
-    row(f"sec1_decode<{nm}> compressed (decompression)", n2, timeit(lambda: e.sec1_decode(cv, wire, True)), ((253 + 33 + 4) if cv == 0 else (253 + 13 + 4)) * 136, 33 + 64, "points")
+    row(f"sec1_decode<{nm}> compressed (decompression)", n2, timeit(lambda: e.sec1_decode(cv, wire, True)), ((253 + 7 + 4) if cv == 0 else (253 + 13 + 4)) * 136, 33 + 64, "points")
     wire = e.sec1_encode(cv, b2x, b2y, False)
     row(f"sec1_decode<{nm}> uncompressed (validation)", n2, timeit(lambda: e.sec1_decode(cv, wire, False)), 4 * 136, 65 + 64, "points")
     del k, s2, b2x, b2y, P2, outj, wire
