@@ -115,7 +115,9 @@ def main():
     # ---- inputs, resident in HBM before anything is timed
     k = eng.fill_random(n, SEED, 1, first_index=first)                       # scalars: uniform 256-bit
     s = eng.fill_random(n, SEED, 2, first_index=first)                       # point seeds: P_i = s_i * G
-    bx, by = eng.scalar_mult_base(curve, s, flags=OUT_AFFINE | ALG_WINDOWED_BIG)   # affine classical (x, y)
+    # the base points come from the ladder kernel itself, at this step's own launch size: every k_scalar_mult launch of the
+    # run -- this one, the warm-up, the timed steps -- is the same launch, so rocprofv3's per-kernel average is the step's time
+    bx, by = eng.scalar_mult_base(curve, s, flags=OUT_AFFINE)                      # affine classical (x, y)
     P = eng.from_affine(curve, bx, by)                                        # Montgomery form, Z = mgry(1)
     xm, ym = P[0], P[1]
     del s, P
