@@ -180,8 +180,9 @@ int ecsimd_hip_mgry_to_classical(ecsimd_hip_ctx*, int curve, const uint64_t* a, 
 int ecsimd_hip_mgry_pow(ecsimd_hip_ctx*, int curve, const uint64_t* a, const uint64_t exponent[4], uint64_t* out, size_t n);
 /* gfp.h:42-44 inverse, :60-64 opposite, :46-54 sqrt.  sqrt reports validity PER ELEMENT in ok[]
  * (the reference collapses a wide to all-or-nothing; the C++ header reproduces that on top).  inverse shares one
- * inversion among ~64 elements (Montgomery's trick) when out and a are different buffers; out == a runs one
- * addition chain per element; 0 maps to 0 either way. */
+ * inversion among up to 128 elements (Montgomery's trick) when out and a are different buffers; out == a inverts every
+ * element on its own; 0 maps to 0 either way.  The inversion itself is the constant-time division-step ("safegcd") one,
+ * not a^(p-2): the same unique inverse for every CANONICAL operand (a < p), which is what these two entry points take. */
 int ecsimd_hip_gfp_inverse(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t* out, size_t n);
 int ecsimd_hip_gfp_opposite(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t* out, size_t n);
 int ecsimd_hip_gfp_sqrt(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n);
