@@ -586,7 +586,13 @@ ECS_DEV fe2 mul8x8(const fe& a, const fe& b) {
   acc >>= 32;
   uint32_t ex;
 #define ECS_COL(K) mul_col<K>(acc, ex, a, b); t.w[K] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)ex << 32);
-  ECS_COL(1) ECS_COL(2) ECS_COL(3) ECS_COL(4) ECS_COL(5) ECS_COL(6) ECS_COL(7)
+  // column 1: a0*b1 lands on hi(a0*b0) < 2^32 and cannot carry; only a1*b0 can
+  asm("v_mad_u64_u32 %0, vcc, %2, %5, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, 0, vcc"
+      : "+v"(acc), "=&v"(ex) : "v"(a.w[0]), "v"(a.w[1]), "v"(b.w[0]), "v"(b.w[1]) : "vcc");
+  t.w[1] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)ex << 32);
+  ECS_COL(2) ECS_COL(3) ECS_COL(4) ECS_COL(5) ECS_COL(6) ECS_COL(7)
   ECS_COL(8) ECS_COL(9) ECS_COL(10) ECS_COL(11) ECS_COL(12) ECS_COL(13)
 #undef ECS_COL
   mac_nocarry(acc, a.w[7], b.w[7]);                                 // top column: total < 2^512
@@ -617,9 +623,11 @@ ECS_DEV fe2 sqr8(const fe& a) {
   c[2] = (uint32_t)acc; acc >>= 32;
 #define ECS_SQCOL(K) sqr_col<K>(acc, ex, a); c[K] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)ex << 32);
   ECS_SQCOL(3) ECS_SQCOL(4) ECS_SQCOL(5) ECS_SQCOL(6) ECS_SQCOL(7) ECS_SQCOL(8)
-  ECS_SQCOL(9) ECS_SQCOL(10) ECS_SQCOL(11) ECS_SQCOL(12) ECS_SQCOL(13)
+  ECS_SQCOL(9) ECS_SQCOL(10) ECS_SQCOL(11) ECS_SQCOL(12)
 #undef ECS_SQCOL
-  c[14] = (uint32_t)acc;            // cross < 2^479: word 14 is the top word
+  mac_nocarry(acc, a.w[6], a.w[7]);  // cross < 2^479: columns 13 and 14 together are < 2^63, the last product cannot carry
+  c[13] = (uint32_t)acc;
+  c[14] = (uint32_t)(acc >> 32);    // word 14 is the top word
   // double: (c << 1), 16 words
   c[15] = c[14] >> 31;
 #pragma unroll
