@@ -95,6 +95,8 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 #define REQUIRE_CTX() do { if (!ctx) return ECSIMD_HIP_ERR_BAD_ARG; } while (0)
 #define REQUIRE_PTR(p) do { if (!(p) && n) return bad(ctx, #p " is null"); if (!aligned16(p)) return bad(ctx, #p " is not 16-byte aligned"); } while (0)
+// the y output of an affine result is optional (x-coordinate only); a Jacobian result needs it
+#define REQUIRE_OUT_Y(p) do { if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(p); else if ((p) && !aligned16(p)) return bad(ctx, #p " is not 16-byte aligned"); } while (0)
 #define REQUIRE_CURVE() do { if (curve != ECSIMD_HIP_P256 && curve != ECSIMD_HIP_SECP256K1) return bad(ctx, "unknown curve"); } while (0)
 
 // Enqueue one launcher call on the context's stream; report launch errors.
@@ -261,7 +263,7 @@ int run_varwin(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, 
   uint64_t* scratch = ctx->workspace + reserve / 8;
   for (size_t first = 0; first < n; first += chunk) {
     const size_t m = (n - first) < chunk ? (n - first) : chunk;
-    launch::varwin_scalar_mult(ctx->stream, curve, k + (size_t)k_stride * first, k_stride, x + 4 * first, y + 4 * first, flags, scratch, ox + 4 * first, oy + 4 * first, m);
+    launch::varwin_scalar_mult(ctx->stream, curve, k + (size_t)k_stride * first, k_stride, x + 4 * first, y + 4 * first, flags, scratch, ox + 4 * first, oy ? oy + 4 * first : nullptr, m);
   }
   e = hipGetLastError();
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult (windowed) launch");
@@ -481,9 +483,10 @@ int ecsimd_hip_gfp_sqrt(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint6
 int ecsimd_hip_from_affine(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); RUN(launch::from_affine(s, instance(ctx, curve), x, y, jx, jy, jz, n)); }
 int ecsimd_hip_to_affine(ecsimd_hip_ctx* ctx, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); REQUIRE_PTR(x); REQUIRE_PTR(y);
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); REQUIRE_PTR(x);
+  if (y && !aligned16(y)) return bad(ctx, "y is not 16-byte aligned");       // y == NULL: the x coordinate only
   // Simultaneous inversion uses x[] as scratch: only when the outputs do not alias the inputs.
-  const bool alias = overlaps(x, jx) || overlaps(x, jy) || overlaps(x, jz) || overlaps(y, jx) || overlaps(y, jy) || overlaps(y, jz) || overlaps(x, y);
+  const bool alias = overlaps(x, jx) || overlaps(x, jy) || overlaps(x, jz) || (y && (overlaps(y, jx) || overlaps(y, jy) || overlaps(y, jz) || overlaps(x, y)));
   if (alias || ctx->ref_square) RUN(launch::to_affine(s, instance(ctx, curve), jx, jy, jz, x, y, n));
   RUN(launch::to_affine_batched(s, curve, jx, jy, jz, x, y, n, false)); }
 int ecsimd_hip_compute_y(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, uint64_t* y, uint8_t* ok, size_t n) {
@@ -507,7 +510,7 @@ int ecsimd_hip_trplu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py,
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz); RUN(launch::trplu(s, instance(ctx, curve), px, py, pz, rx, ry, rz, n)); }
 
 int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_PTR(oy);
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy);
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED)) {
     // per-lane window tables (8 multiples of P) in HBM + signed 4-bit windows (k_varwin.inc): a different algorithm from
@@ -518,7 +521,7 @@ int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, co
   }
   return run_ladder(ctx, curve, k, 4, x, y, ox, oy, oz, n, flags); }
 int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[4], const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_PTR(oy); if (!k1) return bad(ctx, "k1 is null");
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy); if (!k1) return bad(ctx, "k1 is null");
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
   launch::words8 w; for (int i = 0; i < 4; ++i) { w.w[2 * i] = (uint32_t)k1[i]; w.w[2 * i + 1] = (uint32_t)(k1[i] >> 32); }
   uint32_t* kdev = ctx->sink + 1024 - 8;    // 32-byte aligned slot at the end of the scratch page
@@ -532,7 +535,7 @@ int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[
   }
   return run_ladder(ctx, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, oz, n, flags); }
 int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(ox); REQUIRE_PTR(oy);
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy);
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG)) {
     const bool big = (flags & ECSIMD_HIP_ALG_WINDOWED_BIG) != 0;         // signed 20-bit windows, table in device memory

@@ -260,8 +260,8 @@ class Engine:
         n = x.shape[0]; j = [self.empty(n) for _ in range(3)]
         self._call("from_affine", C.c_int(curve), self._ptr(x), self._ptr(y), *[self._ptr(t) for t in j], C.c_size_t(n)); return tuple(j)
 
-    def to_affine(self, curve, j):
-        n = j[0].shape[0]; x, y = self.empty(n), self.empty(n)
+    def to_affine(self, curve, j, x_only=False):
+        n = j[0].shape[0]; x = self.empty(n); y = None if x_only else self.empty(n)
         self._call("to_affine", C.c_int(curve), *[self._ptr(t) for t in j], self._ptr(x), self._ptr(y), C.c_size_t(n)); return x, y
 
     def on_curve(self, curve, x, y):
@@ -296,11 +296,19 @@ class Engine:
         n = a[0].shape[0]; r = [self.empty(n) for _ in range(3)]
         self._call("add_z2_1", C.c_int(curve), *[self._ptr(t) for t in a], *[self._ptr(t) for t in bxy], *[self._ptr(t) for t in r], C.c_size_t(n)); return tuple(r)
 
-    def scalar_mult(self, curve, k, x, y, flags=0, out=None):
+    def scalar_mult(self, curve, k, x, y, flags=0, out=None, x_only=False):
+        """x_only (with OUT_AFFINE): no y output -- returns (x, None); ECDH's shared secret is x of k*Q."""
         n = k.shape[0]
-        r = out if out is not None else [self.empty(n) for _ in range(3)]
+        r = out if out is not None else self._fresh_out(n, flags, x_only)
         self._call("scalar_mult", C.c_int(curve), self._ptr(k), self._ptr(x), self._ptr(y), *[self._ptr(t) for t in r], C.c_size_t(n), C.c_int(flags))
         return tuple(r[:2]) if flags & 2 else tuple(r)
+
+    def _fresh_out(self, n, flags, x_only):
+        if x_only:
+            if not flags & 2:
+                raise ValueError("x_only needs OUT_AFFINE")
+            return [self.empty(n), None, None]
+        return [self.empty(n) for _ in range(3)]
 
     def scalar_mult_1s(self, curve, k1, x, y, flags=0):
         n = x.shape[0]; r = [self.empty(n) for _ in range(3)]
@@ -308,9 +316,9 @@ class Engine:
         self._call("scalar_mult_1s", C.c_int(curve), e, self._ptr(x), self._ptr(y), *[self._ptr(t) for t in r], C.c_size_t(n), C.c_int(flags))
         return tuple(r[:2]) if flags & 2 else tuple(r)
 
-    def scalar_mult_base(self, curve, k, flags=0, out=None):
+    def scalar_mult_base(self, curve, k, flags=0, out=None, x_only=False):
         n = k.shape[0]
-        r = out if out is not None else [self.empty(n) for _ in range(3)]
+        r = out if out is not None else self._fresh_out(n, flags, x_only)
         self._call("scalar_mult_base", C.c_int(curve), self._ptr(k), *[self._ptr(t) for t in r], C.c_size_t(n), C.c_int(flags))
         return tuple(r[:2]) if flags & 2 else tuple(r)
 

@@ -54,7 +54,8 @@ enum {
   ECSIMD_HIP_BASE_CLASSICAL = 0,   /* base point (x, y) classical: from_affine is applied first */
   ECSIMD_HIP_BASE_MGRY = 1,        /* base point already Montgomery form (what scalar_mult_p256 receives) */
   ECSIMD_HIP_OUT_JACOBIAN = 0,     /* out = (X, Y, Z) Montgomery form, as curve_group::scalar_mult returns */
-  ECSIMD_HIP_OUT_AFFINE = 2,       /* out = to_affine(): (x, y) classical; oz may be NULL */
+  ECSIMD_HIP_OUT_AFFINE = 2,       /* out = to_affine(): (x, y) classical; oz may be NULL; oy may be NULL too: the x coordinate only
+                                      (ECDH's shared secret, ECDSA's r): the conversion then skips y's two field multiplications */
   ECSIMD_HIP_ALG_WINDOWED = 4,     /* with OUT_AFFINE only.  scalar_mult_base: 4-bit windows over an LDS-resident table of
                                       d*16^w*G and one simultaneous inversion instead of the reference's ladder.
                                       scalar_mult / double_scalar_mult (variable base): a per-element table of 8 multiples
@@ -189,7 +190,8 @@ int ecsimd_hip_gfp_sqrt(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t*
 
 /* ---- L4/L5: points and the group ------------------------------------------------------ */
 /* jacobian_curve_point.h:25-31 from_affine (Z := R mod p), :33-42 to_affine.  to_affine uses Montgomery's
- * simultaneous inversion (one inversion per ~32 elements; identical values) unless x/y alias the inputs. */
+ * simultaneous inversion (one inversion per ~32 elements; identical values) unless x/y alias the inputs.
+ * to_affine: y may be NULL (the x coordinate only: 5 field multiplications per element instead of 7). */
 int ecsimd_hip_from_affine(ecsimd_hip_ctx*, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n);
 int ecsimd_hip_to_affine(ecsimd_hip_ctx*, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n);
 /* curve_group.h:43-58 compute_y for y^2 = x^3 + a x + b (classical in/out), per-element ok[] */

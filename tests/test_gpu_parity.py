@@ -746,6 +746,36 @@ def test_config2_point_add_double_2pow20(engine, oracle):
     assert torch.equal(lx, fx) and torch.equal(ly, fy)
 
 
+@pytest.mark.parametrize("cv", CURVES)
+def test_x_coordinate_only_outputs(engine, cv):
+    """an affine result without y (ECDH's shared secret, ECDSA's r).  Every algorithm's x-only
+    output equals the x of its full output; a Jacobian result still needs y."""
+    import ctypes as C
+    import torch
+    from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG
+    n = (1 << 17) + 77                       # ragged; BIG's table is built from 2^16 up
+    k = engine.fill_random(n, SEED, 1); s = engine.fill_random(n, SEED, 2)
+    bx, by = engine.scalar_mult_base(cv, s, flags=OUT_AFFINE)
+    for alg in (0, ALG_WINDOWED):
+        fx, fy = engine.scalar_mult(cv, k, bx, by, flags=OUT_AFFINE | alg)
+        ox, none = engine.scalar_mult(cv, k, bx, by, flags=OUT_AFFINE | alg, x_only=True)
+        assert none is None and torch.equal(ox, fx), f"variable base, alg {alg}"
+    for alg in (0, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG):
+        fx, fy = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | alg)
+        ox, none = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | alg, x_only=True)
+        assert none is None and torch.equal(ox, fx), f"fixed base, alg {alg}"
+    J = engine.scalar_mult_base(cv, k)
+    ax, ay = engine.to_affine(cv, J)
+    ox, none = engine.to_affine(cv, J, x_only=True)
+    assert none is None and torch.equal(ox, ax) and torch.equal(fx, ax)
+    # in place over the Jacobian X (the per-element kernel): still x only
+    Jc = tuple(t.clone() for t in J)
+    engine._call("to_affine", C.c_int(cv), *[engine._ptr(t) for t in Jc], engine._ptr(Jc[0]), C.c_void_p(0), C.c_size_t(n))
+    assert torch.equal(Jc[0], ax) and torch.equal(Jc[1], J[1])
+    with pytest.raises(RuntimeError):        # Jacobian output without y
+        engine._call("scalar_mult_base", C.c_int(cv), engine._ptr(k), engine._ptr(ox), C.c_void_p(0), engine._ptr(Jc[2]), C.c_size_t(n), C.c_int(0))
+
+
 @pytest.mark.parametrize("cv,log2n", [(P256, 22), (SECP256K1, 22)])
 def test_config3_and_5_fixed_base_2pow22(engine, oracle, cv, log2n):
     """BASELINE configs[2] and [4]: k*G for 2^22 random scalars.  Oracle on a strided sample (level J)
