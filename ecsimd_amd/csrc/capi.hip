@@ -233,6 +233,14 @@ int run_ladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, 
   if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
   hipError_t e = hipSetDevice(ctx->device);
   if (e != hipSuccess) return fail(ctx, e, "hipSetDevice");
+  if ((flags & ECSIMD_HIP_OUT_AFFINE) && oy == nullptr && curve == ECSIMD_HIP_P256 && instance(ctx, curve, flags) == curve) {
+    // x only: the ladder without Z (point.cuh scalar_mult_ladder_x) -- 8M + 6S per bit instead of 9M + 7S
+    int rc = ensure_workspace(ctx, launch::scalar_mult_x_scratch_bytes(n));
+    if (rc != ECSIMD_HIP_OK) return rc;
+    launch::point_launch<CURVE_P256>::scalar_mult_x(ctx->stream, k, k_stride, x, y, ox, ctx->workspace, n, flags);
+    e = hipGetLastError();
+    return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult (x only) launch");
+  }
   if (flags & ECSIMD_HIP_OUT_AFFINE) {
     int rc = ensure_workspace(ctx, 3 * n * 32);
     if (rc != ECSIMD_HIP_OK) return rc;

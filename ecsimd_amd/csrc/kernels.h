@@ -103,6 +103,8 @@ template <int C> struct point_launch {
   static void add_z2_1(hipStream_t, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
   static void trplu(hipStream_t, uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
   static void scalar_mult(hipStream_t, const uint64_t*, int, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t, int);
+  // x(kP) only, by the ladder without Z (defined for P-256 only: needs a != 0; k_ladder.inc)
+  static void scalar_mult_x(hipStream_t, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* scratch, size_t n, int flags);
   // k_affine_<curve>.hip
   static void to_affine_batched(hipStream_t, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool in_fast_domain);
   static void inverse_batched(hipStream_t, const uint64_t* a, uint64_t* out, size_t n);
@@ -118,6 +120,7 @@ template <int C> struct point_launch {
   static void add_mixed_complete(hipStream_t, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
   static void varwin_scalar_mult(hipStream_t, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, int flags, uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n);
 };
+inline size_t scalar_mult_x_scratch_bytes(size_t n) { return 4 * n * 32 + ((n + 31) & ~(size_t)31); }   // odd scalars, num, den, 1/den, zero flags
 constexpr size_t WINDOW_TABLE_BYTES = 64 * 16 * 64;   // 64 windows x 16 digits x (x, y)
 
 }  // namespace launch

@@ -63,7 +63,8 @@ template <int C> ECS_DEV void zaddu(fe& x1, fe& y1, const fe& x2, const fe& y2, 
 // `oswap` (a per-lane all-ones / all-zeros word) exchanges the two OUTPUT points: (x1,y1) and (x2,y2) are
 // (ym^2 - W12, ym*(W1 - x) - A1) and the same with yp, so swapping the outputs is swapping (ym, yp) -- one
 // field-element swap instead of two.  The ladder folds its per-bit swaps into it; the point kernel passes 0.
-template <int C> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe& y2, fe& z, uint32_t oswap = 0u) {
+// NOZ: the Z update (1M + 1S + 3 linear operations of the 9M + 7S) is left out -- the x-only ladder below does not need it.
+template <int C, bool NOZ = false> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe& y2, fe& z, uint32_t oswap = 0u) {
   const fe dx = fe_sub<C>(x1, x2);
   const fe Cp = fe_sqr<C>(dx);
   const fe W1p = fe_mul<C>(x1, Cp);
@@ -90,9 +91,11 @@ template <int C> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe& y2, fe& z, uint32
   const fe2 A1wide = mul8x8(Y3p, fe_sub<C>(W1, W2));
   const fe W12 = fe_add<C>(W1, W2);
   // Z3 = Z * ((dx + X3' - W1')^2 - C' - C)
-  fe zz = fe_sqr<C>(fe_add<C>(dx, u));
-  zz = fe_sub<C>(fe_sub<C>(zz, Cp), Cc);
-  z = fe_mul<C>(z, zz);
+  if constexpr (!NOZ) {
+    fe zz = fe_sqr<C>(fe_add<C>(dx, u));
+    zz = fe_sub<C>(fe_sub<C>(zz, Cp), Cc);
+    z = fe_mul<C>(z, zz);
+  }
   fe_cswap(oswap, ym, yp);
   const fe D = fe_sqr<C>(ym);
   x1 = fe_sub<C>(D, W12);
@@ -389,8 +392,9 @@ template <int C> ECS_DEV void to_affine(const jpoint& P, fe& ax, fe& ay) {     /
 // point in Montgomery form with implicit Z = R mod p.  `kwords` points at this lane's 8 scalar
 // words in global memory: one word is (re)read per 32 iterations so the scalar does not occupy
 // VGPRs across the ZDAU body.
-template <int C> ECS_DEV jpoint scalar_mult_ladder(const uint32_t* __restrict__ kwords, const fe& xm, const fe& ym) {
-  fe px = xm, py = ym, bx, by, z;
+// The ladder up to (not including) the even-k correction: (px, py) = k'P with k' = k | 1, (bx, by) the other register, common z.
+template <int C, bool NOZ> ECS_DEV uint32_t ladder_core(const uint32_t* __restrict__ kwords, const fe& xm, const fe& ym, fe& px, fe& py, fe& bx, fe& by, fe& z) {
+  px = xm; py = ym;
   // base = TRPLU(P): DBLU then ZADDU (curve_group.h:183-186)
   {
     fe dx2, dy2;
@@ -413,9 +417,15 @@ template <int C> ECS_DEV jpoint scalar_mult_ladder(const uint32_t* __restrict__ 
     const int nb = b + 1;
     if ((nb & 31) == 0) kw = (nb < 256) ? kwords[nb >> 5] : 0u;       // one word per 32 bits: the scalar is not kept in VGPRs
     const uint32_t next = 0u - ((kw >> (nb & 31)) & 1u);              // m_(b+1); 0 after the last bit: the closing swap(m_255)
-    zdau<C>(bx, by, px, py, z, cur ^ next);                           // base = ZDAU(base, P), outputs swapped by m_b ^ m_(b+1)
+    zdau<C, NOZ>(bx, by, px, py, z, cur ^ next);                      // base = ZDAU(base, P), outputs swapped by m_b ^ m_(b+1)
     cur = next;
   }
+  return k0;
+}
+
+template <int C> ECS_DEV jpoint scalar_mult_ladder(const uint32_t* __restrict__ kwords, const fe& xm, const fe& ym) {
+  fe px, py, bx, by, z;
+  const uint32_t k0 = ladder_core<C, false>(kwords, xm, ym, px, py, bx, by, z);
   // even k: subtract the original point once (curve_group.h:214-217)
   const fe oppy = fe_opposite<C>(ym);                    // jacobian_curve_point.h:48-54 via gfp.h:60-64
   const jpoint Psub = add_z2_1<C>(px, py, z, xm, oppy);
@@ -425,6 +435,27 @@ template <int C> ECS_DEV jpoint scalar_mult_ladder(const uint32_t* __restrict__ 
   R.y = fe_select(meven, Psub.y, py);
   R.z = fe_select(meven, Psub.z, z);
   return R;
+}
+
+// x(k*P) for ODD k* without carrying Z (a != 0 curves: P-256).  Not the reference's return value -- an x-coordinate-only
+// product for callers like ECDH: the loop is the reference's ladder minus the Z update (8M + 6S per bit instead of 9M + 7S).
+// At the end the two registers (X0, Y0) = k*P and (X1, Y1) share an unknown Z; with w = Z^2 the curve equation
+// Y^2 = X^3 + a X w^2 + b w^3 holds for both, so
+//     D = (Y0^2 - X0^3) - (Y1^2 - X1^3) = a (X0 - X1) w^2        G = X1 (Y0^2 - X0^3) - X0 (Y1^2 - X1^3) = b (X1 - X0) w^3
+// give w = -(a / b) G / D and the affine x = X0 / w = X0 * b * D / (-a * G) = num / den (one simultaneous inversion over the
+// batch follows).  Only Z^2 is determined by this -- the sign of Z, hence y, is not (both are consistent with everything but the
+// input point), which is why the reference-identical Jacobian result cannot be had this way.
+// With a = 0 (secp256k1) only w^3 is determined and x keeps a cube-root ambiguity: not offered there.
+template <int C> ECS_DEV void scalar_mult_ladder_x(const uint32_t* __restrict__ kwords_odd, const fe& xm, const fe& ym, fe& num, fe& den) {
+  static_assert(curve_prime<C>::is_p256, "a = -3");
+  fe x0, y0, x1, y1, z;
+  (void)ladder_core<C, true>(kwords_odd, xm, ym, x0, y0, x1, y1, z);
+  const fe e0 = fe_sub<C>(fe_sqr<C>(y0), fe_mul<C>(fe_sqr<C>(x0), x0));
+  const fe e1 = fe_sub<C>(fe_sqr<C>(y1), fe_mul<C>(fe_sqr<C>(x1), x1));
+  const fe D = fe_sub<C>(e0, e1);
+  const fe G = fe_mul_sub_product<C>(x1, e0, mul8x8(x0, e1));
+  num = fe_mul<C>(fe_mul<C>(x0, FE_CONST(C, BM)), D);
+  den = fe_add<C>(fe_dbl<C>(G), G);                      // -a * G = 3G
 }
 
 }  // namespace ecsimd_hip

@@ -310,8 +310,8 @@ class Engine:
             return [self.empty(n), None, None]
         return [self.empty(n) for _ in range(3)]
 
-    def scalar_mult_1s(self, curve, k1, x, y, flags=0):
-        n = x.shape[0]; r = [self.empty(n) for _ in range(3)]
+    def scalar_mult_1s(self, curve, k1, x, y, flags=0, x_only=False):
+        n = x.shape[0]; r = self._fresh_out(n, flags, x_only)
         e = (C.c_uint64 * 4)(*[int(v) for v in np.asarray(k1, dtype=np.uint64).reshape(4)])
         self._call("scalar_mult_1s", C.c_int(curve), e, self._ptr(x), self._ptr(y), *[self._ptr(t) for t in r], C.c_size_t(n), C.c_int(flags))
         return tuple(r[:2]) if flags & 2 else tuple(r)

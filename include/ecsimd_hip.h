@@ -55,7 +55,11 @@ enum {
   ECSIMD_HIP_BASE_MGRY = 1,        /* base point already Montgomery form (what scalar_mult_p256 receives) */
   ECSIMD_HIP_OUT_JACOBIAN = 0,     /* out = (X, Y, Z) Montgomery form, as curve_group::scalar_mult returns */
   ECSIMD_HIP_OUT_AFFINE = 2,       /* out = to_affine(): (x, y) classical; oz may be NULL; oy may be NULL too: the x coordinate only
-                                      (ECDH's shared secret, ECDSA's r): the conversion then skips y's two field multiplications */
+                                      (ECDH's shared secret, ECDSA's r): the conversion then skips y's two field multiplications, and on P-256 the
+                                      ladder itself (no ALG_* flag, no REF_SQUARE_COMPAT) runs WITHOUT the Z coordinate -- 8M + 6S per bit instead
+                                      of 9M + 7S, x recovered from the two co-Z results and the curve equation, 55 M/s against 48 -- on the odd one
+                                      of k mod n and n - k mod n.  Same constant-time shape as the ladder; correct for EVERY 256-bit k (x = 0 for
+                                      k = 0 mod n), including the reference ladder's degenerate scalars */
   ECSIMD_HIP_ALG_WINDOWED = 4,     /* with OUT_AFFINE only.  scalar_mult_base: 4-bit windows over an LDS-resident table of
                                       d*16^w*G and one simultaneous inversion instead of the reference's ladder.
                                       scalar_mult / double_scalar_mult (variable base): a per-element table of 8 multiples

@@ -774,6 +774,31 @@ def test_x_coordinate_only_outputs(engine, cv):
     assert torch.equal(Jc[0], ax) and torch.equal(Jc[1], J[1])
     with pytest.raises(RuntimeError):        # Jacobian output without y
         engine._call("scalar_mult_base", C.c_int(cv), engine._ptr(k), engine._ptr(ox), C.c_void_p(0), engine._ptr(Jc[2]), C.c_size_t(n), C.c_int(0))
+    # every 256-bit scalar, the ladder's own degenerate ones included: on P-256 the x-only ladder runs on the odd one of
+    # k mod n and n - k mod n (point.cuh scalar_mult_ladder_x) and is right where the reference's ladder is not; the
+    # windowed kernels, which reduce k mod n, are the witness.  k = 0 mod n gives x = 0.
+    order = CURVE_PARAMS[cv]["n"]
+    edge = [0, 1, 2, 3, 4, 5, order - 2, order - 1, order, order + 1, order + 2, 2**256 - 1, 2**256 - 2, 2**255, 2**255 + 1,
+            2**256 - order, 2**256 - order - 1, 2**256 - order + 1, 2 * order - 2**256, 2**64, int("55" * 32, 16), int("aa" * 32, 16)]
+    m = 4096
+    ke = fill_random_np(m, SEED, 9); ke[:len(edge)] = ints_to_arr(edge)
+    kd = engine.to_device(ke)
+    qx, qy = bx[:m].contiguous(), by[:m].contiguous()
+    wx, _ = engine.scalar_mult(cv, kd, qx, qy, flags=OUT_AFFINE | ALG_WINDOWED)
+    lx, _ = engine.scalar_mult(cv, kd, qx, qy, flags=OUT_AFFINE, x_only=True)
+    if cv == P256:
+        assert torch.equal(lx, wx)
+        assert not lx[0].any() and not lx[8].any()          # k = 0, k = n
+        for j in (77, 1, 7):                                 # one scalar for all lanes (odd, 1, n - 1)
+            k1 = engine.to_numpy(kd[j:j + 1])[0]
+            fx1, _ = engine.scalar_mult(cv, kd[j:j + 1].expand(m, 4).contiguous(), qx, qy, flags=OUT_AFFINE | ALG_WINDOWED)
+            sx, none = engine.scalar_mult_1s(cv, k1, qx, qy, flags=OUT_AFFINE, x_only=True)
+            assert none is None and torch.equal(sx, fx1)
+        gx1, _ = engine.scalar_mult_base(cv, kd, flags=OUT_AFFINE | ALG_WINDOWED)
+        gx2, _ = engine.scalar_mult_base(cv, kd, flags=OUT_AFFINE, x_only=True)
+        assert torch.equal(gx1, gx2)
+    else:                                                    # secp256k1 (a = 0) keeps the reference's ladder: equal off the degenerate scalars
+        assert torch.equal(lx[len(edge):], wx[len(edge):])
 
 
 @pytest.mark.parametrize("cv,log2n", [(P256, 22), (SECP256K1, 22)])

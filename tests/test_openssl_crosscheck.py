@@ -68,6 +68,10 @@ def test_gpu_scalar_mult_agrees_with_openssl(engine, openssl, cv):
     for flags in (OUT_AFFINE, OUT_AFFINE | ALG_WINDOWED):                           # reference ladder; per-lane window tables
         px, py = engine.scalar_mult(cv, dk, dbx, dby, flags=flags)
         assert np.array_equal(engine.to_numpy(px), vx) and np.array_equal(engine.to_numpy(py), vy), flags
+    xo, none = engine.scalar_mult(cv, dk, dbx, dby, flags=OUT_AFFINE, x_only=True)   # P-256: the ladder without Z (ECDH's x)
+    assert none is None and np.array_equal(engine.to_numpy(xo), vx)
+    xo, _ = engine.scalar_mult_base(cv, ds, flags=OUT_AFFINE, x_only=True)
+    assert np.array_equal(engine.to_numpy(xo), bx)
     wx, wy, inf = openssl.double_scalar_mult(cv, u1, k, bx, by, threads=THREADS)
     assert not inf.any()
     rx, ry, fin = engine.double_scalar_mult(cv, du1, dk, dbx, dby)

@@ -68,6 +68,9 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     outj = [e.empty(n2) for _ in range(3)]
     row(f"scalar_mult<{nm}> ladder, Jacobian out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=1, out=outj), 5), 555968, 192, "scalar mults")
     row(f"scalar_mult<{nm}> ladder, affine out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=3, out=outj), 5), 555968 + 19 * 136, 160, "scalar mults")
+    # x only: P-256 runs the ladder without Z (8M + 6S per bit, point.cuh scalar_mult_ladder_x); secp256k1 (a = 0) the full ladder + an x-only conversion
+    row(f"scalar_mult<{nm}> ladder, x coordinate only (ECDH)", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=3, out=[outj[0], None, None]), 5),
+        ((6 + 7) + 254 * 14 + 20 + 7) * 136 if cv == 0 else 555968 + 17 * 136, 128, "scalar mults")
     dblm = 8 if cv == 0 else 7
     vw = int((55 + 7 * (7 + inv_m / 224) + 63 * (3 * dblm + 18) + (7 + inv_m / 32)) * 136)          # odd digits, fused double-add
     if cv == 1:                                      # secp256k1: GLV split (k_varwin.inc)
