@@ -63,9 +63,10 @@ def parse_args(argv=None):
     ap.add_argument("--global-log2-batch", type=int, default=24, help="strong scaling: scalar mults per step over ALL GPUs = 2^this")
     ap.add_argument("--log2-batch", type=int, default=22, help="weak scaling: scalar mults per GPU per step = 2^this")
     ap.add_argument("--curve", default="p256", choices=["p256", "secp256k1"])
-    ap.add_argument("--workload", default="ladder", choices=["ladder", "ladder-ref-compat", "windowed", "fixed-base", "fixed-base-signed", "fixed-base-big"],
+    ap.add_argument("--workload", default="ladder", choices=["ladder", "ladder-ref-compat", "ladder-x", "windowed", "fixed-base", "fixed-base-signed", "fixed-base-big"],
                     help="ladder: scalar_mult_p256 variable base, the reference's co-Z ladder, Jacobian out (headline, BASELINE configs[3]); "
                          "ladder-ref-compat: the same with ECSIMD_HIP_REF_SQUARE_COMPAT (the reference's square() as written, dropped carry included); "
+                         "ladder-x: x(k*P) only, the constant-time ladder without its Z coordinate (P-256; ECDH's shared secret; affine-level parity); "
                          "windowed: variable base with per-element tables of 8 multiples of P and signed 4-bit windows, affine out (ALG_WINDOWED; affine-level parity); "
                          "fixed-base: k*G with the 4-bit-window LDS table + simultaneous inversion, affine out (BASELINE configs[2]); "
                          "fixed-base-signed: the same with signed 7-bit windows (37 additions instead of 64); "
@@ -129,6 +130,10 @@ def main():
 
         def compute(o):
             eng.scalar_mult(curve, k, xm, ym, flags=flags, out=view(o))
+    elif args.workload == "ladder-x":
+        def compute(o):                                     # affine x; o[1], o[2] are unused
+            eng.scalar_mult(curve, k, bx, by, flags=OUT_AFFINE, out=[view(o)[0], None, None])
+        compute([eng.empty(rows) for _ in range(3)])        # sizes the context workspace
     elif args.workload == "windowed":
         def compute(o):                                     # affine (x, y); o[2] is unused
             eng.scalar_mult(curve, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED, out=view(o))
@@ -176,6 +181,8 @@ def main():
     names = {
         "ladder": f"scalar_mult_{args.curve} variable-base co-Z ladder (reference algorithm), batch {sizes}, Jacobian Montgomery out",
         "ladder-ref-compat": f"scalar_mult_{args.curve} variable-base co-Z ladder with ECSIMD_HIP_REF_SQUARE_COMPAT (the reference's square() as written), batch {sizes}, Jacobian Montgomery out",
+        "ladder-x": f"scalar_mult_{args.curve} variable-base, x coordinate only: " + ("the co-Z ladder without Z (8M + 6S per bit), x from the curve equation + simultaneous inversion"
+                    if args.curve == "p256" else "the co-Z ladder + x-only simultaneous inversion") + f", batch {sizes}, affine x out",
         "windowed": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 multiples of P) + signed 4-bit windows + simultaneous "
                     f"inversion{' + GLV split k = k1 + k2*lambda' if args.curve == 'secp256k1' else ''}, batch {sizes}, affine out",
     }
@@ -206,6 +213,12 @@ def main():
         peak = mads / (ms * 1e-3) / 1e12
         if args.workload in ("ladder", "ladder-ref-compat"):
             mad32_unit, bytes_unit, kname = MAD32_PER_SCALAR_MULT, ALGO_BYTES_PER_SCALAR_MULT, "k_scalar_mult"
+        elif args.workload == "ladder-x":
+            # P-256: TRPLU (6 + 7), 254 x (8M + 6S), the recovery (12) and the inversion walk (7 + 267 / share); secp256k1: the full ladder + 5 + 267 / share
+            share = min(128, max(1, n >> 17))
+            fm = ((13 + 254 * 14 + 12) if args.curve == "p256" else 4088 + 5) + 3 + (267 if args.curve == "p256" else 270) / share
+            mad32_unit, bytes_unit = int(fm * 136), 128
+            kname = ("k_scalar_mult_x + k_inverse_batched" if args.curve == "p256" else "k_scalar_mult + k_to_affine_batched")
         elif args.workload == "windowed":
             # what THIS algorithm needs per scalar.  P-256: table {1,3,..,15}P = DBLU + 7 co-Z additions
             # (6 + 7 x 7), its inversion 7 x (7 + 267/224) (224 points share one inversion at 2^22), 63 windows x (3 doublings
@@ -243,6 +256,8 @@ def main():
                 out = [t[:n] for t in runner.last_result()]
                 if args.workload == "windowed":
                     result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, base=(bx, by))
+                elif args.workload == "ladder-x":
+                    result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, base=(bx, by), x_only=True)
                 elif args.workload in ("ladder", "ladder-ref-compat"):
                     result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, out, args.cpu_seconds, failures, compat=(args.workload == "ladder-ref-compat"))
                     comp = competitor_openssl(eng, curve, k, bx, by, out, failures)
@@ -274,7 +289,7 @@ def committed_traffic(args, n):
         table = json.load(open(tpath))
     except ValueError:
         return None, None
-    key = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult", "windowed": "varwin", "fixed-base-big": "fixed_base_big"}.get(args.workload, "fixed_base")
+    key = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult", "ladder-x": "k_scalar_mult_x", "windowed": "varwin", "fixed-base-big": "fixed_base_big"}.get(args.workload, "fixed_base")
     for log2 in (24, 22):                                 # a pass at this run's own launch size first
         per = table.get(f"{key}_{args.curve}_2^{log2}")
         if per is not None:
@@ -308,7 +323,7 @@ def openssl_checker():
     return loader.OpenSSLCheck()
 
 
-def cpu_baseline_affine(eng, curve, k, gpu_out, target_s, failures, base=None):
+def cpu_baseline_affine(eng, curve, k, gpu_out, target_s, failures, base=None, x_only=False):
     """Affine-output workloads on the CPU: the reference has ONE way to compute k*P -- scalar_mult(k, P) followed
     by to_affine() (exactly what its benchmark times, benchs/curve_group.cpp:23-35; P = G for config 3, `base` =
     the per-element points for the windowed variable-base workload).  Compared with the GPU's windowed result at
@@ -327,17 +342,18 @@ def cpu_baseline_affine(eng, curve, k, gpu_out, target_s, failures, base=None):
     m = int(min(k.shape[0], max(m0, (target_s / dt) * m0))); m -= m % 4
     kn = eng.to_numpy(k[:m]); gx, gy = points(m)
     t = time.perf_counter(); J = impl.scalar_mult(curve, kn, gx, gy, threads=cores); ax, ay = impl.to_affine(curve, J); dt = time.perf_counter() - t
-    gx_, gy_ = eng.to_numpy(gpu_out[0][:m]), eng.to_numpy(gpu_out[1][:m])
+    gx_ = eng.to_numpy(gpu_out[0][:m])
+    gy_ = ay.copy() if x_only else eng.to_numpy(gpu_out[1][:m])       # x only: nothing to compare y with
     bad = np.nonzero((gx_ != ax).any(axis=1) | (gy_ != ay).any(axis=1))[0]
     explained, by_ossl = True, None
     if len(bad):                                        # reference square() defect: the exact oracle must side with the GPU
         ex = loader.Oracle(faithful=False)
         ea = ex.to_affine(curve, ex.scalar_mult(curve, kn[bad], gx[bad], gy[bad], threads=min(cores, len(bad))))
-        explained = bool(np.array_equal(ea[0], gx_[bad]) and np.array_equal(ea[1], gy_[bad]))
+        explained = bool(np.array_equal(ea[0], gx_[bad]) and (x_only or np.array_equal(ea[1], gy_[bad])))
         ossl = openssl_checker()
         if ossl is not None:
             vx, vy, inf = ossl.scalar_mult(curve, kn[bad], gx[bad], gy[bad], threads=1)
-            by_ossl = int(np.count_nonzero(~((gx_[bad] != vx).any(axis=1) | (gy_[bad] != vy).any(axis=1) | (inf != 0))))
+            by_ossl = int(np.count_nonzero(~((gx_[bad] != vx).any(axis=1) | ((gy_[bad] != vy).any(axis=1) & (not x_only)) | (inf != 0))))
     if not explained:
         failures.append("cpu_baseline: a lane differs from the reference and the exact oracle does not side with the GPU")
     if by_ossl is not None and by_ossl != len(bad):
