@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak run on the GPU alone: the three ways this library computes an affine k*P must agree lane for lane --
 the reference ladder (+ simultaneous inversion), the per-element-table windowed path (ALG_WINDOWED) and, for
-P = G, the three window-table kernels.  Different algorithms over the same field layer: a disagreement means a bug
+P = G, the three window-table kernels; and the x-only products (on P-256 the ladder without Z) must give the same x.  Different algorithms over the same field layer: a disagreement means a bug
 in one of them.  Usage: soak_windowed.py [lanes_per_batch_log2=22] [batches=8]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -25,7 +25,10 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
         w = e.scalar_mult(cv, k, gl[0], gl[1], flags=OUT_AFFINE | ALG_WINDOWED)
         l = e.scalar_mult(cv, k, gl[0], gl[1], flags=OUT_AFFINE)
         d_var = int(((w[0] != l[0]).any(dim=1) | (w[1] != l[1]).any(dim=1)).sum())
-        tot += 2 * n; bad += d_fixed + d_var
-        print(f"{nm} batch {b}: {n} fixed-base + {n} variable-base lanes, differing: {d_fixed} / {d_var}   [{time.time()-t0:.0f}s]", flush=True)
+        xo = e.scalar_mult(cv, k, gl[0], gl[1], flags=OUT_AFFINE, x_only=True)[0]      # P-256: the ladder without Z
+        xg = e.scalar_mult_base(cv, s, flags=OUT_AFFINE, x_only=True)[0]
+        d_x = int(((xo != l[0]).any(dim=1) | (xg != gl[0]).any(dim=1)).sum())
+        tot += 3 * n; bad += d_fixed + d_var + d_x
+        print(f"{nm} batch {b}: {n} fixed-base + {n} variable-base + {n} x-only lanes, differing: {d_fixed} / {d_var} / {d_x}   [{time.time()-t0:.0f}s]", flush=True)
 print(f"TOTAL {tot} scalar multiplications compared across algorithms, {bad} lanes differ")
 sys.exit(1 if bad else 0)
