@@ -49,6 +49,19 @@ def test_bench_defaults_are_config_4_verbatim():
     assert plan(a.scaling, 1 << a.global_log2_batch, 5, 8) == (5 << 21, 1 << 21, 1 << 24, 1 << 21)
 
 
+def test_committed_ladder_traffic_is_the_ladder_kernels_own():
+    """roofline.traffic comes from profiles/pmc_traffic.json (the counters cannot be read inside the run): the default
+    workload's figure must be the ladder kernel's alone -- its algorithmic 192 B per scalar plus a little -- not the sum
+    over every kernel of the profiled command."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    n = 1 << 24
+    traffic, src = bench.committed_traffic(bench.parse_args([]), n)
+    assert traffic is not None and "not measured in this run" in src
+    assert 1.0 <= traffic / (bench.ALGO_BYTES_PER_SCALAR_MULT * n) < 1.1
+
+
 def test_a_wrong_gpu_result_fails_the_benchmark():
     """a kernel regression must not print a headline and exit 0.  bench.py's cpu_baseline leg is driven here with a
     stand-in "GPU" (numpy arrays holding the exact oracle's results): untouched it reports no failure; with ONE corrupted lane the
