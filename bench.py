@@ -18,6 +18,15 @@ compute (BASELINE.json north_star: "RCCL over xGMI only for the final gather"); 
 the timed region, and a second, untimed-for-`value` loop without them gives the compute-only rate
 ("throughput with and without the gather"; `config.gather`).
 
+Started plainly with --gpus N > 1 (no RANK in the environment, the way the driver starts the N = 1 run) this process
+becomes a LAUNCHER: before anything touches a GPU -- it imports neither torch nor the HIP library -- it starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a
+fresh child process, relays rank 0's one JSON line and exits with the child's code.
+`--multi group` is the other way to use N GPUs: ONE process, the C ABI's device group (ecsimd_hip_group_*: one context
+per device, ncclCommInitAll communicators, the result shards gathered to device 0 by grouped ncclSend / ncclRecv).  In
+the one-process-per-GPU mode with N > 1, rank 0 also runs that mode once in a child process after the timed loops
+(`multi_group` in the line; --no-group-check skips it) so that a multi-GPU node measures both.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : integer-VALU bound.  achieved = scalar-mults/s x 555 968 mad32 (SURVEY.md 8(d):
                  (2299 M + 1789 S) x 136), kernel time from HIP events on the launch stream;
@@ -71,13 +80,64 @@ def parse_args(argv=None):
                          "fixed-base: k*G with the 4-bit-window LDS table + simultaneous inversion, affine out (BASELINE configs[2]); "
                          "fixed-base-signed: the same with signed 7-bit windows (37 additions instead of 64); "
                          "fixed-base-big: 20-bit windows (odd digits) over a 436 MB table in device memory (12 additions)")
+    ap.add_argument("--multi", default="procs", choices=["procs", "group"],
+                    help="procs: one process per GPU under torch.distributed.run, one RCCL gather per step (what the driver launches; "
+                         "started without it, --gpus N > 1 launches it); group: ONE process driving N GPUs through the C ABI's device "
+                         "group (ecsimd_hip_group_*), the gather by grouped ncclSend / ncclRecv")
+    ap.add_argument("--no-group-check", action="store_true", help="N > 1, --multi procs: do not run the --multi group leg in a child process")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args(argv)
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` (N > 1) started without torch.distributed.run: start it, as a fresh child process, and
+    relay.  Nothing here may touch a GPU (a process that has initialised HIP must not be replaced, and the ranks must find
+    the devices untouched): no torch, no ecsimd_amd, no HIP library is imported by this process.
+    ECSIMD_BENCH_LAUNCHER (tests): a replacement for the `python -m torch.distributed.run ...` prefix of the command line."""
+    import shlex
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    override = os.environ.get("ECSIMD_BENCH_LAUNCHER")
+    prefix = shlex.split(override) if override else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                                     "--master-addr", "127.0.0.1", "--master-port", str(free_port())]
+    child = subprocess.run(prefix + [os.path.abspath(__file__)] + list(argv), stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in child.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln                                   # rank 0's one line (the last one, should a wrapper echo)
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if os.environ.get("ECSIMD_BENCH_LAUNCHER_REPORT"):  # tests: what this process has loaded by now
+        maps = open("/proc/self/maps").read()
+        print("launcher: hip_loaded=%s torch_imported=%s" % (("libamdhip64" in maps) or ("libecsimd_hip" in maps), "torch" in sys.modules), file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if child.returncode == 0 and line is None:
+        print("launcher: the ranks exited 0 without printing a result line", file=sys.stderr)
+        return 1
+    return child.returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.multi == "group":
+        if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise SystemExit("--multi group is one process driving every GPU: start it without torch.distributed.run")
+        return main_group(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args, sys.argv[1:])
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -87,10 +147,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+    args.gpus = world                   # under torch.distributed.run the launcher's world size is the number of GPUs
     torch.cuda.set_device(local_rank)
     # ECSIMD_BENCH_FORCE_DIST=1 runs the process-group + gather path even with one rank (a single-GPU
     # rehearsal of the N > 1 code: RCCL init, side stream, dist.gather, barrier).
@@ -175,7 +232,36 @@ def main():
         runner.gather = True
 
     total = float(total_units) * args.steps
-    value = total / elapsed
+    result = base_line(args, world, total_units, n, total / elapsed, elapsed)
+    result["config"]["rccl"] = ({"ranks": dist.get_world_size(), "version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                                  "via": "torch.distributed backend nccl, one process per GPU"} if distributed else {"ranks": 0})
+    if distributed:
+        result["config"]["gather"] = {
+            "what": "one RCCL gather of every rank's result shard to rank 0 per step, on a side stream, into one pre-sized receive buffer",
+            "bytes_per_rank_per_step": 3 * rows * 32, "ms_avg_on_the_side_stream_rank0": (float(np.mean(gather_ms)) if gather_ms else None),
+            "ms_per_step_with_gather": 1e3 * elapsed / args.steps, "ms_per_step_compute_only": 1e3 * compute_only / args.steps,
+            "value_compute_only": total / compute_only}
+
+    failures = []
+    if rank == 0:
+        result["roofline"] = roofline_object(args, eng, n, float(np.mean(kernel_ms)))
+        if world == 1 and not args.no_cpu_baseline:
+            attach_cpu_baseline(args, result, eng, curve, k, bx, by, [t[:n] for t in runner.last_result()], failures)
+        if force_dist and not torch.equal(runner.gathered[0], runner.last_result()):
+            failures.append("the gathered shard differs from the computed one")
+        if world > 1 and not args.no_group_check:
+            result["multi_group"] = group_leg(args, world)          # the other ranks wait at the barrier below
+        if failures:
+            result["parity_failures"] = failures
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    return EXIT_PARITY if failures else 0
+
+
+def base_line(args, world, total_units, n, value, elapsed):
+    """The contract fields of the one JSON line."""
     sizes = f"2^{args.global_log2_batch} per step over {world} GPU(s) (strong scaling, BASELINE configs[3])" if args.scaling == "strong" \
         else f"2^{args.log2_batch} per GPU per step (weak scaling)"
     names = {
@@ -188,7 +274,7 @@ def main():
     }
     fixed = {"fixed-base": "4-bit window table in LDS", "fixed-base-signed": "signed 7-bit window table in LDS",
              "fixed-base-big": "20-bit window table of odd multiples (436 MB) in device memory"}
-    result = {
+    return {
         "metric": "P-256 scalar mults/sec (batched)" if args.curve == "p256" else "secp256k1 scalar mults/sec (batched)",
         "value": value, "unit": "scalar_mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
@@ -196,86 +282,189 @@ def main():
         "config": {"workload": names.get(args.workload) or (f"scalar_mult_{args.curve} fixed-base (G), {sizes}, random scalars, "
                                                              + fixed[args.workload] + " + simultaneous inversion, affine out"),
                    "element": "256-bit integers: 8 x u32 words (= 4 x u64 limbs) in VGPRs, v_mad_u64_u32 carry chains",
-                   "global_batch": total_units, "per_gpu_batch": n, "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
+                   "global_batch": total_units, "per_gpu_batch": n,
+                   "parallelism": (f"group{world}" + ("+rccl_gather" if world > 1 else "") if args.multi == "group" else f"shard{world}" + ("+rccl_gather" if world > 1 else ""))},
     }
-    if distributed:
-        result["config"]["gather"] = {
-            "what": "one RCCL gather of every rank's result shard to rank 0 per step, on a side stream, into one pre-sized receive buffer",
-            "bytes_per_rank_per_step": 3 * rows * 32, "ms_avg_on_the_side_stream_rank0": (float(np.mean(gather_ms)) if gather_ms else None),
-            "ms_per_step_with_gather": 1e3 * elapsed / args.steps, "ms_per_step_compute_only": 1e3 * compute_only / args.steps,
-            "value_compute_only": total / compute_only}
 
-    failures = []
-    if rank == 0:
-        # ---- roofline of the dominant kernel (k_scalar_mult), measured live
-        avg_ms = float(np.mean(kernel_ms))
-        mads, ms = eng.peak_mad32(8192, reps=5)
-        peak = mads / (ms * 1e-3) / 1e12
-        if args.workload in ("ladder", "ladder-ref-compat"):
-            mad32_unit, bytes_unit, kname = MAD32_PER_SCALAR_MULT, ALGO_BYTES_PER_SCALAR_MULT, "k_scalar_mult"
+
+def roofline_object(args, eng, n, avg_ms):
+    """Roofline of the dominant kernel, measured live: achieved = lanes of ONE launch x algorithmic mad32 per lane / the
+    launch's device time (HIP events on the launch stream); peak = the dependency-free v_mad_u64_u32 stream on the same GPU."""
+    mads, ms = eng.peak_mad32(8192, reps=5)
+    peak = mads / (ms * 1e-3) / 1e12
+    if args.workload in ("ladder", "ladder-ref-compat"):
+        mad32_unit, bytes_unit, kname = MAD32_PER_SCALAR_MULT, ALGO_BYTES_PER_SCALAR_MULT, "k_scalar_mult"
+    elif args.workload == "ladder-x":
+        # P-256: TRPLU (6 + 7), 254 x (8M + 6S), the recovery (12) and the inversion walk (7 + 267 / share); secp256k1: the full ladder + 5 + 267 / share
+        share = min(128, max(1, n >> 17))
+        fm = ((13 + 254 * 14 + 12) if args.curve == "p256" else 4088 + 5) + 3 + (267 if args.curve == "p256" else 270) / share
+        mad32_unit, bytes_unit = int(fm * 136), 128
+        kname = ("k_scalar_mult_x + k_inverse_batched" if args.curve == "p256" else "k_scalar_mult + k_to_affine_batched")
+    elif args.workload == "windowed":
+        # what THIS algorithm needs per scalar (DESIGN.md section 4).  P-256: table {1,3,..,15}P = DBLU + 7 co-Z additions
+        # (6 + 7 x 7), its inversion 7 x (7 + 267/224) (224 points share one inversion at 2^22), 63 windows x (3 doublings
+        # + one fused double-add of 13M + 5S), the final inversion walk; a doubling is 4M + 4S (P-256) / 3M + 4S
+        # (secp256k1), a mixed addition 8M + 3S; 96 B in, 64 B out.
+        dbl = 8 if args.curve == "p256" else 7
+        inv = 267 if args.curve == "p256" else 270                  # addition-chain inversion (point.cuh fe_inverse)
+        share = min(128, max(1, min(n, 1 << 22) >> 17))            # elements per shared inversion (k_affine.inc; the windowed path works in chunks of 2^22)
+        fm = (6 + 7 * 7) + 7 * (7 + inv / min(256, 7 * share)) + 63 * (3 * dbl + 18) + (7 + inv / share)
+        if args.curve == "secp256k1":     # GLV split: 32 windows x (4 doublings + 2 mixed additions + beta) + the top window's two additions
+            fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / min(256, 7 * share)) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + (7 + inv / share)   # table {1..8}P
+        mad32_unit, bytes_unit = int(fm * 136), 160
+        kname = ("k_varwin_mult_odd + k_varwin_odd_multiples" if args.curve == "p256" else "k_varwin_mult_glv + k_varwin_multiples") + " + k_varwin_to_table + k_to_affine_batched"
+    else:
+        # what THIS algorithm needs per scalar (DESIGN.md section 4): 64 mixed additions x 11 field mults,
+        # 7 mults of the simultaneous-inversion walk and 267/m (secp256k1: 270/m) of the inversion m = min(128, n / 2^17) points share; 32 B in, 64 B out.
+        adds = {"fixed-base": 64, "fixed-base-signed": 37, "fixed-base-big": 12}[args.workload]
+        share = min(128, max(1, n >> 17))
+        mad32_unit, bytes_unit = int((adds * 11 + 7 + (267 if args.curve == "p256" else 270) / share) * 136), 96
+        kname = {64: "k_base_windowed", 37: "k_base_windowed_s<7>", 12: "k_base_windowed_g"}[adds] + " + k_to_affine_batched"
+    achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
+    traffic, traffic_src = committed_traffic(args, n)
+    return {
+        "bound": "valu", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "Tmad32/s", "frac": achieved / peak,
+        "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": avg_ms, "algorithmic_mad32_per_unit": mad32_unit,
+        "hbm": {"achieved": n / (avg_ms * 1e-3) * bytes_unit / 1e9, "peak": 8000.0, "unit": "GB/s",
+                "algorithmic_bytes_per_unit": bytes_unit},
+        "peak_source": "ecsimd_hip_peak_mad32: dependency-free v_mad_u64_u32 stream, 8 waves/SIMD, same GPU, same run",
+    }
+
+
+def attach_cpu_baseline(args, result, eng, curve, k, bx, by, out, failures):
+    """The baseline is a reported side figure: a checker that cannot LOAD (e.g. the prebuilt reference on a host without
+    AVX2) costs the run neither its line nor its exit code.  A parity DISAGREEMENT does: it is in the object and the
+    process exits EXIT_PARITY after printing."""
+    try:
+        if args.workload == "windowed":
+            result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, base=(bx, by))
         elif args.workload == "ladder-x":
-            # P-256: TRPLU (6 + 7), 254 x (8M + 6S), the recovery (12) and the inversion walk (7 + 267 / share); secp256k1: the full ladder + 5 + 267 / share
-            share = min(128, max(1, n >> 17))
-            fm = ((13 + 254 * 14 + 12) if args.curve == "p256" else 4088 + 5) + 3 + (267 if args.curve == "p256" else 270) / share
-            mad32_unit, bytes_unit = int(fm * 136), 128
-            kname = ("k_scalar_mult_x + k_inverse_batched" if args.curve == "p256" else "k_scalar_mult + k_to_affine_batched")
-        elif args.workload == "windowed":
-            # what THIS algorithm needs per scalar.  P-256: table {1,3,..,15}P = DBLU + 7 co-Z additions
-            # (6 + 7 x 7), its inversion 7 x (7 + 267/224) (224 points share one inversion at 2^22), 63 windows x (3 doublings
-            # + one fused double-add of 13M + 5S), the final inversion walk; a doubling is 4M + 4S (P-256) / 3M + 4S
-            # (secp256k1), a mixed addition 8M + 3S; 96 B in, 64 B out.
-            dbl = 8 if args.curve == "p256" else 7
-            inv = 267 if args.curve == "p256" else 270                  # addition-chain inversion (point.cuh fe_inverse)
-            share = min(128, max(1, min(n, 1 << 22) >> 17))            # elements per shared inversion (k_affine.inc; the windowed path works in chunks of 2^22)
-            fm = (6 + 7 * 7) + 7 * (7 + inv / min(256, 7 * share)) + 63 * (3 * dbl + 18) + (7 + inv / share)
-            if args.curve == "secp256k1":     # GLV split: 32 windows x (4 doublings + 2 mixed additions + beta) + the top window's two additions
-                fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / min(256, 7 * share)) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + (7 + inv / share)   # table {1..8}P
-            mad32_unit, bytes_unit = int(fm * 136), 160
-            kname = ("k_varwin_mult_odd + k_varwin_odd_multiples" if args.curve == "p256" else "k_varwin_mult_glv + k_varwin_multiples") + " + k_varwin_to_table + k_to_affine_batched"
+            result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, base=(bx, by), x_only=True)
+        elif args.workload in ("ladder", "ladder-ref-compat"):
+            result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, out, args.cpu_seconds, failures, compat=(args.workload == "ladder-ref-compat"))
+            comp = competitor_openssl(eng, curve, k, bx, by, out, failures)
+            if comp is not None:
+                result["cpu_baseline"]["competitor_openssl"] = comp
         else:
-            # what THIS algorithm needs per scalar: 64 mixed additions x 11 field mults,
-            # 7 mults of the simultaneous-inversion walk and 267/m (secp256k1: 270/m) of the inversion m = min(128, n / 2^17) points share; 32 B in, 64 B out.
-            adds = {"fixed-base": 64, "fixed-base-signed": 37, "fixed-base-big": 12}[args.workload]
-            share = min(128, max(1, n >> 17))
-            mad32_unit, bytes_unit = int((adds * 11 + 7 + (267 if args.curve == "p256" else 270) / share) * 136), 96
-            kname = {64: "k_base_windowed", 37: "k_base_windowed_s<7>", 12: "k_base_windowed_g"}[adds] + " + k_to_affine_batched"
-        achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
-        traffic, traffic_src = committed_traffic(args, n)
-        result["roofline"] = {
-            "bound": "valu", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "Tmad32/s", "frac": achieved / peak,
-            "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": avg_ms, "algorithmic_mad32_per_unit": mad32_unit,
-            "hbm": {"achieved": n / (avg_ms * 1e-3) * bytes_unit / 1e9, "peak": 8000.0, "unit": "GB/s",
-                    "algorithmic_bytes_per_unit": bytes_unit},
-            "peak_source": "ecsimd_hip_peak_mad32: dependency-free v_mad_u64_u32 stream, 8 waves/SIMD, same GPU, same run",
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            # The baseline is a reported side figure: a checker that cannot LOAD (e.g. the prebuilt reference on a host
-            # without AVX2) costs the run neither its line nor its exit code.  A parity DISAGREEMENT does: it is in the
-            # object and the process exits EXIT_PARITY after printing.
-            try:
-                out = [t[:n] for t in runner.last_result()]
-                if args.workload == "windowed":
-                    result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, base=(bx, by))
-                elif args.workload == "ladder-x":
-                    result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, base=(bx, by), x_only=True)
-                elif args.workload in ("ladder", "ladder-ref-compat"):
-                    result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, out, args.cpu_seconds, failures, compat=(args.workload == "ladder-ref-compat"))
-                    comp = competitor_openssl(eng, curve, k, bx, by, out, failures)
-                    if comp is not None:
-                        result["cpu_baseline"]["competitor_openssl"] = comp
-                else:
-                    result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures)
-            except (CheckerUnavailable, OSError) as exc:
-                result["cpu_baseline"] = {"value": None, "unit": "scalar_mults/s", "cores": usable_cores(), "kind": "unavailable",
-                                          "sample": "the CPU checkers could not be loaded here", "error": repr(exc)[:300]}
-        if force_dist and not torch.equal(runner.gathered[0], runner.last_result()):
-            failures.append("the gathered shard differs from the computed one")
-        if failures:
-            result["parity_failures"] = failures
-        print(json.dumps(result), flush=True)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+            result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures)
+    except (CheckerUnavailable, OSError) as exc:
+        result["cpu_baseline"] = {"value": None, "unit": "scalar_mults/s", "cores": usable_cores(), "kind": "unavailable",
+                                  "sample": "the CPU checkers could not be loaded here", "error": repr(exc)[:300]}
+
+
+def group_leg(args, world, timeout_s=240):
+    """N > 1, one process per GPU: after the timed loops rank 0 runs `bench.py --multi group` over the same N devices in a
+    CHILD process (the ranks idle at a barrier meanwhile) -- the C ABI's device group, whose RCCL branch (ncclCommInitAll
+    communicators, grouped ncclSend / ncclRecv) only a multi-GPU node can execute.  A side figure: a failure here is
+    recorded, it does not cost the line or the exit code."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--multi", "group", "--gpus", str(world), "--steps", str(min(args.steps, 5)), "--warmup", "1",
+           "--scaling", args.scaling, "--global-log2-batch", str(args.global_log2_batch), "--log2-batch", str(args.log2_batch),
+           "--curve", args.curve, "--workload", args.workload, "--no-cpu-baseline"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        if out.returncode != 0 or not lines:
+            return {"ok": False, "returncode": out.returncode, "stderr_tail": out.stderr[-600:]}
+        d = json.loads(lines[-1])
+        return {"ok": True, "value": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "rccl": d["config"].get("rccl"),
+                "gather": d["config"].get("gather"), "parity": d["config"].get("group_parity")}
+    except (subprocess.SubprocessError, ValueError, KeyError) as exc:
+        return {"ok": False, "error": repr(exc)[:300]}
+
+
+def main_group(args):
+    """--multi group: ONE process, ecsimd_hip_group_* (include/ecsimd_hip.h "device groups"): one context per device, member m
+    owns shard_range(units, m, N) resident in ITS memory, every step is one ecsimd_hip_group_scalar_mult -- N ladders and one
+    exchange into device 0's arrays (RCCL when N > 1: grouped ncclSend / ncclRecv on ncclCommInitAll communicators) -- with
+    double-buffered outputs, no host synchronisation inside the timed loop, ecsimd_hip_group_sync at its end."""
+    import numpy as np
+    import torch
+    from ecsimd_amd import Engine, DeviceGroup, CURVES, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, GROUP_NO_GATHER, REF_SQUARE_COMPAT
+    from ecsimd_amd.shard import plan
+    import ecsimd_amd
+    if args.workload not in ("ladder", "ladder-ref-compat", "ladder-x"):
+        raise SystemExit("--multi group runs the ladder workloads (the group entry point is ecsimd_hip_group_scalar_mult)")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    N = args.gpus
+    if torch.cuda.device_count() < N:
+        raise SystemExit(f"--multi group --gpus {N}: only {torch.cuda.device_count()} device(s) visible")
+    if not os.path.exists(ecsimd_amd.lib_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    curve = CURVES[args.curve]
+    units = (1 << args.global_log2_batch) if args.scaling == "strong" else (1 << args.log2_batch)
+    spans = [plan(args.scaling, units, m, N) for m in range(N)]
+    total_units = spans[0][2]
+    if any(sp[1] == 0 for sp in spans):
+        raise SystemExit("the batch is smaller than the number of GPUs")
+    grp = DeviceGroup(list(range(N)))
+    engs, ks, xs, ys, bxs, bys = [], [], [], [], [], []
+    for m in range(N):                                   # inputs generated where they will be used (seed, global index): nothing moves
+        with torch.cuda.device(m):
+            eng = Engine(m)
+            first, cnt = spans[m][0], spans[m][1]
+            k = eng.fill_random(cnt, SEED, 1, first_index=first)
+            sd = eng.fill_random(cnt, SEED, 2, first_index=first)
+            bx, by = eng.scalar_mult_base(curve, sd, flags=OUT_AFFINE)
+            if args.workload == "ladder-x":
+                xm, ym = bx, by
+            else:
+                P = eng.from_affine(curve, bx, by); xm, ym = P[0], P[1]
+            torch.cuda.synchronize(m)
+            engs.append(eng); ks.append(k); xs.append(xm); ys.append(ym); bxs.append(bx); bys.append(by)
+    x_only = args.workload == "ladder-x"
+    flags = (OUT_AFFINE if x_only else (BASE_MGRY | OUT_JACOBIAN)) | (REF_SQUARE_COMPAT if args.workload == "ladder-ref-compat" else 0)
+    outs = [grp.alloc_outputs(total_units, flags, x_only) for _ in range(2)]
+    torch.cuda.synchronize(0)
+
+    def loop(steps, fl):
+        grp.sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            grp.enqueue(curve, ks, xs, ys, outs[i & 1], total_units, fl)
+        g_ms = grp.sync()
+        return time.perf_counter() - t0, g_ms
+
+    loop(max(1, args.warmup), flags)                      # sizes staging and workspaces, creates RCCL's channels
+    elapsed, gather_ms = loop(args.steps, flags)
+    member_ms = [grp.member_ms(m) for m in range(N)]
+    compute_only, _ = loop(args.steps, flags | GROUP_NO_GATHER)
+    loop(1, flags)                                        # the arrays hold a gathered result again
+    total = float(total_units) * args.steps
+    n0 = spans[0][1]
+    result = base_line(args, N, total_units, n0, total / elapsed, elapsed)
+    result["config"]["rccl"] = {"ranks": N if grp.uses_rccl else 0, "version": grp.rccl_version or None,
+                                "via": "ecsimd_hip_group_* (C ABI): one process, ncclCommInitAll, grouped ncclSend / ncclRecv" if grp.uses_rccl
+                                       else "ecsimd_hip_group_* (C ABI): one member, no exchange"}
+    result["config"]["gather"] = {
+        "what": "every other member's result shard into device 0's arrays by one grouped ncclSend / ncclRecv exchange per step, on device 0's gather stream",
+        "bytes_per_member_per_step": (1 if x_only else 3) * spans[0][3] * 32, "ms_last_on_the_gather_stream": (gather_ms if gather_ms >= 0 else None),
+        "ms_per_step_with_gather": 1e3 * elapsed / args.steps, "ms_per_step_compute_only": 1e3 * compute_only / args.steps,
+        "value_compute_only": total / compute_only}
+    failures = []
+    # every member's shard of the gathered result against that member's own single-device ladder (bit for bit, on the devices)
+    last = outs[0]
+    ok = True
+    for m in range(N):
+        with torch.cuda.device(m):
+            first, cnt = spans[m][0], spans[m][1]
+            ref = engs[m].scalar_mult(curve, ks[m], xs[m], ys[m], flags=flags, x_only=x_only)
+            torch.cuda.synchronize(m)
+            for a, b in zip(last, ref):
+                if b is not None:
+                    ok = ok and bool(torch.equal(a[first:first + cnt].to(b.device), b))
+    result["config"]["group_parity"] = {"gathered_equals_each_members_own_ladder": ok, "members": N}
+    if not ok:
+        failures.append("multi group: the gathered result differs from a member's own ladder")
+    result["roofline"] = roofline_object(args, engs[0], n0, float(max(member_ms)))
+    result["roofline"]["kernel_ms_per_member"] = member_ms
+    if N == 1 and not args.no_cpu_baseline:
+        attach_cpu_baseline(args, result, engs[0], curve, ks[0], bxs[0], bys[0], [t[:n0] for t in last] + [None] * (3 - len(last)), failures)
+    if failures:
+        result["parity_failures"] = failures
+    print(json.dumps(result), flush=True)
+    grp.close()
     return EXIT_PARITY if failures else 0
 
 

@@ -410,31 +410,53 @@ class DeviceGroup:
     def uses_rccl(self):
         return bool(self.lib.ecsimd_hip_group_uses_rccl(self.g))
 
-    def scalar_mult(self, curve, k_shards, x_shards, y_shards, n, flags=0):
-        """Device-resident form: *_shards[m] = member m's slice (torch tensor on that member's device).
-        Returns (ox, oy[, oz]) on member 0's device and the gather time in ms."""
+    @property
+    def rccl_version(self):
+        """ncclGetVersion of the RCCL the gather goes through (22606 = 2.26.6); 0 when the group needs none."""
+        return int(self.lib.ecsimd_hip_group_rccl_version(self.g))
+
+    def alloc_outputs(self, n, flags=0, x_only=False):
         torch = self.torch
-        G = self.size
         dev0 = torch.device("cuda", self.devices[0])
-        outs = [torch.empty((n, 4), dtype=torch.int64, device=dev0) for _ in range(2 if flags & 2 else 3)]
+        return [torch.empty((n, 4), dtype=torch.int64, device=dev0) for _ in range((1 if x_only else 2) if flags & 2 else 3)]
+
+    def enqueue(self, curve, k_shards, x_shards, y_shards, outs, n, flags=0):
+        """ecsimd_hip_group_scalar_mult without the wait: *_shards[m] = member m's slice (a tensor on that member's device),
+        outs = 1 (x only), 2 (affine) or 3 (Jacobian) tensors of n rows on member 0's device.  The inputs must be complete
+        (they were produced on torch's streams, the group runs on its own)."""
+        G = self.size
         ptrs = lambda ts: (C.c_void_p * G)(*[C.c_void_p(t.data_ptr() if t is not None and t.numel() else 0) for t in ts])
-        for m in range(G):
-            torch.cuda.synchronize(self.devices[m])         # the inputs were produced on torch's streams
         o = [C.c_void_p(t.data_ptr()) for t in outs] + [C.c_void_p(0)] * (3 - len(outs))
         self._check(self.lib.ecsimd_hip_group_scalar_mult(self.g, C.c_int(curve), ptrs(k_shards), ptrs(x_shards), ptrs(y_shards),
                                                           o[0], o[1], o[2], C.c_size_t(n), C.c_int(flags)), "group_scalar_mult")
+
+    def sync(self):
+        """ecsimd_hip_group_sync: waits for every member and the gather; returns the last gather's duration in ms (-1: none)."""
         ms = C.c_double(0)
         self._check(self.lib.ecsimd_hip_group_sync(self.g, C.byref(ms)), "group_sync")
-        return tuple(outs), float(ms.value)
+        return float(ms.value)
+
+    def member_ms(self, member):
+        ms = C.c_double(0)
+        self._check(self.lib.ecsimd_hip_group_member_ms(self.g, C.c_int(member), C.byref(ms)), "group_member_ms")
+        return float(ms.value)
+
+    def scalar_mult(self, curve, k_shards, x_shards, y_shards, n, flags=0, x_only=False):
+        """Device-resident form, synchronous: returns (ox[, oy[, oz]]) on member 0's device and the gather time in ms."""
+        outs = self.alloc_outputs(n, flags, x_only)
+        for m in range(self.size):
+            self.torch.cuda.synchronize(self.devices[m])         # the inputs were produced on torch's streams
+        self.enqueue(curve, k_shards, x_shards, y_shards, outs, n, flags)
+        return tuple(outs), self.sync()
 
     def rccl_selftest(self, elements=1 << 16):
         self._check(self.lib.ecsimd_hip_group_rccl_selftest(self.g, C.c_size_t(elements)), "group_rccl_selftest")
 
-    def scalar_mult_host(self, curve, k, x, y, flags=0):
+    def scalar_mult_host(self, curve, k, x, y, flags=0, x_only=False):
         """Host-array form: numpy uint64 (n, 4) arrays in, numpy arrays out."""
         k, x, y = (np.ascontiguousarray(a, dtype=np.uint64) for a in (k, x, y))
         n = len(k)
-        outs = [np.empty((n, 4), dtype=np.uint64) for _ in range(2 if flags & 2 else 3)]
+        outs = [np.empty((n, 4), dtype=np.uint64) for _ in range((1 if x_only else 2) if flags & 2 else 3)]
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         o = [p(a) for a in outs] + [C.c_void_p(0)] * (3 - len(outs))
         self._check(self.lib.ecsimd_hip_group_scalar_mult_host(self.g, C.c_int(curve), p(k), p(x), p(y), o[0], o[1], o[2], C.c_size_t(n), C.c_int(flags)),

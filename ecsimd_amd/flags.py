@@ -8,3 +8,4 @@ ALG_WINDOWED_SIGNED = 8
 ALG_NO_ENDOMORPHISM = 16
 ALG_WINDOWED_BIG = 32
 REF_SQUARE_COMPAT = 64
+GROUP_NO_GATHER = 0x10000    # ecsimd_hip_group_scalar_mult only: compute without the exchange

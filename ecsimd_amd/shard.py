@@ -13,6 +13,8 @@ Two partitions of the global index space (bench.py `--scaling`):
 """
 from __future__ import annotations
 
+import collections
+
 import torch
 import torch.distributed as dist
 
@@ -48,7 +50,8 @@ class ShardedRunner:
     gather allocates nothing.  `gather=False` skips the collective (compute-only timing).
     """
 
-    def __init__(self, shape, dtype, device, world: int, rank: int, group=None, always_gather: bool = False):
+    def __init__(self, shape, dtype, device, world: int, rank: int, group=None, always_gather: bool = False, time_gathers: bool = True,
+                 keep_timings: int = 1024):
         self.world, self.rank, self.group = world, rank, group
         self.dist = world > 1 or always_gather          # always_gather: rehearse the collective path with one rank
         self.cuda = torch.device(device).type == "cuda"
@@ -57,7 +60,8 @@ class ShardedRunner:
         self.gathered = [self.received[r] for r in range(world)] if self.received is not None else None
         self.comm = torch.cuda.Stream(device=device) if (self.cuda and self.dist) else None
         self._gather_done = [None, None]      # per buffer: event after its last gather (GPU only)
-        self._gather_events = []              # (start, end) per gathered step, on the side stream
+        self._gather_events = collections.deque(maxlen=keep_timings)   # (start, end) of the last gathers, on the side stream: bounded,
+        self.time_gathers = time_gathers                               # a long-running runner must not pile up HIP events
         self.gather = True
         self.steps = 0
 
@@ -77,11 +81,13 @@ class ShardedRunner:
                 ready.record()
                 with torch.cuda.stream(self.comm):
                     self.comm.wait_event(ready)
-                    t0 = torch.cuda.Event(enable_timing=True); t0.record()
+                    if self.time_gathers:
+                        t0 = torch.cuda.Event(enable_timing=True); t0.record()
                     dist.gather(out, self.gathered, dst=0, group=self.group)
-                    fin = torch.cuda.Event(enable_timing=True); fin.record()
+                    fin = torch.cuda.Event(enable_timing=self.time_gathers); fin.record()
                 self._gather_done[i] = fin
-                self._gather_events.append((t0, fin))
+                if self.time_gathers:
+                    self._gather_events.append((t0, fin))
             else:
                 dist.gather(out, self.gathered, dst=0, group=self.group)
         self.steps += 1
@@ -89,7 +95,7 @@ class ShardedRunner:
 
     def gather_ms(self, last: int):
         """Side-stream durations (ms) of the last `last` gathers (GPU only; call after fence())."""
-        return [a.elapsed_time(b) for a, b in self._gather_events[-last:]] if (self.cuda and last) else []
+        return [a.elapsed_time(b) for a, b in list(self._gather_events)[-last:]] if (self.cuda and last) else []
 
     def fence(self):
         """Everything enqueued so far has finished on every rank."""

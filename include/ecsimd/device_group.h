@@ -23,6 +23,7 @@ class device_group {
   ~device_group() { if (g_) ecsimd_hip_group_destroy(g_); }
   int size() const { return ecsimd_hip_group_size(g_); }
   bool uses_rccl() const { return ecsimd_hip_group_uses_rccl(g_) == 1; }
+  int rccl_version() const { return ecsimd_hip_group_rccl_version(g_); }     // e.g. 22606; 0 when the gather needs no RCCL
   ecsimd_hip_group* handle() const { return g_; }
   // (first index, count) of member m: the partition every group entry point uses
   static std::pair<size_t, size_t> shard_range(size_t n, int member, int members) {

@@ -269,30 +269,53 @@ int ecsimd_hip_peak_mad32(ecsimd_hip_ctx*, int iters, double* mads, double* ms);
  * batches sharded across the GPUs of a node "with RCCL over xGMI only for the final gather", host code behind this ABI.
  * A group owns one context per listed device.  Member m of G owns the contiguous slice shard_range(n, m, G) of a
  * batch (the first n % G members take one element more); no collective touches the data path; the result shards
- * are gathered to member 0's device memory by one grouped ncclSend / ncclRecv exchange.  RCCL is loaded at run time
- * (dlopen) when the group has more than one device; a device may be listed twice, in which case those members exchange
- * by device copies (how a one-GPU machine exercises the bookkeeping).  One host thread drives a group. */
+ * are gathered to member 0's device memory by one grouped ncclSend / ncclRecv exchange on a second stream of member 0's
+ * device, so that member 0's next ladder overlaps it.  RCCL is looked up at run time when the group has more than one
+ * device -- the copy the process already has (soname librccl.so.1, e.g. torch's) if there is one, else ROCm's; the library
+ * needs RCCL neither to build nor to link.  A device may be listed twice, in which case those members exchange
+ * by device copies (how a one-GPU machine exercises the bookkeeping).  One host thread drives a group; every group
+ * entry point leaves the caller's current HIP device as it found it (the per-context entry points above select their
+ * context's device and leave it selected).
+ *
+ * EXPERIMENTAL until a machine with two or more GPUs has run tests/test_gpu_parity.py::test_device_group_behind_the_c_abi
+ * with distinct devices: the bookkeeping, staging, offsets and the device-copy gather run in every GPU test run, RCCL is
+ * loaded and exercised on a one-rank communicator (ecsimd_hip_group_rccl_selftest), but the ncclCommInitAll +
+ * multi-device ncclSend / ncclRecv exchange itself has only been checked against RCCL's documented contract. */
 typedef struct ecsimd_hip_group ecsimd_hip_group;
+enum {
+  ECSIMD_HIP_GROUP_NO_GATHER = 0x10000   /* ecsimd_hip_group_scalar_mult only: compute, leave every shard where its member wrote it
+                                            (member 0: its slice of ox/oy/oz; the others: group staging).  For timing the ladders
+                                            without the exchange ("throughput with and without the gather") */
+};
 int ecsimd_hip_shard_range(size_t n_total, int member, int members, size_t* first, size_t* count);   /* pure host arithmetic */
 int ecsimd_hip_group_init(const int* devices, int n_devices, ecsimd_hip_group** group);
 int ecsimd_hip_group_destroy(ecsimd_hip_group* group);
 int ecsimd_hip_group_size(const ecsimd_hip_group* group);
 int ecsimd_hip_group_uses_rccl(const ecsimd_hip_group* group);                 /* 1 when the gather goes through RCCL */
+int ecsimd_hip_group_rccl_version(const ecsimd_hip_group* group);              /* ncclGetVersion of that RCCL (22606 = 2.26.6); 0 without RCCL */
 ecsimd_hip_ctx* ecsimd_hip_group_context(ecsimd_hip_group* group, int member); /* e.g. to allocate on that device, set options */
 const char* ecsimd_hip_group_last_error(const ecsimd_hip_group* group);
 /* curve_group.h:189-218 over the group, device-resident: k[m], x[m], y[m] = member m's slice in ITS device memory;
- * ox, oy, oz = n elements each in member 0's device memory (oz may be NULL with OUT_AFFINE); flags as
- * ecsimd_hip_scalar_mult.  Asynchronous; ecsimd_hip_group_sync waits for every member and reports how long the last
- * gather took on member 0's stream (milliseconds; NULL to skip; -1 if there was none). */
+ * ox, oy, oz = n elements each in member 0's device memory; flags as ecsimd_hip_scalar_mult (| GROUP_NO_GATHER): with
+ * OUT_AFFINE oz may be NULL, and oy too (x only: P-256 then runs the ladder without Z on every member).
+ * Asynchronous -- except that a call which has to grow a member's staging block (the first one, or a larger batch than
+ * any before) drains that member's stream and the gather stream first.  Calls may follow one another without a sync:
+ * a member's next ladder is ordered behind the exchange that reads its staging.  ecsimd_hip_group_sync waits for every
+ * member and the gather stream and reports how long the last gather took (milliseconds; NULL to skip; -1 if there was none). */
 int ecsimd_hip_group_scalar_mult(ecsimd_hip_group* group, int curve, const uint64_t* const* k, const uint64_t* const* x, const uint64_t* const* y,
                                  uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
 int ecsimd_hip_group_sync(ecsimd_hip_group* group, double* last_gather_ms);
+/* Device time (ms, HIP events on that member's stream) of member `member`'s LAST ladder launch; call after group_sync.
+ * -1 if the member has not launched anything. */
+int ecsimd_hip_group_member_ms(ecsimd_hip_group* group, int member, double* ms);
 /* What one GPU can verify of the RCCL side: loads RCCL as group_init does, creates a one-rank communicator on member 0's
  * device and moves `elements` 256-bit elements between two buffers with the calls the gather uses (grouped ncclSend /
- * ncclRecv of ncclUint64, member 0's stream).  0 = the bytes arrived intact. */
+ * ncclRecv of ncclUint64, the gather stream).  0 = the bytes arrived intact. */
 int ecsimd_hip_group_rccl_selftest(ecsimd_hip_group* group, size_t elements);
 /* The same with every array in HOST memory (n elements each): slices copied in, computed, gathered, copied out.
- * Synchronous. */
+ * Synchronous, and a CONVENIENCE path: the arrays are pageable as far as the library knows, so the runtime stages the
+ * copies and they do not overlap the ladders (1.5 GB each way at BASELINE config 4).  Callers that want the overlap keep
+ * pinned buffers, device-resident shards and the device form above. */
 int ecsimd_hip_group_scalar_mult_host(ecsimd_hip_group* group, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y,
                                       uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
 

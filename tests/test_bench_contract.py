@@ -100,3 +100,71 @@ def test_a_wrong_gpu_result_fails_the_benchmark():
         assert res["lanes_differing_confirmed_by_openssl"] == 0 and any("libcrypto" in f for f in failures)
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "return EXIT_PARITY if failures else 0" in src and "sys.exit(code)" in src and bench.EXIT_PARITY != 0
+
+
+# ---------------------------------------------------------------- the N > 1 launcher
+STUB = r'''
+import json, os, sys
+print("some chatter from a rank")
+print(json.dumps({"metric": "stub", "argv": sys.argv[1:], "hsa": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "has_rank": "RANK" in os.environ}))
+sys.exit(int(os.environ.get("STUB_RC", "0")))
+'''
+
+
+def _run_launcher(tmp_path, extra_env, args):
+    import subprocess
+    import sys
+    stub = tmp_path / "stub_ranks.py"
+    stub.write_text(STUB)
+    env = dict(os.environ)
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(key, None)
+    env.update({"ECSIMD_BENCH_LAUNCHER": f"{sys.executable} {stub}", "ECSIMD_BENCH_LAUNCHER_REPORT": "1"})
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=120)
+
+
+def test_gpus_n_without_torchrun_launches_the_ranks_as_a_child(tmp_path):
+    """`python bench.py --gpus 8` started the way the driver starts the N = 1 run: the parent starts the ranks as a fresh
+    child process BEFORE it has touched a GPU (it has loaded neither the HIP runtime nor torch by the time the child has
+    finished), relays the flags unchanged, prints the child's one JSON line and nothing else on stdout."""
+    r = _run_launcher(tmp_path, {}, ["--gpus", "8", "--steps", "3", "--warmup", "1", "--curve", "secp256k1"])
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["argv"] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--curve", "secp256k1"]
+    assert d["hsa"] == "0"                                   # dmabuf IPC for RCCL (see the environment notes)
+    assert "launcher: hip_loaded=False torch_imported=False" in r.stderr
+    assert "some chatter from a rank" in r.stderr            # a rank's other output goes to stderr, never between the driver and the line
+
+
+def test_the_launcher_propagates_a_failing_rank(tmp_path):
+    r = _run_launcher(tmp_path, {"STUB_RC": "3"}, ["--gpus", "2"])
+    assert r.returncode == 3 and json.loads(r.stdout.strip())["metric"] == "stub"      # EXIT_PARITY after printing survives the relay
+
+
+def test_the_real_launch_command_starts_and_fails_loudly_without_gpus():
+    """No stub: torch.distributed.run really starts two ranks here; without a GPU each dies at its first device call and
+    the launcher must come back non-zero with no result line -- never a silent CPU run."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ECSIMD_BENCH_LAUNCHER")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+
+
+def test_under_torchrun_bench_does_not_launch_again():
+    """With RANK set (the driver's own torch.distributed.run) the process is a rank, not a launcher; and --multi group
+    refuses to run as one of several ranks."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'if args.gpus > 1 and "RANK" not in os.environ:\n        return launch_ranks(args, sys.argv[1:])' in src
+    import subprocess
+    import sys
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--multi", "group"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "one process driving every GPU" in r.stderr

@@ -11,7 +11,7 @@ import pytest
 from helpers import (CURVE_PARAMS, CURVE_NAMES, P256, SECP256K1, SEED, hexes_to_arr, arr_to_hexes, from_int, to_int, ints_to_arr,
                      arr_to_ints, from_hex, fill_random_np, ec_mul, ec_add, jacobian_mgry_to_affine_int)
 from test_oracle import run_against_golden, structured_words
-from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG, REF_SQUARE_COMPAT, EcsimdHipError
+from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG, REF_SQUARE_COMPAT, GROUP_NO_GATHER, EcsimdHipError
 
 pytestmark = pytest.mark.gpu
 CURVES = [P256, SECP256K1]
@@ -747,9 +747,12 @@ def test_config2_point_add_double_2pow20(engine, oracle):
 
 
 @pytest.mark.parametrize("cv", CURVES)
-def test_x_coordinate_only_outputs(engine, cv):
+def test_x_coordinate_only_outputs(engine, oracle, cv):
     """an affine result without y (ECDH's shared secret, ECDSA's r).  Every algorithm's x-only
-    output equals the x of its full output; a Jacobian result still needs y."""
+    output equals the x of its full output; a Jacobian result still needs y.  The x-only ladder (P-256: the ladder without
+    Z, k_scalar_mult_x) is pinned to the ORACLE -- to_affine(scalar_mult(k, P)).x, curve_group.h:189-218 +
+    jacobian_curve_point.h:33-42 -- on 4 096 non-degenerate lanes per entry point, and its two fixed-up scalars
+    k = +-2^256 (mod n) to the big-int model."""
     import ctypes as C
     import torch
     from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG
@@ -799,6 +802,36 @@ def test_x_coordinate_only_outputs(engine, cv):
         assert torch.equal(gx1, gx2)
     else:                                                    # secp256k1 (a = 0) keeps the reference's ladder: equal off the degenerate scalars
         assert torch.equal(lx[len(edge):], wx[len(edge):])
+    # ---- the external witness: the oracle's ladder + to_affine, x coordinate, on the non-degenerate lanes of every form
+    lanes = np.arange(len(edge), m)                           # random scalars: none of the reference ladder's degenerate ones
+    kn, qxn, qyn = ke[lanes], engine.to_numpy(qx)[lanes], engine.to_numpy(qy)[lanes]
+    ox_var = oracle.to_affine(cv, oracle.scalar_mult(cv, kn, qxn, qyn, threads=THREADS))[0]
+    assert np.array_equal(engine.to_numpy(lx)[lanes], ox_var), "scalar_mult(x_only) vs the oracle"
+    c = oracle.constants(cv)
+    gxn, gyn = np.tile(c["gx"], (len(lanes), 1)), np.tile(c["gy"], (len(lanes), 1))
+    ox_base = oracle.to_affine(cv, oracle.scalar_mult(cv, kn, gxn, gyn, threads=THREADS))[0]
+    bx_only, none = engine.scalar_mult_base(cv, kd, flags=OUT_AFFINE, x_only=True)
+    assert none is None and np.array_equal(engine.to_numpy(bx_only)[lanes], ox_base), "scalar_mult_base(x_only) vs the oracle"
+    k1 = ke[len(edge) + 5]                                    # one (random, non-degenerate) scalar for all lanes
+    ox_1s = oracle.to_affine(cv, oracle.scalar_mult(cv, np.tile(k1, (len(lanes), 1)), qxn, qyn, threads=THREADS))[0]
+    sx, none = engine.scalar_mult_1s(cv, k1, qx, qy, flags=OUT_AFFINE, x_only=True)
+    assert none is None and np.array_equal(engine.to_numpy(sx)[lanes], ox_1s), "scalar_mult_1s(x_only) vs the oracle"
+    # ---- k = +-2^256 (mod n): the two scalars the Z-less ladder hands to k_x_fixup (k_ladder.inc) -- and their 256-bit
+    # representatives k + n where those exist -- against the independent big-int model, per-element and generator forms
+    cc = (1 << 256) % order
+    fix = [cc, order - cc] + [v for v in (cc + order, 2 * order - cc) if v < (1 << 256)]
+    kf = engine.to_device(ints_to_arr(fix))
+    fqx, fqy = qx[:len(fix)].contiguous(), qy[:len(fix)].contiguous()
+    fx_var, _ = engine.scalar_mult(cv, kf, fqx, fqy, flags=OUT_AFFINE, x_only=True)
+    fx_base, _ = engine.scalar_mult_base(cv, kf, flags=OUT_AFFINE, x_only=True)
+    pts = list(zip(arr_to_ints(engine.to_numpy(fqx)), arr_to_ints(engine.to_numpy(fqy))))
+    G = (CURVE_PARAMS[cv]["gx"], CURVE_PARAMS[cv]["gy"])
+    if cv == P256:                                           # secp256k1 keeps the reference ladder, whose own degenerate scalars these are
+        assert arr_to_ints(engine.to_numpy(fx_var)) == [ec_mul(cv, kk, P)[0] for kk, P in zip(fix, pts)]
+        assert arr_to_ints(engine.to_numpy(fx_base)) == [ec_mul(cv, kk, G)[0] for kk in fix]
+        for kk in fix[:2]:
+            s1, _ = engine.scalar_mult_1s(cv, ints_to_arr([kk])[0], fqx, fqy, flags=OUT_AFFINE, x_only=True)
+            assert arr_to_ints(engine.to_numpy(s1)) == [ec_mul(cv, kk, P)[0] for P in pts]
 
 
 @pytest.mark.parametrize("cv,log2n", [(P256, 22), (SECP256K1, 22)])
@@ -982,7 +1015,7 @@ def test_device_group_behind_the_c_abi(engine, oracle, devices):
         spans = [shard_range_c(n, m, G) for m in range(G)]
         cut = lambda t: [t[f:f + c].contiguous() for f, c in spans]
         got, gather_ms = grp.scalar_mult(cv, cut(k), cut(bx), cut(by), n)
-        assert all(torch.equal(a, b) for a, b in zip(got, exp)) and gather_ms >= 0
+        assert all(torch.equal(a, b) for a, b in zip(got, exp)) and (gather_ms >= 0 if G > 1 else gather_ms == -1)     # one member: nothing to gather
         (ax, ay), _ = grp.scalar_mult(cv, cut(k), cut(bx), cut(by), n, flags=OUT_AFFINE | ALG_WINDOWED)
         ex, ey = engine.to_affine(cv, exp)
         assert torch.equal(ax, ex) and torch.equal(ay, ey)
@@ -997,6 +1030,32 @@ def test_device_group_behind_the_c_abi(engine, oracle, devices):
         assert all(np.array_equal(h, engine.to_numpy(e)[:2]) for h, e in zip(small, exp))
         with pytest.raises(EcsimdHipError):
             grp.scalar_mult(cv, cut(k), cut(bx), [None] * G, n)
+        # x coordinate only through the group (oy = NULL with OUT_AFFINE: P-256 runs the ladder without Z on every member)
+        (x1,), _ = grp.scalar_mult(cv, cut(k), cut(bx), cut(by), n, flags=OUT_AFFINE, x_only=True)
+        assert torch.equal(x1, ex)
+        (hx,) = grp.scalar_mult_host(cv, kn, xn, yn, flags=OUT_AFFINE, x_only=True)
+        assert np.array_equal(hx, engine.to_numpy(ex))
+        with pytest.raises(EcsimdHipError):
+            grp.enqueue(cv, cut(k), cut(bx), cut(by), grp.alloc_outputs(n)[:1], n)      # a Jacobian result needs all three arrays
+        # calls may follow one another without a sync: each member's next ladder waits for the exchange that reads its
+        # staging.  Two different batches back to back into two sets of arrays, one sync at the end.
+        k2 = engine.fill_random(n, SEED, 5, first_index=11)
+        exp2 = engine.scalar_mult(cv, k2, bx, by)
+        torch.cuda.synchronize()
+        o1, o2 = grp.alloc_outputs(n), grp.alloc_outputs(n)
+        grp.enqueue(cv, cut(k), cut(bx), cut(by), o1, n)
+        grp.enqueue(cv, cut(k2), cut(bx), cut(by), o2, n)
+        assert grp.sync() >= (0 if G > 1 else -1)
+        assert all(torch.equal(a, b) for a, b in zip(o1, exp)) and all(torch.equal(a, b) for a, b in zip(o2, exp2))
+        # the ladders without the exchange: member 0's slice is in place, the rest of the arrays is left alone
+        o3 = [torch.full_like(t, 7) for t in o1]
+        grp.enqueue(cv, cut(k), cut(bx), cut(by), o3, n, flags=GROUP_NO_GATHER)
+        grp.sync()
+        f0, c0 = spans[0]
+        assert all(torch.equal(a[f0:f0 + c0], b[f0:f0 + c0]) for a, b in zip(o3, exp))
+        assert G == 1 or all(bool((a[f0 + c0:] == 7).all()) for a in o3)
+        assert all(grp.member_ms(m) > 0 for m in range(G)) and grp.rccl_version == 0
+        assert torch.cuda.current_device() == 0
         if G == 1:
             # what one GPU can run of the RCCL side: dlopen, a one-rank communicator, the gather's own send / recv calls
             grp.rccl_selftest(1 << 16)
