@@ -548,6 +548,8 @@ def cpu_baseline_affine(eng, curve, k, gpu_out, target_s, failures, base=None, x
     if by_ossl is not None and by_ossl != len(bad):
         failures.append("cpu_baseline: libcrypto does not confirm the GPU on a lane where it differs from the reference")
     return {"value": m / dt, "unit": "scalar_mults/s", "cores": cores, "kind": kind,
+            "per_core": (m / dt) / cores, "cpu_model": cpu_model(), "flags": build_flags(kind),
+            "one_thread": one_thread_rate(lambda m1: impl.to_affine(curve, impl.scalar_mult(curve, kn[:m1], gx[:m1], gy[:m1], threads=1)), (m / dt) / cores, m),
             "sample": f"first {m} scalars of the GPU batch through scalar_mult(k, {'G' if base is None else 'P'}) + to_affine (the reference's only path to affine k*P), "
                       f"{dt:.1f} s wall, {cores} threads (to_affine single-threaded)",
             "lanes_compared": int(m), "lanes_differing_from_gpu": int(len(bad)),
@@ -602,6 +604,65 @@ def usable_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def build_flags(kind):
+    return "g++ -std=c++20 -O2 -mavx2 -DNDEBUG (oracle/Makefile; the reference's headers, eve 4-lane AVX2 wides)" if kind == "reference" \
+        else "gcc -O2 (oracle/Makefile; scalar C restatement)"
+
+
+def one_thread_rate(run, per_core_guess, limit, seconds=2.2):
+    """"also run 1-thread" -- `run(m)` = the same CPU path over the first m units on ONE thread; sized for
+    >= 2 s from the all-cores figure.  Returns {value, units, seconds}."""
+    m = int(min(limit, max(64, per_core_guess * seconds)))
+    m -= m % 4
+    t = time.perf_counter(); run(m); dt = time.perf_counter() - t
+    if dt < 2.0 and m < limit:                       # the guess was low (turbo on one core): once more, scaled
+        m = int(min(limit, m * 2.3 / max(dt, 1e-3))); m -= m % 4
+        t = time.perf_counter(); run(m); dt = time.perf_counter() - t
+    return {"value": m / dt, "units": m, "seconds": dt, "threads": 1}
+
+
+def config1_ops8(kind):
+    """BASELINE.json configs[0] / SURVEY.md 8(d) "Config 1": benchs/ops.cpp (mgry_sqr_256 :81-90, mgry_reduce_512 :92-100,
+    mul_256 :36-45, the secp256k1 prime of :22-24) on 2 wides = 8 lanes, CPU only, timed inside the checker library
+    (oracle/ref_driver.cpp bench_ops: a noinline call per wide per pass, like the Google Benchmark harness the reference
+    uses and this image lacks), outputs hashed for parity between the compiled reference and the C restatement."""
+    import hashlib
+    import numpy as np
+    from oracle import loader
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import fill_random_np
+    curve = loader.SECP256K1
+    a = fill_random_np(8, SEED, 31, clear_top_bits=1); b = fill_random_np(8, SEED, 32, clear_top_bits=1)
+    a8 = np.concatenate([fill_random_np(8, SEED, 33), fill_random_np(8, SEED, 34, clear_top_bits=2)], axis=1)     # < p * 2^256
+    libs = {"port": loader.Oracle(faithful=True)}
+    if kind == "reference":
+        libs["reference"] = loader.Reference()
+    out = {"what": "benchs/ops.cpp on 2 wides (8 lanes), secp256k1 prime, CPU only; ns per call on one 4-lane wide", "timed": kind, "ops": {}}
+    for op, (name, x, y) in enumerate([("mgry_sqr_256", a, None), ("mgry_reduce_512", a8, None), ("mul_256", a, b)]):
+        hashes, ns = {}, None
+        for lname, lib in libs.items():
+            iters = 2000
+            dt, res = lib.bench_ops(curve, op, x, y, iters)
+            if lname == kind:
+                iters = int(max(iters, min(5e6, 0.3 / max(dt / iters, 1e-9))))        # ~0.3 s
+                dt, res = lib.bench_ops(curve, op, x, y, iters)
+                ns = dt / iters / 2 * 1e9
+            hashes[lname] = hashlib.sha256(res.tobytes()).hexdigest()[:16]
+        out["ops"][name] = {"ns_per_wide": ns, "output_sha256_16": hashes[kind], "equals_the_restatement": len(set(hashes.values())) == 1}
+    return out
+
+
 def cpu_baseline(eng, curve, k, bx, by, gpu_out, target_s, failures, compat=False):
     """ecsimd's own CPU path (or the C port) on the host cores, bounded sample, rank 0 only; the
     sample's CPU result is also compared bit-for-bit with what the GPU produced for those elements."""
@@ -648,7 +709,16 @@ def cpu_baseline(eng, curve, k, bx, by, gpu_out, target_s, failures, compat=Fals
             by_ossl = int(np.count_nonzero(~((to_np(ax) != vx).any(axis=1) | (to_np(ay) != vy).any(axis=1) | (inf != 0))))
             if by_ossl != len(bad):
                 failures.append("cpu_baseline: libcrypto does not confirm the GPU on a lane where it differs from the reference")
+    one = one_thread_rate(lambda m1: impl.scalar_mult(curve, kn[:m1], xn[:m1], yn[:m1], threads=1), (m / dt) / cores, m)
+    c1 = None
+    try:
+        c1 = config1_ops8(kind)
+        if not all(o["equals_the_restatement"] for o in c1["ops"].values()):
+            failures.append("config 1: the compiled reference and the restatement disagree on benchs/ops.cpp's operations")
+    except (OSError, AttributeError) as exc:                # a prebuilt checker without bench_ops: a side figure, not a failure
+        c1 = {"error": repr(exc)[:200]}
     return {"value": m / dt, "unit": "scalar_mults/s", "cores": cores, "kind": kind,
+            "per_core": (m / dt) / cores, "one_thread": one, "cpu_model": cpu_model(), "flags": build_flags(kind), "config1_ops8": c1,
             "sample": f"first {m} (scalar, point) pairs of the GPU batch, {dt:.1f} s wall, {cores} threads, "
                       + ("g++ -O2 -mavx2 build of the reference headers" if kind == "reference" else "gcc -O2 C restatement"),
             "lanes_compared": int(m), "lanes_differing_from_gpu": int(len(bad)),

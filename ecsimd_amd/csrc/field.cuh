@@ -675,10 +675,23 @@ ECS_DEV fe2 sqr8(const fe& a) {
 // The reference's square() AS WRITTEN (mul.h:160-212 square_u32_zext between zext_u32x64 and trunc_u64x32): operand
 // scanning on 32-bit digits held in 64-bit lanes, the cross products doubled one by one.  At mul.h:186-190 the sum
 // 2*a_i*a_j + ret + prevs[0] can exceed 2^64 and the lane wraps (the reference's "TODO: carry?", mul.h:207); the
-// digits are truncated to 32 bits at the end (mul.h:100-107).  uint64_t arithmetic wraps exactly like the AVX2
-// lanes do, so this returns the reference's bits on every input -- including the ones where they are not a^2.
-// Only the ECSIMD_HIP_REF_SQUARE_COMPAT instances use it (curve_prime<C>::ref_square); it is ~3x sqr8's cost.
-ECS_DEV fe2 sqr8_ref(const fe& a) {
+// digits are truncated to 32 bits at the end (mul.h:100-107).  This returns the reference's bits on every input --
+// including the ones where they are not a^2.  Only the ECSIMD_HIP_REF_SQUARE_COMPAT instances use it
+// (curve_prime<C>::ref_square).
+//
+// sqr8_ref_c is the restatement in wrapping uint64_t C (round 2; proven equal to the compiled reference on 200 000
+// carry-heavy operands): ~230 instructions as the compiler lowers it.  sqr8_ref is the same function of a, hand-laid for
+// gfx950 (round 3, ~150 instructions), one "node" (i, j) = one doubled cross product:
+//   * c = bit 63 of a_i*a_j (mul.h:184 `carry`) is the CARRY-OUT of the multiply itself when 2^63 is the accumulator
+//     input -- v_mad_u64_u32 writes it to an SGPR pair as a lane mask -- and the result's flipped bit 63 is the bit the
+//     doubling shifts out anyway;
+//   * u = 2*P + (ret + prevs0) mod 2^64 (mul.h:185-187) is ONE v_lshl_add_u64: a 64-bit add with no carry-out, which is
+//     exactly the reference's dropped carry;
+//   * the next node's addend ret' + prevs1 + (u >> 32) (mul.h:189-192: the digit below is renormalised, prevs shift) is a
+//     two-word carry chain whose carry-IN is the lane mask of the node before.
+// The digit a row leaves unnormalised (mul.h:207 `ret[i+nlimbs] += prevs[0]`) stays a 64-bit value until the next row's
+// last node (or the last diagonal) consumes it, as in the reference.
+ECS_DEV fe2 sqr8_ref_c(const fe& a) {
   uint64_t ret[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) ret[i] = 0;
@@ -706,6 +719,113 @@ ECS_DEV fe2 sqr8_ref(const fe& a) {
   fe2 r;
 #pragma unroll
   for (int i = 0; i < 16; ++i) r.w[i] = (uint32_t)ret[i];
+  return r;
+}
+
+// One node: u = (2*a*b + S) mod 2^64 and c = the lanes where a*b >= 2^63.  The multiply accumulates onto 2^63: its carry-out
+// IS c, and the bit it flips is the one the doubling shifts out.  (One statement: a compiler-scheduled instruction that
+// reads the result of an asm statement is held back by an s_nop -- the gfx950 trans-forwarding hazard it cannot rule out.)
+ECS_DEV uint64_t node_ref(uint32_t a, uint32_t b, uint64_t S, lane_mask& c) {
+  uint64_t u;
+  const uint64_t k63 = 0x8000000000000000ull;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %5\n\t"
+      "v_lshl_add_u64 %0, %0, 1, %4"
+      : "=&v"(u), "=&s"(c) : "v"(a), "v"(b), "v"(S), "s"(k63));
+  return u;
+}
+// x + y + (hi << 32) [+ 1 where cin], hi in {absent = 0}: the next node's 64-bit addend from 32-bit pieces
+ECS_DEV uint64_t sum33(uint32_t x, uint32_t y) {
+  uint32_t lo, hi;
+  asm("v_add_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc" : "=&v"(lo), "=&v"(hi) : "v"(x), "v"(y) : "vcc");
+  return ((uint64_t)hi << 32) | lo;
+}
+ECS_DEV uint64_t sum33c(uint32_t x, uint32_t y, lane_mask cin) {
+  uint32_t lo, hi;
+  asm("v_addc_co_u32 %0, vcc, %2, %3, %4\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc" : "=&v"(lo), "=&v"(hi) : "v"(x), "v"(y), "s"(cin) : "vcc");
+  return ((uint64_t)hi << 32) | lo;
+}
+// the same with a 64-bit x (the unnormalised digit)
+ECS_DEV uint64_t sum33w(uint64_t x, uint32_t y) {
+  uint32_t lo, hi;
+  asm("v_add_co_u32 %0, vcc, %2, %4\n\tv_addc_co_u32 %1, vcc, 0, %3, vcc" : "=&v"(lo), "=&v"(hi) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)), "v"(y) : "vcc");
+  return ((uint64_t)hi << 32) | lo;
+}
+ECS_DEV uint64_t sum33wc(uint64_t x, uint32_t y, lane_mask cin) {
+  uint32_t lo, hi;
+  asm("v_addc_co_u32 %0, vcc, %2, %4, %5\n\tv_addc_co_u32 %1, vcc, 0, %3, vcc" : "=&v"(lo), "=&v"(hi) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)), "v"(y), "s"(cin) : "vcc");
+  return ((uint64_t)hi << 32) | lo;
+}
+// x + [c1] + [c2] as a 64-bit value (x a 32-bit word, c1 and c2 lane masks)
+ECS_DEV uint64_t sum_two_carries(uint32_t x, lane_mask c1, lane_mask c2) {
+  uint32_t lo, hi;
+  lane_mask k;
+  asm("v_addc_co_u32 %0, %2, %3, 0, %4\n\t"          /* x + c1, carry k */
+      "v_addc_co_u32 %0, vcc, %0, 0, %5\n\t"          /* + c2, carry vcc: at most one of the two can carry */
+      "s_or_b64 vcc, vcc, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, 0, vcc"
+      : "=&v"(lo), "=&v"(hi), "=&s"(k) : "v"(x), "s"(c1), "s"(c2) : "vcc", "scc");
+  return ((uint64_t)hi << 32) | lo;
+}
+
+ECS_DEV fe2 sqr8_ref(const fe& a) {
+  uint32_t R[16];                       // normalised digits (mul.h:188 `& low_mask`)
+  uint64_t W = 0;                       // the unnormalised digit at position i + 8 after row i (mul.h:207)
+  lane_mask c9 = 0;                     // ret[i + 9] = prevs[1] after row i (mul.h:208-210): a 0/1 digit, kept as a lane mask
+#pragma unroll
+  for (int i = 0; i < 16; ++i) R[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    // ---- the diagonal square joins digit 2i (mul.h:172-175); prevs[0] = its high half
+    uint64_t S;                          // addend of the next node: ret[i + j] + prevs[0]
+    if (i == 0) {
+      const uint64_t t = mul_wide(a.w[0], a.w[0]);
+      R[0] = (uint32_t)t;
+      S = t >> 32;                       // ret[1] is still zero
+    } else if (i < 7) {
+      const uint64_t t = mul_wide(a.w[i], a.w[i]);      // < 2^64 - 2^33 + 2: adding a 32-bit digit cannot wrap
+      uint32_t lo; lane_mask k;
+      asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(lo), "=s"(k) : "v"((uint32_t)t), "v"(R[2 * i]));
+      R[2 * i] = lo;
+      // prevs[0] = (t + ret[2i]) >> 32 = t.hi + k; the next addend is ret[2i + 1] + prevs[0]
+      if (i == 6) S = sum33wc(W, (uint32_t)(t >> 32), k);          // 2i + 1 = 13 = the unnormalised digit of row 5
+      else S = sum33c(R[2 * i + 1], (uint32_t)(t >> 32), k);
+    } else {
+      // i = 7: digit 14 is row 6's unnormalised one; the 64-bit lane wraps like the reference's (mul.h:173-174)
+      uint64_t t;
+      asm("v_mad_u64_u32 %0, vcc, %1, %1, %2" : "=v"(t) : "v"(a.w[7]), "v"(W) : "vcc");
+      R[14] = (uint32_t)t;
+      uint32_t top;                      // ret[15] = prevs[1] of row 6 + (t >> 32), truncated to 32 bits (mul.h:100-107)
+      asm("v_addc_co_u32 %0, vcc, %1, 0, %2" : "=v"(top) : "v"((uint32_t)(t >> 32)), "s"(c9) : "vcc");
+      R[15] = top;
+      break;
+    }
+    // ---- the doubled cross products of row i (mul.h:180-196)
+    lane_mask cm1 = 0, cm2 = 0;          // carry of node j - 1 and of node j - 2 (prevs[1] and what moved into prevs[0])
+    uint32_t uhi = 0;
+#pragma unroll
+    for (int j = i + 1; j < 8; ++j) {
+      lane_mask c;
+      const uint64_t u = node_ref(a.w[i], a.w[j], S, c);   // the 64-bit add wraps where the reference's lane wraps
+      R[i + j] = (uint32_t)u;
+      uhi = (uint32_t)(u >> 32);
+      cm2 = cm1; cm1 = c;
+      if (j < 7) {
+        // addend of node j + 1: ret[i + j + 1] + (prevs[1] of node j - 1) + (u >> 32)
+        const bool wide = (j + 1 == 7) && (i >= 1);               // position i + 7 holds row i - 1's unnormalised digit
+        if (j == i + 1) S = wide ? sum33w(W, uhi) : sum33(R[i + j + 1], uhi);      // prevs[1] is still zero
+        else S = wide ? sum33wc(W, uhi, cm2) : sum33c(R[i + j + 1], uhi, cm2);
+      }
+    }
+    // ---- row end (mul.h:207-210): ret[i + 8] += prevs[0] = (carry of node 6) + (u_7 >> 32), on top of row i - 1's 0/1 digit;
+    // ret[i + 9] = the carry of node 7
+    if (i == 6) { W = (i >= 1) ? sum_two_carries(uhi, 0, c9) : 0; }   // row 6 has one node: its prevs[1] before it is zero
+    else if (i == 0) { uint32_t lo, hi; asm("v_addc_co_u32 %0, vcc, %2, 0, %3\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc" : "=&v"(lo), "=&v"(hi) : "v"(uhi), "s"(cm2) : "vcc"); W = ((uint64_t)hi << 32) | lo; }
+    else W = sum_two_carries(uhi, cm2, c9);
+    c9 = cm1;
+  }
+  fe2 r;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r.w[i] = R[i];
   return r;
 }
 

@@ -64,6 +64,12 @@ template <int C> ECS_DEV void zaddu(fe& x1, fe& y1, const fe& x2, const fe& y2, 
 // (ym^2 - W12, ym*(W1 - x) - A1) and the same with yp, so swapping the outputs is swapping (ym, yp) -- one
 // field-element swap instead of two.  The ladder folds its per-bit swaps into it; the point kernel passes 0.
 // NOZ: the Z update (1M + 1S + 3 linear operations of the 9M + 7S) is left out -- the x-only ladder below does not need it.
+// ECS_ZDAU_Z_EARLY (round 3): the Z update moves up to where C = u^2 is formed, so dx and C' die before W1, W2 and the 16-word
+// A1 exist.  Same instruction count (3 400 / 3 471 VALU per iteration), shorter live ranges: the P-256 ladder allocates 138
+// VGPRs instead of 147, the secp256k1 one 162 with NO spill instead of 168 with 14 spilled (60 B of scratch per lane).
+#ifndef ECS_ZDAU_Z_EARLY
+#define ECS_ZDAU_Z_EARLY 1
+#endif
 template <int C, bool NOZ = false> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe& y2, fe& z, uint32_t oswap = 0u) {
   const fe dx = fe_sub<C>(x1, x2);
   const fe Cp = fe_sqr<C>(dx);
@@ -75,6 +81,14 @@ template <int C, bool NOZ = false> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe&
   const fe X3pc = fe_sub<C>(fe_sub<C>(Dp, W1p), W2p);
   const fe u = fe_sub<C>(X3pc, W1p);
   const fe Cc = fe_sqr<C>(u);
+#if ECS_ZDAU_Z_EARLY
+  // Z3 = Z * ((dx + X3' - W1')^2 - C' - C): as soon as C exists -- dx and C' die here instead of living across W1, W2 and A1
+  if constexpr (!NOZ) {
+    fe zz = fe_sqr<C>(fe_add<C>(dx, u));
+    zz = fe_sub<C>(fe_sub<C>(zz, Cp), Cc);
+    z = fe_mul<C>(z, zz);
+  }
+#endif
   const fe A1p2 = fe_dbl<C>(A1p);
   // Y3' = (dy + (W1' - X3'))^2 - D' - C - 2A1'
   fe yp = fe_sqr<C>(fe_sub<C>(dy, u));
@@ -91,11 +105,13 @@ template <int C, bool NOZ = false> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe&
   const fe2 A1wide = mul8x8(Y3p, fe_sub<C>(W1, W2));
   const fe W12 = fe_add<C>(W1, W2);
   // Z3 = Z * ((dx + X3' - W1')^2 - C' - C)
+#if !ECS_ZDAU_Z_EARLY
   if constexpr (!NOZ) {
     fe zz = fe_sqr<C>(fe_add<C>(dx, u));
     zz = fe_sub<C>(fe_sub<C>(zz, Cp), Cc);
     z = fe_mul<C>(z, zz);
   }
+#endif
   fe_cswap(oswap, ym, yp);
   const fe D = fe_sqr<C>(ym);
   x1 = fe_sub<C>(D, W12);

@@ -49,7 +49,10 @@ enum ecsimd_hip_status {
   ECSIMD_HIP_ERR_HIP = -3          /* a HIP runtime call failed; see ecsimd_hip_last_error() */
 };
 
-/* scalar_mult flags */
+/* scalar_mult flags.  SECRET SCALARS: only the default algorithm (no ALG_* bit: the reference's co-Z ladder, and its Z-less
+ * form for x-only P-256 output) is constant-time -- one instruction stream, no branch or address that depends on a scalar
+ * bit or an intermediate value, checked on the shipped ISA by tests/test_constant_time_isa.py.  Every ALG_* bit selects a
+ * table-driven algorithm whose memory addresses are scalar digits: for PUBLIC scalars only (each flag says so below). */
 enum {
   ECSIMD_HIP_BASE_CLASSICAL = 0,   /* base point (x, y) classical: from_affine is applied first */
   ECSIMD_HIP_BASE_MGRY = 1,        /* base point already Montgomery form (what scalar_mult_p256 receives) */
@@ -69,19 +72,24 @@ enum {
                                       element, at most 2^22 elements at a time.  Same affine result as
                                       the ladder for every k except the ladder's degenerate scalars k = n-1, 2^256-n-1,
                                       2^256-n (there the reference returns a meaningless point, these paths the right
-                                      one); k = 0 mod n -> (0, 0) */
+                                      one); k = 0 mod n -> (0, 0).  NOT for secret scalars: table reads (LDS for the fixed
+                                      base, device memory for the per-element tables) are indexed by scalar digits */
   ECSIMD_HIP_ALG_WINDOWED_SIGNED = 8, /* as ALG_WINDOWED with signed 7-bit windows: 37 mixed additions instead of 64, a 148 KiB
-                                      table of m*2^(7i)*G (m = 1..64) in LDS, negative digits negate y; same results */
+                                      table of m*2^(7i)*G (m = 1..64) in LDS, negative digits negate y; same results.
+                                      NOT for secret scalars (LDS reads indexed by scalar digits) */
   ECSIMD_HIP_ALG_NO_ENDOMORPHISM = 16, /* secp256k1 + ALG_WINDOWED on a variable base splits k = k1 + k2*lambda (GLV) and runs
-                                      half as many windows; this flag keeps the plain odd-digit loop of 63 windows (same results) */
+                                      half as many windows; this flag keeps the plain odd-digit loop of 63 windows (same results);
+                                      a modifier of ALG_WINDOWED: NOT for secret scalars either way */
   ECSIMD_HIP_REF_SQUARE_COMPAT = 64, /* ladder only: square with the reference's square() AS WRITTEN (mul.h:160-212), which drops a
                                       carry at mul.h:186-190 (its "TODO: carry?", mul.h:207) on ~2e-9 of random operands -- ~3e-6 of
                                       random scalar multiplications then differ from the exact result.  With this flag (or the
-                                      context option below) the output is the reference's bits on EVERY input, at ~0.6x the speed;
-                                      without it, it is the exact k*P (what the reference's own tests assume) */
+                                      context option below) the output is the reference's bits on EVERY input, at ~0.9x the speed;
+                                      without it, it is the exact k*P (what the reference's own tests assume).  Same ladder, same
+                                      constant-time shape: safe for secret scalars */
   ECSIMD_HIP_ALG_WINDOWED_BIG = 32 /* scalar_mult_base + OUT_AFFINE: 20-bit windows with odd digits over a 436 MB table of the odd
                                       multiples (2d+1)*2^(20i)*G (13 windows x 2^19 entries) in device memory, built on first
-                                      use (0.23 s per curve): 12 mixed additions per scalar; same results */
+                                      use (0.23 s per curve): 12 mixed additions per scalar; same results.  NOT for secret scalars:
+                                      each window is a 64-byte read from device memory at an address formed from 20 scalar bits */
 };
 
 /* ---- context, stream and memory ------------------------------------------------------- */
@@ -194,7 +202,7 @@ int ecsimd_hip_gfp_sqrt(ecsimd_hip_ctx*, int curve, const uint64_t* a, uint64_t*
 
 /* ---- L4/L5: points and the group ------------------------------------------------------ */
 /* jacobian_curve_point.h:25-31 from_affine (Z := R mod p), :33-42 to_affine.  to_affine uses Montgomery's
- * simultaneous inversion (one inversion per ~32 elements; identical values) unless x/y alias the inputs.
+ * simultaneous inversion (one shared inversion per up to 128 elements (k_affine.inc BATCH_INVERSION_MAX); identical values) unless x/y alias the inputs.
  * to_affine: y may be NULL (the x coordinate only: 5 field multiplications per element instead of 7). */
 int ecsimd_hip_from_affine(ecsimd_hip_ctx*, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n);
 int ecsimd_hip_to_affine(ecsimd_hip_ctx*, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n);
@@ -229,7 +237,7 @@ int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx*, int curve, const uint64_t k1[4], 
 /* curve_group.h:35-41 WJG + scalar_mult: k[i] * G (base = the curve generator). */
 int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx*, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
 /* Extensions built on the kernels above (not in the reference):
- * affine_add: R = A + B for affine classical points, one inversion per ~32 points.  (0, 0) encodes the point
+ * affine_add: R = A + B for affine classical points, one shared inversion per up to 128 points (Montgomery's trick).  (0, 0) encodes the point
  * at infinity on input and output; finite[i] = 0 marks an infinite result (finite and ry may be NULL; rx must
  * not alias an input). */
 int ecsimd_hip_affine_add(ecsimd_hip_ctx*, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by,

@@ -624,4 +624,22 @@ EXPORT unsigned long long oracle_dropped_carries(void) { return __atomic_load_n(
 EXPORT void oracle_reset_dropped_carries(void) { __atomic_store_n(&g_dropped_carries, 0ull, __ATOMIC_RELAXED); }
 
 /* Wall-clock seconds (CLOCK_MONOTONIC) for bench.py's cpu_baseline leg. */
+/* BASELINE.json configs[0] = benchs/ops.cpp (mgry_sqr_256 :81-90, mgry_reduce_512 :92-100, mul_256 :36-45) as a timed loop over
+ * the same n = 8 elements, `iters` passes; the twin of ref_bench_ops in ref_driver.cpp, so that bench.py can compare the
+ * two libraries' outputs (a hash of `out`) and report the port's time where the reference build is absent. */
+EXPORT double oracle_bench_ops(int curve, int op, cu64p a, cu64p b, uint64_t *out, size_t n, size_t iters) {
+  const oracle_curve *c = curve_of(curve); if (!c || op < 0 || op > 2) return -1.0;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (size_t it = 0; it < iters; ++it) {
+    for (size_t i = 0; i < n; ++i) {
+      if (op == 0) { bn512 t; bn_square(&t, CBN(a, i)); mgry_reduce(BN(out, i), &t, c); }      /* mgry_ops.h:37-42 */
+      else if (op == 1) mgry_reduce(BN(out, i), (const bn512 *)(a + 8 * i), c);
+      else bn_mul((bn512 *)(out + 8 * i), CBN(a, i), CBN(b, i));
+    }
+    __asm__ volatile("" : : "g"(out) : "memory");
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
 EXPORT double oracle_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }

@@ -232,6 +232,18 @@ class _Lib:
         return tuple(r)
 
 
+    def bench_ops(self, curve, op, a, b, iters):
+        """BASELINE configs[0] (benchs/ops.cpp) as a timed loop inside the library: op 0 mgry_sqr_256, 1 mgry_reduce_512
+        (a = 512-bit values), 2 mul_256.  Returns (seconds for `iters` passes over the len(a) elements, last results)."""
+        a = _arr(a, 8 if op == 1 else 4)
+        b = _arr(b) if b is not None else a
+        out = np.zeros((len(a), 8 if op == 2 else 4), dtype=np.uint64)
+        f = self._f("bench_ops"); f.restype = C.c_double
+        dt = f(C.c_int(curve), C.c_int(op), _p(a), _p(b), _p(out), C.c_size_t(len(a)), C.c_size_t(iters))
+        assert dt >= 0, dt
+        return float(dt), out
+
+
 class Oracle(_Lib):
     """The C restatement.  ``faithful=False`` (default): exact squaring, the arithmetic the reference
     specifies -- what the HIP path is checked against.  ``faithful=True``: bug-for-bug restatement of

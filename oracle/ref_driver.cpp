@@ -201,6 +201,53 @@ template <class Curve> struct ops {
 using P256 = ops<curve_nist_p256>;
 using K256 = ops<curve_secp256k1>;
 
+// BASELINE.json configs[0]: benchs/ops.cpp restated as a timed loop (its harness, Google Benchmark, is not installed and
+// cannot be fetched: SURVEY.md 8(c)).  Like the benchmark, the operands are built before the timed region and every pass
+// calls the function through a noinline lambda on the same wide; the result is kept from being optimised away the way
+// benchmark::DoNotOptimize does (an empty asm that takes its address).  n = 8 elements = 2 wides = "batch = 8".
+//   op 0  mgry_sqr_256     benchs/ops.cpp:81-90      op 1  mgry_reduce_512  benchs/ops.cpp:92-100
+//   op 2  mul_256          benchs/ops.cpp:36-45 (registered at :108)
+// Returns the seconds the `iters` passes over all wides took; `out` gets the last pass's results (4 limbs per element
+// for ops 0 and 1, 8 for op 2) so that a checker can hash them.
+template <class T> inline void keep(T const& v) { asm volatile("" : : "g"(&v) : "memory"); }
+template <class Curve> double bench_ops(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t iters) {
+  using O = ops<Curve>;
+  using Pm = typename O::P;
+  using WMBN = typename O::WMBN;
+  const size_t nw = nwides(n);
+  if (op == 0) {
+    std::vector<WMBN> in; for (size_t w = 0; w < nw; ++w) in.emplace_back(load_wide<BN>(a, w, n));
+    std::vector<WMBN> res(in);
+    auto func = [](auto const& v) __attribute__((noinline)) { return mgry_sqr(v); };
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t it = 0; it < iters; ++it) for (size_t w = 0; w < nw; ++w) { res[w] = func(in[w]); keep(res[w]); }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t w = 0; w < nw; ++w) store_wide(out, w, n, res[w].wbn());
+    return dt;
+  }
+  if (op == 1) {
+    std::vector<WBN512> in; for (size_t w = 0; w < nw; ++w) in.push_back(load_wide<BN512>(a, w, n));
+    std::vector<WBN> res(nw);
+    auto func = [](auto const& v) __attribute__((noinline)) { return details::mgry_reduce<Pm>(v); };
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t it = 0; it < iters; ++it) for (size_t w = 0; w < nw; ++w) { res[w] = func(in[w]); keep(res[w]); }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t w = 0; w < nw; ++w) store_wide(out, w, n, res[w]);
+    return dt;
+  }
+  if (op == 2) {
+    std::vector<WBN> ia, ib; for (size_t w = 0; w < nw; ++w) { ia.push_back(load_wide<BN>(a, w, n)); ib.push_back(load_wide<BN>(b, w, n)); }
+    std::vector<WBN512> res(nw);
+    auto func = [](auto const& x, auto const& y) __attribute__((noinline)) { return mul(x, y); };
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t it = 0; it < iters; ++it) for (size_t w = 0; w < nw; ++w) { res[w] = func(ia[w], ib[w]); keep(res[w]); }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t w = 0; w < nw; ++w) store_wide(out, w, n, res[w]);
+    return dt;
+  }
+  return -1.0;
+}
+
 } // namespace
 
 #define DISPATCH(fn, ...) (curve == 0 ? P256::fn(__VA_ARGS__) : curve == 1 ? K256::fn(__VA_ARGS__) : -1)
@@ -248,5 +295,7 @@ EXPORT int ref_compute_y(int curve, cu64p x, uint64_t* y, uint8_t* ok, size_t n)
 EXPORT int ref_scalar_mult(int curve, cu64p k, cu64p x, cu64p y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int threads) { return DISPATCH(scalar_mult_, k, x, y, ox, oy, oz, n, threads, false); }
 EXPORT int ref_scalar_mult_mgry(int curve, cu64p k, cu64p xm, cu64p ym, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int threads) { return DISPATCH(scalar_mult_, k, xm, ym, ox, oy, oz, n, threads, true); }
 EXPORT int ref_scalar_mult_1s(int curve, cu64p k1, cu64p x, cu64p y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { return DISPATCH(scalar_mult_1s_, k1, x, y, ox, oy, oz, n); }
+EXPORT double ref_bench_ops(int curve, int op, cu64p a, cu64p b, uint64_t* out, size_t n, size_t iters) {
+  return curve == 0 ? bench_ops<curve_nist_p256>(op, a, b, out, n, iters) : curve == 1 ? bench_ops<curve_secp256k1>(op, a, b, out, n, iters) : -1.0; }
 EXPORT double ref_now(void) { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }

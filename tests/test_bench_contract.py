@@ -168,3 +168,21 @@ def test_under_torchrun_bench_does_not_launch_again():
     env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--multi", "group"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode != 0 and "one process driving every GPU" in r.stderr
+
+
+def test_config1_ops8_times_the_reference_and_hashes_its_outputs():
+    """BASELINE.json configs[0] (benchs/ops.cpp, batch 8, CPU only): the timed loops run inside the checker libraries; the
+    compiled reference's outputs hash equal to the restatement's for mgry_sqr_256 / mgry_reduce_512 / mul_256."""
+    import importlib.util
+    from oracle import loader
+    spec = importlib.util.spec_from_file_location("bench_for_test3", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    kind = "reference" if loader.reference_available() else "port"
+    c1 = bench.config1_ops8(kind)
+    assert set(c1["ops"]) == {"mgry_sqr_256", "mgry_reduce_512", "mul_256"} and c1["timed"] == kind
+    for name, o in c1["ops"].items():
+        assert o["equals_the_restatement"] is True and 1.0 < o["ns_per_wide"] < 1e6, (name, o)
+    # the restatement's own results for these inputs, pinned (any change of the oracle's arithmetic shows here)
+    assert c1["ops"]["mgry_sqr_256"]["output_sha256_16"] == "92f54302a1cbfc86"
+    assert c1["ops"]["mgry_reduce_512"]["output_sha256_16"] == "6dc7617274355fcf"
+    assert c1["ops"]["mul_256"]["output_sha256_16"] == "7e57ffaf6954b9b0"

@@ -1,0 +1,88 @@
+"""CPU suite: the constant-time claim of INTEGRATION.md ("timing") is checked on the ISA the build ships.
+
+The ladder translation units are compiled to gfx950 assembly with the Makefile's own flags and tools/ct_check.py walks the
+254-iteration bit loop of k_scalar_mult (both curves) and k_scalar_mult_x: every branch must hang on a scalar compare of the
+iteration counter, no lane mask or VALU result may reach SCC / a branch / an address, the one global load (the scalar-word
+reload kwords[nb >> 5], point.cuh ladder_core) must be addressed by loop-invariant registers and the counter, and nothing may
+move a field word to the scalar unit.  The same checker must REFUSE the build variant DESIGN.md section 3 rejected for this
+very reason (-DECS_COND_SUB=2: a wave-uniform branch on r[7] == 0xffffffff)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ecsimd_amd", "csrc")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ct_check  # noqa: E402
+
+
+def shipped_flags():
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    flags = re.search(r"^HIPFLAGS\s*\?=\s*(.*)$", mk, re.M).group(1)
+    arch = re.search(r"^ARCH\s*\?=\s*(\S+)", mk, re.M).group(1)
+    return flags.replace("$(ARCH)", arch).split()
+
+
+def assembly(tmp_path_factory, unit, extra=()):
+    out = tmp_path_factory.mktemp("isa") / (unit + "".join(extra).replace("=", "_").replace("-", "") + ".s")
+    cmd = ["hipcc"] + [f for f in shipped_flags() if f != "-fPIC"] + list(extra) + ["-S", "--cuda-device-only", os.path.join(CSRC, unit + ".hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, cwd=CSRC, timeout=900)
+    return out.read_text()
+
+
+@pytest.fixture(scope="module")
+def p256_asm(tmp_path_factory):
+    return assembly(tmp_path_factory, "k_ladder_p256")
+
+
+@pytest.fixture(scope="module")
+def secp256k1_asm(tmp_path_factory):
+    return assembly(tmp_path_factory, "k_ladder_secp256k1")
+
+
+def test_the_shipped_build_uses_the_branch_free_conditional_subtraction():
+    src = open(os.path.join(CSRC, "field.cuh")).read()
+    assert re.search(r"#ifndef ECS_COND_SUB\s*\n#define ECS_COND_SUB 1\s*\n#endif", src)
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    assert "ECS_COND_SUB" not in mk and "ECS_COND_SUB" not in open(os.path.join(ROOT, "__graft_entry__.py")).read()
+
+
+@pytest.mark.parametrize("kernel", ["13k_scalar_multE", "15k_scalar_mult_xE"])
+def test_p256_bit_loop_is_constant_time(p256_asm, kernel):
+    rep = ct_check.check(p256_asm, kernel)
+    assert rep["instructions"] > 2500                               # it IS the ZDAU loop, not some small one
+    # the loop's branches: the exit test on the bit counter and the two tests that gate the scalar-word reload -- nothing else
+    assert len(rep["branches"]) == 3 and all(re.match(r"s_cmpk?_(lg|eq)_[iu]32 s\d+, (0x101|0x100|0) ; s_cbranch_scc[01] ", b) for b in rep["branches"]), rep["branches"]
+    assert len(rep["global_loads"]) == 1 and rep["global_loads"][0].startswith("global_load_dword ") and rep["scratch"] == 0
+
+
+def test_secp256k1_bit_loop_is_constant_time(secp256k1_asm):
+    rep = ct_check.check(secp256k1_asm, "13k_scalar_multE")
+    assert rep["instructions"] > 2500 and len(rep["branches"]) == 3 and len(rep["global_loads"]) == 1
+    # register spills, if the allocation has any, are constant-address scratch accesses (checked inside ct_check)
+
+
+def test_the_checker_refuses_the_data_dependent_variant(tmp_path_factory):
+    """-DECS_COND_SUB=2 (field.cuh cond_sub_p_guard) branches on `r[7] == 0xffffffff`: the checker has to see it."""
+    bad = assembly(tmp_path_factory, "k_ladder_p256", extra=("-DECS_COND_SUB=2",))
+    with pytest.raises(ct_check.Violation):
+        ct_check.check(bad, "13k_scalar_multE")
+
+
+def test_the_checker_refuses_planted_leaks(p256_asm):
+    """Mutation checks on the real assembly: a lane-mask branch, a field word moved to the scalar unit, and a reload whose
+    address was touched by a data register must each be caught."""
+    lines = p256_asm.splitlines()
+    at = next(i for i, ln in enumerate(lines) if "s_cmpk_lg_i32" in ln and "0x101" in ln)
+    for planted in ("\ts_cbranch_vccnz .LBB0_7", "\tv_readfirstlane_b32 s40, v20", "\tv_cmp_eq_u32_e64 s[40:41], v20, v21\n\ts_cmp_lg_u64 s[40:41], 0\n\ts_cbranch_scc1 .LBB0_7"):
+        mutated = "\n".join(lines[:at] + planted.split("\n") + lines[at:])
+        with pytest.raises(ct_check.Violation):
+            ct_check.check(mutated, "13k_scalar_multE")
+    ld = next(i for i, ln in enumerate(lines) if ln.strip().startswith("global_load_dword") and "in Loop" not in ln and i > at)
+    addr = re.search(r"global_load_dword v\d+, v\[(\d+):\d+\]", lines[ld]).group(1)
+    mutated = "\n".join(lines[:ld] + [f"\tv_add_u32_e32 v{addr}, v{addr}, v20"] + lines[ld:])
+    with pytest.raises(ct_check.Violation):
+        ct_check.check(mutated, "13k_scalar_multE")

@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Constant-time guard on the SHIPPED ISA: reads `hipcc -S --cuda-device-only` output of a ladder translation unit and checks
+the bit loop of a kernel (the 254 ZDAU iterations of curve_group.h:196-211) for anything whose timing could depend on the
+scalar:
+
+  * every branch in the loop is an s_cbranch_scc* whose SCC comes from a scalar compare of CLEAN scalars -- registers that
+    inside the loop are only ever written by scalar instructions reading clean scalars or immediates (the iteration counter);
+    a lane mask a VALU instruction wrote to SGPRs (carry-outs, v_cmp) is dirty, and so is VCC / EXEC: s_cbranch_vcc* /
+    s_cbranch_exec* are refused outright;
+  * no v_readfirstlane / v_readlane / v_permlane / ds_* / buffer_* / flat_* / stores to global memory / atomics;
+  * the only global load is the scalar-word reload kwords[nb >> 5] (point.cuh ladder_core): its address registers are,
+    walking back through the basic block, made of loop-invariant registers and clean scalars only;
+  * scratch (spill) accesses use the constant `off` addressing form.
+
+Usage: ct_check.py file.s kernel-substring        (prints a report; exit 1 on a violation)
+"""
+import re
+import sys
+
+SCC_WRITERS = re.compile(r"^s_(cmp|cmpk|bitcmp|add|sub|addc|subb|and|or|xor|andn2|orn2|nand|nor|xnor|lshl|lshr|ashr|bfe|bfm|mul_i32|min|max|abs|not|wqm|brev|"
+                         r"and_saveexec|or_saveexec|xor_saveexec|andn2_saveexec|orn2_saveexec|cselect|absdiff|ff|flbit|bcnt|quadmask|sext)")
+SCC_COMPARES = re.compile(r"^s_(cmp|cmpk|bitcmp)")
+
+
+class Violation(AssertionError):
+    pass
+
+
+def regs_of(tok):
+    """Scalar / vector registers named by one operand token: ('s', n) / ('v', n) tuples; 'vcc', 'exec', 'scc', 'm0' as names."""
+    tok = tok.strip()
+    out = []
+    m = re.fullmatch(r"([sv])\[(\d+):(\d+)\]", tok)
+    if m:
+        return [(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)]
+    m = re.fullmatch(r"([sv])(\d+)", tok)
+    if m:
+        return [(m.group(1), int(m.group(2)))]
+    for name in ("vcc", "exec", "scc", "m0"):
+        if tok.startswith(name):
+            out.append(name)
+    return out
+
+
+def parse_function(text, want):
+    """[(block_label, in_loop_header_or_None, [instructions])] of the first function whose name contains `want`."""
+    lines = text.splitlines()
+    start = None
+    for i, ln in enumerate(lines):
+        m = re.match(r"^([A-Za-z_][\w.$]*):", ln)
+        if m and not ln.startswith(".L") and want in m.group(1):
+            start = i
+            break
+    if start is None:
+        raise Violation(f"no function matching {want!r}")
+    blocks = [["entry", None, []]]
+    for ln in lines[start + 1:]:
+        if ln.startswith(".Lfunc_end"):
+            break
+        t = ln.strip()
+        m = re.match(r"^(?:(\.LBB\w+):|; %bb\.(\d+):)\s*(;.*)?$", t)
+        if m:
+            comment = m.group(3) or ""
+            hdr = None
+            mh = re.search(r"in Loop: Header=(BB\w+)", comment)
+            if mh:
+                hdr = mh.group(1)
+            elif "Loop Header" in comment and m.group(1):
+                hdr = m.group(1)[2:]               # the header belongs to its own loop
+            blocks.append([m.group(1) or f"bb.{m.group(2)}", hdr, []])
+            continue
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        blocks[-1][2].append(t.split(";")[0].strip())
+    return blocks
+
+
+def split_ops(inst):
+    parts = inst.split(None, 1)
+    if len(parts) == 1:
+        return parts[0], []
+    return parts[0], [o.strip() for o in parts[1].split(",")]
+
+
+def dest_count(op):
+    """How many leading operands an instruction writes."""
+    if op.startswith("v_cmp") and not op.startswith("v_cmpx"):
+        return 1
+    if op.startswith(("v_mad_u64_u32", "v_mad_i64_i32", "v_add_co", "v_addc_co", "v_sub_co", "v_subb_co", "v_subrev_co", "v_subbrev_co", "v_div_scale")):
+        return 2
+    if op.startswith(("s_cmp", "s_cmpk", "s_bitcmp", "s_cbranch", "s_branch", "s_waitcnt", "s_nop", "s_setprio", "s_sleep", "s_barrier", "s_endpgm")):
+        return 0
+    if op.startswith(("global_store", "scratch_store", "flat_store", "buffer_store", "ds_write")):
+        return 0
+    return 1
+
+
+def check(text, want, allow_global_loads=1):
+    blocks = parse_function(text, want)
+    # the bit loop = the loop with the most instructions
+    sizes = {}
+    for _, hdr, insts in blocks:
+        if hdr:
+            sizes[hdr] = sizes.get(hdr, 0) + len(insts)
+    if not sizes:
+        raise Violation("no loop found")
+    header = max(sizes, key=sizes.get)
+    loop = [(lab, insts) for lab, hdr, insts in blocks if hdr == header]
+    flat = [i for _, insts in loop for i in insts]
+    report = {"kernel": want, "loop_header": header, "instructions": len(flat), "branches": [], "global_loads": [], "scratch": 0}
+
+    # ---- clean scalars: fixpoint over the whole loop (flow-insensitive part)
+    written_by_valu, scalar_writes = set(), {}
+    written_v = set()
+    for inst in flat:
+        op, ops = split_ops(inst)
+        nd = dest_count(op)
+        dests = [r for o in ops[:nd] for r in regs_of(o)]
+        srcs = [r for o in ops[nd:] for r in regs_of(o)]
+        if op.startswith("v_") or op.startswith(("global_load", "scratch_load", "ds_read", "buffer_load", "flat_load")):
+            for r in dests:
+                if isinstance(r, tuple) and r[0] == "s" or r in ("vcc", "exec"):
+                    written_by_valu.add(r)
+                if isinstance(r, tuple) and r[0] == "v":
+                    written_v.add(r)
+        elif op.startswith("s_"):
+            for r in dests:
+                scalar_writes.setdefault(r, []).append(srcs)
+            if "saveexec" in op:
+                scalar_writes.setdefault("exec", []).append(srcs + dests)
+    # asm blocks may write exec / vcc by s_ instructions reading dirty masks: handled by the same table
+    dirty = set(written_by_valu) | {"vcc", "exec"}
+    changed = True
+    while changed:
+        changed = False
+        for r, lists in scalar_writes.items():
+            if r in dirty:
+                continue
+            if any(any(s in dirty for s in srcs) for srcs in lists):
+                dirty.add(r); changed = True
+
+    def clean_scalar_at(block_insts, idx, reg, depth=0):
+        """Is scalar `reg`, read by instruction idx of this block, made of clean values?  Walk back to its definition in the
+        block; without one, it must be clean over the whole loop."""
+        for k in range(idx - 1, -1, -1):
+            op, ops = split_ops(block_insts[k])
+            nd = dest_count(op)
+            if reg in [r for o in ops[:nd] for r in regs_of(o)]:
+                if not op.startswith("s_"):
+                    return False
+                return all(clean_scalar_at(block_insts, k, s, depth + 1) for o in ops[nd:] for s in regs_of(o) if s != "scc")
+        return reg not in dirty and reg not in ("vcc", "exec")
+
+    def scratch_slot(inst):
+        """(first byte, last byte + 1) of a constant-addressed scratch access."""
+        op, ops = split_ops(inst)
+        m = re.search(r"offset:(\d+)", inst)
+        first = int(m.group(1)) if m else 0
+        mw = re.search(r"dwordx(\d)", op)
+        return first, first + 4 * (int(mw.group(1)) if mw else 1)
+    stored_in_loop = [scratch_slot(i) for i in flat if i.startswith("scratch_store")]
+
+    def clean_vector_at(block_insts, idx, reg):
+        for k in range(idx - 1, -1, -1):
+            op, ops = split_ops(block_insts[k])
+            nd = dest_count(op)
+            if reg in [r for o in ops[:nd] for r in regs_of(o)]:
+                if op.startswith("scratch_load"):
+                    # a reload of a spill slot nothing in the loop stores to: a loop-invariant value (the spilled scalar pointer)
+                    a, b = scratch_slot(block_insts[k])
+                    return all(o.split()[0] == "off" for o in ops[1:]) and not any(a < d and c < b for c, d in stored_in_loop)
+                if not op.startswith(("v_lshl_add_u64", "v_add_co_u32", "v_addc_co_u32", "v_add_u32", "v_mov_b32", "v_lshlrev_b32", "v_lshl_add_u32", "v_add_lshl_u32", "v_or_b32")):
+                    return False
+                for o in ops[nd:]:
+                    for s in regs_of(o):
+                        if isinstance(s, tuple) and s[0] == "v":
+                            if not clean_vector_at(block_insts, k, s):
+                                return False
+                        elif s != "scc" and not clean_scalar_at(block_insts, k, s):
+                            return False
+                return True
+        return reg not in written_v           # loop-invariant
+
+    for lab, insts in loop:
+        for idx, inst in enumerate(insts):
+            op, ops = split_ops(inst)
+            if re.match(r"^(v_readfirstlane|v_readlane|v_writelane|v_permlane|ds_|buffer_|flat_|global_store|global_atomic|s_setpc|s_swappc|s_call|s_cbranch_vcc|s_cbranch_exec|s_cbranch_cd|s_cbranch_g_fork|s_cbranch_i_fork|s_cbranch_join)", op):
+                raise Violation(f"{lab}: `{inst}` is not allowed in the bit loop")
+            if op.startswith("s_cbranch_scc"):
+                k = idx - 1
+                while k >= 0 and not SCC_WRITERS.match(split_ops(insts[k])[0]):
+                    k -= 1
+                if k < 0:
+                    raise Violation(f"{lab}: `{inst}` has no SCC definition in its block")
+                cop, cops = split_ops(insts[k])
+                if not SCC_COMPARES.match(cop):
+                    raise Violation(f"{lab}: `{inst}` takes SCC from `{insts[k]}`, not from a scalar compare")
+                for o in cops:
+                    for r in regs_of(o):
+                        if not clean_scalar_at(insts, k, r):
+                            raise Violation(f"{lab}: `{inst}` depends on `{insts[k]}` whose operand {o} is not a clean scalar")
+                report["branches"].append(f"{insts[k]} ; {inst}")
+            if op.startswith("global_load"):
+                # global_load_dword vdst, v[addr], off|s[base] [offset:n]
+                addr = ops[1]
+                for r in regs_of(addr):
+                    if not clean_vector_at(insts, idx, r):
+                        raise Violation(f"{lab}: the address {addr} of `{inst}` is not made of loop-invariant registers and the iteration counter")
+                base = ops[2].split()[0]
+                if base != "off":
+                    for r in regs_of(base):
+                        if not clean_scalar_at(insts, idx, r):
+                            raise Violation(f"{lab}: the scalar base of `{inst}` is not clean")
+                report["global_loads"].append(inst)
+            if op.startswith("scratch_"):
+                addr_ops = ops[1:] if op.startswith("scratch_load") else [ops[0]] + ops[2:]
+                if not all(o.split()[0] == "off" for o in addr_ops):
+                    raise Violation(f"{lab}: `{inst}` does not use constant `off` addressing")
+                report["scratch"] += 1
+    if len(report["global_loads"]) > allow_global_loads:
+        raise Violation(f"{len(report['global_loads'])} global loads in the bit loop, expected at most {allow_global_loads}: {report['global_loads']}")
+    return report
+
+
+if __name__ == "__main__":
+    try:
+        rep = check(open(sys.argv[1]).read(), sys.argv[2] if len(sys.argv) > 2 else "k_scalar_mult")
+    except Violation as exc:
+        print("VIOLATION:", exc)
+        sys.exit(1)
+    for key, val in rep.items():
+        print(f"{key}: {val}")
