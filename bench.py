@@ -53,6 +53,7 @@ sys.path.insert(0, ROOT)
 
 MAD32_PER_SCALAR_MULT = 555968          # 4088 field mults x 136 mad32
 ALGO_BYTES_PER_SCALAR_MULT = 192        # 32 B scalar + 64 B point in, 96 B Jacobian out
+A_PRIORI_PEAK_TMAD32 = 256 * 4 * 16 * 2.4e9 / 1e12    # 39.32: one full-rate wave64 VALU instruction per 4 cycles per SIMD at the 2.4 GHz maximum clock
 SEED = 0x5EEDEC51D0000001
 EXIT_PARITY = 3                         # a checker contradicts the GPU result
 
@@ -153,9 +154,14 @@ def main():
     # rehearsal of the N > 1 code: RCCL init, side stream, dist.gather, barrier).
     force_dist = os.environ.get("ECSIMD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
     distributed = world > 1 or force_dist
+    host_group = None
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world > 1 and not args.no_group_check:
+            # while rank 0's child process drives all N GPUs through the C ABI's device group (group_leg), the other ranks must
+            # wait on the HOST: an RCCL barrier would keep a spinning kernel on every GPU the child is measuring
+            host_group = dist.new_group(backend="gloo")
 
     curve = CURVES[args.curve]
     import ecsimd_amd
@@ -203,6 +209,11 @@ def main():
         eng.scalar_mult_base(curve, k[:1024].contiguous(), flags=OUT_AFFINE | alg)   # builds the table and the workspace
         compute([eng.empty(rows) for _ in range(3)])
 
+    # ECSIMD_BENCH_STEP_MARKER=1 (tools/profile_traffic.sh): a one-element fill_random launch in front of every timed step, so
+    # that a per-dispatch counter listing can be cut into steps (tools/summarize_traffic.py).  Off in every measured run.
+    mark_buf = eng.empty(1) if os.environ.get("ECSIMD_BENCH_STEP_MARKER") == "1" else None
+    marker = (lambda: eng.fill_random(1, SEED, 99, out=mark_buf)) if mark_buf is not None else (lambda: None)
+
     def timed(steps, record_events):
         """`steps` steps between two fences; wall time = max over ranks."""
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if record_events else None
@@ -210,7 +221,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(steps):
             if evs:
-                runner.step(compute, before=evs[i][0].record, after=evs[i][1].record)
+                runner.step(compute, before=(lambda i=i: (marker(), evs[i][0].record())), after=evs[i][1].record)
             else:
                 runner.step(compute)
         runner.fence()
@@ -255,6 +266,8 @@ def main():
             result["parity_failures"] = failures
         print(json.dumps(result), flush=True)
     if distributed:
+        if host_group is not None:
+            dist.barrier(group=host_group)
         dist.barrier()
         dist.destroy_process_group()
     return EXIT_PARITY if failures else 0
@@ -328,6 +341,9 @@ def roofline_object(args, eng, n, avg_ms):
         "hbm": {"achieved": n / (avg_ms * 1e-3) * bytes_unit / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "algorithmic_bytes_per_unit": bytes_unit},
         "peak_source": "ecsimd_hip_peak_mad32: dependency-free v_mad_u64_u32 stream, 8 waves/SIMD, same GPU, same run",
+        # MI355X_MICROARCH.md lists no integer-multiply peak; from its chip parameters a full-rate wave64 VALU instruction
+        # peaks at 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
+        "peak_a_priori": A_PRIORI_PEAK_TMAD32, "frac_of_a_priori_peak": achieved / A_PRIORI_PEAK_TMAD32,
     }
 
 
@@ -478,13 +494,14 @@ def committed_traffic(args, n):
         table = json.load(open(tpath))
     except ValueError:
         return None, None
-    key = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult", "ladder-x": "k_scalar_mult_x", "windowed": "varwin", "fixed-base-big": "fixed_base_big"}.get(args.workload, "fixed_base")
+    key = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult_refsqr", "ladder-x": "k_scalar_mult_x", "windowed": "varwin",
+           "fixed-base": "fixed_base", "fixed-base-signed": "fixed_base_signed", "fixed-base-big": "fixed_base_big"}[args.workload]
     for log2 in (24, 22):                                 # a pass at this run's own launch size first
         per = table.get(f"{key}_{args.curve}_2^{log2}")
         if per is not None:
             exact = n == (1 << log2)
-            return per * n / float(1 << log2), (f"profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at 2^{log2} lanes per launch"
-                                                 + ("" if exact else ", scaled by lanes") + "; not measured in this run")
+            return per * n / float(1 << log2), (f"profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at 2^{log2} lanes per launch, every kernel of one step "
+                                                 "(FETCH_SIZE x 2: profiles/r03/hbm_counter_calibration.json)" + ("" if exact else ", scaled by lanes") + "; not measured in this run")
     return None, None
 
 

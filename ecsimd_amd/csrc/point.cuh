@@ -64,12 +64,17 @@ template <int C> ECS_DEV void zaddu(fe& x1, fe& y1, const fe& x2, const fe& y2, 
 // (ym^2 - W12, ym*(W1 - x) - A1) and the same with yp, so swapping the outputs is swapping (ym, yp) -- one
 // field-element swap instead of two.  The ladder folds its per-bit swaps into it; the point kernel passes 0.
 // NOZ: the Z update (1M + 1S + 3 linear operations of the 9M + 7S) is left out -- the x-only ladder below does not need it.
-// ECS_ZDAU_Z_EARLY (round 3): the Z update moves up to where C = u^2 is formed, so dx and C' die before W1, W2 and the 16-word
-// A1 exist.  Same instruction count (3 400 / 3 471 VALU per iteration), shorter live ranges: the P-256 ladder allocates 138
-// VGPRs instead of 147, the secp256k1 one 162 with NO spill instead of 168 with 14 spilled (60 B of scratch per lane).
+// Where ZDAU updates Z (round 3).  "Early" = as soon as C = u^2 exists, so that dx and C' die before W1, W2 and the 16-word A1:
+// same instruction count (3 400 / 3 471 VALU per iteration), shorter live ranges -- the P-256 ladder allocates 138 VGPRs instead
+// of 147, the secp256k1 one 162 with NO spill instead of 168 with 14 spilled (60 B of scratch per lane, all but the scalar
+// pointer's reload outside the bit loop).  Measured on one box, 2^24 lanes (profiles/r03/ab_zdau_z_placement_*.txt): P-256 48.29
+// (early) against 48.45 M/s (late); secp256k1 48.33 against 48.41 -- registers are not what limits the ladder (the VALU is
+// saturated at 3 waves per SIMD either way), so P-256 keeps the late placement and secp256k1 takes the spill-free one.
+// -DECS_ZDAU_Z_EARLY=0 / 1 forces one placement for both curves (the A/B builds).
 #ifndef ECS_ZDAU_Z_EARLY
-#define ECS_ZDAU_Z_EARLY 1
+#define ECS_ZDAU_Z_EARLY (-1)
 #endif
+template <int C> struct zdau_z_early { static constexpr bool value = (ECS_ZDAU_Z_EARLY < 0) ? !curve_prime<C>::is_p256 : (ECS_ZDAU_Z_EARLY != 0); };
 template <int C, bool NOZ = false> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe& y2, fe& z, uint32_t oswap = 0u) {
   const fe dx = fe_sub<C>(x1, x2);
   const fe Cp = fe_sqr<C>(dx);
@@ -81,14 +86,12 @@ template <int C, bool NOZ = false> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe&
   const fe X3pc = fe_sub<C>(fe_sub<C>(Dp, W1p), W2p);
   const fe u = fe_sub<C>(X3pc, W1p);
   const fe Cc = fe_sqr<C>(u);
-#if ECS_ZDAU_Z_EARLY
   // Z3 = Z * ((dx + X3' - W1')^2 - C' - C): as soon as C exists -- dx and C' die here instead of living across W1, W2 and A1
-  if constexpr (!NOZ) {
+  if constexpr (!NOZ && zdau_z_early<C>::value) {
     fe zz = fe_sqr<C>(fe_add<C>(dx, u));
     zz = fe_sub<C>(fe_sub<C>(zz, Cp), Cc);
     z = fe_mul<C>(z, zz);
   }
-#endif
   const fe A1p2 = fe_dbl<C>(A1p);
   // Y3' = (dy + (W1' - X3'))^2 - D' - C - 2A1'
   fe yp = fe_sqr<C>(fe_sub<C>(dy, u));
@@ -105,13 +108,11 @@ template <int C, bool NOZ = false> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe&
   const fe2 A1wide = mul8x8(Y3p, fe_sub<C>(W1, W2));
   const fe W12 = fe_add<C>(W1, W2);
   // Z3 = Z * ((dx + X3' - W1')^2 - C' - C)
-#if !ECS_ZDAU_Z_EARLY
-  if constexpr (!NOZ) {
+  if constexpr (!NOZ && !zdau_z_early<C>::value) {
     fe zz = fe_sqr<C>(fe_add<C>(dx, u));
     zz = fe_sub<C>(fe_sub<C>(zz, Cp), Cc);
     z = fe_mul<C>(z, zz);
   }
-#endif
   fe_cswap(oswap, ym, yp);
   const fe D = fe_sqr<C>(ym);
   x1 = fe_sub<C>(D, W12);
