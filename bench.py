@@ -91,6 +91,19 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries print there too (RCCL writes a five-line version banner with
+    printf when rank 0 creates its first communicator), so file descriptor 1 is pointed at stderr for the life of the process
+    and the returned function writes to the real stdout."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(real, (line + "\n").encode())
+    return emit
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -139,6 +152,7 @@ def main():
         return main_group(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         return launch_ranks(args, sys.argv[1:])
+    emit = claim_stdout()
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -264,7 +278,7 @@ def main():
             result["multi_group"] = group_leg(args, world)          # the other ranks wait at the barrier below
         if failures:
             result["parity_failures"] = failures
-        print(json.dumps(result), flush=True)
+        emit(json.dumps(result))
     if distributed:
         if host_group is not None:
             dist.barrier(group=host_group)
@@ -394,6 +408,7 @@ def main_group(args):
     owns shard_range(units, m, N) resident in ITS memory, every step is one ecsimd_hip_group_scalar_mult -- N ladders and one
     exchange into device 0's arrays (RCCL when N > 1: grouped ncclSend / ncclRecv on ncclCommInitAll communicators) -- with
     double-buffered outputs, no host synchronisation inside the timed loop, ecsimd_hip_group_sync at its end."""
+    emit = claim_stdout()
     import numpy as np
     import torch
     from ecsimd_amd import Engine, DeviceGroup, CURVES, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, GROUP_NO_GATHER, REF_SQUARE_COMPAT
@@ -479,7 +494,7 @@ def main_group(args):
         attach_cpu_baseline(args, result, engs[0], curve, ks[0], bxs[0], bys[0], [t[:n0] for t in last] + [None] * (3 - len(last)), failures)
     if failures:
         result["parity_failures"] = failures
-    print(json.dumps(result), flush=True)
+    emit(json.dumps(result))
     grp.close()
     return EXIT_PARITY if failures else 0
 

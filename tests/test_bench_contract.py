@@ -186,3 +186,45 @@ def test_config1_ops8_times_the_reference_and_hashes_its_outputs():
     assert c1["ops"]["mgry_sqr_256"]["output_sha256_16"] == "92f54302a1cbfc86"
     assert c1["ops"]["mgry_reduce_512"]["output_sha256_16"] == "6dc7617274355fcf"
     assert c1["ops"]["mul_256"]["output_sha256_16"] == "7e57ffaf6954b9b0"
+
+
+def test_native_chatter_cannot_reach_stdout(tmp_path):
+    """RCCL printf()s a version banner on stdout when rank 0 creates its first communicator; the contract is ONE JSON line
+    there.  bench.claim_stdout() points file descriptor 1 at stderr and hands back the real stdout."""
+    import subprocess
+    import sys
+    prog = (f"import importlib.util, os, ctypes\n"
+            f"spec = importlib.util.spec_from_file_location('b', {os.path.join(ROOT, 'bench.py')!r}); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            f"emit = b.claim_stdout()\n"
+            f"libc = ctypes.CDLL(None); libc.printf(b'RCCL version : 2.26.6 (a native library talking)\\n'); libc.fflush(None)\n"
+            f"print('python chatter')\n"
+            f"emit('{{\"metric\": \"x\"}}')\n")
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"metric": "x"}\n'
+    assert "RCCL version" in r.stderr and "python chatter" in r.stderr
+
+
+def test_designs_results_table_is_the_committed_json():
+    """VERDICT r2 "record drift": DESIGN.md section 4's table is generated from profiles/r03/bench_n1_*.json."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "results_table.py"), "r03", "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+
+
+def test_round3_lines_carry_traffic_and_the_full_cpu_baseline():
+    """no `traffic: null`, and cpu_baseline has per_core / one_thread / cpu_model / flags."""
+    r3 = [p for p in LINES if os.sep + "r03" + os.sep in p]
+    assert len(r3) >= 12
+    for path in r3:
+        d = json.load(open(path))
+        assert d["roofline"]["traffic"] is not None and d["roofline"]["traffic"] > 0, path
+        assert 0.6 < d["roofline"]["frac_of_a_priori_peak"] < d["roofline"]["frac"] < 0.8 or "compat" in path, path
+        c = d.get("cpu_baseline")
+        if c:
+            for key in ("per_core", "one_thread", "cpu_model", "flags"):
+                assert key in c, (path, key)
+            assert c["one_thread"]["seconds"] >= 2.0 and c["one_thread"]["threads"] == 1
+            if "config1_ops8" in c:
+                assert all(o["equals_the_restatement"] for o in c["config1_ops8"]["ops"].values())
