@@ -274,6 +274,23 @@ def main():
             attach_cpu_baseline(args, result, eng, curve, k, bx, by, [t[:n] for t in runner.last_result()], failures)
         if force_dist and not torch.equal(runner.gathered[0], runner.last_result()):
             failures.append("the gathered shard differs from the computed one")
+        if distributed and args.workload in ("ladder", "ladder-ref-compat"):
+            # what arrived from the other ranks: rank 0 regenerates the first lanes of every rank's slice of the synthetic streams
+            # (seed, global index), runs them through its own ladder and compares with that rank's block of the receive buffer
+            m, bad_ranks = 1024, []
+            for r in (range(1, world) if world > 1 else [0]):         # one rank (the rehearsal): its own block, so that this code has run
+                f_r, n_r, _, _ = plan(args.scaling, units, r, world)
+                mm = min(m, n_r)
+                kr = eng.fill_random(mm, SEED, 1, first_index=f_r); sr = eng.fill_random(mm, SEED, 2, first_index=f_r)
+                rx, ry = eng.scalar_mult_base(curve, sr, flags=OUT_AFFINE)
+                Pr = eng.from_affine(curve, rx, ry)
+                exp = eng.scalar_mult(curve, kr, Pr[0], Pr[1], flags=flags)
+                got = runner.gathered[r]
+                if not all(torch.equal(got[j][:mm], exp[j]) for j in range(3)):
+                    bad_ranks.append(r)
+            result["config"]["gather"]["sample_check"] = {"lanes_per_rank": m, "ranks_checked": max(1, world - 1), "ranks_differing": bad_ranks}
+            if bad_ranks:
+                failures.append(f"the shards gathered from ranks {bad_ranks} differ from rank 0's own ladder on the same inputs")
         if world > 1 and not args.no_group_check:
             result["multi_group"] = group_leg(args, world)          # the other ranks wait at the barrier below
         if failures:

@@ -1124,9 +1124,24 @@ template <int CURVE> ECS_DEV fe fe_to_classical(const fe& n) {
 
 // ---------------------------------------------------------------- masked select / swap
 // m is an all-ones / all-zeros word per lane (the reference's lane mask, utility.h:45-51).
+#ifndef ECS_CSWAP_CNDMASK
+#define ECS_CSWAP_CNDMASK 0       // 1: one v_cmp + 16 v_cndmask by an SGPR mask instead of the XOR / AND form (the compiler lowers that to 9 v_xor +
+                                  // 16 v_bitop3 per ladder iteration).  Measured (profiles/r03/ab_cswap_cndmask.txt): see DESIGN.md section 9
+#endif
 ECS_DEV void fe_cswap(uint32_t m, fe& a, fe& b) {                            // swap.h:15-22
+#if ECS_CSWAP_CNDMASK
+  lane_mask k;
+  asm("v_cmp_ne_u32_e64 %0, %1, 0" : "=s"(k) : "v"(m));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t na, nb;
+    asm("v_cndmask_b32_e64 %0, %2, %3, %4\n\tv_cndmask_b32_e64 %1, %3, %2, %4" : "=&v"(na), "=&v"(nb) : "v"(a.w[i]), "v"(b.w[i]), "s"(k));
+    a.w[i] = na; b.w[i] = nb;
+  }
+#else
 #pragma unroll
   for (int i = 0; i < 8; ++i) { uint32_t t = (a.w[i] ^ b.w[i]) & m; a.w[i] ^= t; b.w[i] ^= t; }
+#endif
 }
 ECS_DEV fe fe_select(uint32_t m, const fe& a, const fe& b) {                 // ifelse.h:15-22 (m ? a : b)
   fe r;

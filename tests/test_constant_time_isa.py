@@ -65,6 +65,14 @@ def test_secp256k1_bit_loop_is_constant_time(secp256k1_asm):
     # register spills, if the allocation has any, are constant-address scratch accesses (checked inside ct_check)
 
 
+@pytest.mark.parametrize("unit", ["k_ladder_p256_refsqr", "k_ladder_secp256k1_refsqr"])
+def test_reference_compatible_ladders_are_constant_time_too(tmp_path_factory, unit):
+    """ECSIMD_HIP_REF_SQUARE_COMPAT swaps the squaring (field.cuh sqr8_ref: lane-mask carries, no compare, no branch): the header
+    calls it safe for secret scalars, so its bit loop passes the same checks."""
+    rep = ct_check.check(assembly(tmp_path_factory, unit), "13k_scalar_multE")
+    assert rep["instructions"] > 3500 and len(rep["branches"]) == 3 and len(rep["global_loads"]) == 1
+
+
 def test_the_checker_refuses_the_data_dependent_variant(tmp_path_factory):
     """-DECS_COND_SUB=2 (field.cuh cond_sub_p_guard) branches on `r[7] == 0xffffffff`: the checker has to see it."""
     bad = assembly(tmp_path_factory, "k_ladder_p256", extra=("-DECS_COND_SUB=2",))

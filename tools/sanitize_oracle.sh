@@ -11,4 +11,4 @@ FLAGS="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -shared
 gcc $FLAGS -o oracle/libecsimd_oracle.so oracle/ecsimd_oracle.c -lpthread
 [ -f /usr/include/openssl/ec.h ] && gcc $FLAGS -o oracle/libecsimd_ossl.so oracle/ossl_check.c -lcrypto -lpthread
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 \
-  python -m pytest tests/test_oracle.py tests/test_oracle_properties.py tests/test_openssl_crosscheck.py -x -q -m "not gpu"
+  python -m pytest tests/test_oracle.py tests/test_oracle_properties.py tests/test_openssl_crosscheck.py "tests/test_bench_contract.py::test_config1_ops8_times_the_reference_and_hashes_its_outputs" -x -q -m "not gpu"
