@@ -408,8 +408,12 @@ def group_leg(args, world, timeout_s=240):
     cmd = [sys.executable, os.path.abspath(__file__), "--multi", "group", "--gpus", str(world), "--steps", str(min(args.steps, 5)), "--warmup", "1",
            "--scaling", args.scaling, "--global-log2-batch", str(args.global_log2_batch), "--log2-batch", str(args.log2_batch),
            "--curve", args.curve, "--workload", args.workload, "--no-cpu-baseline"]
+    # the child is NOT a rank: it must not inherit torch.distributed.run's environment
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+                        "MASTER_PORT", "ECSIMD_BENCH_FORCE_DIST") and not k.startswith("TORCHELASTIC_")}
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
         lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
         if out.returncode != 0 or not lines:
             return {"ok": False, "returncode": out.returncode, "stderr_tail": out.stderr[-600:]}

@@ -228,3 +228,25 @@ def test_round3_lines_carry_traffic_and_the_full_cpu_baseline():
             assert c["one_thread"]["seconds"] >= 2.0 and c["one_thread"]["threads"] == 1
             if "config1_ops8" in c:
                 assert all(o["equals_the_restatement"] for o in c["config1_ops8"]["ops"].values())
+
+
+def test_the_group_leg_child_is_not_a_rank():
+    """At N > 1 rank 0 starts `bench.py --multi group` in a child process; the child must not inherit RANK / WORLD_SIZE (it
+    would refuse to run as "one of several ranks").  Without GPUs here it has to get as far as counting devices."""
+    import importlib.util
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without GPUs")
+    spec = importlib.util.spec_from_file_location("bench_for_test4", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    old = {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    os.environ.update({"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
+    try:
+        res = bench.group_leg(bench.parse_args(["--gpus", "2", "--steps", "2"]), 2, timeout_s=120)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert res["ok"] is False and "device(s) visible" in res["stderr_tail"] and "torch.distributed.run" not in res["stderr_tail"], res
