@@ -203,13 +203,17 @@ using K256 = ops<curve_secp256k1>;
 
 // BASELINE.json configs[0]: benchs/ops.cpp restated as a timed loop (its harness, Google Benchmark, is not installed and
 // cannot be fetched: SURVEY.md 8(c)).  Like the benchmark, the operands are built before the timed region and every pass
-// calls the function through a noinline lambda on the same wide; the result is kept from being optimised away the way
-// benchmark::DoNotOptimize does (an empty asm that takes its address).  n = 8 elements = 2 wides = "batch = 8".
+// makes one out-of-line call per wide; the result is kept from being optimised away by an empty asm that takes its
+// address.  n = 8 elements = 2 wides = "batch = 8".
 //   op 0  mgry_sqr_256     benchs/ops.cpp:81-90      op 1  mgry_reduce_512  benchs/ops.cpp:92-100
 //   op 2  mul_256          benchs/ops.cpp:36-45 (registered at :108)
 // Returns the seconds the `iters` passes over all wides took; `out` gets the last pass's results (4 limbs per element
 // for ops 0 and 1, 8 for op 2) so that a checker can hash them.
 template <class T> inline void keep(T const& v) { asm volatile("" : : "g"(&v) : "memory"); }
+// one out-of-line call per wide and pass, as a benchmark harness makes it
+template <class W> __attribute__((noinline)) static W timed_sqr(W const& v) { return mgry_sqr(v); }
+template <class Pm, class W> __attribute__((noinline)) static auto timed_reduce(W const& v) { return details::mgry_reduce<Pm>(v); }
+template <class W> __attribute__((noinline)) static auto timed_mul(W const& x, W const& y) { return mul(x, y); }
 template <class Curve> double bench_ops(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, size_t iters) {
   using O = ops<Curve>;
   using Pm = typename O::P;
@@ -218,9 +222,8 @@ template <class Curve> double bench_ops(int op, const uint64_t* a, const uint64_
   if (op == 0) {
     std::vector<WMBN> in; for (size_t w = 0; w < nw; ++w) in.emplace_back(load_wide<BN>(a, w, n));
     std::vector<WMBN> res(in);
-    auto func = [](auto const& v) __attribute__((noinline)) { return mgry_sqr(v); };
     const auto t0 = std::chrono::steady_clock::now();
-    for (size_t it = 0; it < iters; ++it) for (size_t w = 0; w < nw; ++w) { res[w] = func(in[w]); keep(res[w]); }
+    for (size_t it = 0; it < iters; ++it) for (size_t w = 0; w < nw; ++w) { res[w] = timed_sqr(in[w]); keep(res[w]); }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (size_t w = 0; w < nw; ++w) store_wide(out, w, n, res[w].wbn());
     return dt;
@@ -228,9 +231,8 @@ template <class Curve> double bench_ops(int op, const uint64_t* a, const uint64_
   if (op == 1) {
     std::vector<WBN512> in; for (size_t w = 0; w < nw; ++w) in.push_back(load_wide<BN512>(a, w, n));
     std::vector<WBN> res(nw);
-    auto func = [](auto const& v) __attribute__((noinline)) { return details::mgry_reduce<Pm>(v); };
     const auto t0 = std::chrono::steady_clock::now();
-    for (size_t it = 0; it < iters; ++it) for (size_t w = 0; w < nw; ++w) { res[w] = func(in[w]); keep(res[w]); }
+    for (size_t it = 0; it < iters; ++it) for (size_t w = 0; w < nw; ++w) { res[w] = timed_reduce<Pm>(in[w]); keep(res[w]); }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (size_t w = 0; w < nw; ++w) store_wide(out, w, n, res[w]);
     return dt;
@@ -238,9 +240,8 @@ template <class Curve> double bench_ops(int op, const uint64_t* a, const uint64_
   if (op == 2) {
     std::vector<WBN> ia, ib; for (size_t w = 0; w < nw; ++w) { ia.push_back(load_wide<BN>(a, w, n)); ib.push_back(load_wide<BN>(b, w, n)); }
     std::vector<WBN512> res(nw);
-    auto func = [](auto const& x, auto const& y) __attribute__((noinline)) { return mul(x, y); };
     const auto t0 = std::chrono::steady_clock::now();
-    for (size_t it = 0; it < iters; ++it) for (size_t w = 0; w < nw; ++w) { res[w] = func(ia[w], ib[w]); keep(res[w]); }
+    for (size_t it = 0; it < iters; ++it) for (size_t w = 0; w < nw; ++w) { res[w] = timed_mul(ia[w], ib[w]); keep(res[w]); }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (size_t w = 0; w < nw; ++w) store_wide(out, w, n, res[w]);
     return dt;
