@@ -984,6 +984,30 @@ def test_ladder_vs_the_live_reference_2pow20(engine, oracle, reference, openssl,
     print(f"curve {cv}: {len(bad)} of {n} lanes differ from the compiled reference without the flag, 0 with it")
 
 
+def test_ref_square_compat_every_digit_pattern(engine, gpu, oracle, oracle_faithful):
+    """The hand-laid reference squaring (field.cuh sqr8_ref: carry of the doubled product = carry-out of the multiply, the dropped
+    carry = a 64-bit add without carry-out) on EVERY operand whose eight 32-bit digits are drawn from {0, 1, 7fffffff, 80000000,
+    fffffffe, ffffffff}: 6^8 = 1 679 616 operands, the ones that drive its rare paths (a 33-bit addend, both row-end carries,
+    the unnormalised digit wrapping the last diagonal).  Bit for bit against the bug-for-bug restatement of mul.h:160-212,
+    which tests/test_oracle.py pins to the compiled reference; and the exact squaring on the same operands against mul(a, a)."""
+    pat = np.array([0, 1, 0x7fffffff, 0x80000000, 0xfffffffe, 0xffffffff], dtype=np.uint64)
+    idx = np.indices((6,) * 8).reshape(8, -1).T                              # every digit combination
+    w = pat[idx]
+    a = (w[:, 0::2] | (w[:, 1::2] << np.uint64(32))).astype(np.uint64)
+    assert a.shape == (6 ** 8, 4)
+    exact = gpu.square(a)
+    assert np.array_equal(exact, oracle.square(a))
+    engine.set_ref_square_compat(True)
+    try:
+        got = gpu.square(a)
+    finally:
+        engine.set_ref_square_compat(False)
+    assert np.array_equal(got, oracle_faithful.square(a))
+    wrong = int((got != exact).any(axis=1).sum())
+    assert wrong > 100000, wrong                                             # the defect is everywhere in this family
+    print(f"{len(a)} digit-pattern operands: the reference's square() differs from a^2 on {wrong} of them; the compat kernel reproduces every one")
+
+
 def test_operands_must_agree_on_the_batch_length(engine):
     """The C ABI takes one length for all operands; the binding refuses tensors that disagree (they would be read or
     written out of bounds on the device)."""
