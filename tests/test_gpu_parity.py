@@ -321,6 +321,30 @@ def test_point_formulas_vs_oracle(gpu, oracle, cv):
 
 
 @pytest.mark.parametrize("cv", CURVES)
+def test_point_formulas_on_digit_pattern_coordinates(gpu, oracle, cv):
+    """DBLU / ZADDU / ZDAU / ADD_Z2_1 as expression DAGs over GF(p) (parity level J does not need curve points): coordinates from the
+    carry-heavy digit-pattern family, every 7th operand (239 946 points), so that the formulas' add / subtract / double chains and
+    the fused forms (one reduction for a difference of products, quadrupling in one pass) see saturated words everywhere."""
+    from test_oracle import digit_pattern_operands
+    a = digit_pattern_operands()[::7]
+    p = np.tile(oracle.constants(cv)["p"], (len(a), 1))
+    x, y = oracle.sub_if_above(a, p), oracle.sub_if_above(np.roll(a, 1234, axis=0), p)
+    P = oracle.from_affine(cv, x, y)
+    (R, Pu), (Rg, Pug) = oracle.dblu(cv, P), gpu.dblu(cv, P)
+    assert all(np.array_equal(u, v) for u, v in zip(Rg + Pug, R + Pu)), "DBLU"
+    (R3, Pu2), (R3g, Pu2g) = oracle.zaddu(cv, Pu, R), gpu.zaddu(cv, Pu, R)
+    assert all(np.array_equal(u, v) for u, v in zip(R3g + Pu2g, R3 + Pu2)), "ZADDU"
+    (Rz, Qu), (Rzg, Qug) = oracle.zdau(cv, R3, Pu2), gpu.zdau(cv, R3, Pu2)
+    assert all(np.array_equal(u, v) for u, v in zip(Rzg + Qug, Rz + Qu)), "ZDAU"
+    # ZDAU again on its own output, with the raw patterns as a co-Z partner: arbitrary field elements in every slot
+    Q = (x, y, Rz[2])
+    (Rz2, Qu2), (Rz2g, Qu2g) = oracle.zdau(cv, Rz, Q), gpu.zdau(cv, Rz, Q)
+    assert all(np.array_equal(u, v) for u, v in zip(Rz2g + Qu2g, Rz2 + Qu2)), "ZDAU on arbitrary field elements"
+    Ra, Rag = oracle.add_z2_1(cv, Rz2, (x, y)), gpu.add_z2_1(cv, Rz2, (x, y))
+    assert all(np.array_equal(u, v) for u, v in zip(Rag, Ra)), "ADD_Z2_1"
+
+
+@pytest.mark.parametrize("cv", CURVES)
 def test_scalar_mult_vs_oracle(gpu, oracle, cv):
     c = CURVE_PARAMS[cv]; order = c["n"]
     edge = [0, 1, 2, 3, 4, 5, 6, 7, 8, order - 2, order - 1, order, order + 1, order + 2, 2**256 - 1, 2**256 - 2, 2**255, 2**255 - 1,
@@ -982,6 +1006,25 @@ def test_ladder_vs_the_live_reference_2pow20(engine, oracle, reference, openssl,
         rx, ry = reference.to_affine(cv, tuple(v[bad] for v in ref))             # the reference's own point on those lanes is NOT k*P
         assert ((rx != vx) | (ry != vy)).any(axis=1).all()
     print(f"curve {cv}: {len(bad)} of {n} lanes differ from the compiled reference without the flag, 0 with it")
+
+
+@pytest.mark.parametrize("cv", CURVES)
+def test_field_ops_on_every_digit_pattern(gpu, oracle, cv):
+    """The default (exact) field arithmetic on the same exhaustive family -- every operand with digits from {0, 1, 7fffffff, 80000000,
+    fffffffe, ffffffff}, brought below p like the reference's operands are (sub.h:46-69) -- against the oracle: 256 x 256 -> 512
+    multiply and square, Montgomery multiply and square, modular add / subtract / double.  1 679 616 operand pairs per operation."""
+    from test_oracle import digit_pattern_operands
+    a = digit_pattern_operands()
+    b = np.roll(a, 271828, axis=0)
+    assert np.array_equal(gpu.mul(a, b), oracle.mul(a, b))
+    p = np.tile(oracle.constants(cv)["p"], (len(a), 1))
+    ar, br = oracle.sub_if_above(a, p), oracle.sub_if_above(b, p)
+    assert np.array_equal(gpu.sub_if_above(a, p), ar)
+    for name in ("mgry_mul", "mod_add", "mod_sub"):
+        assert np.array_equal(getattr(gpu, name)(cv, ar, br), getattr(oracle, name)(cv, ar, br)), name
+    assert np.array_equal(gpu.mgry_sqr(cv, ar), oracle.mgry_sqr(cv, ar))
+    assert np.array_equal(gpu.mod_shift_left(cv, ar, 1), oracle.mod_shift_left(cv, ar, 1))
+    assert np.array_equal(gpu.mod_shift_left(cv, ar, 2), oracle.mod_shift_left(cv, ar, 2))
 
 
 def test_ref_square_compat_every_digit_pattern(engine, gpu, oracle, oracle_faithful):
