@@ -345,6 +345,29 @@ def test_point_formulas_on_digit_pattern_coordinates(gpu, oracle, cv):
 
 
 @pytest.mark.parametrize("cv", CURVES)
+def test_ladder_on_digit_pattern_scalars_and_coordinates(gpu, oracle, cv):
+    """The whole ladder (curve_group.h:189-218) at level J on structured inputs: 16 796 scalars from the digit-pattern family (runs of
+    ones and zeros, lone top / bottom bits: long stretches without a swap, then swaps every bit) over lane-distinct curve points, and
+    4 107 random scalars over BASE "points" whose coordinates come from the family (any (x, y) drives the same expression DAG)."""
+    from test_oracle import digit_pattern_operands
+    fam = digit_pattern_operands()
+    k = fam[::100]
+    n = len(k)
+    bx, by = _lane_distinct_points(gpu, cv, n)
+    exp = oracle.scalar_mult(cv, k, bx, by, threads=THREADS)
+    assert all(np.array_equal(u, v) for u, v in zip(gpu.scalar_mult(cv, k, bx, by), exp)), "pattern scalars"
+    a = fam[::409]
+    m = len(a)
+    p = np.tile(oracle.constants(cv)["p"], (m, 1))
+    x, y = oracle.sub_if_above(a, p), oracle.sub_if_above(np.roll(a, 77, axis=0), p)
+    kr = fill_random_np(m, SEED, 21)
+    exp = oracle.scalar_mult(cv, kr, x, y, threads=THREADS)
+    assert all(np.array_equal(u, v) for u, v in zip(gpu.scalar_mult(cv, kr, x, y), exp)), "pattern coordinates"
+    exp = oracle.scalar_mult(cv, k[:m], x, y, threads=THREADS)
+    assert all(np.array_equal(u, v) for u, v in zip(gpu.scalar_mult(cv, k[:m], x, y), exp)), "pattern scalars on pattern coordinates"
+
+
+@pytest.mark.parametrize("cv", CURVES)
 def test_scalar_mult_vs_oracle(gpu, oracle, cv):
     c = CURVE_PARAMS[cv]; order = c["n"]
     edge = [0, 1, 2, 3, 4, 5, 6, 7, 8, order - 2, order - 1, order, order + 1, order + 2, 2**256 - 1, 2**256 - 2, 2**255, 2**255 - 1,
