@@ -368,6 +368,39 @@ def test_ladder_on_digit_pattern_scalars_and_coordinates(gpu, oracle, cv):
 
 
 @pytest.mark.parametrize("cv", CURVES)
+def test_windowed_paths_on_digit_pattern_scalars(engine, cv):
+    """The window algorithms recode the scalar (signed 4-, 7- and 20-bit digits with carries between windows, odd-digit forms on k or
+    n - k, the GLV split with its rounding on secp256k1): 16 796 scalars from the digit-pattern family -- nibbles 0, 7, 8, f in every
+    position, runs of ones across window boundaries -- through every one of them and the x-only ladder, against the reference ladder's
+    affine result (itself held to the oracle on these scalars by the test above).  None of the family is a degenerate scalar of the
+    ladder except k = 0, where both sides give (0, 0)."""
+    import torch
+    from ecsimd_amd import ALG_NO_ENDOMORPHISM
+    from test_oracle import digit_pattern_operands
+    kn = digit_pattern_operands()[::100]
+    n = len(kn)
+    k = engine.to_device(kn)
+    s = engine.fill_random(n, SEED, 2)
+    bx, by = engine.scalar_mult_base(cv, s, flags=OUT_AFFINE)
+    lx, ly = engine.scalar_mult(cv, k, bx, by, flags=OUT_AFFINE)                       # the reference's algorithm
+    for alg, name in ((ALG_WINDOWED, "per-element tables"), (ALG_WINDOWED | ALG_NO_ENDOMORPHISM, "per-element tables, plain odd-digit loop")):
+        wx, wy = engine.scalar_mult(cv, k, bx, by, flags=OUT_AFFINE | alg)
+        assert torch.equal(wx, lx) and torch.equal(wy, ly), name
+    xo, none = engine.scalar_mult(cv, k, bx, by, flags=OUT_AFFINE, x_only=True)
+    assert none is None and torch.equal(xo, lx), "x-only ladder"
+    gx, gy = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE)
+    for alg, name in ((ALG_WINDOWED, "4-bit LDS table"), (ALG_WINDOWED_SIGNED, "signed 7-bit LDS table"), (ALG_WINDOWED_BIG, "20-bit table")):
+        fx, fy = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | alg)
+        assert torch.equal(fx, gx) and torch.equal(fy, gy), name
+    # u1*G + u2*Q with both scalars from the family (Q valid public keys): against the two ladders and an affine addition
+    u2 = engine.to_device(np.roll(kn, 4321, axis=0))
+    px, py = engine.scalar_mult(cv, u2, bx, by, flags=OUT_AFFINE)
+    ex, ey, efin = engine.affine_add(cv, (gx, gy), (px, py))
+    rx, ry, fin = engine.double_scalar_mult(cv, k, u2, bx, by)
+    assert torch.equal(rx, ex) and torch.equal(ry, ey) and torch.equal(fin, efin), "u1*G + u2*Q"
+
+
+@pytest.mark.parametrize("cv", CURVES)
 def test_scalar_mult_vs_oracle(gpu, oracle, cv):
     c = CURVE_PARAMS[cv]; order = c["n"]
     edge = [0, 1, 2, 3, 4, 5, 6, 7, 8, order - 2, order - 1, order, order + 1, order + 2, 2**256 - 1, 2**256 - 2, 2**255, 2**255 - 1,
