@@ -1060,7 +1060,11 @@ template <int CURVE> ECS_DEV fe fe_mul(const fe& a, const fe& b) {
 // a*a*R^-1 mod p                                                           mgry_ops.h:37-42
 template <int CURVE> ECS_DEV fe fe_sqr(const fe& a) {
   fe2 t;
+#if defined(ECS_SQR8_REF_C) && ECS_SQR8_REF_C
+  if constexpr (curve_prime<CURVE>::ref_square) t = sqr8_ref_c(a); else t = sqr8(a);     // A/B build: round 2's restatement in C
+#else
   if constexpr (curve_prime<CURVE>::ref_square) t = sqr8_ref(a); else t = sqr8(a);
+#endif
   return mgry_reduce<CURVE>(t);
 }
 // (a*b - T) * R^-1 mod p for an UNREDUCED 512-bit product T < p^2: one reduction for a difference of two products.
