@@ -316,7 +316,7 @@ def base_line(args, world, total_units, n, value, elapsed):
         "windowed": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 multiples of P) + signed 4-bit windows + simultaneous "
                     f"inversion{' + GLV split k = k1 + k2*lambda' if args.curve == 'secp256k1' else ''}, batch {sizes}, affine out",
     }
-    fixed = {"fixed-base": "4-bit window table in LDS", "fixed-base-signed": "signed 7-bit window table in LDS",
+    fixed = {"fixed-base": "4-bit window table in LDS (odd digits, 32 KiB)", "fixed-base-signed": "signed 7-bit window table in LDS",
              "fixed-base-big": "20-bit window table of odd multiples (436 MB) in device memory"}
     return {
         "metric": "P-256 scalar mults/sec (batched)" if args.curve == "p256" else "secp256k1 scalar mults/sec (batched)",
@@ -358,12 +358,12 @@ def roofline_object(args, eng, n, avg_ms):
         mad32_unit, bytes_unit = int(fm * 136), 160
         kname = ("k_varwin_mult_odd + k_varwin_odd_multiples" if args.curve == "p256" else "k_varwin_mult_glv + k_varwin_multiples") + " + k_varwin_to_table + k_to_affine_batched"
     else:
-        # what THIS algorithm needs per scalar: 64 mixed additions x 11 field mults,
+        # what THIS algorithm needs per scalar: 63 / 37 / 12 mixed additions x 11 field mults,
         # 7 mults of the simultaneous-inversion walk and 267/m (secp256k1: 270/m) of the inversion m = min(128, n / 2^17) points share; 32 B in, 64 B out.
-        adds = {"fixed-base": 64, "fixed-base-signed": 37, "fixed-base-big": 12}[args.workload]
+        adds = {"fixed-base": 63, "fixed-base-signed": 37, "fixed-base-big": 12}[args.workload]      # fixed-base: odd digits, the first entry starts the sum (round 3)
         share = min(128, max(1, n >> 17))
         mad32_unit, bytes_unit = int((adds * 11 + 7 + (267 if args.curve == "p256" else 270) / share) * 136), 96
-        kname = {64: "k_base_windowed", 37: "k_base_windowed_s<7>", 12: "k_base_windowed_g"}[adds] + " + k_to_affine_batched"
+        kname = {63: "k_base_windowed", 37: "k_base_windowed_s<7>", 12: "k_base_windowed_g"}[adds] + " + k_to_affine_batched"
     achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
     traffic, traffic_src = committed_traffic(args, n)
     return {

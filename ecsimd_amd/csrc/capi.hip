@@ -148,21 +148,49 @@ int ensure_valid(ecsimd_hip_ctx* ctx, size_t bytes) {
 }
 
 // Window tables, produced with the (parity-checked) ladder kernel itself.
-//   bits = 4: 64 x 16 entries d * 16^w * G (d = 0 unused);  bits = 6 / 7 (signed windows): 43 x 32 / 37 x 64
+//   bits = 4: 64 x 8 entries (2d + 1) * 16^w * G (odd digits; 64 x 16 entries d * 16^w * G with -DECS_FIXED4_ODD=0);  bits = 6 / 7 (signed windows): 43 x 32 / 37 x 64
 //   entries m * 2^(bits i) * G, m = slot + 1.
 constexpr int SIGNED_WBITS = 7;     // 37 additions, 151 552 B of LDS (6 -> 43 additions, 88 064 B): measured faster
 int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
   uint32_t** slot = (bits == 4) ? &ctx->window_table[curve] : (bits == launch::BIG_WINDOW_BITS) ? &ctx->window16_table[curve] : &ctx->window6_table[curve];
   if (*slot) return ECSIMD_HIP_OK;
   const bool big = (bits == launch::BIG_WINDOW_BITS);        // odd multiples (2d + 1) * 2^(bits w) * G, ceil(256 / bits) windows, no carry window
-  const int windows = (bits == 4) ? 64 : big ? (256 + bits - 1) / bits : (256 + bits) / bits, per = (bits == 4) ? 16 : 1 << (bits - 1);
-  const size_t entries = (size_t)windows * per;
+  const bool odd4 = (bits == 4) && (launch::FIXED4_ENTRIES == 8);        // the 4-bit LDS table with odd digits (kernels.h ECS_FIXED4_ODD)
+  const int windows = (bits == 4) ? 64 : big ? (256 + bits - 1) / bits : (256 + bits) / bits, per = (bits == 4) ? launch::FIXED4_ENTRIES : 1 << (bits - 1);
+  const size_t table_entries = (size_t)windows * per;
+  // odd-digit combs: one more scalar, k*, whose point the kernel substitutes for its own sum (k_affine.inc comb_special: the one
+  // odd scalar at which the comb's last mixed addition meets R = T), and a 64-byte record holding k* itself behind it
+  const bool odd = big || odd4;
+  const size_t entries = table_entries + (odd ? 1 : 0);
   std::vector<uint64_t> host_k;
   try { host_k.assign(entries * 4, 0); }                       // up to 218 MB of host memory (20-bit windows): nothing may throw across the C ABI
   catch (...) { return bad(ctx, "window table: out of host memory"); }
+  uint64_t kstar[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (odd) {
+    // high-to-low accumulation (the 4-bit LDS kernel): k* = n - 2 (n mod 2^bits), and only if bit `bits` of k* is 0 (then its lowest digit
+    // is -(n mod 2^bits)); low-to-high (the device-memory table): k* = n - 2 (n mod 2^(bits (windows - 1)))
+    uint64_t nn[4], m[4] = {0, 0, 0, 0};
+    words_to_limbs(curve == ECSIMD_HIP_P256 ? curve_order<CURVE_P256>::N : curve_order<CURVE_SECP256K1>::N, nn);
+    const int low_bits = big ? bits * (windows - 1) : bits;
+    for (int l = 0; l < 4; ++l) {
+      const int lo = 64 * l;
+      if (low_bits >= lo + 64) m[l] = nn[l];
+      else if (low_bits > lo) m[l] = nn[l] & ((1ull << (low_bits - lo)) - 1ull);
+    }
+    unsigned __int128 acc = 0; uint64_t m2[4];                                 // 2m (m < 2^255)
+    for (int l = 0; l < 4; ++l) { acc += (unsigned __int128)m[l] * 2u; m2[l] = (uint64_t)acc; acc >>= 64; }
+    uint64_t borrow = 0;
+    for (int l = 0; l < 4; ++l) {
+      const unsigned __int128 d = (unsigned __int128)nn[l] - m2[l] - borrow;
+      kstar[l] = (uint64_t)d; borrow = (uint64_t)(d >> 64) & 1u;
+    }
+    if (borrow || (odd4 && ((kstar[bits / 64] >> (bits % 64)) & 1u))) { for (int l = 0; l < 4; ++l) kstar[l] = 0; }   // no such scalar for this kernel
+    const bool have = (kstar[0] | kstar[1] | kstar[2] | kstar[3]) != 0;
+    for (int l = 0; l < 4; ++l) host_k[table_entries * 4 + l] = have ? kstar[l] : (l == 0 ? 1u : 0u);        // without a k*: any scalar, the point is never used
+  }
   for (int w = 0; w < windows; ++w)
     for (int d = 0; d < per; ++d) {
-      const unsigned mult = (bits == 4) ? (unsigned)d : big ? 2u * (unsigned)d + 1u : (unsigned)d + 1u;   // multiplier m
+      const unsigned mult = (big || odd4) ? 2u * (unsigned)d + 1u : (bits == 4) ? (unsigned)d : (unsigned)d + 1u;   // multiplier m
       const int pos = bits * w;                                                         // entry = m * 2^pos * G
       uint64_t* e = &host_k[((size_t)w * per + d) * 4];
       const int limb = pos / 64, off = pos % 64;
@@ -184,7 +212,7 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
   uint64_t* kd = nullptr;
   uint32_t* table = nullptr;
   hipError_t e = hipMalloc(&kd, 6 * entries * 32);
-  if (e == hipSuccess) e = hipMalloc(&table, entries * 64);
+  if (e == hipSuccess) e = hipMalloc(&table, (entries + (odd ? 1 : 0)) * 64);      // odd-digit combs: + the record that holds k*
   uint64_t* tx = kd + entries * 4; uint64_t* ty = tx + entries * 4;
   if (e == hipSuccess) e = hipMemcpyAsync(kd, host_k.data(), entries * 32, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // host_k must outlive the copy
@@ -208,6 +236,7 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
       launch::pack_table(ctx->stream, curve, tx, ty, table);
     }
   }
+  if (e == hipSuccess && odd) e = hipMemcpyAsync(table + entries * 16, kstar, 64, hipMemcpyHostToDevice, ctx->stream);   // {k*, 0}: read by comb_special
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e == hipSuccess) e = hipGetLastError();
   (void)hipFree(kd);

@@ -121,7 +121,14 @@ template <int C> struct point_launch {
   static void varwin_scalar_mult(hipStream_t, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, int flags, uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n);
 };
 inline size_t scalar_mult_x_scratch_bytes(size_t n) { return 4 * n * 32 + ((n + 31) & ~(size_t)31); }   // odd scalars, num, den, 1/den, zero flags
-constexpr size_t WINDOW_TABLE_BYTES = 64 * 16 * 64;   // 64 windows x 16 digits x (x, y)
+// The 4-bit fixed-base table in LDS (BASELINE configs[2]).  ECS_FIXED4_ODD = 1 (round 3): odd digits only -- the regular recoding of the
+// odd one of k mod n, n - k, as in the big-window kernel: 64 windows x 8 odd multiples (2d + 1) 16^w G = 32 KiB, 63 mixed additions, no
+// zero digit and therefore no "skip" / "infinity" selects.  0: round 1's unsigned digits (64 x 16 entries d 16^w G, 64 additions).
+#ifndef ECS_FIXED4_ODD
+#define ECS_FIXED4_ODD 1
+#endif
+constexpr int FIXED4_ENTRIES = ECS_FIXED4_ODD ? 8 : 16;
+constexpr size_t WINDOW_TABLE_BYTES = 64 * FIXED4_ENTRIES * 64;   // 64 windows x entries x (x, y)
 
 }  // namespace launch
 }  // namespace ecsimd_hip

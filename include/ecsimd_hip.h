@@ -63,8 +63,10 @@ enum {
                                       of 9M + 7S, x recovered from the two co-Z results and the curve equation, 55 M/s against 48 -- on the odd one
                                       of k mod n and n - k mod n.  Same constant-time shape as the ladder; correct for EVERY 256-bit k (x = 0 for
                                       k = 0 mod n), including the reference ladder's degenerate scalars */
-  ECSIMD_HIP_ALG_WINDOWED = 4,     /* with OUT_AFFINE only.  scalar_mult_base: 4-bit windows over an LDS-resident table of
-                                      d*16^w*G and one simultaneous inversion instead of the reference's ladder.
+  ECSIMD_HIP_ALG_WINDOWED = 4,     /* with OUT_AFFINE only.  scalar_mult_base: 4-bit windows over an LDS-resident table (32 KiB: the odd
+                                      multiples (2d+1)*16^w*G; the odd one of k mod n, n - k is recoded into 64 odd digits, so the sum is
+                                      63 mixed additions with no zero digit to skip) and one simultaneous inversion instead of the
+                                      reference's ladder.
                                       scalar_mult / double_scalar_mult (variable base): a per-element table of 8 multiples
                                       of P in device memory and signed 4-bit windows (odd digits, 3 doublings + one fused
                                       double-add per window: ~2 770 field multiplications against the ladder's 4 064;

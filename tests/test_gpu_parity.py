@@ -432,6 +432,57 @@ def test_scalar_mult_vs_oracle(gpu, oracle, cv):
     assert all(np.array_equal(u, v) for u, v in zip(gpu.scalar_mult_1s(cv, k1, bx[:256], by[:256]), exp1)), "scalar_mult_1s"
 
 
+def comb_exceptional_scalars(cv):
+    """For an odd-digit comb with B = 2^bits the last mixed addition meets R = T at exactly one odd scalar: k* = n - 2 (n mod B) when the
+    windows are summed from the top (the 4-bit LDS kernel), k* = n - 2 (n mod B^(windows - 1)) from the bottom (the 20-bit table); the even
+    n - k* reaches it through the k -> n - k flip, and k* + n where that still fits 256 bits through the reduction (k_affine.inc comb_special)."""
+    n = CURVE_PARAMS[cv]["n"]
+    out = []
+    for low_bits in (4, 20, 240, 252, 7, 249):
+        m = n % (1 << low_bits)
+        out += [n - 2 * m, (2 * m) % n, n - 2 * m + 1, n - 2 * m - 1]
+    out += [v + n for v in out if v + n < (1 << 256)]
+    return [v for v in out if v % n != 0]
+
+
+@pytest.mark.parametrize("cv", CURVES)
+def test_comb_kernels_on_their_exceptional_scalars(engine, cv):
+    """Round 3 found k = 2 wrong in the odd-digit 4-bit kernel on P-256 (R = T at its last addition) and, by the same argument, k = +-(n - 2
+    (n mod 2^240)) wrong in the 20-bit kernel on BOTH curves since round 1 -- scalars no random test meets.  The kernels now substitute
+    the point of that one scalar (built with the table); every fixed-base algorithm and u1*G + u2*Q must give the big-int model's point on
+    them, on their neighbours, in waves where every / one / no lane is such a scalar."""
+    import torch
+    c = CURVE_PARAMS[cv]; order = c["n"]; G = (c["gx"], c["gy"])
+    sp = comb_exceptional_scalars(cv)
+    rnd = arr_to_ints(fill_random_np(192, SEED, 33))
+    ks = sp * 3 + rnd[:64] + [sp[0]] + rnd[64:127] + rnd[127:]              # waves full of them, one wave with a single one, one without
+    k = engine.to_device(ints_to_arr(ks))
+    model = {v: ec_mul(cv, v % order, G) for v in set(ks)}                    # the independent big-int model is the witness: n - 1, one of the
+    exp = np.array([[from_int(model[v][0]), from_int(model[v][1])] for v in ks])   # ladder's own degenerate scalars, is a neighbour of k* = n - 2
+    ex_, ey_ = engine.to_device(exp[:, 0]), engine.to_device(exp[:, 1])
+    degenerate = {order - 1, 2**256 - order - 1, 2**256 - order}
+    lx, ly = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE)
+    assert all(torch.equal(lx[i], ex_[i]) and torch.equal(ly[i], ey_[i]) for i in range(len(ks)) if ks[i] not in degenerate), "ladder"
+    for alg, name in ((ALG_WINDOWED, "4-bit LDS table"), (ALG_WINDOWED_SIGNED, "signed 7-bit LDS table"), (ALG_WINDOWED_BIG, "20-bit table")):
+        wx, wy = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | alg)
+        bad = [hex(ks[i]) for i in range(len(ks)) if not (torch.equal(wx[i], ex_[i]) and torch.equal(wy[i], ey_[i]))]
+        assert not bad, (name, bad)
+    lx, ly = ex_, ey_
+    # u1*G + u2*Q with u1 from the list (the 20-bit table now exists in this context, so u1*G goes through it)
+    u2 = engine.fill_random(len(ks), SEED, 34)
+    qx, qy = engine.scalar_mult_base(cv, engine.fill_random(len(ks), SEED, 35), flags=OUT_AFFINE)
+    px, py = engine.scalar_mult(cv, u2, qx, qy, flags=OUT_AFFINE)
+    ex, ey, efin = engine.affine_add(cv, (lx, ly), (px, py))
+    rx, ry, fin = engine.double_scalar_mult(cv, k, u2, qx, qy)
+    assert torch.equal(rx, ex) and torch.equal(ry, ey) and torch.equal(fin, efin)
+    # variable base: the per-element window loops (Horner form: no such scalar, checked all the same)
+    for alg in (ALG_WINDOWED,):
+        vx, vy = engine.scalar_mult(cv, k, qx, qy, flags=OUT_AFFINE | alg)
+        wx, wy = engine.scalar_mult(cv, k, qx, qy, flags=OUT_AFFINE)
+        ok = [i for i in range(len(ks)) if ks[i] not in degenerate]
+        assert all(torch.equal(vx[i], wx[i]) and torch.equal(vy[i], wy[i]) for i in ok)
+
+
 @pytest.mark.parametrize("cv", CURVES)
 def test_windowed_fixed_base_matches_the_ladder_at_affine_level(engine, oracle, cv):
     """BASELINE configs[2] algorithm: 4-bit windows over an LDS table + simultaneous inversion.  A different
