@@ -79,7 +79,7 @@ def parse_args(argv=None):
                          "ladder-x: x(k*P) only, the constant-time ladder without its Z coordinate (P-256; ECDH's shared secret; affine-level parity); "
                          "windowed: variable base with per-element tables of 8 multiples of P and signed 4-bit windows, affine out (ALG_WINDOWED; affine-level parity); "
                          "fixed-base: k*G with the 4-bit-window LDS table + simultaneous inversion, affine out (BASELINE configs[2]); "
-                         "fixed-base-signed: the same with signed 7-bit windows (37 additions instead of 64); "
+                         "fixed-base-signed: the same with signed 7-bit windows (36 additions instead of 63); "
                          "fixed-base-big: 20-bit windows (odd digits) over a 436 MB table in device memory (12 additions)")
     ap.add_argument("--multi", default="procs", choices=["procs", "group"],
                     help="procs: one process per GPU under torch.distributed.run, one RCCL gather per step (what the driver launches; "
@@ -163,7 +163,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world                   # under torch.distributed.run the launcher's world size is the number of GPUs
-    torch.cuda.set_device(local_rank)
+    # ECSIMD_BENCH_REHEARSE_ONE_GPU=1: N ranks SHARE cuda:0 and talk over gloo (RCCL refuses two ranks on one device) -- the
+    # control flow of an N > 1 run (shard plan, per-rank streams, gather, sample check of the other ranks' shards, the device-group
+    # leg, the barriers) executed on a one-GPU box.  The line says "rehearsal" and is no scaling result.
+    rehearse = os.environ.get("ECSIMD_BENCH_REHEARSE_ONE_GPU") == "1" and world > 1
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
     # ECSIMD_BENCH_FORCE_DIST=1 runs the process-group + gather path even with one rank (a single-GPU
     # rehearsal of the N > 1 code: RCCL init, side stream, dist.gather, barrier).
     force_dist = os.environ.get("ECSIMD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
@@ -171,7 +176,10 @@ def main():
     host_group = None
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         if world > 1 and not args.no_group_check:
             # while rank 0's child process drives all N GPUs through the C ABI's device group (group_leg), the other ranks must
             # wait on the HOST: an RCCL barrier would keep a spinning kernel on every GPU the child is measuring
@@ -184,7 +192,7 @@ def main():
         __graft_entry__.build()         # built artefacts normally travel with the snapshot
     if world > 1:
         dist.barrier()
-    eng = Engine(local_rank)            # raises if the HIP library / a gfx950 device is missing: no fallback
+    eng = Engine(dev_index)             # raises if the HIP library / a gfx950 device is missing: no fallback
     units = (1 << args.global_log2_batch) if args.scaling == "strong" else (1 << args.log2_batch)
     first, n, total_units, rows = plan(args.scaling, units, rank, world)       # this rank's slice of the global synthetic streams
     if n == 0:
@@ -199,7 +207,7 @@ def main():
     P = eng.from_affine(curve, bx, by)                                        # Montgomery form, Z = mgry(1)
     xm, ym = P[0], P[1]
     del s, P
-    runner = ShardedRunner((3, rows, 4), torch.int64, eng.tdev, world, rank, always_gather=force_dist)
+    runner = ShardedRunner((3, rows, 4), torch.int64, eng.tdev, world, rank, always_gather=force_dist, via_host=rehearse)
     view = (lambda o: [o[0][:n], o[1][:n], o[2][:n]]) if rows != n else (lambda o: [o[0], o[1], o[2]])
 
     if args.workload in ("ladder", "ladder-ref-compat"):
@@ -241,7 +249,7 @@ def main():
         runner.fence()
         elapsed = time.perf_counter() - t0
         if distributed:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=eng.tdev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=("cpu" if rehearse else eng.tdev))
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, ([a.elapsed_time(b) for a, b in evs] if evs else None)      # events: same stream as the launches
@@ -259,10 +267,14 @@ def main():
     total = float(total_units) * args.steps
     result = base_line(args, world, total_units, n, total / elapsed, elapsed)
     result["config"]["rccl"] = ({"ranks": dist.get_world_size(), "version": ".".join(str(v) for v in torch.cuda.nccl.version()),
-                                  "via": "torch.distributed backend nccl, one process per GPU"} if distributed else {"ranks": 0})
+                                  "via": "torch.distributed backend nccl, one process per GPU"} if (distributed and not rehearse) else {"ranks": 0})
+    if rehearse:
+        result["rehearsal"] = (f"{world} ranks sharing ONE GPU, gathers staged through pinned host memory over gloo (ECSIMD_BENCH_REHEARSE_ONE_GPU=1): "
+                               "the N > 1 control flow executed on a one-GPU box; n_gpus counts ranks here and the value is NOT a scaling result")
     if distributed:
         result["config"]["gather"] = {
-            "what": "one RCCL gather of every rank's result shard to rank 0 per step, on a side stream, into one pre-sized receive buffer",
+            "what": ("one gloo gather of every rank's result shard, staged through pinned host memory (rehearsal)" if rehearse else
+                     "one RCCL gather of every rank's result shard to rank 0 per step, on a side stream, into one pre-sized receive buffer"),
             "bytes_per_rank_per_step": 3 * rows * 32, "ms_avg_on_the_side_stream_rank0": (float(np.mean(gather_ms)) if gather_ms else None),
             "ms_per_step_with_gather": 1e3 * elapsed / args.steps, "ms_per_step_compute_only": 1e3 * compute_only / args.steps,
             "value_compute_only": total / compute_only}
@@ -272,7 +284,7 @@ def main():
         result["roofline"] = roofline_object(args, eng, n, float(np.mean(kernel_ms)))
         if world == 1 and not args.no_cpu_baseline:
             attach_cpu_baseline(args, result, eng, curve, k, bx, by, [t[:n] for t in runner.last_result()], failures)
-        if force_dist and not torch.equal(runner.gathered[0], runner.last_result()):
+        if (force_dist or rehearse) and not torch.equal(runner.gathered[0].to(eng.tdev), runner.last_result()):
             failures.append("the gathered shard differs from the computed one")
         if distributed and args.workload in ("ladder", "ladder-ref-compat"):
             # what arrived from the other ranks: rank 0 regenerates the first lanes of every rank's slice of the synthetic streams
@@ -286,7 +298,7 @@ def main():
                 Pr = eng.from_affine(curve, rx, ry)
                 exp = eng.scalar_mult(curve, kr, Pr[0], Pr[1], flags=flags)
                 got = runner.gathered[r]
-                if not all(torch.equal(got[j][:mm], exp[j]) for j in range(3)):
+                if not all(torch.equal(got[j][:mm].to(exp[j].device), exp[j]) for j in range(3)):
                     bad_ranks.append(r)
             result["config"]["gather"]["sample_check"] = {"lanes_per_rank": m, "ranks_checked": max(1, world - 1), "ranks_differing": bad_ranks}
             if bad_ranks:
@@ -316,7 +328,7 @@ def base_line(args, world, total_units, n, value, elapsed):
         "windowed": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 multiples of P) + signed 4-bit windows + simultaneous "
                     f"inversion{' + GLV split k = k1 + k2*lambda' if args.curve == 'secp256k1' else ''}, batch {sizes}, affine out",
     }
-    fixed = {"fixed-base": "4-bit window table in LDS (odd digits, 32 KiB)", "fixed-base-signed": "signed 7-bit window table in LDS",
+    fixed = {"fixed-base": "4-bit window table in LDS (odd digits, 32 KiB)", "fixed-base-signed": "signed 7-bit window table in LDS (odd digits, 148 KiB)",
              "fixed-base-big": "20-bit window table of odd multiples (436 MB) in device memory"}
     return {
         "metric": "P-256 scalar mults/sec (batched)" if args.curve == "p256" else "secp256k1 scalar mults/sec (batched)",
@@ -358,12 +370,12 @@ def roofline_object(args, eng, n, avg_ms):
         mad32_unit, bytes_unit = int(fm * 136), 160
         kname = ("k_varwin_mult_odd + k_varwin_odd_multiples" if args.curve == "p256" else "k_varwin_mult_glv + k_varwin_multiples") + " + k_varwin_to_table + k_to_affine_batched"
     else:
-        # what THIS algorithm needs per scalar: 63 / 37 / 12 mixed additions x 11 field mults,
+        # what THIS algorithm needs per scalar: 63 / 36 / 12 mixed additions x 11 field mults,
         # 7 mults of the simultaneous-inversion walk and 267/m (secp256k1: 270/m) of the inversion m = min(128, n / 2^17) points share; 32 B in, 64 B out.
-        adds = {"fixed-base": 63, "fixed-base-signed": 37, "fixed-base-big": 12}[args.workload]      # fixed-base: odd digits, the first entry starts the sum (round 3)
+        adds = {"fixed-base": 63, "fixed-base-signed": 36, "fixed-base-big": 12}[args.workload]      # odd digits everywhere: the first entry starts the sum (round 3)
         share = min(128, max(1, n >> 17))
         mad32_unit, bytes_unit = int((adds * 11 + 7 + (267 if args.curve == "p256" else 270) / share) * 136), 96
-        kname = {63: "k_base_windowed", 37: "k_base_windowed_s<7>", 12: "k_base_windowed_g"}[adds] + " + k_to_affine_batched"
+        kname = {63: "k_base_windowed", 36: "k_base_windowed_s<7>", 12: "k_base_windowed_g"}[adds] + " + k_to_affine_batched"
     achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
     traffic, traffic_src = committed_traffic(args, n)
     return {
@@ -439,7 +451,9 @@ def main_group(args):
         raise SystemExit("--multi group runs the ladder workloads (the group entry point is ecsimd_hip_group_scalar_mult)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     N = args.gpus
-    if torch.cuda.device_count() < N:
+    rehearse = os.environ.get("ECSIMD_BENCH_REHEARSE_ONE_GPU") == "1" and N > 1      # N members on ONE device: the group's shared-device gather
+    devices = [0] * N if rehearse else list(range(N))
+    if torch.cuda.device_count() <= max(devices):
         raise SystemExit(f"--multi group --gpus {N}: only {torch.cuda.device_count()} device(s) visible")
     if not os.path.exists(ecsimd_amd.lib_path()):
         import __graft_entry__
@@ -450,11 +464,11 @@ def main_group(args):
     total_units = spans[0][2]
     if any(sp[1] == 0 for sp in spans):
         raise SystemExit("the batch is smaller than the number of GPUs")
-    grp = DeviceGroup(list(range(N)))
+    grp = DeviceGroup(devices)
     engs, ks, xs, ys, bxs, bys = [], [], [], [], [], []
     for m in range(N):                                   # inputs generated where they will be used (seed, global index): nothing moves
-        with torch.cuda.device(m):
-            eng = Engine(m)
+        with torch.cuda.device(devices[m]):
+            eng = Engine(devices[m])
             first, cnt = spans[m][0], spans[m][1]
             k = eng.fill_random(cnt, SEED, 1, first_index=first)
             sd = eng.fill_random(cnt, SEED, 2, first_index=first)
@@ -463,7 +477,7 @@ def main_group(args):
                 xm, ym = bx, by
             else:
                 P = eng.from_affine(curve, bx, by); xm, ym = P[0], P[1]
-            torch.cuda.synchronize(m)
+            torch.cuda.synchronize(devices[m])
             engs.append(eng); ks.append(k); xs.append(xm); ys.append(ym); bxs.append(bx); bys.append(by)
     x_only = args.workload == "ladder-x"
     flags = (OUT_AFFINE if x_only else (BASE_MGRY | OUT_JACOBIAN)) | (REF_SQUARE_COMPAT if args.workload == "ladder-ref-compat" else 0)
@@ -488,7 +502,10 @@ def main_group(args):
     result = base_line(args, N, total_units, n0, total / elapsed, elapsed)
     result["config"]["rccl"] = {"ranks": N if grp.uses_rccl else 0, "version": grp.rccl_version or None,
                                 "via": "ecsimd_hip_group_* (C ABI): one process, ncclCommInitAll, grouped ncclSend / ncclRecv" if grp.uses_rccl
-                                       else "ecsimd_hip_group_* (C ABI): one member, no exchange"}
+                                       else ("ecsimd_hip_group_* (C ABI): members share one device, device-to-device copies (rehearsal)" if N > 1
+                                             else "ecsimd_hip_group_* (C ABI): one member, no exchange")}
+    if rehearse:
+        result["rehearsal"] = f"{N} group members on ONE GPU (ECSIMD_BENCH_REHEARSE_ONE_GPU=1): not a scaling result"
     result["config"]["gather"] = {
         "what": "every other member's result shard into device 0's arrays by one grouped ncclSend / ncclRecv exchange per step, on device 0's gather stream",
         "bytes_per_member_per_step": (1 if x_only else 3) * spans[0][3] * 32, "ms_last_on_the_gather_stream": (gather_ms if gather_ms >= 0 else None),
@@ -499,10 +516,10 @@ def main_group(args):
     last = outs[0]
     ok = True
     for m in range(N):
-        with torch.cuda.device(m):
+        with torch.cuda.device(devices[m]):
             first, cnt = spans[m][0], spans[m][1]
             ref = engs[m].scalar_mult(curve, ks[m], xs[m], ys[m], flags=flags, x_only=x_only)
-            torch.cuda.synchronize(m)
+            torch.cuda.synchronize(devices[m])
             for a, b in zip(last, ref):
                 if b is not None:
                     ok = ok and bool(torch.equal(a[first:first + cnt].to(b.device), b))

@@ -156,11 +156,12 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
   if (*slot) return ECSIMD_HIP_OK;
   const bool big = (bits == launch::BIG_WINDOW_BITS);        // odd multiples (2d + 1) * 2^(bits w) * G, ceil(256 / bits) windows, no carry window
   const bool odd4 = (bits == 4) && (launch::FIXED4_ENTRIES == 8);        // the 4-bit LDS table with odd digits (kernels.h ECS_FIXED4_ODD)
-  const int windows = (bits == 4) ? 64 : big ? (256 + bits - 1) / bits : (256 + bits) / bits, per = (bits == 4) ? launch::FIXED4_ENTRIES : 1 << (bits - 1);
+  const bool odds = !big && bits != 4 && ECS_SIGNED_ODD;                  // the 6- / 7-bit LDS table with odd digits (kernels.h ECS_SIGNED_ODD)
+  const int windows = (bits == 4) ? 64 : big ? (256 + bits - 1) / bits : launch::signed_windows(bits), per = (bits == 4) ? launch::FIXED4_ENTRIES : 1 << (bits - 1);
   const size_t table_entries = (size_t)windows * per;
   // odd-digit combs: one more scalar, k*, whose point the kernel substitutes for its own sum (k_affine.inc comb_special: the one
   // odd scalar at which the comb's last mixed addition meets R = T), and a 64-byte record holding k* itself behind it
-  const bool odd = big || odd4;
+  const bool odd = big || odd4 || odds;
   const size_t entries = table_entries + (odd ? 1 : 0);
   std::vector<uint64_t> host_k;
   try { host_k.assign(entries * 4, 0); }                       // up to 218 MB of host memory (20-bit windows): nothing may throw across the C ABI
@@ -171,7 +172,7 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
     // is -(n mod 2^bits)); low-to-high (the device-memory table): k* = n - 2 (n mod 2^(bits (windows - 1)))
     uint64_t nn[4], m[4] = {0, 0, 0, 0};
     words_to_limbs(curve == ECSIMD_HIP_P256 ? curve_order<CURVE_P256>::N : curve_order<CURVE_SECP256K1>::N, nn);
-    const int low_bits = big ? bits * (windows - 1) : bits;
+    const int low_bits = (big || odds) ? bits * (windows - 1) : bits;       // summed from the bottom (20-bit table, 6- / 7-bit LDS tables) or from the top (4 bits)
     for (int l = 0; l < 4; ++l) {
       const int lo = 64 * l;
       if (low_bits >= lo + 64) m[l] = nn[l];
@@ -190,7 +191,7 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
   }
   for (int w = 0; w < windows; ++w)
     for (int d = 0; d < per; ++d) {
-      const unsigned mult = (big || odd4) ? 2u * (unsigned)d + 1u : (bits == 4) ? (unsigned)d : (unsigned)d + 1u;   // multiplier m
+      const unsigned mult = odd ? 2u * (unsigned)d + 1u : (bits == 4) ? (unsigned)d : (unsigned)d + 1u;   // multiplier m
       const int pos = bits * w;                                                         // entry = m * 2^pos * G
       uint64_t* e = &host_k[((size_t)w * per + d) * 4];
       const int limb = pos / 64, off = pos % 64;
@@ -222,6 +223,8 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
     launch::to_affine_batched(ctx->stream, curve, jx, jy, jz, tx, ty, entries, true);
     if (big) {
       launch::pack_table_big(ctx->stream, curve, tx, ty, table);           // odd digits: no carry, no 2^256 * G entry
+    } else if (odds) {
+      launch::pack_table_signed(ctx->stream, curve, bits, tx, ty, table);  // odd digits: no carry, no 2^256 * G entry
     } else if (bits != 4) {
       // The one reachable entry with m * 2^pos = 2^256 (top digit + carry): the ladder cannot produce 2^256 * G (a degenerate
       // scalar, see above), so it is the entry holding 2^255 * G doubled by the affine-addition kernel.

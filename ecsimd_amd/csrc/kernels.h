@@ -128,6 +128,12 @@ inline size_t scalar_mult_x_scratch_bytes(size_t n) { return 4 * n * 32 + ((n + 
 #define ECS_FIXED4_ODD 1
 #endif
 constexpr int FIXED4_ENTRIES = ECS_FIXED4_ODD ? 8 : 16;
+// The signed 6- / 7-bit LDS tables (ALG_WINDOWED_SIGNED).  ECS_SIGNED_ODD = 1 (round 3): odd digits as above -- 37 windows x 64 odd multiples
+// (2d + 1) 2^(7w) G for 7 bits, 36 mixed additions, no carry window and no skip / infinity selects; 0: round 1's carry recoding (digits in [-63, 64]).
+#ifndef ECS_SIGNED_ODD
+#define ECS_SIGNED_ODD 1
+#endif
+constexpr int signed_windows(int bits) { return ECS_SIGNED_ODD ? (256 + bits - 1) / bits : (256 + bits) / bits; }
 constexpr size_t WINDOW_TABLE_BYTES = 64 * FIXED4_ENTRIES * 64;   // 64 windows x entries x (x, y)
 
 }  // namespace launch

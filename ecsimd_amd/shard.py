@@ -51,12 +51,17 @@ class ShardedRunner:
     """
 
     def __init__(self, shape, dtype, device, world: int, rank: int, group=None, always_gather: bool = False, time_gathers: bool = True,
-                 keep_timings: int = 1024):
+                 keep_timings: int = 1024, via_host: bool = False):
         self.world, self.rank, self.group = world, rank, group
         self.dist = world > 1 or always_gather          # always_gather: rehearse the collective path with one rank
         self.cuda = torch.device(device).type == "cuda"
+        # via_host: REHEARSAL ONLY (bench.py, ECSIMD_BENCH_REHEARSE_ONE_GPU=1).  RCCL refuses two ranks on one device, so N ranks
+        # sharing ONE GPU gather over gloo instead: the finished buffer goes to pinned host memory on the side stream, the host waits
+        # for that copy (no overlap with the next step) and gloo gathers host tensors.  Results still come from the HIP kernels.
+        self.via_host = bool(via_host and self.cuda and self.dist)
         self.outs = [torch.empty(shape, dtype=dtype, device=device) for _ in range(2)]
-        self.received = torch.empty((world,) + tuple(shape), dtype=dtype, device=device) if (self.dist and rank == 0) else None
+        self.host_outs = [torch.empty(shape, dtype=dtype, pin_memory=True) for _ in range(2)] if self.via_host else None
+        self.received = torch.empty((world,) + tuple(shape), dtype=dtype, device=("cpu" if self.via_host else device)) if (self.dist and rank == 0) else None
         self.gathered = [self.received[r] for r in range(world)] if self.received is not None else None
         self.comm = torch.cuda.Stream(device=device) if (self.cuda and self.dist) else None
         self._gather_done = [None, None]      # per buffer: event after its last gather (GPU only)
@@ -76,7 +81,16 @@ class ShardedRunner:
         if after is not None:
             after()
         if self.dist and self.gather:
-            if self.cuda:
+            if self.via_host:
+                ready = torch.cuda.Event()
+                ready.record()
+                with torch.cuda.stream(self.comm):
+                    self.comm.wait_event(ready)
+                    self.host_outs[i].copy_(out, non_blocking=True)
+                    fin = torch.cuda.Event(); fin.record()
+                fin.synchronize()
+                dist.gather(self.host_outs[i], self.gathered, dst=0, group=self.group)
+            elif self.cuda:
                 ready = torch.cuda.Event()
                 ready.record()
                 with torch.cuda.stream(self.comm):
@@ -95,7 +109,7 @@ class ShardedRunner:
 
     def gather_ms(self, last: int):
         """Side-stream durations (ms) of the last `last` gathers (GPU only; call after fence())."""
-        return [a.elapsed_time(b) for a, b in list(self._gather_events)[-last:]] if (self.cuda and last) else []
+        return [a.elapsed_time(b) for a, b in list(self._gather_events)[-last:]] if (self.cuda and last and not self.via_host) else []
 
     def fence(self):
         """Everything enqueued so far has finished on every rank."""

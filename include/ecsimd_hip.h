@@ -76,8 +76,8 @@ enum {
                                       2^256-n (there the reference returns a meaningless point, these paths the right
                                       one); k = 0 mod n -> (0, 0).  NOT for secret scalars: table reads (LDS for the fixed
                                       base, device memory for the per-element tables) are indexed by scalar digits */
-  ECSIMD_HIP_ALG_WINDOWED_SIGNED = 8, /* as ALG_WINDOWED with signed 7-bit windows: 37 mixed additions instead of 64, a 148 KiB
-                                      table of m*2^(7i)*G (m = 1..64) in LDS, negative digits negate y; same results.
+  ECSIMD_HIP_ALG_WINDOWED_SIGNED = 8, /* as ALG_WINDOWED with signed 7-bit windows: 36 mixed additions instead of 63, a 148 KiB
+                                      table of the odd multiples (2d+1)*2^(7i)*G (d = 0..63) in LDS, negative digits negate y; same results.
                                       NOT for secret scalars (LDS reads indexed by scalar digits) */
   ECSIMD_HIP_ALG_NO_ENDOMORPHISM = 16, /* secp256k1 + ALG_WINDOWED on a variable base splits k = k1 + k2*lambda (GLV) and runs
                                       half as many windows; this flag keeps the plain odd-digit loop of 63 windows (same results);

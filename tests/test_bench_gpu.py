@@ -32,3 +32,28 @@ def test_group_mode_matches_the_plain_line_at_one_gpu():
     for d in (plain, group):
         assert d["n_gpus"] == 1 and d["steps"] == 8 and d["roofline"]["traffic"] is not None and "parity_failures" not in d
         assert 0.6 < d["roofline"]["frac"] < 0.85
+
+
+def test_two_ranks_rehearsed_on_one_gpu():
+    """`python bench.py --gpus 2` as the driver may start it (no torch.distributed.run around it): the launcher starts two
+    ranks; with ECSIMD_BENCH_REHEARSE_ONE_GPU=1 both use cuda:0 and gather over gloo (RCCL refuses two ranks on one device),
+    so everything an N > 1 run does except RCCL itself executes on this one-GPU box: the strong-scaling shard plan, rank 1's
+    shard arriving at rank 0 and being checked against rank 0's own ladder, the device-group leg in a child process (two
+    members on one device) while the ranks wait on the host group, one JSON line, exit code 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["ECSIMD_BENCH_REHEARSE_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--global-log2-batch", "21", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and "rehearsal" in d and "parity_failures" not in d
+    assert d["config"]["global_batch"] == 1 << 21 and d["config"]["per_gpu_batch"] == 1 << 20 and d["config"]["parallelism"] == "shard2+rccl_gather"
+    g = d["config"]["gather"]
+    assert g["sample_check"] == {"lanes_per_rank": 1024, "ranks_checked": 1, "ranks_differing": []}
+    assert g["bytes_per_rank_per_step"] == 3 * (1 << 20) * 32 and g["value_compute_only"] > 0
+    mg = d["multi_group"]
+    assert mg["ok"] is True, mg
+    assert mg["parity"] == {"gathered_equals_each_members_own_ladder": True, "members": 2}
+    assert d["roofline"]["frac"] > 0.2            # two ranks share the card: each ladder runs at about half rate
