@@ -26,6 +26,9 @@ fresh child process, relays rank 0's one JSON line and exits with the child's co
 per device, ncclCommInitAll communicators, the result shards gathered to device 0 by grouped ncclSend / ncclRecv).  In
 the one-process-per-GPU mode with N > 1, rank 0 also runs that mode once in a child process after the timed loops
 (`multi_group` in the line; --no-group-check skips it) so that a multi-GPU node measures both.
+ECSIMD_BENCH_REHEARSE_ONE_GPU=1 (a one-GPU box): N ranks share cuda:0 and gather over gloo through pinned host memory, the
+group leg puts N members on the one device -- an N > 1 run's control flow on hardware, RCCL excepted (it refuses two ranks
+per device); the line says `rehearsal` and its value is no scaling result.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : integer-VALU bound.  achieved = scalar-mults/s x 555 968 mad32 (SURVEY.md 8(d):
