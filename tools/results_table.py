@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORDER = ["ladder", "ladder_secp256k1", "ladder_ref_compat_p256", "ladder_ref_compat_secp256k1", "ladder_x_only", "ladder_x_only_secp256k1",
-         "windowed_variable_base", "windowed_variable_base_secp256k1", "fixed_base", "fixed_base_secp256k1", "fixed_base_signed7", "fixed_base_big20",
+         "windowed_variable_base", "windowed_variable_base_secp256k1", "fixed_base", "fixed_base_secp256k1", "fixed_base_signed7", "fixed_base_signed7_secp256k1", "fixed_base_big20",
          "group_mode", "nccl_single_rank_rehearsal"]
 LABEL = {
     "ladder": "**P-256 variable-base ladder, 2²⁴ per step (headline, BASELINE configs[3])**",
@@ -28,6 +28,7 @@ LABEL = {
     "fixed_base": "P-256 fixed base, 4-bit windows in LDS (configs[2])",
     "fixed_base_secp256k1": "secp256k1 fixed base, 4-bit windows in LDS",
     "fixed_base_signed7": "P-256 fixed base, signed 7-bit windows in LDS (`ALG_WINDOWED_SIGNED`)",
+    "fixed_base_signed7_secp256k1": "secp256k1 fixed base, signed 7-bit windows in LDS",
     "fixed_base_big20": "P-256 fixed base, 20-bit windows, 436 MB table in device memory (`ALG_WINDOWED_BIG`)",
     "group_mode": "the headline through the C ABI's device group (`--multi group`, one member)",
     "nccl_single_rank_rehearsal": "the headline through the N > 1 code path on one rank (RCCL gather on a side stream)",
