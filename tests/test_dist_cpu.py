@@ -97,7 +97,7 @@ def _worker(rank, world, port, n_per_rank, steps, q):
         assert (first, count) == (rank * n_per_rank, n_per_rank)
         c = CURVE_PARAMS[P256]
         gx, gy = ints_to_arr([c["gx"]] * count), ints_to_arr([c["gy"]] * count)
-        runner = ShardedRunner((3, count, 4), torch.int64, "cpu", world, rank)
+        runner = ShardedRunner((3, count, 4), torch.int64, "cpu", world, rank, via_host=True)   # host staging is a GPU-rehearsal detail: ignored for CPU tensors
         for s in range(steps):
             k = fill_random_np(count, SEED, 1 + s, first_index=first)          # a different stream per step
 
