@@ -83,3 +83,49 @@ def test_batches_beyond_4_gib_per_array(engine):
     assert torch.equal(w[0], aff[0]) and torch.equal(w[1], aff[1]), "the window tables and the ladder disagree somewhere in 2^27 + 3 lanes"
     del w, aff, k, bx, by
     torch.cuda.empty_cache()
+
+
+def test_one_context_per_host_thread(engine):
+    """SURVEY.md 8(b) "Threading": a context is not thread-safe, the rule is one context per host thread -- so four host threads, each
+    with its OWN context and stream on the same GPU, run different workloads at the same time (ctypes releases the GIL inside a call;
+    every thread builds its own window tables and grows its own workspace) and each gets what the session's context computes for the
+    same inputs afterwards, alone.  Fails if the library keeps anything mutable outside its contexts."""
+    import threading
+    from ecsimd_amd import Engine
+    n, rounds = 1 << 16, 3
+    results, errors = {}, []
+
+    def work(t):
+        try:
+            cv = (P256, SECP256K1)[t & 1]
+            e = Engine(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                out = []
+                for r in range(rounds):
+                    k = e.fill_random(n, SEED + t, 1 + r); s = e.fill_random(n, SEED + t, 20 + r)
+                    alg = (ALG_WINDOWED_BIG, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED)[(t + r) & 3]
+                    bx, by = e.scalar_mult_base(cv, s, flags=OUT_AFFINE | alg)
+                    J = e.scalar_mult(cv, k, bx, by)
+                    w = e.scalar_mult(cv, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)
+                    out.append([x.clone() for x in (bx, by) + tuple(J) + tuple(w)])
+                e.sync()
+                torch.cuda.current_stream().synchronize()
+            results[t] = (cv, out)
+            e.close()
+        except Exception as exc:                       # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    e = engine
+    for t, (cv, out) in results.items():
+        for r in range(rounds):
+            k = e.fill_random(n, SEED + t, 1 + r); s = e.fill_random(n, SEED + t, 20 + r)
+            bx, by = e.scalar_mult_base(cv, s, flags=OUT_AFFINE | ALG_WINDOWED_BIG)
+            exp = (bx, by) + tuple(e.scalar_mult(cv, k, bx, by)) + tuple(e.scalar_mult(cv, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED))
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(out[r], exp)), f"thread {t}, round {r}: a context running beside three others computed something else"
