@@ -76,12 +76,13 @@ def parse_args(argv=None):
     ap.add_argument("--global-log2-batch", type=int, default=24, help="strong scaling: scalar mults per step over ALL GPUs = 2^this")
     ap.add_argument("--log2-batch", type=int, default=22, help="weak scaling: scalar mults per GPU per step = 2^this")
     ap.add_argument("--curve", default="p256", choices=["p256", "secp256k1"])
-    ap.add_argument("--workload", default="ladder", choices=["ladder", "ladder-ref-compat", "ladder-x", "windowed", "fixed-base", "fixed-base-signed", "fixed-base-big"],
+    ap.add_argument("--workload", default="ladder", choices=["ladder", "ladder-ref-compat", "ladder-x", "windowed", "fixed-base", "fixed-base-ct", "fixed-base-signed", "fixed-base-big"],
                     help="ladder: scalar_mult_p256 variable base, the reference's co-Z ladder, Jacobian out (headline, BASELINE configs[3]); "
                          "ladder-ref-compat: the same with ECSIMD_HIP_REF_SQUARE_COMPAT (the reference's square() as written, dropped carry included); "
                          "ladder-x: x(k*P) only, the constant-time ladder without its Z coordinate (P-256; ECDH's shared secret; affine-level parity); "
                          "windowed: variable base with per-element tables of 8 multiples of P and signed 4-bit windows, affine out (ALG_WINDOWED; affine-level parity); "
                          "fixed-base: k*G with the 4-bit-window LDS table + simultaneous inversion, affine out (BASELINE configs[2]); "
+                         "fixed-base-ct: the same kernel with ALG_CONSTANT_TIME (every table entry read, kept under lane masks: safe for secret scalars); "
                          "fixed-base-signed: the same with signed 7-bit windows (36 additions instead of 63); "
                          "fixed-base-big: 20-bit windows (odd digits) over a 436 MB table in device memory (12 additions)")
     ap.add_argument("--multi", default="procs", choices=["procs", "group"],
@@ -159,7 +160,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from ecsimd_amd import Engine, CURVES, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG, REF_SQUARE_COMPAT
+    from ecsimd_amd import Engine, CURVES, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG, ALG_CONSTANT_TIME, REF_SQUARE_COMPAT
     from ecsimd_amd.shard import ShardedRunner, plan
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -227,7 +228,8 @@ def main():
             eng.scalar_mult(curve, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED, out=view(o))
         compute([eng.empty(rows) for _ in range(3)])        # sizes the context workspace (1 408 B per element)
     else:
-        alg = {"fixed-base": ALG_WINDOWED, "fixed-base-signed": ALG_WINDOWED_SIGNED, "fixed-base-big": ALG_WINDOWED_BIG}[args.workload]
+        alg = {"fixed-base": ALG_WINDOWED, "fixed-base-ct": ALG_WINDOWED | ALG_CONSTANT_TIME, "fixed-base-signed": ALG_WINDOWED_SIGNED,
+               "fixed-base-big": ALG_WINDOWED_BIG}[args.workload]
 
         def compute(o):                                     # affine (x, y); o[2] is unused
             eng.scalar_mult_base(curve, k, flags=OUT_AFFINE | alg, out=view(o))
@@ -331,7 +333,9 @@ def base_line(args, world, total_units, n, value, elapsed):
         "windowed": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 multiples of P) + signed 4-bit windows + simultaneous "
                     f"inversion{' + GLV split k = k1 + k2*lambda' if args.curve == 'secp256k1' else ''}, batch {sizes}, affine out",
     }
-    fixed = {"fixed-base": "4-bit window table in LDS (odd digits, 32 KiB)", "fixed-base-signed": "signed 7-bit window table in LDS (odd digits, 148 KiB)",
+    fixed = {"fixed-base": "4-bit window table in LDS (odd digits, 32 KiB)",
+             "fixed-base-ct": "4-bit window table in LDS (odd digits, 32 KiB), ALG_CONSTANT_TIME: all 8 entries of a window read, one kept under lane masks",
+             "fixed-base-signed": "signed 7-bit window table in LDS (odd digits, 148 KiB)",
              "fixed-base-big": "20-bit window table of odd multiples (436 MB) in device memory"}
     return {
         "metric": "P-256 scalar mults/sec (batched)" if args.curve == "p256" else "secp256k1 scalar mults/sec (batched)",
@@ -375,10 +379,10 @@ def roofline_object(args, eng, n, avg_ms):
     else:
         # what THIS algorithm needs per scalar: 63 / 36 / 12 mixed additions x 11 field mults,
         # 7 mults of the simultaneous-inversion walk and 267/m (secp256k1: 270/m) of the inversion m = min(128, n / 2^17) points share; 32 B in, 64 B out.
-        adds = {"fixed-base": 63, "fixed-base-signed": 36, "fixed-base-big": 12}[args.workload]      # odd digits everywhere: the first entry starts the sum (round 3)
+        adds = {"fixed-base": 63, "fixed-base-ct": 63, "fixed-base-signed": 36, "fixed-base-big": 12}[args.workload]      # odd digits everywhere: the first entry starts the sum (round 3)
         share = min(128, max(1, n >> 17))
         mad32_unit, bytes_unit = int((adds * 11 + 7 + (267 if args.curve == "p256" else 270) / share) * 136), 96
-        kname = {63: "k_base_windowed", 36: "k_base_windowed_s<7>", 12: "k_base_windowed_g"}[adds] + " + k_to_affine_batched"
+        kname = ("k_base_windowed<true>" if args.workload == "fixed-base-ct" else {63: "k_base_windowed<false>", 36: "k_base_windowed_s<7>", 12: "k_base_windowed_g"}[adds]) + " + k_to_affine_batched"
     achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
     traffic, traffic_src = committed_traffic(args, n)
     return {
@@ -551,7 +555,7 @@ def committed_traffic(args, n):
     except ValueError:
         return None, None
     key = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult_refsqr", "ladder-x": "k_scalar_mult_x", "windowed": "varwin",
-           "fixed-base": "fixed_base", "fixed-base-signed": "fixed_base_signed", "fixed-base-big": "fixed_base_big"}[args.workload]
+           "fixed-base": "fixed_base", "fixed-base-ct": "fixed_base", "fixed-base-signed": "fixed_base_signed", "fixed-base-big": "fixed_base_big"}[args.workload]
     for log2 in (24, 22):                                 # a pass at this run's own launch size first
         per = table.get(f"{key}_{args.curve}_2^{log2}")
         if per is not None:

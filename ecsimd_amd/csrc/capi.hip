@@ -53,7 +53,7 @@ void base_windowed_signed(hipStream_t s, int curve, int wbits, const uint64_t* k
 void inverse_batched(hipStream_t s, int curve, const uint64_t* a, uint64_t* out, size_t n) { DISPATCH2(inverse_batched, s, a, out, n); }
 void x_mod_n_equals(hipStream_t s, int curve, const uint64_t* x, const uint8_t* finite, const uint64_t* r, uint8_t* ok, size_t n) { DISPATCH2(x_mod_n_equals, s, x, finite, r, ok, n); }
 void affine_add_batched(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) { DISPATCH2(affine_add_batched, s, ax, ay, bx, by, rx, ry, finite, n); }
-void base_windowed(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH2(base_windowed, s, k, table, ox, oy, oz, n); }
+void base_windowed(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, bool constant_time) { DISPATCH2(base_windowed, s, k, table, ox, oy, oz, n, constant_time); }
 void pack_table_big(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH2(pack_table_big, s, tx, ty, table); }
 void base_windowed_big(hipStream_t s, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH2(base_windowed_big, s, k, table, ox, oy, oz, n); }
 void add_mixed_complete(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH2(add_mixed_complete, s, ax, ay, az, bx, by, rx, ry, rz, n); }
@@ -556,6 +556,7 @@ int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, co
     // per-lane window tables (8 multiples of P) in HBM + signed 4-bit windows (k_varwin.inc): a different algorithm from
     // the reference ladder, so affine output only (SURVEY.md 8(a) level A)
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
+    if (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) return bad(ctx, "ALG_CONSTANT_TIME is a fixed-base option (scalar_mult_base + ALG_WINDOWED); a variable base has the ladder");
     NO_COMPAT("ALG_WINDOWED");
     return run_varwin(ctx, curve, k, 4, x, y, ox, oy, n, flags, 0);
   }
@@ -570,6 +571,7 @@ int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[
   store_words(ctx->stream, w, kdev);
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED)) {
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
+    if (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) return bad(ctx, "ALG_CONSTANT_TIME is a fixed-base option (scalar_mult_base + ALG_WINDOWED); a variable base has the ladder");
     NO_COMPAT("ALG_WINDOWED");
     return run_varwin(ctx, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, n, flags, 0);
   }
@@ -583,6 +585,8 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* 
     // windows over a precomputed table, then one simultaneous inversion: affine output only
     // (the Jacobian representative differs from the reference ladder's -- SURVEY.md 8(a) level A).
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
+    const bool ct = (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) != 0;
+    if (ct && (big || six)) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED (the 4-bit table in LDS) only");
     NO_COMPAT("ALG_WINDOWED");
     if (n == 0) return ECSIMD_HIP_OK;
     (void)hipSetDevice(ctx->device);
@@ -592,9 +596,10 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* 
     uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
     RUN(((big ? launch::base_windowed_big(s, curve, k, ctx->window16_table[curve], jx, jy, jz, n)
           : six ? launch::base_windowed_signed(s, curve, SIGNED_WBITS, k, ctx->window6_table[curve], jx, jy, jz, n)
-                : launch::base_windowed(s, curve, k, ctx->window_table[curve], jx, jy, jz, n)),
+                : launch::base_windowed(s, curve, k, ctx->window_table[curve], jx, jy, jz, n, ct)),
          launch::to_affine_batched(s, curve, jx, jy, jz, ox, oy, n, true)));
   }
+  if (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED (the ladder is constant-time as it is)");
   return run_ladder(ctx, curve, k, 4, nullptr, nullptr, ox, oy, oz, n, flags); }
 int ecsimd_hip_affine_add(ecsimd_hip_ctx* ctx, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by,
                           uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) {

@@ -69,7 +69,7 @@ void inverse_batched(hipStream_t, int curve, const uint64_t* a, uint64_t* out, s
 void x_mod_n_equals(hipStream_t, int curve, const uint64_t* x, const uint8_t* finite, const uint64_t* r, uint8_t* ok, size_t n);
 void affine_add_batched(hipStream_t, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
 void pack_table(hipStream_t, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
-void base_windowed(hipStream_t, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
+void base_windowed(hipStream_t, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, bool constant_time);
 // signed windows of wbits = 6 or 7 bits
 void pack_table_signed(hipStream_t, int curve, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
 void base_windowed_signed(hipStream_t, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
@@ -111,7 +111,7 @@ template <int C> struct point_launch {
   static void x_mod_n_equals(hipStream_t, const uint64_t* x, const uint8_t* finite, const uint64_t* r, uint8_t* ok, size_t n);
   static void affine_add_batched(hipStream_t, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
   static void pack_table(hipStream_t, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
-  static void base_windowed(hipStream_t, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
+  static void base_windowed(hipStream_t, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, bool constant_time);
   static void pack_table_signed(hipStream_t, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
   static void base_windowed_signed(hipStream_t, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
   static void pack_table_big(hipStream_t, const uint64_t* tx, const uint64_t* ty, uint32_t* table);

@@ -8,4 +8,5 @@ ALG_WINDOWED_SIGNED = 8
 ALG_NO_ENDOMORPHISM = 16
 ALG_WINDOWED_BIG = 32
 REF_SQUARE_COMPAT = 64
+ALG_CONSTANT_TIME = 128       # scalar_mult_base + ALG_WINDOWED: every table entry read, the wanted one kept under lane masks
 GROUP_NO_GATHER = 0x10000    # ecsimd_hip_group_scalar_mult only: compute without the exchange

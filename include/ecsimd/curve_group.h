@@ -90,6 +90,14 @@ struct curve_group {
                                            ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_ALG_WINDOWED_BIG), "ecsimd_hip_scalar_mult_base");
     return r;
   }
+  // k[i] * G for SECRET scalars (key generation, ECDSA nonces): the 4-bit LDS comb with ECSIMD_HIP_ALG_CONSTANT_TIME -- every table entry
+  // read, the wanted one kept under lane masks, no address or branch formed from the scalar; ~5.8 x the ladder on G.  Affine classical.
+  static WCP scalar_mult_base_affine_secret(WBN const& x) {
+    WCP r{WBN::uninitialized(x.size()), WBN::uninitialized(x.size())};
+    hip::check(ecsimd_hip_scalar_mult_base(hip::context(), curve_id, x.data(), r.x().data(), r.y().data(), nullptr, x.size(),
+                                           ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_CONSTANT_TIME), "ecsimd_hip_scalar_mult_base");
+    return r;
+  }
   // u1[i] * G + u2[i] * Q[i] (the ECDSA-verification shape), affine classical; finite[i] is false where the sum
   // is the point at infinity (coordinates (0, 0)).
   static WCP double_scalar_mult(WBN const& u1, WBN const& u2, WCP const& Q, hip::mask& finite) {

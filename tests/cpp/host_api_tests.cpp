@@ -342,6 +342,7 @@ template <class K> static void windowed_paths_agree() {
   W256 s(n, [](size_t i, size_t) { bignum_256 b; b.limbs = {i + 1, i * i, 0x0123456789abcdefull * (i + 7), 0x7000000000000000ull ^ (i << 9)}; return b; });
   const auto P = KG::scalar_mult(s, KG::WJG(n)).to_affine();                                   // lane-distinct points (ladder)
   EXPECT_TRUE(all(KG::scalar_mult_base_affine(s) == P));
+  EXPECT_TRUE(all(KG::scalar_mult_base_affine_secret(s) == P));                               // the constant-time comb: same points
   const auto ladder = KG::scalar_mult_affine(k, P, false);
   EXPECT_TRUE(all(ladder == KG::scalar_mult(k, wide_jacobian_curve_point<K>::from_affine(P)).to_affine()));
   EXPECT_TRUE(all(KG::scalar_mult_affine(k, P) == ladder));

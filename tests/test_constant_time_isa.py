@@ -94,3 +94,25 @@ def test_the_checker_refuses_planted_leaks(p256_asm):
     mutated = "\n".join(lines[:ld] + [f"\tv_add_u32_e32 v{addr}, v{addr}, v20"] + lines[ld:])
     with pytest.raises(ct_check.Violation):
         ct_check.check(mutated, "13k_scalar_multE")
+
+
+# ---- the constant-time fixed-base kernel (ECSIMD_HIP_ALG_CONSTANT_TIME: scalar_mult_base + ALG_WINDOWED)
+@pytest.fixture(scope="module", params=["k_affine_p256", "k_affine_secp256k1"])
+def affine_asm(request, tmp_path_factory):
+    return assembly(tmp_path_factory, request.param)
+
+
+def test_constant_time_fixed_base_kernel_reads_every_entry_and_branches_on_nothing(affine_asm):
+    """k_base_windowed<true>: the window loop has ONE branch (the window counter), no global access, and its 32 LDS reads -- all 8
+    entries of the window -- are addressed by loop-invariant registers and the counter; around the loop (first window, the
+    exceptional scalar k*, k = 0 mod n) nothing branches on a lane mask once the scalar has been loaded."""
+    rep = ct_check.check(affine_asm, "15k_base_windowedILb1E", allow_global_loads=0, allow_lds_reads=True)
+    assert rep["instructions"] > 2000 and rep["lds_reads"] == 32 and rep["scratch"] == 0 and rep["global_loads"] == []
+    assert len(rep["branches"]) == 1 and re.match(r"s_cmpk?_(lg|eq)_[iu]32 s\d+, \S+ ; s_cbranch_scc[01] ", rep["branches"][0]), rep["branches"]
+    assert ct_check.check_after_secret_load(affine_asm, "15k_base_windowedILb1E") > 2500
+
+
+def test_the_checker_refuses_the_table_lookup_by_digit(affine_asm):
+    """The default kernel reads ONE entry per window at an address made of scalar digits: the same check must refuse it."""
+    with pytest.raises(ct_check.Violation, match="LDS address"):
+        ct_check.check(affine_asm, "15k_base_windowedILb0E", allow_global_loads=0, allow_lds_reads=True)

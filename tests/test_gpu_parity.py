@@ -11,7 +11,7 @@ import pytest
 from helpers import (CURVE_PARAMS, CURVE_NAMES, P256, SECP256K1, SEED, hexes_to_arr, arr_to_hexes, from_int, to_int, ints_to_arr,
                      arr_to_ints, from_hex, fill_random_np, ec_mul, ec_add, jacobian_mgry_to_affine_int)
 from test_oracle import run_against_golden, structured_words
-from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG, REF_SQUARE_COMPAT, GROUP_NO_GATHER, EcsimdHipError
+from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG, ALG_CONSTANT_TIME, REF_SQUARE_COMPAT, GROUP_NO_GATHER, EcsimdHipError
 
 pytestmark = pytest.mark.gpu
 CURVES = [P256, SECP256K1]
@@ -446,6 +446,38 @@ def comb_exceptional_scalars(cv):
 
 
 @pytest.mark.parametrize("cv", CURVES)
+def test_constant_time_fixed_base(engine, oracle, cv):
+    """ECSIMD_HIP_ALG_CONSTANT_TIME (scalar_mult_base + ALG_WINDOWED): the same 4-bit comb reading every table entry under lane masks.
+    Same (x, y) as the default kernel on 2^18 random scalars, on k = 0, n, 1, n - 1 and ragged lengths; a sample against the oracle's
+    ladder; x only; and the flag is refused wherever it would promise something the kernel behind it does not do."""
+    import torch
+    c = CURVE_PARAMS[cv]; order = c["n"]
+    n = (1 << 18) + 37
+    k = engine.fill_random(n, SEED, 61)
+    edge = engine.to_device(ints_to_arr([0, order, 1, order - 1, 2, order + 1, 2**256 - 1, order - 2]))
+    k[:8] = edge
+    ct = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME)
+    pl = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | ALG_WINDOWED)
+    assert torch.equal(ct[0], pl[0]) and torch.equal(ct[1], pl[1])
+    assert not ct[0][:2].any() and not ct[1][:2].any()                        # k = 0 mod n: (0, 0)
+    m = 2048
+    kk = engine.to_numpy(k[8:8 + m])
+    gx, gy = ints_to_arr([c["gx"]] * m), ints_to_arr([c["gy"]] * m)
+    ex, ey = oracle.to_affine(cv, oracle.scalar_mult(cv, kk, gx, gy, threads=THREADS))
+    assert np.array_equal(engine.to_numpy(ct[0][8:8 + m]), ex) and np.array_equal(engine.to_numpy(ct[1][8:8 + m]), ey)
+    xo = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME, x_only=True)
+    assert torch.equal(xo[0], ct[0])
+    for n_small in (1, 63, 65, 257):
+        a = engine.scalar_mult_base(cv, k[:n_small].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME)
+        assert torch.equal(a[0], ct[0][:n_small]) and torch.equal(a[1], ct[1][:n_small])
+    for flags in (OUT_AFFINE | ALG_WINDOWED_SIGNED | ALG_CONSTANT_TIME, OUT_AFFINE | ALG_WINDOWED_BIG | ALG_CONSTANT_TIME, OUT_AFFINE | ALG_CONSTANT_TIME):
+        with pytest.raises(EcsimdHipError, match="ALG_CONSTANT_TIME"):
+            engine.scalar_mult_base(cv, k[:64].contiguous(), flags=flags)
+    with pytest.raises(EcsimdHipError, match="ALG_CONSTANT_TIME"):
+        engine.scalar_mult(cv, k[:64].contiguous(), ct[0][:64].contiguous(), ct[1][:64].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME)
+
+
+@pytest.mark.parametrize("cv", CURVES)
 def test_comb_kernels_on_their_exceptional_scalars(engine, cv):
     """Round 3 found k = 2 wrong in the odd-digit 4-bit kernel on P-256 (R = T at its last addition) and, by the same argument, k = +-(n - 2
     (n mod 2^240)) wrong in the 20-bit kernel on BOTH curves since round 1 -- scalars no random test meets.  The kernels now substitute
@@ -463,7 +495,8 @@ def test_comb_kernels_on_their_exceptional_scalars(engine, cv):
     degenerate = {order - 1, 2**256 - order - 1, 2**256 - order}
     lx, ly = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE)
     assert all(torch.equal(lx[i], ex_[i]) and torch.equal(ly[i], ey_[i]) for i in range(len(ks)) if ks[i] not in degenerate), "ladder"
-    for alg, name in ((ALG_WINDOWED, "4-bit LDS table"), (ALG_WINDOWED_SIGNED, "signed 7-bit LDS table"), (ALG_WINDOWED_BIG, "20-bit table")):
+    for alg, name in ((ALG_WINDOWED, "4-bit LDS table"), (ALG_WINDOWED | ALG_CONSTANT_TIME, "4-bit LDS table, constant time"),
+                      (ALG_WINDOWED_SIGNED, "signed 7-bit LDS table"), (ALG_WINDOWED_BIG, "20-bit table")):
         wx, wy = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | alg)
         bad = [hex(ks[i]) for i in range(len(ks)) if not (torch.equal(wx[i], ex_[i]) and torch.equal(wy[i], ey_[i]))]
         assert not bad, (name, bad)

@@ -95,7 +95,9 @@ def dest_count(op):
     return 1
 
 
-def check(text, want, allow_global_loads=1):
+def check(text, want, allow_global_loads=1, allow_lds_reads=False):
+    """allow_lds_reads (the constant-time fixed-base kernel): ds_read_* may appear in the loop when its address register is, like
+    the scalar-word reload's, made of loop-invariant registers and clean scalars only -- every lane reads the SAME table entries."""
     blocks = parse_function(text, want)
     # the bit loop = the loop with the most instructions
     sizes = {}
@@ -107,7 +109,7 @@ def check(text, want, allow_global_loads=1):
     header = max(sizes, key=sizes.get)
     loop = [(lab, insts) for lab, hdr, insts in blocks if hdr == header]
     flat = [i for _, insts in loop for i in insts]
-    report = {"kernel": want, "loop_header": header, "instructions": len(flat), "branches": [], "global_loads": [], "scratch": 0}
+    report = {"kernel": want, "loop_header": header, "instructions": len(flat), "branches": [], "global_loads": [], "scratch": 0, "lds_reads": 0}
 
     # ---- clean scalars: fixpoint over the whole loop (flow-insensitive part)
     written_by_valu, scalar_writes = set(), {}
@@ -184,6 +186,13 @@ def check(text, want, allow_global_loads=1):
     for lab, insts in loop:
         for idx, inst in enumerate(insts):
             op, ops = split_ops(inst)
+            if allow_lds_reads and op.startswith("ds_read"):
+                addr = ops[1].split()[0]
+                for r in regs_of(addr):
+                    if not clean_vector_at(insts, idx, r):
+                        raise Violation(f"{lab}: the LDS address {addr} of `{inst}` is not made of loop-invariant registers and the window counter")
+                report["lds_reads"] += 1
+                continue
             if re.match(r"^(v_readfirstlane|v_readlane|v_writelane|v_permlane|ds_|buffer_|flat_|global_store|global_atomic|s_setpc|s_swappc|s_call|s_cbranch_vcc|s_cbranch_exec|s_cbranch_cd|s_cbranch_g_fork|s_cbranch_i_fork|s_cbranch_join)", op):
                 raise Violation(f"{lab}: `{inst}` is not allowed in the bit loop")
             if op.startswith("s_cbranch_scc"):
@@ -220,6 +229,24 @@ def check(text, want, allow_global_loads=1):
     if len(report["global_loads"]) > allow_global_loads:
         raise Violation(f"{len(report['global_loads'])} global loads in the bit loop, expected at most {allow_global_loads}: {report['global_loads']}")
     return report
+
+
+def check_after_secret_load(text, want):
+    """The parts of a kernel AROUND its loop (the first window, the exceptional scalar, k = 0): after the first global load that
+    follows the workgroup barrier -- the scalar -- no instruction of the function may branch on a lane mask (s_cbranch_vcc* /
+    s_cbranch_exec*), move a lane's value to the scalar unit (v_readfirstlane / v_readlane / v_permlane) or write LDS; every
+    s_cbranch_scc* left is the loop's own (check() looks at those).  Returns the number of instructions looked at."""
+    flat = [i for _, _, insts in parse_function(text, want) for i in insts]
+    try:
+        bar = next(k for k, i in enumerate(flat) if i.startswith("s_barrier"))
+        first = next(k for k in range(bar, len(flat)) if flat[k].startswith("global_load"))
+    except StopIteration:
+        raise Violation("no barrier followed by a global load: not the kernel shape this check is for")
+    for inst in flat[first:]:
+        op = inst.split()[0]
+        if re.match(r"^(s_cbranch_vcc|s_cbranch_exec|v_readfirstlane|v_readlane|v_writelane|v_permlane|ds_write|ds_bpermute|ds_permute|ds_swizzle|global_atomic|s_setpc|s_swappc|s_call)", op):
+            raise Violation(f"`{inst}` after the scalar has been loaded")
+    return len(flat) - first
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORDER = ["ladder", "ladder_secp256k1", "ladder_ref_compat_p256", "ladder_ref_compat_secp256k1", "ladder_x_only", "ladder_x_only_secp256k1",
-         "windowed_variable_base", "windowed_variable_base_secp256k1", "fixed_base", "fixed_base_secp256k1", "fixed_base_signed7", "fixed_base_signed7_secp256k1", "fixed_base_big20",
+         "windowed_variable_base", "windowed_variable_base_secp256k1", "fixed_base", "fixed_base_secp256k1", "fixed_base_constant_time", "fixed_base_constant_time_secp256k1", "fixed_base_signed7", "fixed_base_signed7_secp256k1", "fixed_base_big20",
          "group_mode", "nccl_single_rank_rehearsal"]
 LABEL = {
     "ladder": "**P-256 variable-base ladder, 2²⁴ per step (headline, BASELINE configs[3])**",
@@ -27,6 +27,8 @@ LABEL = {
     "windowed_variable_base_secp256k1": "secp256k1 variable base, per-element tables + GLV split",
     "fixed_base": "P-256 fixed base, 4-bit windows in LDS (configs[2])",
     "fixed_base_secp256k1": "secp256k1 fixed base, 4-bit windows in LDS",
+    "fixed_base_constant_time": "P-256 fixed base, 4-bit windows in LDS, `ALG_CONSTANT_TIME` (every entry read, lane masks: secret scalars)",
+    "fixed_base_constant_time_secp256k1": "secp256k1 fixed base, 4-bit windows in LDS, `ALG_CONSTANT_TIME`",
     "fixed_base_signed7": "P-256 fixed base, signed 7-bit windows in LDS (`ALG_WINDOWED_SIGNED`)",
     "fixed_base_signed7_secp256k1": "secp256k1 fixed base, signed 7-bit windows in LDS",
     "fixed_base_big20": "P-256 fixed base, 20-bit windows, 436 MB table in device memory (`ALG_WINDOWED_BIG`)",
