@@ -49,7 +49,7 @@ void scalar_mult(hipStream_t s, int curve, const uint64_t* k, int k_stride, cons
 void to_affine_batched(hipStream_t s, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool in_fast) { DISPATCH2(to_affine_batched, s, jx, jy, jz, x, y, n, in_fast); }
 void pack_table(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH2(pack_table, s, tx, ty, table); }
 void pack_table_signed(hipStream_t s, int curve, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH2(pack_table_signed, s, wbits, tx, ty, table); }
-void base_windowed_signed(hipStream_t s, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) { DISPATCH2(base_windowed_signed, s, wbits, k, table, ox, oy, oz, n); }
+void base_windowed_signed(hipStream_t s, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, bool constant_time) { DISPATCH2(base_windowed_signed, s, wbits, k, table, ox, oy, oz, n, constant_time); }
 void inverse_batched(hipStream_t s, int curve, const uint64_t* a, uint64_t* out, size_t n) { DISPATCH2(inverse_batched, s, a, out, n); }
 void x_mod_n_equals(hipStream_t s, int curve, const uint64_t* x, const uint8_t* finite, const uint64_t* r, uint8_t* ok, size_t n) { DISPATCH2(x_mod_n_equals, s, x, finite, r, ok, n); }
 void affine_add_batched(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) { DISPATCH2(affine_add_batched, s, ax, ay, bx, by, rx, ry, finite, n); }
@@ -71,6 +71,7 @@ struct ecsimd_hip_ctx {
   int cus;
   uint32_t* sink;      // 4 KiB scratch: peak-probe sink [0, 1024) and the shared scalar at word 1024-8
   uint32_t* window_table[2];   // per curve: 64 x 16 affine multiples d*16^w*G (built on first use)
+  uint32_t* windowct_table[2]; // per curve: the 6-bit odd-digit table of the constant-time comb (CT_WBITS; 88 064 B of LDS)
   uint32_t* window6_table[2];  // per curve: signed-window table (SIGNED_WBITS bits): m * 2^(WB i) * G, m = 1..2^(WB-1)
   uint32_t* window16_table[2]; // per curve: signed BIG_WINDOW_BITS-bit windows in device memory (20 bits: 13 x 524 288 entries, 436 MB)
   uint64_t* workspace;         // grow-only scratch for the windowed path's Jacobian intermediates
@@ -150,9 +151,16 @@ int ensure_valid(ecsimd_hip_ctx* ctx, size_t bytes) {
 // Window tables, produced with the (parity-checked) ladder kernel itself.
 //   bits = 4: 64 x 8 entries (2d + 1) * 16^w * G (odd digits; 64 x 16 entries d * 16^w * G with -DECS_FIXED4_ODD=0);  bits = 6 / 7 (signed windows): 43 x 32 / 37 x 64
 //   entries m * 2^(bits i) * G, m = slot + 1.
+// ALG_CONSTANT_TIME reads EVERY entry of a window, so the best window is narrower than without it: on P-256 6 bits (43 windows x 32 entries, 42
+// additions, the signed kernel's template at WB = 6: 323.8 M/s) beat 4 bits (64 x 8, 63 additions: 280.7) and 7 bits (36 additions, 64 entries to read:
+// 294.1); on secp256k1 6 bits spill 19 registers and tie with 4 bits (279.5 against 277.1), which stay (profiles/r03/ab_constant_time_window_width.txt).
+#ifndef ECS_CT_SIX
+#define ECS_CT_SIX 1                // 0: the 4-bit constant-time comb on both curves
+#endif
+constexpr int CT_WBITS = 6;
 constexpr int SIGNED_WBITS = 7;     // 37 additions, 151 552 B of LDS (6 -> 43 additions, 88 064 B): measured faster
 int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
-  uint32_t** slot = (bits == 4) ? &ctx->window_table[curve] : (bits == launch::BIG_WINDOW_BITS) ? &ctx->window16_table[curve] : &ctx->window6_table[curve];
+  uint32_t** slot = (bits == 4) ? &ctx->window_table[curve] : (bits == launch::BIG_WINDOW_BITS) ? &ctx->window16_table[curve] : (bits == CT_WBITS) ? &ctx->windowct_table[curve] : &ctx->window6_table[curve];
   if (*slot) return ECSIMD_HIP_OK;
   const bool big = (bits == launch::BIG_WINDOW_BITS);        // odd multiples (2d + 1) * 2^(bits w) * G, ceil(256 / bits) windows, no carry window
   const bool odd4 = (bits == 4) && (launch::FIXED4_ENTRIES == 8);        // the 4-bit LDS table with odd digits (kernels.h ECS_FIXED4_ODD)
@@ -325,7 +333,7 @@ int ecsimd_hip_init(int device, ecsimd_hip_ctx** out) {
   ecsimd_hip_ctx* ctx = new (std::nothrow) ecsimd_hip_ctx();
   if (!ctx) return ECSIMD_HIP_ERR_HIP;
   ctx->device = device; ctx->cus = prop.multiProcessorCount; ctx->err[0] = 0; ctx->sink = nullptr;
-  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->window6_table[0] = ctx->window6_table[1] = nullptr; ctx->window16_table[0] = ctx->window16_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0; ctx->ref_square = 0; ctx->valid = nullptr; ctx->valid_bytes = 0;
+  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->window6_table[0] = ctx->window6_table[1] = nullptr; ctx->windowct_table[0] = ctx->windowct_table[1] = nullptr; ctx->window16_table[0] = ctx->window16_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0; ctx->ref_square = 0; ctx->valid = nullptr; ctx->valid_bytes = 0;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ECSIMD_HIP_ERR_HIP; }
   ctx->stream = ctx->own_stream;
   if (hipEventCreateWithFlags(&ctx->handoff, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ECSIMD_HIP_ERR_HIP; }
@@ -338,7 +346,7 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->sink);
-  (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->window16_table[0]); (void)hipFree(ctx->window16_table[1]); (void)hipFree(ctx->workspace); (void)hipFree(ctx->valid);
+  (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->windowct_table[0]); (void)hipFree(ctx->windowct_table[1]); (void)hipFree(ctx->window16_table[0]); (void)hipFree(ctx->window16_table[1]); (void)hipFree(ctx->workspace); (void)hipFree(ctx->valid);
   (void)hipEventDestroy(ctx->handoff);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -590,12 +598,14 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* 
     NO_COMPAT("ALG_WINDOWED");
     if (n == 0) return ECSIMD_HIP_OK;
     (void)hipSetDevice(ctx->device);
-    int rc = ensure_window_table(ctx, curve, big ? launch::BIG_WINDOW_BITS : six ? SIGNED_WBITS : 4);
+    const bool ct6 = ct && !six && ECS_CT_SIX && curve == ECSIMD_HIP_P256;    // the constant-time comb: 6-bit windows on P-256, 4-bit ones on secp256k1
+    int rc = ensure_window_table(ctx, curve, big ? launch::BIG_WINDOW_BITS : six ? SIGNED_WBITS : ct6 ? CT_WBITS : 4);
     if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 3 * n * 32);
     if (rc != ECSIMD_HIP_OK) return rc;
     uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
     RUN(((big ? launch::base_windowed_big(s, curve, k, ctx->window16_table[curve], jx, jy, jz, n)
-          : six ? launch::base_windowed_signed(s, curve, SIGNED_WBITS, k, ctx->window6_table[curve], jx, jy, jz, n)
+          : six ? launch::base_windowed_signed(s, curve, SIGNED_WBITS, k, ctx->window6_table[curve], jx, jy, jz, n, false)
+          : ct6 ? launch::base_windowed_signed(s, curve, CT_WBITS, k, ctx->windowct_table[curve], jx, jy, jz, n, true)
                 : launch::base_windowed(s, curve, k, ctx->window_table[curve], jx, jy, jz, n, ct)),
          launch::to_affine_batched(s, curve, jx, jy, jz, ox, oy, n, true)));
   }
@@ -633,7 +643,7 @@ int double_scalar_mult_impl(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, 
   for (size_t first = 0; first < n; first += chunk) {
     const size_t m = (n - first) < chunk ? (n - first) : chunk;
     if (big) launch::base_windowed_big(s, curve, u1 + 4 * first, ctx->window16_table[curve], jx, jy, jz, m);   // u1*G
-    else launch::base_windowed_signed(s, curve, SIGNED_WBITS, u1 + 4 * first, ctx->window6_table[curve], jx, jy, jz, m);
+    else launch::base_windowed_signed(s, curve, SIGNED_WBITS, u1 + 4 * first, ctx->window6_table[curve], jx, jy, jz, m, false);
     launch::to_affine_batched(s, curve, jx, jy, jz, gx, gy, m, true);
     launch::varwin_scalar_mult(s, curve, u2 + 4 * first, 4, qx + 4 * first, qy + 4 * first, ECSIMD_HIP_BASE_CLASSICAL, scratch, px, py, m);   // u2*Q
     launch::affine_add_batched(s, curve, gx, gy, px, py, rx + 4 * first, ry ? ry + 4 * first : nullptr, finite ? finite + first : nullptr, m);

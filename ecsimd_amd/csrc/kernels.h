@@ -72,7 +72,7 @@ void pack_table(hipStream_t, int curve, const uint64_t* tx, const uint64_t* ty, 
 void base_windowed(hipStream_t, int curve, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, bool constant_time);
 // signed windows of wbits = 6 or 7 bits
 void pack_table_signed(hipStream_t, int curve, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
-void base_windowed_signed(hipStream_t, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
+void base_windowed_signed(hipStream_t, int curve, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, bool constant_time);
 
 // k_varwin_<curve>.hip: variable-base multiplication with per-lane window tables of 8 multiples of P (affine out, classical).
 // scratch: varwin_scratch_bytes(n) bytes, 32-byte aligned; k_stride, x, y as for scalar_mult (flags: ECSIMD_HIP_BASE_*).
@@ -113,7 +113,7 @@ template <int C> struct point_launch {
   static void pack_table(hipStream_t, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
   static void base_windowed(hipStream_t, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, bool constant_time);
   static void pack_table_signed(hipStream_t, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
-  static void base_windowed_signed(hipStream_t, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
+  static void base_windowed_signed(hipStream_t, int wbits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, bool constant_time);
   static void pack_table_big(hipStream_t, const uint64_t* tx, const uint64_t* ty, uint32_t* table);
   static void base_windowed_big(hipStream_t, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
   // k_varwin_<curve>.hip

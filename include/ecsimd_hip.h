@@ -88,11 +88,13 @@ enum {
                                       context option below) the output is the reference's bits on EVERY input, at ~0.9x the speed;
                                       without it, it is the exact k*P (what the reference's own tests assume).  Same ladder, same
                                       constant-time shape: safe for secret scalars */
-  ECSIMD_HIP_ALG_CONSTANT_TIME = 128, /* scalar_mult_base + ALG_WINDOWED only (r3): the 4-bit LDS kernel reads ALL 8 entries of every window -- one
-                                      address per wave, an LDS broadcast -- and keeps its own under lane masks; the recoding has no zero digit, the
-                                      exceptional scalar and k = 0 mod n are handled by selects: no address and no branch depends on the scalar
-                                      (tools/ct_check.py checks the shipped ISA, tests/test_constant_time_isa.py).  SAFE for secret scalars:
-                                      k*G for key generation and ECDSA nonces at ~5.6x the ladder's rate (same results as ALG_WINDOWED) */
+  ECSIMD_HIP_ALG_CONSTANT_TIME = 128, /* scalar_mult_base + ALG_WINDOWED only (r3): an odd-digit comb over an LDS table whose lanes read ALL entries of
+                                      every window -- one address per wave, an LDS broadcast -- and keep their own under lane masks (P-256: 43 six-bit
+                                      windows x 32 entries, 42 additions; secp256k1: 64 four-bit windows x 8 entries, 63 additions).  The recoding has no
+                                      zero digit; the exceptional scalar and k = 0 mod n are handled by selects: no address and no branch depends on the
+                                      scalar (tools/ct_check.py checks the shipped ISA, tests/test_constant_time_isa.py).  SAFE for secret scalars: k*G
+                                      for key generation and ECDSA nonces at 6.7x (P-256) / 5.8x (secp256k1) the ladder's rate; same results as
+                                      ALG_WINDOWED */
   ECSIMD_HIP_ALG_WINDOWED_BIG = 32 /* scalar_mult_base + OUT_AFFINE: 20-bit windows with odd digits over a 436 MB table of the odd
                                       multiples (2d+1)*2^(20i)*G (13 windows x 2^19 entries) in device memory, built on first
                                       use (0.23 s per curve): 12 mixed additions per scalar; same results.  NOT for secret scalars:

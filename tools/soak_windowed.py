@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Soak run on the GPU alone: the three ways this library computes an affine k*P must agree lane for lane --
 the reference ladder (+ simultaneous inversion), the per-element-table windowed path (ALG_WINDOWED) and, for
-P = G, the three window-table kernels; and the x-only products (on P-256 the ladder without Z) must give the same x.  Different algorithms over the same field layer: a disagreement means a bug
+P = G, the three window-table kernels and the constant-time form of the 4-bit one; and the x-only products (on P-256 the ladder without Z) must give the same x.  Different algorithms over the same field layer: a disagreement means a bug
 in one of them.  Usage: soak_windowed.py [lanes_per_batch_log2=22] [batches=8]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
-from ecsimd_amd import Engine, P256, SECP256K1, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG
+from ecsimd_amd import Engine, P256, SECP256K1, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG, ALG_CONSTANT_TIME
 log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 batches = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 e = Engine(0); n = 1 << log2n
@@ -19,9 +19,10 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
         g4 = e.scalar_mult_base(cv, s, flags=OUT_AFFINE | ALG_WINDOWED)
         g7 = e.scalar_mult_base(cv, s, flags=OUT_AFFINE | ALG_WINDOWED_SIGNED)
         g16 = e.scalar_mult_base(cv, s, flags=OUT_AFFINE | ALG_WINDOWED_BIG)
+        gct = e.scalar_mult_base(cv, s, flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME)
         gl = e.scalar_mult_base(cv, s, flags=OUT_AFFINE)
         d_fixed = int(((g4[0] != gl[0]).any(dim=1) | (g4[1] != gl[1]).any(dim=1) | (g7[0] != gl[0]).any(dim=1) | (g7[1] != gl[1]).any(dim=1)
-                       | (g16[0] != gl[0]).any(dim=1) | (g16[1] != gl[1]).any(dim=1)).sum())
+                       | (g16[0] != gl[0]).any(dim=1) | (g16[1] != gl[1]).any(dim=1) | (gct[0] != gl[0]).any(dim=1) | (gct[1] != gl[1]).any(dim=1)).sum())
         w = e.scalar_mult(cv, k, gl[0], gl[1], flags=OUT_AFFINE | ALG_WINDOWED)
         l = e.scalar_mult(cv, k, gl[0], gl[1], flags=OUT_AFFINE)
         d_var = int(((w[0] != l[0]).any(dim=1) | (w[1] != l[1]).any(dim=1)).sum())
