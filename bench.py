@@ -76,11 +76,12 @@ def parse_args(argv=None):
     ap.add_argument("--global-log2-batch", type=int, default=24, help="strong scaling: scalar mults per step over ALL GPUs = 2^this")
     ap.add_argument("--log2-batch", type=int, default=22, help="weak scaling: scalar mults per GPU per step = 2^this")
     ap.add_argument("--curve", default="p256", choices=["p256", "secp256k1"])
-    ap.add_argument("--workload", default="ladder", choices=["ladder", "ladder-ref-compat", "ladder-x", "windowed", "fixed-base", "fixed-base-ct", "fixed-base-signed", "fixed-base-big"],
+    ap.add_argument("--workload", default="ladder", choices=["ladder", "ladder-ref-compat", "ladder-x", "windowed", "windowed-ct", "fixed-base", "fixed-base-ct", "fixed-base-signed", "fixed-base-big"],
                     help="ladder: scalar_mult_p256 variable base, the reference's co-Z ladder, Jacobian out (headline, BASELINE configs[3]); "
                          "ladder-ref-compat: the same with ECSIMD_HIP_REF_SQUARE_COMPAT (the reference's square() as written, dropped carry included); "
                          "ladder-x: x(k*P) only, the constant-time ladder without its Z coordinate (P-256; ECDH's shared secret; affine-level parity); "
                          "windowed: variable base with per-element tables of 8 multiples of P and signed 4-bit windows, affine out (ALG_WINDOWED; affine-level parity); "
+                         "windowed-ct: the same with ALG_CONSTANT_TIME (every entry of the lane's table read in every window; no GLV split): secret scalars; "
                          "fixed-base: k*G with the 4-bit-window LDS table + simultaneous inversion, affine out (BASELINE configs[2]); "
                          "fixed-base-ct: the same kernel with ALG_CONSTANT_TIME (every table entry read, kept under lane masks: safe for secret scalars); "
                          "fixed-base-signed: the same with signed 7-bit windows (36 additions instead of 63); "
@@ -223,9 +224,11 @@ def main():
         def compute(o):                                     # affine x; o[1], o[2] are unused
             eng.scalar_mult(curve, k, bx, by, flags=OUT_AFFINE, out=[view(o)[0], None, None])
         compute([eng.empty(rows) for _ in range(3)])        # sizes the context workspace
-    elif args.workload == "windowed":
+    elif args.workload in ("windowed", "windowed-ct"):
+        vflags = OUT_AFFINE | ALG_WINDOWED | (ALG_CONSTANT_TIME if args.workload == "windowed-ct" else 0)
+
         def compute(o):                                     # affine (x, y); o[2] is unused
-            eng.scalar_mult(curve, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED, out=view(o))
+            eng.scalar_mult(curve, k, bx, by, flags=vflags, out=view(o))
         compute([eng.empty(rows) for _ in range(3)])        # sizes the context workspace (1 408 B per element)
     else:
         alg = {"fixed-base": ALG_WINDOWED, "fixed-base-ct": ALG_WINDOWED | ALG_CONSTANT_TIME, "fixed-base-signed": ALG_WINDOWED_SIGNED,
@@ -332,6 +335,8 @@ def base_line(args, world, total_units, n, value, elapsed):
                     if args.curve == "p256" else "the co-Z ladder + x-only simultaneous inversion") + f", batch {sizes}, affine x out",
         "windowed": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 multiples of P) + signed 4-bit windows + simultaneous "
                     f"inversion{' + GLV split k = k1 + k2*lambda' if args.curve == 'secp256k1' else ''}, batch {sizes}, affine out",
+        "windowed-ct": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 odd multiples of P) + signed 4-bit windows (odd digits), ALG_CONSTANT_TIME: "
+                       f"all 8 entries of the lane's table read in every window, one kept under lane masks, no GLV split; + simultaneous inversion, batch {sizes}, affine out",
     }
     fixed = {"fixed-base": "4-bit window table in LDS (odd digits, 32 KiB)",
              "fixed-base-ct": "ALG_CONSTANT_TIME: odd-digit comb in LDS, every entry of a window read and one kept under lane masks (P-256: 43 six-bit windows x 32 entries, 86 KiB; secp256k1: 64 four-bit windows x 8 entries, 32 KiB)",
@@ -363,7 +368,7 @@ def roofline_object(args, eng, n, avg_ms):
         fm = ((13 + 254 * 14 + 12) if args.curve == "p256" else 4088 + 5) + 3 + (267 if args.curve == "p256" else 270) / share
         mad32_unit, bytes_unit = int(fm * 136), 128
         kname = ("k_scalar_mult_x + k_inverse_batched" if args.curve == "p256" else "k_scalar_mult + k_to_affine_batched")
-    elif args.workload == "windowed":
+    elif args.workload in ("windowed", "windowed-ct"):
         # what THIS algorithm needs per scalar.  P-256: table {1,3,..,15}P = DBLU + 7 co-Z additions
         # (6 + 7 x 7), its inversion 7 x (7 + 267/224) (224 points share one inversion at 2^22), 63 windows x (3 doublings
         # + one fused double-add of 13M + 5S), the final inversion walk; a doubling is 4M + 4S (P-256) / 3M + 4S
@@ -372,10 +377,11 @@ def roofline_object(args, eng, n, avg_ms):
         inv = 267 if args.curve == "p256" else 270                  # addition-chain inversion (point.cuh fe_inverse)
         share = min(128, max(1, min(n, 1 << 22) >> 17))            # elements per shared inversion (k_affine.inc; the windowed path works in chunks of 2^22)
         fm = (6 + 7 * 7) + 7 * (7 + inv / min(256, 7 * share)) + 63 * (3 * dbl + 18) + (7 + inv / share)
-        if args.curve == "secp256k1":     # GLV split: 32 windows x (4 doublings + 2 mixed additions + beta) + the top window's two additions
+        if args.curve == "secp256k1" and args.workload == "windowed":     # GLV split: 32 windows x (4 doublings + 2 mixed additions + beta) + the top window's two additions
             fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / min(256, 7 * share)) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + (7 + inv / share)   # table {1..8}P
         mad32_unit, bytes_unit = int(fm * 136), 160
-        kname = ("k_varwin_mult_odd + k_varwin_odd_multiples" if args.curve == "p256" else "k_varwin_mult_glv + k_varwin_multiples") + " + k_varwin_to_table + k_to_affine_batched"
+        kname = ("k_varwin_mult_odd<true> + k_varwin_odd_multiples" if args.workload == "windowed-ct" else "k_varwin_mult_odd<false> + k_varwin_odd_multiples" if args.curve == "p256"
+                 else "k_varwin_mult_glv + k_varwin_multiples") + " + k_varwin_to_table + k_to_affine_batched"
     else:
         # what THIS algorithm needs per scalar: 63 / 36 / 12 mixed additions x 11 field mults,
         # 7 mults of the simultaneous-inversion walk and 267/m (secp256k1: 270/m) of the inversion m = min(128, n / 2^17) points share; 32 B in, 64 B out.
@@ -404,7 +410,7 @@ def attach_cpu_baseline(args, result, eng, curve, k, bx, by, out, failures):
     AVX2) costs the run neither its line nor its exit code.  A parity DISAGREEMENT does: it is in the object and the
     process exits EXIT_PARITY after printing."""
     try:
-        if args.workload == "windowed":
+        if args.workload in ("windowed", "windowed-ct"):
             result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, base=(bx, by))
         elif args.workload == "ladder-x":
             result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, base=(bx, by), x_only=True)
@@ -556,7 +562,7 @@ def committed_traffic(args, n):
         table = json.load(open(tpath))
     except ValueError:
         return None, None
-    key = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult_refsqr", "ladder-x": "k_scalar_mult_x", "windowed": "varwin",
+    key = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult_refsqr", "ladder-x": "k_scalar_mult_x", "windowed": "varwin", "windowed-ct": "varwin_ct",
            "fixed-base": "fixed_base", "fixed-base-ct": "fixed_base_ct", "fixed-base-signed": "fixed_base_signed", "fixed-base-big": "fixed_base_big"}[args.workload]
     for log2 in (24, 22):                                 # a pass at this run's own launch size first
         per = table.get(f"{key}_{args.curve}_2^{log2}")

@@ -564,7 +564,7 @@ int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, co
     // per-lane window tables (8 multiples of P) in HBM + signed 4-bit windows (k_varwin.inc): a different algorithm from
     // the reference ladder, so affine output only (SURVEY.md 8(a) level A)
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
-    if (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) return bad(ctx, "ALG_CONSTANT_TIME is a fixed-base option (scalar_mult_base + ALG_WINDOWED); a variable base has the ladder");
+    if ((flags & ECSIMD_HIP_ALG_CONSTANT_TIME) && (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED)) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED");
     NO_COMPAT("ALG_WINDOWED");
     return run_varwin(ctx, curve, k, 4, x, y, ox, oy, n, flags, 0);
   }
@@ -579,7 +579,7 @@ int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[
   store_words(ctx->stream, w, kdev);
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED)) {
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
-    if (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) return bad(ctx, "ALG_CONSTANT_TIME is a fixed-base option (scalar_mult_base + ALG_WINDOWED); a variable base has the ladder");
+    if ((flags & ECSIMD_HIP_ALG_CONSTANT_TIME) && (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED)) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED");
     NO_COMPAT("ALG_WINDOWED");
     return run_varwin(ctx, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, n, flags, 0);
   }

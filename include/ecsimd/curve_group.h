@@ -90,6 +90,15 @@ struct curve_group {
                                            ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_ALG_WINDOWED_BIG), "ecsimd_hip_scalar_mult_base");
     return r;
   }
+  // k[i] * P[i] for SECRET scalars (ECDH): the per-element window tables with ECSIMD_HIP_ALG_CONSTANT_TIME -- every entry of the lane's
+  // table read in every window, kept under lane masks; 1.44 x (P-256) / 1.55 x (secp256k1) the ladder.  Affine classical in and out.
+  static WCP scalar_mult_affine_secret(WBN const& x, WCP const& P) {
+    same_length(x.size(), P.size(), "scalar_mult_affine_secret");
+    WCP r{WBN::uninitialized(P.size()), WBN::uninitialized(P.size())};
+    hip::check(ecsimd_hip_scalar_mult(hip::context(), curve_id, x.data(), P.x().data(), P.y().data(), r.x().data(), r.y().data(), nullptr, P.size(),
+                                      ECSIMD_HIP_BASE_CLASSICAL | ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_CONSTANT_TIME), "ecsimd_hip_scalar_mult");
+    return r;
+  }
   // k[i] * G for SECRET scalars (key generation, ECDSA nonces): an LDS comb with ECSIMD_HIP_ALG_CONSTANT_TIME -- every table entry of a
   // window read, the wanted one kept under lane masks, no address or branch formed from the scalar; 6.7 x (P-256) / 5.8 x (secp256k1) the ladder on G.  Affine classical.
   static WCP scalar_mult_base_affine_secret(WBN const& x) {

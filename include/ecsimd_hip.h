@@ -88,13 +88,17 @@ enum {
                                       context option below) the output is the reference's bits on EVERY input, at ~0.9x the speed;
                                       without it, it is the exact k*P (what the reference's own tests assume).  Same ladder, same
                                       constant-time shape: safe for secret scalars */
-  ECSIMD_HIP_ALG_CONSTANT_TIME = 128, /* scalar_mult_base + ALG_WINDOWED only (r3): an odd-digit comb over an LDS table whose lanes read ALL entries of
-                                      every window -- one address per wave, an LDS broadcast -- and keep their own under lane masks (P-256: 43 six-bit
-                                      windows x 32 entries, 42 additions; secp256k1: 64 four-bit windows x 8 entries, 63 additions).  The recoding has no
-                                      zero digit; the exceptional scalar and k = 0 mod n are handled by selects: no address and no branch depends on the
-                                      scalar (tools/ct_check.py checks the shipped ISA, tests/test_constant_time_isa.py).  SAFE for secret scalars: k*G
-                                      for key generation and ECDSA nonces at 6.7x (P-256) / 5.8x (secp256k1) the ladder's rate; same results as
-                                      ALG_WINDOWED */
+  ECSIMD_HIP_ALG_CONSTANT_TIME = 128, /* a modifier of ALG_WINDOWED (r3): the table-driven algorithms WITHOUT a scalar-dependent address or branch -- every
+                                      lane reads ALL entries a window could pick and keeps its own under lane masks; the recodings have no zero digit,
+                                      exceptional scalars and k = 0 mod n are handled by selects (tools/ct_check.py checks the shipped ISA of the window
+                                      loops, tests/test_constant_time_isa.py).  SAFE for secret scalars; same results as ALG_WINDOWED.
+                                      scalar_mult_base: an odd-digit comb over an LDS table -- one address per wave, an LDS broadcast (P-256: 43 six-bit
+                                      windows x 32 entries, 42 additions; secp256k1: 64 four-bit windows x 8 entries): k*G for key generation and ECDSA
+                                      nonces at 6.7x (P-256) / 5.8x (secp256k1) the ladder's rate.
+                                      scalar_mult / scalar_mult_1s: the per-element window tables with all 8 entries of the lane's own table (512
+                                      contiguous bytes) read in every window, no GLV split on secp256k1: ECDH with a secret scalar at 1.44x (P-256:
+                                      69.9 M/s) / 1.55x (secp256k1: 75.2 M/s) the ladder's rate, 1.27x the P-256 ladder without Z (oy = NULL works
+                                      here too).  Not with ALG_WINDOWED_SIGNED / ALG_WINDOWED_BIG (64 or 2^19 entries per window to read) */
   ECSIMD_HIP_ALG_WINDOWED_BIG = 32 /* scalar_mult_base + OUT_AFFINE: 20-bit windows with odd digits over a 436 MB table of the odd
                                       multiples (2d+1)*2^(20i)*G (13 windows x 2^19 entries) in device memory, built on first
                                       use (0.23 s per curve): 12 mixed additions per scalar; same results.  NOT for secret scalars:

@@ -346,6 +346,7 @@ template <class K> static void windowed_paths_agree() {
   const auto ladder = KG::scalar_mult_affine(k, P, false);
   EXPECT_TRUE(all(ladder == KG::scalar_mult(k, wide_jacobian_curve_point<K>::from_affine(P)).to_affine()));
   EXPECT_TRUE(all(KG::scalar_mult_affine(k, P) == ladder));
+  EXPECT_TRUE(all(KG::scalar_mult_affine_secret(k, P) == ladder));                            // the constant-time window loop: same points
   const auto JP = wide_jacobian_curve_point<K>::from_affine(P);
   const auto J = KG::scalar_mult(k, JP);                                                       // k*P, Z != 1
   EXPECT_TRUE(all(KG::add_mixed_complete(J, JP).to_affine() == KG::ADD_Z2_1(J, JP).to_affine()));

@@ -127,3 +127,19 @@ def test_the_checker_refuses_the_table_lookup_by_digit(affine_asm):
     """The default kernel reads ONE entry per window at an address made of scalar digits: the same check must refuse it."""
     with pytest.raises(ct_check.Violation, match="LDS address"):
         ct_check.check(affine_asm, "15k_base_windowedILb0E", allow_global_loads=0, allow_lds_reads=True)
+
+
+@pytest.mark.parametrize("unit", ["k_varwin_p256", "k_varwin_secp256k1"])
+def test_constant_time_variable_base_window_loop(tmp_path_factory, unit):
+    """k_varwin_mult_odd<true> (ALG_WINDOWED | ALG_CONSTANT_TIME on a variable base): per window 32 global loads -- a quarter of each of the
+    lane's 8 table entries, two whole entries (one 128-byte line) at a time -- addressed by loop-invariant registers (the lane's own block), one branch on the window counter,
+    nothing else; and the default loop, whose one entry per window is addressed by a digit, must be refused."""
+    asm = assembly(tmp_path_factory, unit)
+    rep = ct_check.check(asm, "k_varwin_mult_oddILb1E", allow_global_loads=32)
+    assert rep["instructions"] > 5000 and len(rep["global_loads"]) == 32          # (a few spills: scratch accesses are checked for constant addressing)
+    assert all(g.startswith("global_load_dwordx4 ") for g in rep["global_loads"])
+    assert len(rep["branches"]) == 1 and re.match(r"s_cmpk?_(lg|eq|lt|gt|le|ge)_[iu]32 s\d+, \S+ ; s_cbranch_scc[01] ", rep["branches"][0]), rep["branches"]
+    assert rep.get("long_jumps", 0) <= 1                       # the back edge of a 78 KB loop body is a relaxed branch
+    assert ct_check.check_after_secret_load(asm, "k_varwin_mult_oddILb1E") > 5000
+    with pytest.raises(ct_check.Violation, match="address"):
+        ct_check.check(asm, "k_varwin_mult_oddILb0E", allow_global_loads=32)

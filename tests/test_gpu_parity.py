@@ -474,7 +474,33 @@ def test_constant_time_fixed_base(engine, oracle, cv):
         with pytest.raises(EcsimdHipError, match="ALG_CONSTANT_TIME"):
             engine.scalar_mult_base(cv, k[:64].contiguous(), flags=flags)
     with pytest.raises(EcsimdHipError, match="ALG_CONSTANT_TIME"):
-        engine.scalar_mult(cv, k[:64].contiguous(), ct[0][:64].contiguous(), ct[1][:64].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME)
+        engine.scalar_mult(cv, k[:64].contiguous(), ct[0][:64].contiguous(), ct[1][:64].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED_SIGNED | ALG_CONSTANT_TIME)
+
+
+@pytest.mark.parametrize("cv", CURVES)
+def test_constant_time_variable_base(engine, oracle, cv):
+    """ALG_WINDOWED | ALG_CONSTANT_TIME on a variable base: the per-element window tables with EVERY entry of the lane's table read in every
+    window (and no GLV split on secp256k1).  Same (x, y) as the default window loop on 2^17 + 5 lane-distinct (k, P) with the edge scalars
+    in front, x only, the shared-scalar form; a sample against the oracle's ladder."""
+    import torch
+    c = CURVE_PARAMS[cv]; order = c["n"]
+    n = (1 << 17) + 5
+    k = engine.fill_random(n, SEED, 71)
+    k[:8] = engine.to_device(ints_to_arr([0, order, 1, order - 1, 2, order + 1, 2**256 - 1, order - 2]))
+    px, py = engine.scalar_mult_base(cv, engine.fill_random(n, SEED, 72), flags=OUT_AFFINE | ALG_WINDOWED_BIG)
+    ct = engine.scalar_mult(cv, k, px, py, flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME)
+    pl = engine.scalar_mult(cv, k, px, py, flags=OUT_AFFINE | ALG_WINDOWED)
+    assert torch.equal(ct[0], pl[0]) and torch.equal(ct[1], pl[1])
+    assert not ct[0][:2].any() and not ct[1][:2].any()                        # k = 0 mod n: (0, 0)
+    m = 1024
+    ex, ey = oracle.to_affine(cv, oracle.scalar_mult(cv, engine.to_numpy(k[8:8 + m]), engine.to_numpy(px[8:8 + m]), engine.to_numpy(py[8:8 + m]), threads=THREADS))
+    assert np.array_equal(engine.to_numpy(ct[0][8:8 + m]), ex) and np.array_equal(engine.to_numpy(ct[1][8:8 + m]), ey)
+    xo = engine.scalar_mult(cv, k, px, py, flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME, x_only=True)
+    assert torch.equal(xo[0], ct[0])
+    k1 = engine.to_numpy(k[100:101])[0]
+    a = engine.scalar_mult_1s(cv, k1, px[:4096].contiguous(), py[:4096].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME)
+    b = engine.scalar_mult_1s(cv, k1, px[:4096].contiguous(), py[:4096].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
 @pytest.mark.parametrize("cv", CURVES)

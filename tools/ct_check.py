@@ -111,47 +111,60 @@ def check(text, want, allow_global_loads=1, allow_lds_reads=False):
     flat = [i for _, insts in loop for i in insts]
     report = {"kernel": want, "loop_header": header, "instructions": len(flat), "branches": [], "global_loads": [], "scratch": 0, "lds_reads": 0}
 
-    # ---- clean scalars: fixpoint over the whole loop (flow-insensitive part)
-    written_by_valu, scalar_writes = set(), {}
+    # ---- clean scalars.  A scalar register is clean over the loop if EVERY write to it inside the loop is a scalar instruction whose
+    # sources are clean where that instruction stands: each source is followed back to its definition in the same block first (so a
+    # register reused for lane masks elsewhere does not taint `s_add_i32 s2, s16, -1 ; s_mov_b32 s16, s2`), and only then over the whole
+    # loop.  A register on the path of its own evaluation counts as clean (the counter depends on itself).
     written_v = set()
-    for inst in flat:
-        op, ops = split_ops(inst)
-        nd = dest_count(op)
-        dests = [r for o in ops[:nd] for r in regs_of(o)]
-        srcs = [r for o in ops[nd:] for r in regs_of(o)]
-        if op.startswith("v_") or op.startswith(("global_load", "scratch_load", "ds_read", "buffer_load", "flat_load")):
+    writes = {}                                   # scalar reg / "vcc" / "exec" -> [(block instructions, index, written by a scalar instruction?)]
+    for _, insts in loop:
+        for idx, inst in enumerate(insts):
+            op, ops = split_ops(inst)
+            nd = dest_count(op)
+            dests = [r for o in ops[:nd] for r in regs_of(o)]
+            is_vec = op.startswith("v_") or op.startswith(("global_load", "scratch_load", "ds_read", "buffer_load", "flat_load"))
             for r in dests:
-                if isinstance(r, tuple) and r[0] == "s" or r in ("vcc", "exec"):
-                    written_by_valu.add(r)
                 if isinstance(r, tuple) and r[0] == "v":
                     written_v.add(r)
-        elif op.startswith("s_"):
-            for r in dests:
-                scalar_writes.setdefault(r, []).append(srcs)
-            if "saveexec" in op:
-                scalar_writes.setdefault("exec", []).append(srcs + dests)
-    # asm blocks may write exec / vcc by s_ instructions reading dirty masks: handled by the same table
-    dirty = set(written_by_valu) | {"vcc", "exec"}
-    changed = True
-    while changed:
-        changed = False
-        for r, lists in scalar_writes.items():
-            if r in dirty:
-                continue
-            if any(any(s in dirty for s in srcs) for srcs in lists):
-                dirty.add(r); changed = True
+                else:
+                    writes.setdefault(r, []).append((insts, idx, op.startswith("s_") and not is_vec))
+            if op.startswith("s_") and "saveexec" in op:
+                writes.setdefault("exec", []).append((insts, idx, False))       # EXEC := a lane mask
 
-    def clean_scalar_at(block_insts, idx, reg, depth=0):
+    memo = {}
+
+    def clean_over_loop(reg, visiting):
+        if reg in ("vcc", "exec"):
+            return False
+        if reg in memo:
+            return memo[reg]
+        if reg in visiting:
+            return True
+        ok = True
+        for insts, idx, scalar in writes.get(reg, []):
+            if not scalar:
+                ok = False; break
+            op, ops = split_ops(insts[idx])
+            nd = dest_count(op)
+            if not all(clean_scalar_at(insts, idx, s_, visiting | {reg}) for o in ops[nd:] for s_ in regs_of(o) if s_ != "scc"):
+                ok = False; break
+        if not visiting:
+            memo[reg] = ok
+        return ok
+
+    def clean_scalar_at(block_insts, idx, reg, visiting=frozenset()):
         """Is scalar `reg`, read by instruction idx of this block, made of clean values?  Walk back to its definition in the
         block; without one, it must be clean over the whole loop."""
+        if isinstance(reg, tuple) and reg[0] == "v":
+            return False
         for k in range(idx - 1, -1, -1):
             op, ops = split_ops(block_insts[k])
             nd = dest_count(op)
             if reg in [r for o in ops[:nd] for r in regs_of(o)]:
-                if not op.startswith("s_"):
+                if not op.startswith("s_") or "saveexec" in op:
                     return False
-                return all(clean_scalar_at(block_insts, k, s, depth + 1) for o in ops[nd:] for s in regs_of(o) if s != "scc")
-        return reg not in dirty and reg not in ("vcc", "exec")
+                return all(clean_scalar_at(block_insts, k, s_, visiting) for o in ops[nd:] for s_ in regs_of(o) if s_ != "scc")
+        return clean_over_loop(reg, visiting)
 
     def scratch_slot(inst):
         """(first byte, last byte + 1) of a constant-addressed scratch access."""
@@ -193,6 +206,10 @@ def check(text, want, allow_global_loads=1, allow_lds_reads=False):
                         raise Violation(f"{lab}: the LDS address {addr} of `{inst}` is not made of loop-invariant registers and the window counter")
                 report["lds_reads"] += 1
                 continue
+            if op == "s_setpc_b64" and idx >= 3 and insts[idx - 3].startswith("s_getpc_b64") and insts[idx - 2].startswith("s_add_u32") \
+                    and insts[idx - 1].startswith("s_addc_u32") and ".LBB" in insts[idx - 2] and ".LBB" in insts[idx - 1]:
+                report["long_jumps"] = report.get("long_jumps", 0) + 1       # branch relaxation: an unconditional jump to a label beyond s_branch's reach
+                continue
             if re.match(r"^(v_readfirstlane|v_readlane|v_writelane|v_permlane|ds_|buffer_|flat_|global_store|global_atomic|s_setpc|s_swappc|s_call|s_cbranch_vcc|s_cbranch_exec|s_cbranch_cd|s_cbranch_g_fork|s_cbranch_i_fork|s_cbranch_join)", op):
                 raise Violation(f"{lab}: `{inst}` is not allowed in the bit loop")
             if op.startswith("s_cbranch_scc"):
@@ -233,18 +250,18 @@ def check(text, want, allow_global_loads=1, allow_lds_reads=False):
 
 def check_after_secret_load(text, want):
     """The parts of a kernel AROUND its loop (the first window, the exceptional scalar, k = 0): after the first global load that
-    follows the workgroup barrier -- the scalar -- no instruction of the function may branch on a lane mask (s_cbranch_vcc* /
+    follows the workgroup barrier (or, in a kernel without one, the first global load) -- the scalar -- no instruction of the function may branch on a lane mask (s_cbranch_vcc* /
     s_cbranch_exec*), move a lane's value to the scalar unit (v_readfirstlane / v_readlane / v_permlane) or write LDS; every
     s_cbranch_scc* left is the loop's own (check() looks at those).  Returns the number of instructions looked at."""
     flat = [i for _, _, insts in parse_function(text, want) for i in insts]
+    bar = next((k for k, i in enumerate(flat) if i.startswith("s_barrier")), 0)      # no barrier (no LDS table): the first global load is the scalar
     try:
-        bar = next(k for k, i in enumerate(flat) if i.startswith("s_barrier"))
         first = next(k for k in range(bar, len(flat)) if flat[k].startswith("global_load"))
     except StopIteration:
-        raise Violation("no barrier followed by a global load: not the kernel shape this check is for")
+        raise Violation("no global load: not the kernel shape this check is for")
     for inst in flat[first:]:
         op = inst.split()[0]
-        if re.match(r"^(s_cbranch_vcc|s_cbranch_exec|v_readfirstlane|v_readlane|v_writelane|v_permlane|ds_write|ds_bpermute|ds_permute|ds_swizzle|global_atomic|s_setpc|s_swappc|s_call)", op):
+        if re.match(r"^(s_cbranch_vcc|s_cbranch_exec|v_readfirstlane|v_readlane|v_writelane|v_permlane|ds_write|ds_bpermute|ds_permute|ds_swizzle|global_atomic|s_swappc|s_call)", op):
             raise Violation(f"`{inst}` after the scalar has been loaded")
     return len(flat) - first
 

@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORDER = ["ladder", "ladder_secp256k1", "ladder_ref_compat_p256", "ladder_ref_compat_secp256k1", "ladder_x_only", "ladder_x_only_secp256k1",
-         "windowed_variable_base", "windowed_variable_base_secp256k1", "fixed_base", "fixed_base_secp256k1", "fixed_base_constant_time", "fixed_base_constant_time_secp256k1", "fixed_base_signed7", "fixed_base_signed7_secp256k1", "fixed_base_big20",
+         "windowed_variable_base", "windowed_variable_base_secp256k1", "windowed_constant_time", "windowed_constant_time_secp256k1", "fixed_base", "fixed_base_secp256k1", "fixed_base_constant_time", "fixed_base_constant_time_secp256k1", "fixed_base_signed7", "fixed_base_signed7_secp256k1", "fixed_base_big20",
          "group_mode", "nccl_single_rank_rehearsal"]
 LABEL = {
     "ladder": "**P-256 variable-base ladder, 2²⁴ per step (headline, BASELINE configs[3])**",
@@ -25,6 +25,8 @@ LABEL = {
     "ladder_x_only_secp256k1": "secp256k1 variable base, x only (full ladder + x-only inversion walk)",
     "windowed_variable_base": "P-256 variable base, per-element window tables (`ALG_WINDOWED`, affine out)",
     "windowed_variable_base_secp256k1": "secp256k1 variable base, per-element tables + GLV split",
+    "windowed_constant_time": "P-256 variable base, per-element window tables, `ALG_CONSTANT_TIME` (all 8 entries read in every window: secret scalars)",
+    "windowed_constant_time_secp256k1": "secp256k1 variable base, per-element window tables, `ALG_CONSTANT_TIME` (no GLV split)",
     "fixed_base": "P-256 fixed base, 4-bit windows in LDS (configs[2])",
     "fixed_base_secp256k1": "secp256k1 fixed base, 4-bit windows in LDS",
     "fixed_base_constant_time": "P-256 fixed base, `ALG_CONSTANT_TIME` (6-bit windows in LDS, every entry read, lane masks: secret scalars)",

@@ -21,7 +21,7 @@ import os
 import re
 import sys
 
-KEY = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult_refsqr", "ladder-x": "k_scalar_mult_x", "windowed": "varwin",
+KEY = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult_refsqr", "ladder-x": "k_scalar_mult_x", "windowed": "varwin", "windowed-ct": "varwin_ct",
        "fixed-base": "fixed_base", "fixed-base-ct": "fixed_base_ct", "fixed-base-signed": "fixed_base_signed", "fixed-base-big": "fixed_base_big"}
 # kernels that read table entries (64 bytes at a random or per-lane place): their figure contains the unused half lines
 GATHERS = ("k_base_windowed_g", "k_varwin_mult_odd", "k_varwin_mult_glv")
