@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak run on the GPU alone: the three ways this library computes an affine k*P must agree lane for lane --
-the reference ladder (+ simultaneous inversion), the per-element-table windowed path (ALG_WINDOWED) and, for
+the reference ladder (+ simultaneous inversion), the per-element-table windowed path (ALG_WINDOWED, and its constant-time form) and, for
 P = G, the three window-table kernels and the constant-time form of the 4-bit one; and the x-only products (on P-256 the ladder without Z) must give the same x.  Different algorithms over the same field layer: a disagreement means a bug
 in one of them.  Usage: soak_windowed.py [lanes_per_batch_log2=22] [batches=8]"""
 import os, sys, time
@@ -25,7 +25,9 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
                        | (g16[0] != gl[0]).any(dim=1) | (g16[1] != gl[1]).any(dim=1) | (gct[0] != gl[0]).any(dim=1) | (gct[1] != gl[1]).any(dim=1)).sum())
         w = e.scalar_mult(cv, k, gl[0], gl[1], flags=OUT_AFFINE | ALG_WINDOWED)
         l = e.scalar_mult(cv, k, gl[0], gl[1], flags=OUT_AFFINE)
-        d_var = int(((w[0] != l[0]).any(dim=1) | (w[1] != l[1]).any(dim=1)).sum())
+        wct = e.scalar_mult(cv, k, gl[0], gl[1], flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME)      # every table entry read, lane masks
+        d_var = int(((w[0] != l[0]).any(dim=1) | (w[1] != l[1]).any(dim=1) | (wct[0] != l[0]).any(dim=1) | (wct[1] != l[1]).any(dim=1)).sum())
+        del wct
         xo = e.scalar_mult(cv, k, gl[0], gl[1], flags=OUT_AFFINE, x_only=True)[0]      # P-256: the ladder without Z
         xg = e.scalar_mult_base(cv, s, flags=OUT_AFFINE, x_only=True)[0]
         d_x = int(((xo != l[0]).any(dim=1) | (xg != gl[0]).any(dim=1)).sum())
