@@ -594,6 +594,7 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* 
     // (the Jacobian representative differs from the reference ladder's -- SURVEY.md 8(a) level A).
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
     const bool ct = (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) != 0;
+    if (ct && !(ECS_FIXED4_ODD && ECS_SIGNED_ODD)) return bad(ctx, "this build (-DECS_FIXED4_ODD=0 / -DECS_SIGNED_ODD=0) has no constant-time comb");
     if (ct && (big || six)) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED (the 4-bit table in LDS) only");
     NO_COMPAT("ALG_WINDOWED");
     if (n == 0) return ECSIMD_HIP_OK;
