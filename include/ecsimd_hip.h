@@ -75,7 +75,8 @@ enum {
                                       the ladder for every k except the ladder's degenerate scalars k = n-1, 2^256-n-1,
                                       2^256-n (there the reference returns a meaningless point, these paths the right
                                       one); k = 0 mod n -> (0, 0).  NOT for secret scalars: table reads (LDS for the fixed
-                                      base, device memory for the per-element tables) are indexed by scalar digits */
+                                      base, device memory for the per-element tables) are indexed by scalar digits --
+                                      unless ALG_CONSTANT_TIME is added (below) */
   ECSIMD_HIP_ALG_WINDOWED_SIGNED = 8, /* as ALG_WINDOWED with signed 7-bit windows: 36 mixed additions instead of 63, a 148 KiB
                                       table of the odd multiples (2d+1)*2^(7i)*G (d = 0..63) in LDS, negative digits negate y; same results.
                                       NOT for secret scalars (LDS reads indexed by scalar digits) */
