@@ -336,7 +336,8 @@ def base_line(args, world, total_units, n, value, elapsed):
         "windowed": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 multiples of P) + signed 4-bit windows + simultaneous "
                     f"inversion{' + GLV split k = k1 + k2*lambda' if args.curve == 'secp256k1' else ''}, batch {sizes}, affine out",
         "windowed-ct": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 odd multiples of P) + signed 4-bit windows (odd digits), ALG_CONSTANT_TIME: "
-                       f"all 8 entries of the lane's table read in every window, one kept under lane masks, no GLV split; + simultaneous inversion, batch {sizes}, affine out",
+                       f"all 8 entries of the lane's table read in every window, kept under lane masks"
+                       + (" (secp256k1: GLV split k = k1 + k2*lambda on the complete addition law of a = 0 curves)" if args.curve == "secp256k1" else "") + f"; + simultaneous inversion, batch {sizes}, affine out",
     }
     fixed = {"fixed-base": "4-bit window table in LDS (odd digits, 32 KiB)",
              "fixed-base-ct": "ALG_CONSTANT_TIME: odd-digit comb in LDS, every entry of a window read and one kept under lane masks (P-256: 43 six-bit windows x 32 entries, 86 KiB; secp256k1: 64 four-bit windows x 8 entries, 32 KiB)",
@@ -377,10 +378,13 @@ def roofline_object(args, eng, n, avg_ms):
         inv = 267 if args.curve == "p256" else 270                  # addition-chain inversion (point.cuh fe_inverse)
         share = min(128, max(1, min(n, 1 << 22) >> 17))            # elements per shared inversion (k_affine.inc; the windowed path works in chunks of 2^22)
         fm = (6 + 7 * 7) + 7 * (7 + inv / min(256, 7 * share)) + 63 * (3 * dbl + 18) + (7 + inv / share)
+        if args.curve == "secp256k1" and args.workload == "windowed-ct":  # GLV split on the complete addition law: 32 windows x (4 doublings of 6M + 2S, two mixed additions of 11M, beta),
+            fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / min(256, 7 * share)) + 32 * (4 * 8 + 2 * 11 + 1) + (2 * 11 + 1) + 3 + (7 + inv / share)   # the top window's two additions, (X Z, Y Z^2, Z)
         if args.curve == "secp256k1" and args.workload == "windowed":     # GLV split: 32 windows x (4 doublings + 2 mixed additions + beta) + the top window's two additions
             fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / min(256, 7 * share)) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + (7 + inv / share)   # table {1..8}P
         mad32_unit, bytes_unit = int(fm * 136), 160
-        kname = ("k_varwin_mult_odd<true> + k_varwin_odd_multiples" if args.workload == "windowed-ct" else "k_varwin_mult_odd<false> + k_varwin_odd_multiples" if args.curve == "p256"
+        kname = ("k_varwin_mult_glv_ct + k_varwin_multiples" if (args.workload == "windowed-ct" and args.curve == "secp256k1") else
+                 "k_varwin_mult_odd<true> + k_varwin_odd_multiples" if args.workload == "windowed-ct" else "k_varwin_mult_odd<false> + k_varwin_odd_multiples" if args.curve == "p256"
                  else "k_varwin_mult_glv + k_varwin_multiples") + " + k_varwin_to_table + k_to_affine_batched"
     else:
         # what THIS algorithm needs per scalar: 63 / 36 / 12 mixed additions x 11 field mults,

@@ -97,9 +97,10 @@ enum {
                                       windows x 32 entries, 42 additions; secp256k1: 64 four-bit windows x 8 entries): k*G for key generation and ECDSA
                                       nonces at 6.7x (P-256) / 5.8x (secp256k1) the ladder's rate.
                                       scalar_mult / scalar_mult_1s: the per-element window tables with all 8 entries of the lane's own table (512
-                                      contiguous bytes) read in every window, no GLV split on secp256k1: ECDH with a secret scalar at 1.44x (P-256:
-                                      69.9 M/s) / 1.55x (secp256k1: 75.2 M/s) the ladder's rate, 1.27x the P-256 ladder without Z (oy = NULL works
-                                      here too).  Not with ALG_WINDOWED_SIGNED / ALG_WINDOWED_BIG (64 or 2^19 entries per window to read) */
+                                      contiguous bytes) read in every window; on secp256k1 the GLV split stays, run on the COMPLETE addition law of
+                                      a = 0 curves (no exceptional case to branch on; ALG_NO_ENDOMORPHISM: the plain odd-digit loop).  ECDH with a
+                                      secret scalar at 1.44x (P-256: 69.9 M/s) / 1.73x (secp256k1: 83.8 M/s) the ladder's rate, 1.27x the P-256
+                                      ladder without Z (oy = NULL works here too).  Not with ALG_WINDOWED_SIGNED / ALG_WINDOWED_BIG (64 or 2^19 entries per window to read) */
   ECSIMD_HIP_ALG_WINDOWED_BIG = 32 /* scalar_mult_base + OUT_AFFINE: 20-bit windows with odd digits over a 436 MB table of the odd
                                       multiples (2d+1)*2^(20i)*G (13 windows x 2^19 entries) in device memory, built on first
                                       use (0.23 s per curve): 12 mixed additions per scalar; same results.  NOT for secret scalars:

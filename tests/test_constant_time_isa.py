@@ -143,3 +143,17 @@ def test_constant_time_variable_base_window_loop(tmp_path_factory, unit):
     assert ct_check.check_after_secret_load(asm, "k_varwin_mult_oddILb1E") > 5000
     with pytest.raises(ct_check.Violation, match="address"):
         ct_check.check(asm, "k_varwin_mult_oddILb0E", allow_global_loads=32)
+
+
+def test_constant_time_glv_loop_of_secp256k1(tmp_path_factory):
+    """k_varwin_mult_glv_ct (ALG_WINDOWED | ALG_CONSTANT_TIME on secp256k1): the GLV split on the complete addition law.  Per window 32 global
+    loads (the lane's 8 entries, a line at a time) addressed by loop-invariant registers; every branch hangs on the window counter (the exit
+    test and the top window's "no doublings yet"); nothing else -- and the default GLV loop (digit-addressed reads, add_checked's branch on
+    the operands) must be refused."""
+    asm = assembly(tmp_path_factory, "k_varwin_secp256k1")
+    rep = ct_check.check(asm, "k_varwin_mult_glv_ctILi0E", allow_global_loads=32)
+    assert rep["instructions"] > 8000 and len(rep["global_loads"]) == 32
+    assert 1 <= len(rep["branches"]) <= 3 and all(re.match(r"s_cmpk?_(lg|eq|lt|gt|le|ge)_[iu]32 s\d+, \S+ ; s_cbranch_scc[01] ", b) for b in rep["branches"]), rep["branches"]
+    assert ct_check.check_after_secret_load(asm, "k_varwin_mult_glv_ctILi0E") > 8000
+    with pytest.raises(ct_check.Violation):
+        ct_check.check(asm, "17k_varwin_mult_glvILi0E", allow_global_loads=32)

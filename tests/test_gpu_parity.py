@@ -11,7 +11,7 @@ import pytest
 from helpers import (CURVE_PARAMS, CURVE_NAMES, P256, SECP256K1, SEED, hexes_to_arr, arr_to_hexes, from_int, to_int, ints_to_arr,
                      arr_to_ints, from_hex, fill_random_np, ec_mul, ec_add, jacobian_mgry_to_affine_int)
 from test_oracle import run_against_golden, structured_words
-from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG, ALG_CONSTANT_TIME, REF_SQUARE_COMPAT, GROUP_NO_GATHER, EcsimdHipError
+from ecsimd_amd import ALG_NO_ENDOMORPHISM, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG, ALG_CONSTANT_TIME, REF_SQUARE_COMPAT, GROUP_NO_GATHER, EcsimdHipError
 
 pytestmark = pytest.mark.gpu
 CURVES = [P256, SECP256K1]
@@ -480,7 +480,7 @@ def test_constant_time_fixed_base(engine, oracle, cv):
 @pytest.mark.parametrize("cv", CURVES)
 def test_constant_time_variable_base(engine, oracle, cv):
     """ALG_WINDOWED | ALG_CONSTANT_TIME on a variable base: the per-element window tables with EVERY entry of the lane's table read in every
-    window (and no GLV split on secp256k1).  Same (x, y) as the default window loop on 2^17 + 5 lane-distinct (k, P) with the edge scalars
+    window (on secp256k1: the GLV split on the complete addition law, and with ALG_NO_ENDOMORPHISM the plain odd-digit loop).  Same (x, y) as the default window loop on 2^17 + 5 lane-distinct (k, P) with the edge scalars
     in front, x only, the shared-scalar form; a sample against the oracle's ladder."""
     import torch
     c = CURVE_PARAMS[cv]; order = c["n"]
@@ -497,6 +497,8 @@ def test_constant_time_variable_base(engine, oracle, cv):
     assert np.array_equal(engine.to_numpy(ct[0][8:8 + m]), ex) and np.array_equal(engine.to_numpy(ct[1][8:8 + m]), ey)
     xo = engine.scalar_mult(cv, k, px, py, flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME, x_only=True)
     assert torch.equal(xo[0], ct[0])
+    ne = engine.scalar_mult(cv, k, px, py, flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME | ALG_NO_ENDOMORPHISM)     # secp256k1: the other loop
+    assert torch.equal(ne[0], pl[0]) and torch.equal(ne[1], pl[1])
     k1 = engine.to_numpy(k[100:101])[0]
     a = engine.scalar_mult_1s(cv, k1, px[:4096].contiguous(), py[:4096].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME)
     b = engine.scalar_mult_1s(cv, k1, px[:4096].contiguous(), py[:4096].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED)

@@ -111,60 +111,67 @@ def check(text, want, allow_global_loads=1, allow_lds_reads=False):
     flat = [i for _, insts in loop for i in insts]
     report = {"kernel": want, "loop_header": header, "instructions": len(flat), "branches": [], "global_loads": [], "scratch": 0, "lds_reads": 0}
 
-    # ---- clean scalars.  A scalar register is clean over the loop if EVERY write to it inside the loop is a scalar instruction whose
-    # sources are clean where that instruction stands: each source is followed back to its definition in the same block first (so a
-    # register reused for lane masks elsewhere does not taint `s_add_i32 s2, s16, -1 ; s_mov_b32 s16, s2`), and only then over the whole
-    # loop.  A register on the path of its own evaluation counts as clean (the counter depends on itself).
+    # ---- clean scalars: reaching definitions over the loop's control-flow graph.  A scalar register read at some instruction is clean
+    # if, walking back -- through the block, then through every predecessor block inside the loop -- every definition that can reach the
+    # read is a scalar instruction (not a *_saveexec: that is a lane mask) whose own sources are clean where IT stands.  A path that leaves
+    # the loop through the header's entry edge reaches a loop-invariant value: clean.  A (block, register) pair met again on its own path
+    # counts as clean (the counter depends on itself).  VCC, EXEC and anything a vector instruction wrote are dirty.
     written_v = set()
-    writes = {}                                   # scalar reg / "vcc" / "exec" -> [(block instructions, index, written by a scalar instruction?)]
     for _, insts in loop:
-        for idx, inst in enumerate(insts):
+        for inst in insts:
             op, ops = split_ops(inst)
-            nd = dest_count(op)
-            dests = [r for o in ops[:nd] for r in regs_of(o)]
-            is_vec = op.startswith("v_") or op.startswith(("global_load", "scratch_load", "ds_read", "buffer_load", "flat_load"))
-            for r in dests:
+            for r in [r for o in ops[:dest_count(op)] for r in regs_of(o)]:
                 if isinstance(r, tuple) and r[0] == "v":
                     written_v.add(r)
-                else:
-                    writes.setdefault(r, []).append((insts, idx, op.startswith("s_") and not is_vec))
-            if op.startswith("s_") and "saveexec" in op:
-                writes.setdefault("exec", []).append((insts, idx, False))       # EXEC := a lane mask
+    labels = [lab for lab, _ in loop]
+    index_of = {lab: n for n, lab in enumerate(labels)}
+    block_of = {id(insts): n for n, (_, insts) in enumerate(loop)}
+    succs = {n: set() for n in range(len(loop))}
+    for n, (lab, insts) in enumerate(loop):
+        falls = True
+        for k, inst in enumerate(insts):
+            op, ops = split_ops(inst)
+            if op.startswith("s_cbranch") and ops and ops[-1] in index_of:
+                succs[n].add(index_of[ops[-1]])
+            if op == "s_branch":
+                if ops and ops[0] in index_of:
+                    succs[n].add(index_of[ops[0]])
+                falls = False
+            if op == "s_setpc_b64" and k >= 2:
+                m = re.search(r"\((\.LBB\w+)-", insts[k - 2])
+                if m and m.group(1) in index_of:
+                    succs[n].add(index_of[m.group(1)])
+                falls = False
+            if op == "s_endpgm":
+                falls = False
+        if falls and n + 1 < len(loop):
+            succs[n].add(n + 1)
+    preds = {n: {m for m in succs if n in succs[m]} for n in range(len(loop))}
 
-    memo = {}
-
-    def clean_over_loop(reg, visiting):
-        if reg in ("vcc", "exec"):
+    def def_is_clean(insts, k, visiting):
+        op, ops = split_ops(insts[k])
+        if not op.startswith("s_") or "saveexec" in op:
             return False
-        if reg in memo:
-            return memo[reg]
-        if reg in visiting:
-            return True
-        ok = True
-        for insts, idx, scalar in writes.get(reg, []):
-            if not scalar:
-                ok = False; break
-            op, ops = split_ops(insts[idx])
-            nd = dest_count(op)
-            if not all(clean_scalar_at(insts, idx, s_, visiting | {reg}) for o in ops[nd:] for s_ in regs_of(o) if s_ != "scc"):
-                ok = False; break
-        if not visiting:
-            memo[reg] = ok
-        return ok
+        nd = dest_count(op)
+        return all(clean_scalar_at(insts, k, s_, visiting) for o in ops[nd:] for s_ in regs_of(o) if s_ != "scc")
 
     def clean_scalar_at(block_insts, idx, reg, visiting=frozenset()):
-        """Is scalar `reg`, read by instruction idx of this block, made of clean values?  Walk back to its definition in the
-        block; without one, it must be clean over the whole loop."""
-        if isinstance(reg, tuple) and reg[0] == "v":
+        """Is scalar `reg`, read by instruction idx of this block, made of clean values on every path that reaches it?"""
+        if (isinstance(reg, tuple) and reg[0] == "v") or reg in ("vcc", "exec"):
             return False
         for k in range(idx - 1, -1, -1):
             op, ops = split_ops(block_insts[k])
-            nd = dest_count(op)
-            if reg in [r for o in ops[:nd] for r in regs_of(o)]:
-                if not op.startswith("s_") or "saveexec" in op:
-                    return False
-                return all(clean_scalar_at(block_insts, k, s_, visiting) for o in ops[nd:] for s_ in regs_of(o) if s_ != "scc")
-        return clean_over_loop(reg, visiting)
+            if reg in [r for o in ops[:dest_count(op)] for r in regs_of(o)]:
+                return def_is_clean(block_insts, k, visiting)
+        n = block_of[id(block_insts)]
+        key = (n, reg)
+        if key in visiting:
+            return True
+        for m in preds[n]:                                    # (the header's entry edge from outside the loop: a loop-invariant value)
+            pin = loop[m][1]
+            if not clean_scalar_at(pin, len(pin), reg, visiting | {key}):
+                return False
+        return True
 
     def scratch_slot(inst):
         """(first byte, last byte + 1) of a constant-addressed scratch access."""

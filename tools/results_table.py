@@ -26,7 +26,7 @@ LABEL = {
     "windowed_variable_base": "P-256 variable base, per-element window tables (`ALG_WINDOWED`, affine out)",
     "windowed_variable_base_secp256k1": "secp256k1 variable base, per-element tables + GLV split",
     "windowed_constant_time": "P-256 variable base, per-element window tables, `ALG_CONSTANT_TIME` (all 8 entries read in every window: secret scalars)",
-    "windowed_constant_time_secp256k1": "secp256k1 variable base, per-element window tables, `ALG_CONSTANT_TIME` (no GLV split)",
+    "windowed_constant_time_secp256k1": "secp256k1 variable base, per-element window tables, `ALG_CONSTANT_TIME` (GLV split on the complete addition law)",
     "fixed_base": "P-256 fixed base, 4-bit windows in LDS (configs[2])",
     "fixed_base_secp256k1": "secp256k1 fixed base, 4-bit windows in LDS",
     "fixed_base_constant_time": "P-256 fixed base, `ALG_CONSTANT_TIME` (6-bit windows in LDS, every entry read, lane masks: secret scalars)",
