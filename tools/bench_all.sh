@@ -20,10 +20,15 @@ run bench_n1_ladder_x_only --steps 10 --warmup 2 --workload ladder-x
 run bench_n1_ladder_x_only_secp256k1 --steps 10 --warmup 2 --workload ladder-x --curve secp256k1
 run bench_n1_windowed_variable_base --steps 10 --warmup 2 --workload windowed
 run bench_n1_windowed_variable_base_secp256k1 --steps 10 --warmup 2 --workload windowed --curve secp256k1
+run bench_n1_windowed_constant_time --steps 10 --warmup 2 --workload windowed-ct
+run bench_n1_windowed_constant_time_secp256k1 --steps 10 --warmup 2 --workload windowed-ct --curve secp256k1
 run bench_n1_fixed_base --steps 20 --warmup 2 --workload fixed-base
-run bench_n1_fixed_base_signed7 --steps 20 --warmup 2 --workload fixed-base-signed
-run bench_n1_fixed_base_big20 --steps 20 --warmup 2 --workload fixed-base-big
 run bench_n1_fixed_base_secp256k1 --steps 20 --warmup 2 --workload fixed-base --curve secp256k1
+run bench_n1_fixed_base_constant_time --steps 20 --warmup 2 --workload fixed-base-ct
+run bench_n1_fixed_base_constant_time_secp256k1 --steps 20 --warmup 2 --workload fixed-base-ct --curve secp256k1
+run bench_n1_fixed_base_signed7 --steps 20 --warmup 2 --workload fixed-base-signed
+run bench_n1_fixed_base_signed7_secp256k1 --steps 20 --warmup 2 --workload fixed-base-signed --curve secp256k1
+run bench_n1_fixed_base_big20 --steps 20 --warmup 2 --workload fixed-base-big
 run bench_n1_group_mode --steps 10 --warmup 2 --multi group
 # the whole N > 1 code path of the one-process-per-GPU mode on the one GPU a builder's box has: RCCL init, side stream, dist.gather
 f=bench_n1_nccl_single_rank_rehearsal
