@@ -91,7 +91,7 @@ struct curve_group {
     return r;
   }
   // k[i] * P[i] for SECRET scalars (ECDH): the per-element window tables with ECSIMD_HIP_ALG_CONSTANT_TIME -- every entry of the lane's
-  // table read in every window, kept under lane masks; 1.44 x (P-256) / 1.73 x (secp256k1) the ladder.  Affine classical in and out.
+  // table read in every window, kept under lane masks; 1.45 x (P-256) / 1.74 x (secp256k1) the ladder.  Affine classical in and out.
   static WCP scalar_mult_affine_secret(WBN const& x, WCP const& P) {
     same_length(x.size(), P.size(), "scalar_mult_affine_secret");
     WCP r{WBN::uninitialized(P.size()), WBN::uninitialized(P.size())};

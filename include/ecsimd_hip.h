@@ -99,7 +99,7 @@ enum {
                                       scalar_mult / scalar_mult_1s: the per-element window tables with all 8 entries of the lane's own table (512
                                       contiguous bytes) read in every window; on secp256k1 the GLV split stays, run on the COMPLETE addition law of
                                       a = 0 curves (no exceptional case to branch on; ALG_NO_ENDOMORPHISM: the plain odd-digit loop).  ECDH with a
-                                      secret scalar at 1.44x (P-256: 69.9 M/s) / 1.73x (secp256k1: 83.8 M/s) the ladder's rate, 1.27x the P-256
+                                      secret scalar at 1.45x (P-256: 70.4 M/s) / 1.74x (secp256k1: 84.4 M/s) the ladder's rate, 1.28x the P-256
                                       ladder without Z (oy = NULL works here too).  Not with ALG_WINDOWED_SIGNED / ALG_WINDOWED_BIG (64 or 2^19 entries per window to read) */
   ECSIMD_HIP_ALG_WINDOWED_BIG = 32 /* scalar_mult_base + OUT_AFFINE: 20-bit windows with odd digits over a 436 MB table of the odd
                                       multiples (2d+1)*2^(20i)*G (13 windows x 2^19 entries) in device memory, built on first
