@@ -340,7 +340,7 @@ def base_line(args, world, total_units, n, value, elapsed):
                        + (" (secp256k1: GLV split k = k1 + k2*lambda on the complete addition law of a = 0 curves)" if args.curve == "secp256k1" else "") + f"; + simultaneous inversion, batch {sizes}, affine out",
     }
     fixed = {"fixed-base": "4-bit window table in LDS (odd digits, 32 KiB)",
-             "fixed-base-ct": "ALG_CONSTANT_TIME: odd-digit comb in LDS, every entry of a window read and one kept under lane masks (P-256: 43 six-bit windows x 32 entries, 86 KiB; secp256k1: 64 four-bit windows x 8 entries, 32 KiB)",
+             "fixed-base-ct": "ALG_CONSTANT_TIME: odd-digit comb in LDS, every entry of a window read and one kept under lane masks (52 five-bit windows x 16 entries, 53 KB, three 256-thread workgroups per CU)",
              "fixed-base-signed": "signed 7-bit window table in LDS (odd digits, 148 KiB)",
              "fixed-base-big": "20-bit window table of odd multiples (436 MB) in device memory"}
     return {
@@ -389,11 +389,10 @@ def roofline_object(args, eng, n, avg_ms):
     else:
         # what THIS algorithm needs per scalar: 63 / 36 / 12 mixed additions x 11 field mults,
         # 7 mults of the simultaneous-inversion walk and 267/m (secp256k1: 270/m) of the inversion m = min(128, n / 2^17) points share; 32 B in, 64 B out.
-        ct6 = args.workload == "fixed-base-ct" and args.curve == "p256"          # the constant-time comb: 6-bit windows on P-256, 4-bit ones on secp256k1
-        adds = 42 if ct6 else {"fixed-base": 63, "fixed-base-ct": 63, "fixed-base-signed": 36, "fixed-base-big": 12}[args.workload]      # odd digits everywhere: the first entry starts the sum (round 3)
+        adds = {"fixed-base": 63, "fixed-base-ct": 51, "fixed-base-signed": 36, "fixed-base-big": 12}[args.workload]      # (the constant-time comb: 52 five-bit windows)      # odd digits everywhere: the first entry starts the sum (round 3)
         share = min(128, max(1, n >> 17))
         mad32_unit, bytes_unit = int((adds * 11 + 7 + (267 if args.curve == "p256" else 270) / share) * 136), 96
-        kname = {"fixed-base": "k_base_windowed<false>", "fixed-base-ct": "k_base_windowed_s<6, true>" if ct6 else "k_base_windowed<true>",
+        kname = {"fixed-base": "k_base_windowed<false>", "fixed-base-ct": "k_base_windowed_s<5, true, 256>",
                  "fixed-base-signed": "k_base_windowed_s<7, false>", "fixed-base-big": "k_base_windowed_g"}[args.workload] + " + k_to_affine_batched"
     achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
     traffic, traffic_src = committed_traffic(args, n)

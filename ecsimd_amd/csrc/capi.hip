@@ -71,7 +71,7 @@ struct ecsimd_hip_ctx {
   int cus;
   uint32_t* sink;      // 4 KiB scratch: peak-probe sink [0, 1024) and the shared scalar at word 1024-8
   uint32_t* window_table[2];   // per curve: 64 x 16 affine multiples d*16^w*G (built on first use)
-  uint32_t* windowct_table[2]; // per curve: the 6-bit odd-digit table of the constant-time comb (CT_WBITS; 88 064 B of LDS)
+  uint32_t* windowct_table[2]; // per curve: the 5- / 6-bit odd-digit table of the constant-time comb (CT_WBITS, CT_WBITS_SECP)
   uint32_t* window6_table[2];  // per curve: signed-window table (SIGNED_WBITS bits): m * 2^(WB i) * G, m = 1..2^(WB-1)
   uint32_t* window16_table[2]; // per curve: signed BIG_WINDOW_BITS-bit windows in device memory (20 bits: 13 x 524 288 entries, 436 MB)
   uint64_t* workspace;         // grow-only scratch for the windowed path's Jacobian intermediates
@@ -151,16 +151,21 @@ int ensure_valid(ecsimd_hip_ctx* ctx, size_t bytes) {
 // Window tables, produced with the (parity-checked) ladder kernel itself.
 //   bits = 4: 64 x 8 entries (2d + 1) * 16^w * G (odd digits; 64 x 16 entries d * 16^w * G with -DECS_FIXED4_ODD=0);  bits = 6 / 7 (signed windows): 43 x 32 / 37 x 64
 //   entries m * 2^(bits i) * G, m = slot + 1.
-// ALG_CONSTANT_TIME reads EVERY entry of a window, so the best window is narrower than without it: on P-256 6 bits (43 windows x 32 entries, 42
-// additions, the signed kernel's template at WB = 6: 323.8 M/s) beat 4 bits (64 x 8, 63 additions: 280.7) and 7 bits (36 additions, 64 entries to read:
-// 294.1); on secp256k1 6 bits spill 19 registers and tie with 4 bits (279.5 against 277.1), which stay (profiles/r03/ab_constant_time_window_width.txt).
-#ifndef ECS_CT_SIX
-#define ECS_CT_SIX 1                // 0: the 4-bit constant-time comb on both curves
+// ALG_CONSTANT_TIME reads EVERY entry of a window, so the best window is narrower than without it (profiles/r03/ab_constant_time_window_width.txt):
+// 5 bits on both curves -- 52 windows x 16 entries, 51 additions, a 53 KB table, THREE 256-thread workgroups per CU (3 waves per SIMD, 146 VGPRs at most,
+// no spill): P-256 326.0 M/s, secp256k1 323.0.  Measured against it: 4 bits (k_base_windowed<true>: 64 x 8, 63 additions) 280.7 / 278.1; 6 bits (43 x 32,
+// one 1024-thread workgroup per CU) 324.2 / 279.5 (19 spills on secp256k1; at 768 threads 310.8 / 268.4); 7 bits (36 additions, 64 entries to read) 294.1 / 235.2.
+#ifndef ECS_CT_P256_BITS
+#define ECS_CT_P256_BITS 5          // 4: k_base_windowed<true>; 5 / 6: the signed kernel's template
 #endif
-constexpr int CT_WBITS = 6;
+#ifndef ECS_CT_SECP_BITS
+#define ECS_CT_SECP_BITS 5
+#endif
+constexpr int CT_WBITS = (ECS_CT_P256_BITS == 5 || ECS_CT_P256_BITS == 6) ? ECS_CT_P256_BITS : 0;
+constexpr int CT_WBITS_SECP = (ECS_CT_SECP_BITS == 5 || ECS_CT_SECP_BITS == 6) ? ECS_CT_SECP_BITS : 0;
 constexpr int SIGNED_WBITS = 7;     // 37 additions, 151 552 B of LDS (6 -> 43 additions, 88 064 B): measured faster
 int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
-  uint32_t** slot = (bits == 4) ? &ctx->window_table[curve] : (bits == launch::BIG_WINDOW_BITS) ? &ctx->window16_table[curve] : (bits == CT_WBITS) ? &ctx->windowct_table[curve] : &ctx->window6_table[curve];
+  uint32_t** slot = (bits == 4) ? &ctx->window_table[curve] : (bits == launch::BIG_WINDOW_BITS) ? &ctx->window16_table[curve] : (bits == 5 || bits == 6) ? &ctx->windowct_table[curve] : &ctx->window6_table[curve];
   if (*slot) return ECSIMD_HIP_OK;
   const bool big = (bits == launch::BIG_WINDOW_BITS);        // odd multiples (2d + 1) * 2^(bits w) * G, ceil(256 / bits) windows, no carry window
   const bool odd4 = (bits == 4) && (launch::FIXED4_ENTRIES == 8);        // the 4-bit LDS table with odd digits (kernels.h ECS_FIXED4_ODD)
@@ -599,14 +604,15 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* 
     NO_COMPAT("ALG_WINDOWED");
     if (n == 0) return ECSIMD_HIP_OK;
     (void)hipSetDevice(ctx->device);
-    const bool ct6 = ct && !six && ECS_CT_SIX && curve == ECSIMD_HIP_P256;    // the constant-time comb: 6-bit windows on P-256, 4-bit ones on secp256k1
-    int rc = ensure_window_table(ctx, curve, big ? launch::BIG_WINDOW_BITS : six ? SIGNED_WBITS : ct6 ? CT_WBITS : 4);
+    const int ctbits = (ct && !six) ? (curve == ECSIMD_HIP_P256 ? CT_WBITS : CT_WBITS_SECP) : 0;   // the constant-time comb's own table (0: the 4-bit kernel)
+    const bool ct6 = ctbits != 0;
+    int rc = ensure_window_table(ctx, curve, big ? launch::BIG_WINDOW_BITS : six ? SIGNED_WBITS : ct6 ? ctbits : 4);
     if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 3 * n * 32);
     if (rc != ECSIMD_HIP_OK) return rc;
     uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
     RUN(((big ? launch::base_windowed_big(s, curve, k, ctx->window16_table[curve], jx, jy, jz, n)
           : six ? launch::base_windowed_signed(s, curve, SIGNED_WBITS, k, ctx->window6_table[curve], jx, jy, jz, n, false)
-          : ct6 ? launch::base_windowed_signed(s, curve, CT_WBITS, k, ctx->windowct_table[curve], jx, jy, jz, n, true)
+          : ct6 ? launch::base_windowed_signed(s, curve, ctbits, k, ctx->windowct_table[curve], jx, jy, jz, n, true)
                 : launch::base_windowed(s, curve, k, ctx->window_table[curve], jx, jy, jz, n, ct)),
          launch::to_affine_batched(s, curve, jx, jy, jz, ox, oy, n, true)));
   }

@@ -100,7 +100,7 @@ struct curve_group {
     return r;
   }
   // k[i] * G for SECRET scalars (key generation, ECDSA nonces): an LDS comb with ECSIMD_HIP_ALG_CONSTANT_TIME -- every table entry of a
-  // window read, the wanted one kept under lane masks, no address or branch formed from the scalar; 6.7 x (P-256) / 5.8 x (secp256k1) the ladder on G.  Affine classical.
+  // window read, the wanted one kept under lane masks, no address or branch formed from the scalar; 6.7 x the ladder on G.  Affine classical.
   static WCP scalar_mult_base_affine_secret(WBN const& x) {
     WCP r{WBN::uninitialized(x.size()), WBN::uninitialized(x.size())};
     hip::check(ecsimd_hip_scalar_mult_base(hip::context(), curve_id, x.data(), r.x().data(), r.y().data(), nullptr, x.size(),

@@ -93,9 +93,9 @@ enum {
                                       lane reads ALL entries a window could pick and keeps its own under lane masks; the recodings have no zero digit,
                                       exceptional scalars and k = 0 mod n are handled by selects (tools/ct_check.py checks the shipped ISA of the window
                                       loops, tests/test_constant_time_isa.py).  SAFE for secret scalars; same results as ALG_WINDOWED.
-                                      scalar_mult_base: an odd-digit comb over an LDS table -- one address per wave, an LDS broadcast (P-256: 43 six-bit
-                                      windows x 32 entries, 42 additions; secp256k1: 64 four-bit windows x 8 entries): k*G for key generation and ECDSA
-                                      nonces at 6.7x (P-256) / 5.8x (secp256k1) the ladder's rate.
+                                      scalar_mult_base: an odd-digit comb over an LDS table -- one address per wave, an LDS broadcast (52 five-bit
+                                      windows x 16 entries, 51 additions, three 256-thread workgroups per CU): k*G for key generation and ECDSA
+                                      nonces at 6.7x the ladder's rate (P-256 326 M/s, secp256k1 323 M/s).
                                       scalar_mult / scalar_mult_1s: the per-element window tables with all 8 entries of the lane's own table (512
                                       contiguous bytes) read in every window; on secp256k1 the GLV split stays, run on the COMPLETE addition law of
                                       a = 0 curves (no exceptional case to branch on; ALG_NO_ENDOMORPHISM: the plain odd-digit loop).  ECDH with a

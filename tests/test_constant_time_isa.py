@@ -112,15 +112,15 @@ def test_constant_time_fixed_base_kernel_reads_every_entry_and_branches_on_nothi
     assert ct_check.check_after_secret_load(affine_asm, "15k_base_windowedILb1E") > 2500
 
 
-def test_constant_time_six_bit_comb_of_p256(tmp_path_factory):
-    """What ALG_CONSTANT_TIME runs on P-256: k_base_windowed_s<6, true> -- 32 entries x 4 reads per window, one branch, nothing else."""
-    asm = assembly(tmp_path_factory, "k_affine_p256")
-    rep = ct_check.check(asm, "k_base_windowed_sILi6ELb1E", allow_global_loads=0, allow_lds_reads=True)
-    assert rep["instructions"] > 2500 and rep["lds_reads"] == 128 and rep["scratch"] == 0 and rep["global_loads"] == []
-    assert len(rep["branches"]) == 1 and re.match(r"s_cmpk?_(lg|eq)_[iu]32 s\d+, \S+ ; s_cbranch_scc[01] ", rep["branches"][0]), rep["branches"]
-    assert ct_check.check_after_secret_load(asm, "k_base_windowed_sILi6ELb1E") > 3000
-    with pytest.raises(ct_check.Violation, match="LDS address"):                        # the same kernel without the flag: a digit addresses the read
-        ct_check.check(asm, "k_base_windowed_sILi6ELb0E", allow_global_loads=0, allow_lds_reads=True)
+def test_constant_time_five_bit_comb(affine_asm):
+    """What ALG_CONSTANT_TIME runs on a fixed base, both curves: k_base_windowed_s<5, true, 256> -- 16 entries x 4 reads per window, one branch,
+    nothing else; the same template without the flag (a digit addresses the one read) is refused."""
+    rep = ct_check.check(affine_asm, "k_base_windowed_sILi5ELb1ELi256E", allow_global_loads=0, allow_lds_reads=True)
+    assert rep["instructions"] > 2300 and rep["lds_reads"] == 64 and rep["scratch"] == 0 and rep["global_loads"] == []
+    assert len(rep["branches"]) == 1 and re.match(r"s_cmpk?_(lg|eq|lt|gt|le|ge)_[iu]32 s\d+, \S+ ; s_cbranch_scc[01] ", rep["branches"][0]), rep["branches"]
+    assert ct_check.check_after_secret_load(affine_asm, "k_base_windowed_sILi5ELb1ELi256E") > 2800
+    with pytest.raises(ct_check.Violation, match="LDS address"):
+        ct_check.check(affine_asm, "k_base_windowed_sILi7ELb0E", allow_global_loads=0, allow_lds_reads=True)
 
 
 def test_the_checker_refuses_the_table_lookup_by_digit(affine_asm):

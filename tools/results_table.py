@@ -29,8 +29,8 @@ LABEL = {
     "windowed_constant_time_secp256k1": "secp256k1 variable base, per-element window tables, `ALG_CONSTANT_TIME` (GLV split on the complete addition law)",
     "fixed_base": "P-256 fixed base, 4-bit windows in LDS (configs[2])",
     "fixed_base_secp256k1": "secp256k1 fixed base, 4-bit windows in LDS",
-    "fixed_base_constant_time": "P-256 fixed base, `ALG_CONSTANT_TIME` (6-bit windows in LDS, every entry read, lane masks: secret scalars)",
-    "fixed_base_constant_time_secp256k1": "secp256k1 fixed base, `ALG_CONSTANT_TIME` (4-bit windows in LDS, every entry read)",
+    "fixed_base_constant_time": "P-256 fixed base, `ALG_CONSTANT_TIME` (5-bit windows in LDS, every entry read, lane masks: secret scalars)",
+    "fixed_base_constant_time_secp256k1": "secp256k1 fixed base, `ALG_CONSTANT_TIME` (5-bit windows in LDS, every entry read)",
     "fixed_base_signed7": "P-256 fixed base, signed 7-bit windows in LDS (`ALG_WINDOWED_SIGNED`)",
     "fixed_base_signed7_secp256k1": "secp256k1 fixed base, signed 7-bit windows in LDS",
     "fixed_base_big20": "P-256 fixed base, 20-bit windows, 436 MB table in device memory (`ALG_WINDOWED_BIG`)",
