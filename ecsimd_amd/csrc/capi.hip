@@ -164,6 +164,19 @@ int ensure_valid(ecsimd_hip_ctx* ctx, size_t bytes) {
 constexpr int CT_WBITS = (ECS_CT_P256_BITS == 5 || ECS_CT_P256_BITS == 6) ? ECS_CT_P256_BITS : 0;
 constexpr int CT_WBITS_SECP = (ECS_CT_SECP_BITS == 5 || ECS_CT_SECP_BITS == 6) ? ECS_CT_SECP_BITS : 0;
 constexpr int SIGNED_WBITS = 7;     // 37 additions, 151 552 B of LDS (6 -> 43 additions, 88 064 B): measured faster
+// The reference ladder's degenerate scalars (curve_group.h:189-218 as written: k forced odd, R0 + R1 = 2^i P): 0 and n end at Z = 0, n - 1,
+// 2^256 - n - 1 and 2^256 - n meet n P = infinity inside a formula and return a wrong point.  k < 2^256; nn = the group order.
+bool ladder_degenerate(const uint64_t nn[4], const uint64_t k[4]) {
+  uint64_t c[4], b = 0;                                        // c = 2^256 - n
+  for (int l = 0; l < 4; ++l) { const unsigned __int128 d = (unsigned __int128)0 - nn[l] - b; c[l] = (uint64_t)d; b = (uint64_t)(d >> 64) & 1u; }
+  auto eq = [](const uint64_t* a, const uint64_t* v, uint64_t plus) {          // a == v - plus
+    uint64_t t[4], bb = plus;
+    for (int l = 0; l < 4; ++l) { const unsigned __int128 d = (unsigned __int128)v[l] - bb; t[l] = (uint64_t)d; bb = (uint64_t)(d >> 64) & 1u; }
+    return a[0] == t[0] && a[1] == t[1] && a[2] == t[2] && a[3] == t[3];
+  };
+  const bool zero = (k[0] | k[1] | k[2] | k[3]) == 0;
+  return zero || eq(k, nn, 0) || eq(k, nn, 1) || eq(k, c, 0) || eq(k, c, 1);
+}
 int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
   uint32_t** slot = (bits == 4) ? &ctx->window_table[curve] : (bits == launch::BIG_WINDOW_BITS) ? &ctx->window16_table[curve] : (bits == 5 || bits == 6) ? &ctx->windowct_table[curve] : &ctx->window6_table[curve];
   if (*slot) return ECSIMD_HIP_OK;
@@ -180,6 +193,7 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
   try { host_k.assign(entries * 4, 0); }                       // up to 218 MB of host memory (20-bit windows): nothing may throw across the C ABI
   catch (...) { return bad(ctx, "window table: out of host memory"); }
   uint64_t kstar[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool negate_special = false;                                 // the table's k* entry was computed as (n - k*) G: y -> p - y
   if (odd) {
     // high-to-low accumulation (the 4-bit LDS kernel): k* = n - 2 (n mod 2^bits), and only if bit `bits` of k* is 0 (then its lowest digit
     // is -(n mod 2^bits)); low-to-high (the device-memory table): k* = n - 2 (n mod 2^(bits (windows - 1)))
@@ -201,6 +215,16 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
     if (borrow || (odd4 && ((kstar[bits / 64] >> (bits % 64)) & 1u))) { for (int l = 0; l < 4; ++l) kstar[l] = 0; }   // no such scalar for this kernel
     const bool have = (kstar[0] | kstar[1] | kstar[2] | kstar[3]) != 0;
     for (int l = 0; l < 4; ++l) host_k[table_entries * 4 + l] = have ? kstar[l] : (l == 0 ? 1u : 0u);        // without a k*: any scalar, the point is never used
+    // k* G comes from the reference ladder below, and the ladder has degenerate scalars of its own (0, n, n - 1, 2^256 - n - 1, 2^256 - n:
+    // DESIGN.md section 5).  The 5-bit comb summed from the bottom has k* = n - 2 (n mod 2^255) = 2^256 - n -- one of them:
+    // there the ladder multiplies by n - k* instead (never degenerate when k* is: checked) and the entry's y is negated after the conversion.
+    if (have && ladder_degenerate(nn, kstar)) {
+      uint64_t alt[4], b2 = 0;
+      for (int l = 0; l < 4; ++l) { const unsigned __int128 d = (unsigned __int128)nn[l] - kstar[l] - b2; alt[l] = (uint64_t)d; b2 = (uint64_t)(d >> 64) & 1u; }
+      if (b2 || ladder_degenerate(nn, alt)) return bad(ctx, "window table: neither k* nor n - k* is a scalar the ladder multiplies correctly");
+      for (int l = 0; l < 4; ++l) host_k[table_entries * 4 + l] = alt[l];
+      negate_special = true;
+    }
   }
   for (int w = 0; w < windows; ++w)
     for (int d = 0; d < per; ++d) {
@@ -234,6 +258,7 @@ int ensure_window_table(ecsimd_hip_ctx* ctx, int curve, int bits = 4) {
     uint64_t* jx = ty + entries * 4; uint64_t* jy = jx + entries * 4; uint64_t* jz = jy + entries * 4;
     launch::scalar_mult(ctx->stream, curve, kd, 4, nullptr, nullptr, jx, jy, jz, entries, ECSIMD_HIP_OUT_AFFINE);
     launch::to_affine_batched(ctx->stream, curve, jx, jy, jz, tx, ty, entries, true);
+    if (negate_special) launch::field_unop(ctx->stream, curve, launch::F_OPPOSITE, ty + table_entries * 4, ty + table_entries * 4, 1);   // -(x, y) = (x, p - y)
     if (big) {
       launch::pack_table_big(ctx->stream, curve, tx, ty, table);           // odd digits: no carry, no 2^256 * G entry
     } else if (odds) {

@@ -21,6 +21,7 @@
 #include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <set>
@@ -46,9 +47,14 @@ struct rccl_api {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*GetVersion)(int*) = nullptr;
   bool load() {
+    // ECSIMD_HIP_RCCL_LIB=<path>: the RCCL build to use instead of the search below (a deployment's pinned copy; the test double
+    // tests/fake_rccl/libfake_rccl.so).  Nothing else is tried when it is set: a typo must not fall back silently.
+    if (const char* forced = getenv("ECSIMD_HIP_RCCL_LIB")) {
+      if (forced[0]) { lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL); if (!lib) return false; }
+    }
     // the copy this process already has (torch ships its own librccl.so, soname librccl.so.1): a second RCCL in one process
     // would bring a second set of communicators' global state with it
-    lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       if (lib) break;
       lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
@@ -76,6 +82,7 @@ struct member {
   bool timed = false;
   uint64_t* stage = nullptr;          // grow-only: inputs and outputs of the host-array form, outputs of the device form
   size_t stage_bytes = 0;
+  bool stage_read_pending = false;    // the device-copy gather read this member's staging: its next ladder waits for group.copied
 };
 }  // namespace
 
@@ -86,7 +93,6 @@ struct ecsimd_hip_group {
   hipStream_t gstream = nullptr;      // member 0's device: the gather (ncclRecv / device copies) runs beside member 0's next ladder
   hipEvent_t g0 = nullptr, g1 = nullptr;   // on gstream, around the last gather
   hipEvent_t copied = nullptr;        // on gstream, after the device-copy gather has read the members' staging
-  bool copied_pending = false;
   bool timed = false;
   char err[256];
 };
@@ -181,8 +187,12 @@ int ecsimd_hip_group_init(const int* devices, int n_devices, ecsimd_hip_group** 
   if (e == hipSuccess) e = hipEventCreateWithFlags(&g->copied, hipEventDisableTiming);
   if (e != hipSuccess) { (void)ecsimd_hip_group_destroy(g); return ECSIMD_HIP_ERR_HIP; }
   // RCCL communicators: one per member, only when every member has its own device (RCCL refuses two ranks on one GPU)
+  // ECSIMD_HIP_GROUP_FORCE_RCCL=1 (tests only): take the RCCL branch although members share a device.  The real RCCL refuses such a
+  // communicator ("Duplicate GPU detected") and group_init then fails; the test double accepts it, which is how a one-GPU box
+  // executes the grouped ncclSend / ncclRecv bookkeeping below (tests/test_gpu_parity.py::test_device_group_rccl_branch_on_a_double).
   std::set<int> distinct(devices, devices + n_devices);
-  if (n_devices > 1 && (int)distinct.size() == n_devices) {
+  const char* force = getenv("ECSIMD_HIP_GROUP_FORCE_RCCL");
+  if (n_devices > 1 && ((int)distinct.size() == n_devices || (force && force[0] == '1'))) {
     if (!g->rccl.load()) { (void)ecsimd_hip_group_destroy(g); return ECSIMD_HIP_ERR_HIP; }
     g->comm.assign((size_t)n_devices, nullptr);
     ncclResult_t r = g->rccl.CommInitAll(g->comm.data(), n_devices, devices);
@@ -311,7 +321,9 @@ int ecsimd_hip_group_scalar_mult(ecsimd_hip_group* g, int curve, const uint64_t*
     if (!k[i] || !x[i] || !y[i]) return gfail(g, ECSIMD_HIP_ERR_BAD_ARG, "bad argument: a member's shard pointer is null");
     hipError_t e = hipSetDevice(mb.device);
     // the previous device-copy gather may still be reading this member's staging on the gather stream
-    if (e == hipSuccess && i != 0 && g->copied_pending) e = hipStreamWaitEvent(mb.stream, g->copied, 0);
+    // (per member: one that sits a small batch out still waits the next time it writes its staging; the event's latest record is
+    // behind every earlier copy on the in-order gather stream)
+    if (e == hipSuccess && i != 0 && mb.stage_read_pending) { e = hipStreamWaitEvent(mb.stream, g->copied, 0); mb.stage_read_pending = false; }
     if (e == hipSuccess) e = hipEventRecord(mb.c0, mb.stream);
     if (e != hipSuccess) return gfail(g, ECSIMD_HIP_ERR_HIP, "member launch", hipGetErrorString(e));
     int rc = ecsimd_hip_scalar_mult(mb.ctx, curve, k[i], x[i], y[i], o[0], o[1], o[2], count, flags);
@@ -324,8 +336,15 @@ int ecsimd_hip_group_scalar_mult(ecsimd_hip_group* g, int curve, const uint64_t*
   }
   if (!gather || G == 1) return ECSIMD_HIP_OK;
   // ---- the one exchange: every other member's shard into member 0's arrays, on member 0's gather stream
+  // The gather stream first waits for EVERY sending member's ladder (cross-device event waits are legal), and only then is g0
+  // recorded: without the waits RCCL's receive kernel would start at once on member 0's device and spin on its CUs beside member
+  // 0's ladder for the whole step, and g0..g1 would time ladder + transfer instead of the transfer.
   member& root = g->m[0];
   hipError_t e = hipSetDevice(root.device);
+  for (int i = 1; i < G && e == hipSuccess; ++i) {
+    size_t first, count; (void)ecsimd_hip_shard_range(n, i, G, &first, &count);
+    if (count != 0) e = hipStreamWaitEvent(g->gstream, g->m[(size_t)i].done, 0);
+  }
   if (e == hipSuccess) e = hipEventRecord(g->g0, g->gstream);
   if (e != hipSuccess) return gfail(g, ECSIMD_HIP_ERR_HIP, "gather", hipGetErrorString(e));
   if (!g->comm.empty()) {
@@ -350,15 +369,14 @@ int ecsimd_hip_group_scalar_mult(ecsimd_hip_group* g, int curve, const uint64_t*
       size_t first, count; (void)ecsimd_hip_shard_range(n, i, G, &first, &count);
       if (count == 0) continue;
       member& mb = g->m[(size_t)i];
-      e = hipSetDevice(root.device);
-      if (e == hipSuccess) e = hipStreamWaitEvent(g->gstream, mb.done, 0);
+      e = hipSetDevice(root.device);                       // (the gather stream already waits for mb.done, above)
       for (int c = 0; c < outs && e == hipSuccess; ++c)
         e = hipMemcpyAsync(root_out[c] + 4 * first, mb.stage + (size_t)c * count * 4, count * 32, hipMemcpyDeviceToDevice, g->gstream);
+      mb.stage_read_pending = true;
       if (e != hipSuccess) return gfail(g, ECSIMD_HIP_ERR_HIP, "gather copy", hipGetErrorString(e));
     }
     // the members' next ladders overwrite their staging: they wait for these copies (see the compute loop)
     e = hipEventRecord(g->copied, g->gstream);
-    if (e == hipSuccess) g->copied_pending = true;
   }
   if (e == hipSuccess) e = hipEventRecord(g->g1, g->gstream);
   if (e != hipSuccess) return gfail(g, ECSIMD_HIP_ERR_HIP, "gather", hipGetErrorString(e));

@@ -438,7 +438,10 @@ def comb_exceptional_scalars(cv):
     n - k* reaches it through the k -> n - k flip, and k* + n where that still fits 256 bits through the reduction (k_affine.inc comb_special)."""
     n = CURVE_PARAMS[cv]["n"]
     out = []
-    for low_bits in (4, 20, 240, 252, 7, 249):
+    # low_bits per SHIPPED window shape: bits (summed from the top: the 4-bit LDS comb) or bits * (windows - 1) (summed from the bottom):
+    # 20-bit device table 20 * 12, signed 7-bit LDS comb 7 * 36, the constant-time 5-bit comb 5 * 51 (= 255: k* = 2^256 - n, one of the
+    # LADDER's degenerate scalars -- ADVICE r3), its 6-bit alternative 6 * 42; 20 / 7 / 249 are earlier shapes, kept.
+    for low_bits in (4, 20 * 12, 7 * 36, 5 * 51, 6 * 42, 20, 7, 249):
         m = n % (1 << low_bits)
         out += [n - 2 * m, (2 * m) % n, n - 2 * m + 1, n - 2 * m - 1]
     out += [v + n for v in out if v + n < (1 << 256)]
@@ -456,15 +459,22 @@ def test_constant_time_fixed_base(engine, oracle, cv):
     k = engine.fill_random(n, SEED, 61)
     edge = engine.to_device(ints_to_arr([0, order, 1, order - 1, 2, order + 1, 2**256 - 1, order - 2]))
     k[:8] = edge
+    # the comb's own exceptional scalar k* = 2^256 - n (5-bit windows summed from the bottom), the even 2n - 2^256 that the k -> n - k flip
+    # maps onto it, and their neighbours: 2^256 - n is one of the LADDER's degenerate scalars, so the witness is the big-int model
+    star = [2**256 - order, 2 * order - 2**256, 2**256 - order - 1, 2**256 - order + 1, 2 * order - 2**256 - 1, 2 * order - 2**256 + 1, 2**256 - order - 2, 2**256 - order + 2]
+    k[8:16] = engine.to_device(ints_to_arr(star))
     ct = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME)
     pl = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | ALG_WINDOWED)
     assert torch.equal(ct[0], pl[0]) and torch.equal(ct[1], pl[1])
     assert not ct[0][:2].any() and not ct[1][:2].any()                        # k = 0 mod n: (0, 0)
+    for j, v in enumerate(star):
+        mx, my = ec_mul(cv, v % order, (c["gx"], c["gy"]))
+        assert arr_to_ints(engine.to_numpy(ct[0][8 + j:9 + j]))[0] == mx and arr_to_ints(engine.to_numpy(ct[1][8 + j:9 + j]))[0] == my, hex(v)
     m = 2048
-    kk = engine.to_numpy(k[8:8 + m])
+    kk = engine.to_numpy(k[16:16 + m])
     gx, gy = ints_to_arr([c["gx"]] * m), ints_to_arr([c["gy"]] * m)
     ex, ey = oracle.to_affine(cv, oracle.scalar_mult(cv, kk, gx, gy, threads=THREADS))
-    assert np.array_equal(engine.to_numpy(ct[0][8:8 + m]), ex) and np.array_equal(engine.to_numpy(ct[1][8:8 + m]), ey)
+    assert np.array_equal(engine.to_numpy(ct[0][16:16 + m]), ex) and np.array_equal(engine.to_numpy(ct[1][16:16 + m]), ey)
     xo = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME, x_only=True)
     assert torch.equal(xo[0], ct[0])
     for n_small in (1, 63, 65, 257):
@@ -523,7 +533,7 @@ def test_comb_kernels_on_their_exceptional_scalars(engine, cv):
     degenerate = {order - 1, 2**256 - order - 1, 2**256 - order}
     lx, ly = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE)
     assert all(torch.equal(lx[i], ex_[i]) and torch.equal(ly[i], ey_[i]) for i in range(len(ks)) if ks[i] not in degenerate), "ladder"
-    for alg, name in ((ALG_WINDOWED, "4-bit LDS table"), (ALG_WINDOWED | ALG_CONSTANT_TIME, "4-bit LDS table, constant time"),
+    for alg, name in ((ALG_WINDOWED, "4-bit LDS table"), (ALG_WINDOWED | ALG_CONSTANT_TIME, "5-bit LDS comb, every entry read (constant time)"),
                       (ALG_WINDOWED_SIGNED, "signed 7-bit LDS table"), (ALG_WINDOWED_BIG, "20-bit table")):
         wx, wy = engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | alg)
         bad = [hex(ks[i]) for i in range(len(ks)) if not (torch.equal(wx[i], ex_[i]) and torch.equal(wy[i], ey_[i]))]
@@ -1238,12 +1248,49 @@ def test_device_group_behind_the_c_abi(engine, oracle, devices):
     can only build groups on device 0: [0] is the 1-device group of SURVEY.md 8(e); listing the device two or three
     times exercises the multi-member bookkeeping (uneven shards, staging, the gather into member 0's arrays) with
     device copies where RCCL -- which refuses two ranks on one GPU -- would run on a real node."""
+    _device_group_checks(engine, oracle, devices, expect_rccl=False)
+
+
+FAKE_RCCL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "libfake_rccl.so")
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_device_group_rccl_branch_on_a_double(engine, oracle, devices, monkeypatch):
+    """The RCCL branch of ecsimd_hip_group_scalar_mult (group.hip: ncclCommInitAll, the grouped ncclRecv / ncclSend exchange) had never
+    executed: every box has one GPU and the real RCCL refuses two ranks on one device.  Here the library is pointed at the test double
+    tests/fake_rccl (ECSIMD_HIP_RCCL_LIB) and told to take the RCCL branch although the members share device 0
+    (ECSIMD_HIP_GROUP_FORCE_RCCL=1): the same checks as above -- uneven and empty shards, Jacobian / affine / x-only, the host-array form,
+    back-to-back calls without a sync, NO_GATHER -- must pass with uses_rccl == True, and the double's counters must show that every
+    shard went through a paired send / receive.  The double is strict (an unmatched or mismatched pair, a wrong current device, a call
+    outside a group is an error) and models stream order; it says nothing about RCCL's own transport."""
+    import ctypes
+    if not os.path.exists(FAKE_RCCL):
+        pytest.fail("tests/fake_rccl/libfake_rccl.so is missing: __graft_entry__.build() makes it")
+    monkeypatch.setenv("ECSIMD_HIP_RCCL_LIB", FAKE_RCCL)
+    monkeypatch.setenv("ECSIMD_HIP_GROUP_FORCE_RCCL", "1")
+    fake = ctypes.CDLL(FAKE_RCCL)
+    stats = lambda: (lambda a: (fake.fake_rccl_stats(a), list(a))[1])((ctypes.c_ulonglong * 5)())
+    before = stats()
+    _device_group_checks(engine, oracle, devices, expect_rccl=True)
+    after = stats()
+    sends, recvs, groups, nbytes, comms = (a - b for a, b in zip(after, before))
+    G = len(devices); n = 10007
+    assert comms == G and groups == 8                                   # one communicator per member; the eight gathering calls of the checks
+    # per gathering call one pair per (sending member, output array): 3 Jacobian, 2 affine, 1 x-only; the 2-element batch has one sender
+    pairs = (G - 1) * (3 + 2 + 3 + 1 + 1 + 3 + 3) + 3
+    assert sends == recvs == pairs
+    from ecsimd_amd import shard_range_c
+    per = lambda total: sum(shard_range_c(total, m, G)[1] for m in range(1, G))          # elements that travel: every shard but member 0's
+    assert nbytes == 32 * (per(n) * (3 + 2 + 3 + 1 + 1 + 3 + 3) + per(2) * 3)
+
+
+def _device_group_checks(engine, oracle, devices, expect_rccl):
     import torch
     from ecsimd_amd import DeviceGroup, shard_range_c
     cv = P256; n = 10007; G = len(devices)
     grp = DeviceGroup(devices)
     try:
-        assert grp.size == G and grp.uses_rccl is False
+        assert grp.size == G and grp.uses_rccl is expect_rccl
         k = engine.fill_random(n, SEED, 1, first_index=77); s_ = engine.fill_random(n, SEED, 2, first_index=77)
         bx, by = engine.scalar_mult_base(cv, s_, flags=OUT_AFFINE | ALG_WINDOWED_BIG)
         exp = engine.scalar_mult(cv, k, bx, by)
@@ -1289,7 +1336,7 @@ def test_device_group_behind_the_c_abi(engine, oracle, devices):
         f0, c0 = spans[0]
         assert all(torch.equal(a[f0:f0 + c0], b[f0:f0 + c0]) for a, b in zip(o3, exp))
         assert G == 1 or all(bool((a[f0 + c0:] == 7).all()) for a in o3)
-        assert all(grp.member_ms(m) > 0 for m in range(G)) and grp.rccl_version == 0
+        assert all(grp.member_ms(m) > 0 for m in range(G)) and grp.rccl_version == (99999 if expect_rccl else 0)
         assert torch.cuda.current_device() == 0
         if G == 1:
             # what one GPU can run of the RCCL side: dlopen, a one-rank communicator, the gather's own send / recv calls

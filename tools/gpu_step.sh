@@ -1,0 +1,17 @@
+#!/bin/bash
+# tools/gpu_step.sh <name> -- the GPU-box command sequences of a round, one case per step (replaces round 3's tools/dbg/gpu_step_*.sh).
+# Usage here: /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/gpu_step.sh <name>'; everything is written under gpurun_out/<name>/.
+set -o pipefail
+name=${1:?step name}; shift
+out=gpurun_out/$name; mkdir -p "$out"
+export TMPDIR=/tmp
+case "$name" in
+  r4_group_ct)      # round 4: the RCCL branch on the test double, the k* fix of the constant-time comb, the new VALU rates
+    timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "device_group or constant_time_fixed_base or exceptional_scalars" > "$out/pytest.txt" 2>&1; rc=$?
+    tail -5 "$out/pytest.txt"
+    [ $rc -eq 0 ] && timeout -k 10 300 tools/ubench/valu_rates r4 > "$out/valu_rates_r4.txt" 2>&1 && cat "$out/valu_rates_r4.txt"
+    exit $rc ;;
+  pytest_gpu)       # the whole GPU suite, as the driver runs it
+    timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -15 "$out/pytest.txt"; exit $rc ;;
+  *) echo "unknown step $name"; exit 2 ;;
+esac

@@ -6,6 +6,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -o valu_rates valu_rates.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
@@ -168,6 +169,23 @@ KERNEL_BEGIN(k_g_guard) if (i < 2) asm volatile(
     "v_cmp_eq_u32_e64 s[20:21], %7, -1\n\ts_cmp_lg_u64 s[20:21], 0\n\ts_cbranch_scc0 1f\n\tv_add_u32 %7, %7, 1\n\t1:"
     : OPS8 : : "vcc", "scc", "s20", "s21"); KERNEL_END
 
+
+// ---- round 4: the instructions a reduced-radix (9 x 29-bit signed limbs) field arithmetic is built from
+KERNEL_BEGIN(k4_ashrrev_i32)  asm volatile("v_ashrrev_i32 %0, 29, %0" : "+v"(a[i]) : ); KERNEL_END
+KERNEL_BEGIN(k4_lshrrev_b32)  asm volatile("v_lshrrev_b32 %0, 29, %0" : "+v"(a[i]) : ); KERNEL_END
+KERNEL_BEGIN(k4_bfe_i32)      asm volatile("v_bfe_i32 %0, %0, 0, 29" : "+v"(a[i]) : ); KERNEL_END
+KERNEL_BEGIN(k4_and_lit)      asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(a[i]) : ); KERNEL_END
+KERNEL_BEGIN(k4_lshl_or)      asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(b)); KERNEL_END
+KERNEL_BEGIN(k4_add_lshl)     asm volatile("v_add_lshl_u32 %0, %0, %1, 2" : "+v"(a[i]) : "v"(b)); KERNEL_END
+KERNEL_BEGIN(k4_sub_lit)      asm volatile("v_subrev_u32 %0, 0x10000000, %0" : "+v"(a[i]) : ); KERNEL_END
+KERNEL64_BEGIN(k4_ashrrev_i64)   asm volatile("v_ashrrev_i64 %0, 29, %0" : "+v"(a[i]) : ); KERNEL64_END
+KERNEL64_BEGIN(k4_mad_i64_sconst) asm volatile("s_mov_b32 s20, 0x200\n\tv_mad_i64_i32 %0, s[22:23], %1, s20, %0" : "+v"(a[i]) : "v"(b) : "s20", "s22", "s23"); KERNEL64_END
+// a normalisation pass element: c = x >> 29 (arithmetic), y = (x & m) + c'
+KERNEL_BEGIN(k4_norm_limb)    if (i < 5) { uint32_t t;
+    asm volatile("v_ashrrev_i32 %1, 29, %0\n\tv_and_b32 %0, 0x1fffffff, %0\n\tv_add_u32 %0, %0, %2" : "+v"(a[i]), "=&v"(t) : "v"(b)); a[i + 8] ^= t; } KERNEL_END
+// alternating full-rate and dual-rate instructions: do they cost the sum?
+KERNEL64_BEGIN(k4_mad_and_mix) if (i < 8) { asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_and_b32 %3, 0x1fffffff, %3" : "+v"(a[i]), "+v"(*(uint32_t*)&a[i + 8]) : "v"(b), "v"(c) : "vcc"); } KERNEL64_END
+
 typedef void (*kern_t)(uint32_t*, uint32_t);
 struct Entry { const char* name; kern_t k; int insts_per_slot; };
 
@@ -198,14 +216,22 @@ int main(int argc, char** argv) {
     {"8 cndmask e64 sgpr", k_g_cndmask_e64, 1}, {"8 cndmask vcc<-salu", k_g_cndmask_vcc_salu, 1}, {"cmp + 8 cndmask vcc", k_g_cndmask_vcc_valu, 1},
     {"cmp,andn2,8 cndmask", k_g_cndmask_vcc_andn2, 1}, {"8 v_mov under exec", k_g_mov_exec, 1}, {"8 subb under exec", k_g_subb_exec, 1},
     {"8 subb plain", k_g_subb_plain, 1}, {"8 v_swap_b32", k_g_swap, 1}, {"8 v_add_u32 exec", k_g_add_exec, 1}, {"7 subb+cmp+guard", k_g_guard, 1},
+    // round 4 (names start with "r4 ": `valu_rates r4` runs only these).  Slots that execute for i < K only are scaled below.
+    {"r4 v_ashrrev_i32", k4_ashrrev_i32, 1}, {"r4 v_lshrrev_b32", k4_lshrrev_b32, 1}, {"r4 v_bfe_i32", k4_bfe_i32, 1}, {"r4 v_and_b32 literal", k4_and_lit, 1},
+    {"r4 v_lshl_or_b32", k4_lshl_or, 1}, {"r4 v_add_lshl_u32", k4_add_lshl, 1}, {"r4 v_subrev_u32 literal", k4_sub_lit, 1}, {"r4 v_ashrrev_i64", k4_ashrrev_i64, 1},
+    {"r4 v_mad_i64_i32 sgpr", k4_mad_i64_sconst, 1},
+    {"r4 norm limb ashr+and+add /3", k4_norm_limb, 1},
+    {"r4 mad_i64 + v_and pairs /2", k4_mad_and_mix, 1},
   };
+  const char* filter = argc > 1 ? argv[1] : nullptr;
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   const int wps_list[] = {1, 2, 4, 8};   // waves per SIMD
   printf("%-22s", "instruction");
   for (int w : wps_list) printf("  w/SIMD=%d: Tinst/s  cyc@2.4GHz", w);
   printf("\n");
   for (auto& e : es) {
-    printf("%-22s", e.name);
+    if (filter && !strstr(e.name, filter)) continue;
+    printf("%-30s", e.name);
     for (int wps : wps_list) {
       // blocks of 256 threads = 4 waves = one wave per SIMD of a CU; wps blocks per CU
       int grid = cus * wps;
