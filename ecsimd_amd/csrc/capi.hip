@@ -46,6 +46,7 @@ void zdau(hipStream_t s, int curve, const uint64_t* px, const uint64_t* py, cons
 void add_z2_1(hipStream_t s, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH(add_z2_1, s, ax, ay, az, bx, by, rx, ry, rz, n); }
 void trplu(hipStream_t s, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { DISPATCH(trplu, s, px, py, pz, rx, ry, rz, n); }
 void scalar_mult(hipStream_t s, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) { DISPATCH(scalar_mult, s, k, k_stride, x, y, ox, oy, oz, n, flags); }
+void zdau_repeat(hipStream_t s, int curve, const uint64_t* px, const uint64_t* py, const uint64_t* pz, const uint64_t* qx, const uint64_t* qy, uint64_t* rx, uint64_t* ry, uint64_t* sx, uint64_t* sy, uint64_t* oz, size_t n, int iters, uint64_t swap_bits, int radix) { DISPATCH(zdau_repeat, s, px, py, pz, qx, qy, rx, ry, sx, sy, oz, n, iters, swap_bits, radix); }
 void to_affine_batched(hipStream_t s, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool in_fast) { DISPATCH2(to_affine_batched, s, jx, jy, jz, x, y, n, in_fast); }
 void pack_table(hipStream_t s, int curve, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH2(pack_table, s, tx, ty, table); }
 void pack_table_signed(hipStream_t s, int curve, int wbits, const uint64_t* tx, const uint64_t* ty, uint32_t* table) { DISPATCH2(pack_table_signed, s, wbits, tx, ty, table); }
@@ -578,6 +579,13 @@ int ecsimd_hip_zaddu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py,
 int ecsimd_hip_zdau(ecsimd_hip_ctx* ctx, int curve, const uint64_t* px, const uint64_t* py, const uint64_t* pz, uint64_t* qx, uint64_t* qy, uint64_t* qz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(qz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
   RUN(launch::zdau(s, instance(ctx, curve), px, py, pz, qx, qy, qz, rx, ry, rz, n)); }
+int ecsimd_hip_zdau_repeat(ecsimd_hip_ctx* ctx, int curve, const uint64_t* px, const uint64_t* py, const uint64_t* pz, const uint64_t* qx, const uint64_t* qy,
+                           uint64_t* rx, uint64_t* ry, uint64_t* sx, uint64_t* sy, uint64_t* oz, size_t n, int iters, uint64_t swap_bits, int radix) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(sx); REQUIRE_PTR(sy); REQUIRE_PTR(oz);
+  if (iters < 0) return bad(ctx, "iters is negative");
+  if (radix != 29 && radix != 32) return bad(ctx, "radix is 29 or 32");
+  if (radix == 29 && instance(ctx, curve) != curve) return bad(ctx, "the reduced-radix loop has no reference-square form (the dropped carry depends on the 32-bit Montgomery digits)");
+  RUN(launch::zdau_repeat(s, instance(ctx, curve), px, py, pz, qx, qy, rx, ry, sx, sy, oz, n, iters, swap_bits, radix)); }
 int ecsimd_hip_add_z2_1(ecsimd_hip_ctx* ctx, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(ax); REQUIRE_PTR(ay); REQUIRE_PTR(az); REQUIRE_PTR(bx); REQUIRE_PTR(by); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
   RUN(launch::add_z2_1(s, instance(ctx, curve), ax, ay, az, bx, by, rx, ry, rz, n)); }

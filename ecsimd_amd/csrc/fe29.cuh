@@ -1,0 +1,226 @@
+// fe29.cuh -- reduced-radix prime-field arithmetic for the ladder's 254-iteration loop (round 4): nine SIGNED 29-bit limbs.
+//
+// Why a second representation.  field.cuh keeps a field element in 8 x 32-bit words and returns canonical residues; per ladder
+// iteration that is 828 multiplies but 2 033 carry-chain additions (v_addc_co_u32: 4.3 issue cycles each, as dear as a multiply),
+// 40 conditional subtractions and 236 column moves -- 12 580 cycles of which the multiplies are 3 600.
+// Here a field element is value = sum l[i] * 2^(29 i) with nine signed 32-bit limbs and the Montgomery radix R' = 2^261:
+//   * a column of a product is at most 9 x 2^58 x (small factors) < 2^63, so v_mad_i64_i32 accumulates a whole column in its own
+//     64-bit accumulator -- NO carry instruction between the products of a column;
+//   * additions and subtractions are nine v_add_u32 / v_sub_u32 (2.3 cycles each) with no carry chain and no conditional
+//     subtraction: limbs and values are allowed to grow within proven bounds ("lazy"), and one parallel carry pass (norm29)
+//     brings an operand back where a square needs it;
+//   * the Montgomery reduction is folded into the column walk (finely integrated product scanning): q_k is the column's low
+//     29 bits (p = -1 mod 2^29 for P-256), and q_k * p enters four later columns through p's sparse signed form
+//     2^256 - 2^224 + 2^192 + 2^96 - 1 -- 36 multiply-adds by constants per reduction; a column ends with one v_and_b32 and one
+//     v_ashrrev_i64.  secp256k1 (2^256 - 2^32 - 977): q_k = column * 977^-1 mod 2^29, three constants.
+// The VALUES computed are the reference's (curve_group.h:120-153): x -> x * 2^261 is a field isomorphism like x -> x * 2^256, the
+// kernel converts at the loop's boundary and canonicalises at the end, so the ladder's X, Y, Z stay bit-identical (level J).
+//
+// The bounds that make this sound are PROVEN, not assumed: tools/radix29_model.py executes these same functions (same names, same
+// order) on intervals and shows that one zdau29 maps the loop invariant into itself with every limb inside int32 and every
+// column inside int64 (tests/test_radix29_model.py), and on concrete integers against the big-int ZDAU.
+#pragma once
+#include "field.cuh"
+
+namespace ecsimd_hip {
+
+constexpr int R29_LIMBS = 9;
+constexpr int R29_BITS = 29;
+constexpr int32_t R29_MASK = (1 << R29_BITS) - 1;
+
+struct fe29 { int32_t l[R29_LIMBS]; };
+
+// A uniform constant the optimiser cannot see through: keeps `q * 2^9` a v_mad_i64_i32 by an SGPR instead of a 64-bit shift + add.
+ECS_DEV int32_t r29_opaque(int32_t c) { int32_t r; asm("s_mov_b32 %0, %1" : "=s"(r) : "i"(c)); return r; }
+// x + x as ONE dual-rate v_add_u32 (the compiler's canonical form is a shift)
+ECS_DEV int32_t r29_dbl32(int32_t x) { int32_t r; asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x)); return r; }
+
+template <int C> struct r29_prime;                 // the prime's sparse signed form in radix 2^29 (tools/radix29_model.py Curve.terms)
+template <> struct r29_prime<CURVE_P256> { static constexpr bool p256 = true; };
+template <> struct r29_prime<CURVE_SECP256K1_CLASSICAL> { static constexpr bool p256 = false; static constexpr uint32_t QMUL = 0x12253531u; };   // 977^-1 mod 2^29
+
+ECS_DEV fe29 add29(const fe29& a, const fe29& b) { fe29 r;
+#pragma unroll
+  for (int i = 0; i < R29_LIMBS; ++i) r.l[i] = a.l[i] + b.l[i];
+  return r; }
+ECS_DEV fe29 sub29(const fe29& a, const fe29& b) { fe29 r;
+#pragma unroll
+  for (int i = 0; i < R29_LIMBS; ++i) r.l[i] = a.l[i] - b.l[i];
+  return r; }
+ECS_DEV fe29 dbl29(const fe29& a) { fe29 r;
+#pragma unroll
+  for (int i = 0; i < R29_LIMBS; ++i) r.l[i] = r29_dbl32(a.l[i]);
+  return r; }
+// One PARALLEL carry pass over (a << SHIFT): every carry is taken from the input limbs, so limbs 0..7 end in [c_min, 2^29 + c_max)
+// with |c| <= 4 -- "normalised", which is what a square's operand has to be; the top limb keeps the value's sign and excess.
+template <int SHIFT = 0> ECS_DEV fe29 norm29(const fe29& a) {
+  fe29 r;
+  auto shl = [](int32_t v) { return (int32_t)((uint32_t)v << SHIFT); };
+  r.l[0] = shl(a.l[0]) & R29_MASK;
+#pragma unroll
+  for (int i = 1; i < R29_LIMBS - 1; ++i) r.l[i] = (shl(a.l[i]) & R29_MASK) + (a.l[i - 1] >> (R29_BITS - SHIFT));
+  r.l[R29_LIMBS - 1] = shl(a.l[R29_LIMBS - 1]) + (a.l[R29_LIMBS - 2] >> (R29_BITS - SHIFT));
+  return r;
+}
+ECS_DEV void cswap29(uint32_t m, fe29& a, fe29& b) {
+#pragma unroll
+  for (int i = 0; i < R29_LIMBS; ++i) { const int32_t t = (a.l[i] ^ b.l[i]) & (int32_t)m; a.l[i] ^= t; b.l[i] ^= t; }
+}
+
+// Montgomery product a * b / 2^261 (SQR: a * a / 2^261 with the 36 cross products taken once on a doubled operand), reduction
+// folded into the column walk.  Result: limbs 0..7 in [0, 2^29), the top limb signed and small; value in (T / R', T / R' + p).
+template <int C, bool SQR> ECS_DEV fe29 fips29(const fe29& a, const fe29& b) {
+  using PR = r29_prime<C>;
+  int32_t q[R29_LIMBS];
+  int32_t a2[R29_LIMBS];
+  fe29 r;
+  if constexpr (SQR) {
+#pragma unroll
+    for (int i = 0; i < R29_LIMBS; ++i) a2[i] = r29_dbl32(a.l[i]);
+  }
+  // p256: + q 2^9 (3 limbs up), + q 2^18 (6 up), - q 2^21 (7 up), + q 2^24 (8 up); - q at its own column cancels the low bits
+  // secp256k1: - 977 q at its own column, - 8 q one limb up, + q 2^24 eight limbs up
+  const int32_t k9 = r29_opaque(1 << 9), k18 = r29_opaque(1 << 18), km21 = r29_opaque(-(1 << 21)), k24 = r29_opaque(1 << 24);
+  const int32_t km977 = r29_opaque(-977), km8 = r29_opaque(-8);
+  int64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * R29_LIMBS - 1; ++k) {
+#pragma unroll
+    for (int i = 0; i < R29_LIMBS; ++i) {
+      const int j = k - i;
+      if (j < 0 || j >= R29_LIMBS) continue;
+      if constexpr (!SQR) acc += (int64_t)a.l[i] * b.l[j];
+      else { if (i < j) acc += (int64_t)a2[i] * a.l[j]; else if (i == j) acc += (int64_t)a.l[i] * a.l[i]; }
+    }
+    if constexpr (PR::p256) {
+      if (k >= 3 && k - 3 < R29_LIMBS) acc += (int64_t)q[k - 3] * k9;
+      if (k >= 6 && k - 6 < R29_LIMBS) acc += (int64_t)q[k - 6] * k18;
+      if (k >= 7 && k - 7 < R29_LIMBS) acc += (int64_t)q[k - 7] * km21;
+      if (k >= 8 && k - 8 < R29_LIMBS) acc += (int64_t)q[k - 8] * k24;
+      if (k < R29_LIMBS) q[k] = (int32_t)acc & R29_MASK;            // acc - q[k] is a multiple of 2^29: the shift below drops it
+      else r.l[k - R29_LIMBS] = (int32_t)acc & R29_MASK;
+    } else {
+      if (k >= 1 && k - 1 < R29_LIMBS) acc += (int64_t)q[k - 1] * km8;
+      if (k >= 8 && k - 8 < R29_LIMBS) acc += (int64_t)q[k - 8] * k24;
+      if (k < R29_LIMBS) { q[k] = (int32_t)((uint32_t)acc * PR::QMUL) & R29_MASK; acc += (int64_t)q[k] * km977; }
+      else r.l[k - R29_LIMBS] = (int32_t)acc & R29_MASK;
+    }
+    acc >>= R29_BITS;
+  }
+  r.l[R29_LIMBS - 1] = (int32_t)acc;
+  return r;
+}
+template <int C> ECS_DEV fe29 mul29(const fe29& a, const fe29& b) { return fips29<C, false>(a, b); }
+template <int C> ECS_DEV fe29 sqr29(const fe29& a) { return fips29<C, true>(a, a); }
+
+// ---------------------------------------------------------------- conversions at the loop's boundary
+// canonical 8 x 32-bit words (a value < 2^256) -> nine tight limbs of the same integer
+ECS_DEV fe29 to29(const fe& v) {
+  fe29 r;
+#pragma unroll
+  for (int i = 0; i < R29_LIMBS; ++i) {
+    const int bit = R29_BITS * i, j = bit >> 5, sh = bit & 31;
+    uint32_t w = v.w[j] >> sh;
+    if (sh > 32 - R29_BITS && j + 1 < 8) w |= v.w[j + 1] << (32 - sh);
+    r.l[i] = (int32_t)(w & (uint32_t)R29_MASK);
+  }
+  return r;
+}
+// nine tight limbs of an integer < 2^256 -> 8 words
+ECS_DEV fe from29(const fe29& t) {
+  fe r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int bit = 32 * j, k = bit / R29_BITS, o = bit % R29_BITS;
+    uint32_t w = (uint32_t)t.l[k] >> o;
+    w |= (uint32_t)t.l[k + 1] << (R29_BITS - o);
+    if (2 * R29_BITS - o < 32 && k + 2 < R29_LIMBS) w |= (uint32_t)t.l[k + 2] << (2 * R29_BITS - o);
+    r.w[j] = w;
+  }
+  return r;
+}
+template <int C> struct r29_consts;
+template <> struct r29_consts<CURVE_P256> {
+  // tight limbs (tools/radix29_model.py to_limbs) of p, of 2^266 mod p (field.cuh's x * 2^256 -> x * 2^261) and of 2^256 mod p (back)
+  static constexpr int32_t P[9]   = {0x1fffffff, 0x1fffffff, 0x1fffffff, 0x000001ff, 0x00000000, 0x00000000, 0x00040000, 0x1fe00000, 0x00ffffff};
+  static constexpr int32_t IN[9]  = {0x00000400, 0x00000000, 0x00000000, 0x1ff80000, 0x1fffffff, 0x1fffffff, 0x0fffffff, 0x1fffffff, 0x00000003};
+  static constexpr int32_t OUT[9] = {0x00000001, 0x00000000, 0x00000000, 0x1ffffe00, 0x1fffffff, 0x1fffffff, 0x1ffbffff, 0x001fffff, 0x00000000};
+};
+template <> struct r29_consts<CURVE_SECP256K1_CLASSICAL> {
+  // the secp256k1 loops run in the CLASSICAL domain of field.cuh: in = 2^522 mod p (x -> x * 2^261), out = 1
+  static constexpr int32_t P[9]   = {0x1ffffc2f, 0x1ffffff7, 0x1fffffff, 0x1fffffff, 0x1fffffff, 0x1fffffff, 0x1fffffff, 0x1fffffff, 0x00ffffff};
+  static constexpr int32_t IN[9]  = {0x1a428400, 0x00f44001, 0x00010000, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000};
+  static constexpr int32_t OUT[9] = {0x00000001, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000};
+};
+template <const int32_t (&ARR)[9]> ECS_DEV fe29 fe29_const() { fe29 r;
+#pragma unroll
+  for (int i = 0; i < R29_LIMBS; ++i) r.l[i] = ARR[i];
+  return r; }
+// a field element of the loop's surroundings (canonical, field.cuh's fast domain) -> x * 2^261 in tight limbs
+template <int C> ECS_DEV fe29 enter29(const fe& v) { return mul29<C>(to29(v), fe29_const<r29_consts<C>::IN>()); }
+// ... and back: the canonical residue of field.cuh's domain.  `v` is anything the loop holds (|value| < 8 p): the product with a
+// tight constant < p lies in (-p/4, 9p/8), + p makes it positive, a sequential carry pass makes the limbs tight, and two
+// conditional subtractions of p (sign of the top limb after a borrow pass) land in [0, p).
+template <int C> ECS_DEV fe leave29(const fe29& v) {
+  using K = r29_consts<C>;
+  fe29 t = mul29<C>(v, fe29_const<K::OUT>());
+#pragma unroll
+  for (int i = 0; i < R29_LIMBS; ++i) t.l[i] += K::P[i];
+#pragma unroll
+  for (int i = 0; i < R29_LIMBS - 1; ++i) { t.l[i + 1] += t.l[i] >> R29_BITS; t.l[i] &= R29_MASK; }
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    fe29 d;
+#pragma unroll
+    for (int i = 0; i < R29_LIMBS; ++i) d.l[i] = t.l[i] - K::P[i];
+#pragma unroll
+    for (int i = 0; i < R29_LIMBS - 1; ++i) { d.l[i + 1] += d.l[i] >> R29_BITS; d.l[i] &= R29_MASK; }
+    const int32_t keep = d.l[R29_LIMBS - 1] >> 31;                     // all ones where t < p
+#pragma unroll
+    for (int i = 0; i < R29_LIMBS; ++i) t.l[i] = (t.l[i] & keep) | (d.l[i] & ~keep);
+  }
+  return from29(t);
+}
+
+// ---------------------------------------------------------------- the ladder iteration
+// Loop state: the co-Z pair (x1, y1), (x2, y2) with y2 kept as dy = y1 - y2 and dx = x1 - x2 carried beside x1, x2 -- differences of
+// TIGHT values, so the next iteration squares them without a carry pass (tools/radix29_model.py ladder_invariant has the intervals).
+struct coz29 { fe29 x1, x2, dx, y1, dy, z; };
+
+// One iteration: (x1, y1) <- 2 (x1, y1) + (x2, y2), (x2, y2) re-expressed with the new z; `oswap` exchanges the two outputs.
+// The field VALUES are point.cuh zdau<C>'s (curve_group.h:120-153), statement for statement in tools/radix29_model.py zdau29.
+// Differences from the 8-word form: the factor 4 of W1 = 4 X3' C, W2 = 4 W1' C rides in on a normalised 4C (one pass makes both
+// products tight and true-valued); A1 is an ordinary product (a shared 18-column product is dearer than the reduction it saves here).
+template <int C> ECS_DEV void zdau29(coz29& s, uint32_t oswap) {
+  const fe29 Cp = sqr29<C>(s.dx);
+  const fe29 W1p = mul29<C>(s.x1, Cp);
+  const fe29 W2p = mul29<C>(s.x2, Cp);
+  const fe29 Dp = sqr29<C>(s.dy);
+  const fe29 A1p = mul29<C>(s.y1, sub29(W1p, W2p));
+  const fe29 X3 = sub29(sub29(Dp, W1p), W2p);
+  const fe29 u = norm29(sub29(X3, W1p));
+  const fe29 Cc = sqr29<C>(u);
+  fe29 yp = norm29(sub29(sub29(sqr29<C>(norm29(sub29(s.dy, u))), Dp), Cc));      // Y3' + 2 A1'
+  const fe29 A2 = dbl29(A1p);
+  const fe29 Y3p = sub29(yp, A2);
+  fe29 ym = norm29(sub29(Y3p, A2));
+  const fe29 C4 = norm29<2>(Cc);
+  const fe29 W1 = mul29<C>(X3, C4);
+  const fe29 W2 = mul29<C>(W1p, C4);
+  const fe29 A1 = mul29<C>(Y3p, sub29(W1, W2));
+  const fe29 zz = sub29(sub29(sqr29<C>(norm29(add29(s.dx, u))), Cp), Cc);
+  s.z = mul29<C>(s.z, zz);
+  cswap29(oswap, ym, yp);
+  const fe29 D = sqr29<C>(ym);
+  const fe29 Dc = sqr29<C>(yp);
+  const fe29 W12 = add29(W1, W2);
+  s.x1 = sub29(D, W12);
+  s.x2 = sub29(Dc, W12);
+  s.dx = sub29(D, Dc);
+  const fe29 P1 = mul29<C>(ym, sub29(W1, s.x1));
+  const fe29 P2 = mul29<C>(yp, sub29(W1, s.x2));
+  s.y1 = sub29(P1, A1);
+  s.dy = sub29(P1, P2);
+}
+
+}  // namespace ecsimd_hip

@@ -62,6 +62,8 @@ void trplu(hipStream_t, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uin
 // flags: ECSIMD_HIP_BASE_* | ECSIMD_HIP_OUT_*.
 void scalar_mult(hipStream_t, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y,
                  uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
+void zdau_repeat(hipStream_t, int curve, const uint64_t* px, const uint64_t* py, const uint64_t* pz, const uint64_t* qx, const uint64_t* qy,
+                 uint64_t* rx, uint64_t* ry, uint64_t* sx, uint64_t* sy, uint64_t* oz, size_t n, int iters, uint64_t swap_bits, int radix);
 // k_affine_<curve>.hip: simultaneous-inversion to_affine (x, y must not alias the inputs), the
 // 4-bit-window table packer and the fixed-base windowed multiplication (Jacobian out, fast domain).
 void to_affine_batched(hipStream_t, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool in_fast_domain);
@@ -103,6 +105,8 @@ template <int C> struct point_launch {
   static void add_z2_1(hipStream_t, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
   static void trplu(hipStream_t, uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t);
   static void scalar_mult(hipStream_t, const uint64_t*, int, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, size_t, int);
+  static void zdau_repeat(hipStream_t, const uint64_t* px, const uint64_t* py, const uint64_t* pz, const uint64_t* qx, const uint64_t* qy,
+                          uint64_t* rx, uint64_t* ry, uint64_t* sx, uint64_t* sy, uint64_t* oz, size_t n, int iters, uint64_t swap_bits, int radix);
   // x(kP) only, by the ladder without Z (defined for P-256 only: needs a != 0; k_ladder.inc)
   static void scalar_mult_x(hipStream_t, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* scratch, size_t n, int flags);
   // k_affine_<curve>.hip

@@ -6,6 +6,7 @@
 // reference occurs twice it is computed once (u = X3'-W1', W1+W2): the VALUES are unchanged.
 #pragma once
 #include "field.cuh"
+#include "fe29.cuh"
 
 namespace ecsimd_hip {
 
@@ -75,7 +76,12 @@ template <int C> ECS_DEV void zaddu(fe& x1, fe& y1, const fe& x2, const fe& y2, 
 #define ECS_ZDAU_Z_EARLY (-1)
 #endif
 template <int C> struct zdau_z_early { static constexpr bool value = (ECS_ZDAU_Z_EARLY < 0) ? !curve_prime<C>::is_p256 : (ECS_ZDAU_Z_EARLY != 0); };
-template <int C, bool NOZ = false> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe& y2, fe& z, uint32_t oswap = 0u) {
+// ZE: -1 = the curve's placement above, 0 / 1 = late / early for this call site; 2 = early with the factors of z * zz exchanged, which
+// k_zdau_repeat<32> takes: with z as the FIRST factor, updated in place from registers a global load had pinned, the compiler handed
+// mac_col's early-clobber carry counter the register of the still-live z.w[7] (a compiler defect, not a source one: the constraint is
+// "=&v"; tools/asm_clobber_check.py finds it in the ISA and tests/test_isa_guards.py keeps every shipped unit checked).
+template <int C, bool NOZ = false, int ZE = -1> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe& y2, fe& z, uint32_t oswap = 0u) {
+  constexpr bool z_early = (ZE < 0) ? zdau_z_early<C>::value : (ZE != 0);
   const fe dx = fe_sub<C>(x1, x2);
   const fe Cp = fe_sqr<C>(dx);
   const fe W1p = fe_mul<C>(x1, Cp);
@@ -87,10 +93,10 @@ template <int C, bool NOZ = false> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe&
   const fe u = fe_sub<C>(X3pc, W1p);
   const fe Cc = fe_sqr<C>(u);
   // Z3 = Z * ((dx + X3' - W1')^2 - C' - C): as soon as C exists -- dx and C' die here instead of living across W1, W2 and A1
-  if constexpr (!NOZ && zdau_z_early<C>::value) {
+  if constexpr (!NOZ && z_early) {
     fe zz = fe_sqr<C>(fe_add<C>(dx, u));
     zz = fe_sub<C>(fe_sub<C>(zz, Cp), Cc);
-    z = fe_mul<C>(z, zz);
+    if constexpr (ZE == 2) z = fe_mul<C>(zz, z); else z = fe_mul<C>(z, zz);      // ZE == 2: the same product with the factors exchanged
   }
   const fe A1p2 = fe_dbl<C>(A1p);
   // Y3' = (dy + (W1' - X3'))^2 - D' - C - 2A1'
@@ -108,7 +114,7 @@ template <int C, bool NOZ = false> ECS_DEV void zdau(fe& x1, fe& y1, fe& x2, fe&
   const fe2 A1wide = mul8x8(Y3p, fe_sub<C>(W1, W2));
   const fe W12 = fe_add<C>(W1, W2);
   // Z3 = Z * ((dx + X3' - W1')^2 - C' - C)
-  if constexpr (!NOZ && !zdau_z_early<C>::value) {
+  if constexpr (!NOZ && !z_early) {
     fe zz = fe_sqr<C>(fe_add<C>(dx, u));
     zz = fe_sub<C>(fe_sub<C>(zz, Cp), Cc);
     z = fe_mul<C>(z, zz);
@@ -440,9 +446,49 @@ template <int C, bool NOZ> ECS_DEV uint32_t ladder_core(const uint32_t* __restri
   return k0;
 }
 
-template <int C> ECS_DEV jpoint scalar_mult_ladder(const uint32_t* __restrict__ kwords, const fe& xm, const fe& ym) {
+// The same ladder with its 254 ZDAU iterations on fe29.cuh's reduced-radix representation (round 4): TRPLU and the opening swaps as
+// above on canonical words, then the co-Z pair and Z enter the radix-2^29 Montgomery domain (one product by a constant each), the loop
+// runs zdau29, and (px, py, z) = k'P leave it as the canonical residues the 8-word loop would have produced -- the field VALUES of
+// every iteration are the same, so the result is bit-identical (the representation of an intermediate is nobody's business).
+// Which instances have it: every one whose squaring is exact (the reference-square twins depend on the 32-bit Montgomery digits).
+template <int C> struct ladder_has_radix29 { static constexpr bool value = (C == CURVE_P256 || C == CURVE_SECP256K1_CLASSICAL); };
+template <int C> ECS_DEV uint32_t ladder_core29(const uint32_t* __restrict__ kwords, const fe& xm, const fe& ym, fe& px, fe& py, fe& z) {
+  fe bx, by;
+  px = xm; py = ym;
+  {
+    fe dx2, dy2;
+    dblu<C>(px, py, dx2, dy2, z);
+    zaddu<C>(px, py, dx2, dy2, z, bx, by);
+  }
+  uint32_t kw = kwords[0];
+  const uint32_t k0 = kw;
+  uint32_t cur = 0u - ((kw >> 2) & 1u);
+  {
+    const uint32_t m = (0u - ((kw >> 1) & 1u)) ^ cur;
+    fe_cswap(m, px, bx);
+    fe_cswap(m, py, by);
+  }
+  coz29 s;
+  s.x1 = enter29<C>(bx); s.x2 = enter29<C>(px); s.y1 = enter29<C>(by); s.z = enter29<C>(z);
+  s.dx = sub29(s.x1, s.x2);
+  s.dy = sub29(s.y1, enter29<C>(py));
+#pragma unroll 1
+  for (int b = 2; b < 256; ++b) {
+    const int nb = b + 1;
+    if ((nb & 31) == 0) kw = (nb < 256) ? kwords[nb >> 5] : 0u;
+    const uint32_t next = 0u - ((kw >> (nb & 31)) & 1u);
+    zdau29<C>(s, cur ^ next);
+    cur = next;
+  }
+  px = leave29<C>(s.x2); py = leave29<C>(sub29(s.y1, s.dy)); z = leave29<C>(s.z);
+  return k0;
+}
+
+template <int C, int RADIX = 32> ECS_DEV jpoint scalar_mult_ladder(const uint32_t* __restrict__ kwords, const fe& xm, const fe& ym) {
   fe px, py, bx, by, z;
-  const uint32_t k0 = ladder_core<C, false>(kwords, xm, ym, px, py, bx, by, z);
+  uint32_t k0;
+  if constexpr (RADIX == 29) k0 = ladder_core29<C>(kwords, xm, ym, px, py, z);
+  else k0 = ladder_core<C, false>(kwords, xm, ym, px, py, bx, by, z);
   // even k: subtract the original point once (curve_group.h:214-217)
   const fe oppy = fe_opposite<C>(ym);                    // jacobian_curve_point.h:48-54 via gfp.h:60-64
   const jpoint Psub = add_z2_1<C>(px, py, z, xm, oppy);

@@ -288,6 +288,12 @@ class Engine:
         n = p[0].shape[0]; r = [self.empty(n) for _ in range(3)]
         self._call("zdau", C.c_int(curve), *[self._ptr(t) for t in p], *[self._ptr(t) for t in q], *[self._ptr(t) for t in r], C.c_size_t(n)); return tuple(r)
 
+    def zdau_repeat(self, curve, p, qxy, iters, swap_bits=0, radix=29):
+        """ecsimd_hip_zdau_repeat: ZDAU `iters` times in registers; returns (rx, ry, sx, sy, z) = the final P, the final Q, their Z."""
+        n = p[0].shape[0]; r = [self.empty(n) for _ in range(5)]
+        self._call("zdau_repeat", C.c_int(curve), *[self._ptr(t) for t in p], *[self._ptr(t) for t in qxy], *[self._ptr(t) for t in r], C.c_size_t(n),
+                   C.c_int(iters), C.c_uint64(swap_bits), C.c_int(radix)); return tuple(r)
+
     def add_mixed_complete(self, curve, a, bxy):
         n = a[0].shape[0]; r = [self.empty(n) for _ in range(3)]
         self._call("add_mixed_complete", C.c_int(curve), *[self._ptr(t) for t in a], *[self._ptr(t) for t in bxy], *[self._ptr(t) for t in r], C.c_size_t(n)); return tuple(r)

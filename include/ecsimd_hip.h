@@ -101,6 +101,10 @@ enum {
                                       a = 0 curves (no exceptional case to branch on; ALG_NO_ENDOMORPHISM: the plain odd-digit loop).  ECDH with a
                                       secret scalar at 1.45x (P-256: 70.4 M/s) / 1.74x (secp256k1: 84.4 M/s) the ladder's rate, 1.28x the P-256
                                       ladder without Z (oy = NULL works here too).  Not with ALG_WINDOWED_SIGNED / ALG_WINDOWED_BIG (64 or 2^19 entries per window to read) */
+  ECSIMD_HIP_LADDER_RADIX32 = 256, /* ladder only (r4): run the 254 iterations on 8 x 32-bit canonical words (the kernel of rounds 1-3) instead of the
+                                      reduced-radix loop (nine signed 29-bit limbs, carry-free columns: fe29.cuh) that is the default since round 4.
+                                      The field values of every iteration are the same, so X, Y, Z are bit-identical; kept for A/B measurements.
+                                      REF_SQUARE_COMPAT implies it (the dropped carry depends on the 32-bit Montgomery digits).  Same constant-time shape */
   ECSIMD_HIP_ALG_WINDOWED_BIG = 32 /* scalar_mult_base + OUT_AFFINE: 20-bit windows with odd digits over a 436 MB table of the odd
                                       multiples (2d+1)*2^(20i)*G (13 windows x 2^19 entries) in device memory, built on first
                                       use (0.23 s per curve): 12 mixed additions per scalar; same results.  NOT for secret scalars:
@@ -232,6 +236,14 @@ int ecsimd_hip_dblu(ecsimd_hip_ctx*, int curve, uint64_t* px, uint64_t* py, uint
 int ecsimd_hip_zaddu(ecsimd_hip_ctx*, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, const uint64_t* ox, const uint64_t* oy, const uint64_t* oz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
 /* curve_group.h:120-153 ZDAU: r = 2P + Q (co-Z), Q rewritten in place with r's Z. */
 int ecsimd_hip_zdau(ecsimd_hip_ctx*, int curve, const uint64_t* px, const uint64_t* py, const uint64_t* pz, uint64_t* qx, uint64_t* qy, uint64_t* qz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
+/* Diagnostic / micro-benchmark (r4): ZDAU applied `iters` times IN REGISTERS -- the ladder's loop body alone (curve_group.h:206-210 without the
+ * scalar): per iteration (P, Q) <- (2P + Q, Q re-expressed with the new Z), and after iteration t the two outputs are exchanged where bit
+ * (t mod 64) of `swap_bits` is set.  (rx, ry) = the final P, (sx, sy) = the final Q, oz their Z; all Montgomery form, canonical.
+ * radix = 32: on field.cuh's 8 x 32-bit canonical words (rounds 1-3); radix = 29: on fe29.cuh's nine signed 29-bit limbs, the representation
+ * the ladder's loop runs in since round 4 -- the SAME field values, so the same bits out (tests/test_gpu_parity.py pins both to the oracle's
+ * ZDAU iterated on the CPU).  Not available with the reference-square option for radix 29. */
+int ecsimd_hip_zdau_repeat(ecsimd_hip_ctx*, int curve, const uint64_t* px, const uint64_t* py, const uint64_t* pz, const uint64_t* qx, const uint64_t* qy,
+                           uint64_t* rx, uint64_t* ry, uint64_t* sx, uint64_t* sy, uint64_t* oz, size_t n, int iters, uint64_t swap_bits, int radix);
 /* curve_group.h:155-179 ADD_Z2_1: r = A + B with B = (bx, by) Montgomery-form affine (Z2 = mgry(1)). */
 int ecsimd_hip_add_z2_1(ecsimd_hip_ctx*, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n);
 /* Extension: the complete form of the mixed addition -- r = A + B for every input: A = infinity (Z = 0), B = infinity

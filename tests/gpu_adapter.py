@@ -65,6 +65,9 @@ class EngineNP:
     def zdau(self, cv, p, q):
         dq = self._pt(q); r = self.e.zdau(cv, self._pt(p), dq); return self._ptd(r), self._ptd(dq)
 
+    def zdau_repeat(self, cv, p, qxy, iters, swap_bits=0, radix=29):
+        return self._ptd(self.e.zdau_repeat(cv, self._pt(p), self._pt(qxy), iters, swap_bits, radix))
+
     def add_z2_1(self, cv, a, bxy): return self._ptd(self.e.add_z2_1(cv, self._pt(a), self._pt(bxy)))
 
     def scalar_mult(self, cv, k, x, y, threads=1, mgry_in=False, affine=False, ref_compat=False):

@@ -321,6 +321,35 @@ def test_point_formulas_vs_oracle(gpu, oracle, cv):
 
 
 @pytest.mark.parametrize("cv", CURVES)
+def test_reduced_radix_zdau_vs_oracle(gpu, oracle, cv):
+    """The ladder's loop body in the representation it runs in since round 4 -- nine signed 29-bit limbs, lazy carries, Montgomery radix
+    2^261 (fe29.cuh) -- against the oracle's ZDAU (curve_group.h:120-153) iterated on the CPU: ecsimd_hip_zdau_repeat with radix 29 and
+    with radix 32 (round 3's canonical 8-word form) must both return the oracle's X, Y of both points and their Z bit for bit, after
+    1, 2, 7 and 67 iterations, with and without the per-iteration exchange of the two outputs, on curve points (TRPLU's co-Z pairs) and on
+    carry-heavy digit-pattern coordinates (level J does not need curve points).  tools/radix29_model.py proves the bounds; this pins the bits."""
+    from test_oracle import digit_pattern_operands
+    n = 1536
+    bx, by = _lane_distinct_points(gpu, cv, n, stream=9)
+    Rt, Put = oracle.trplu(cv, oracle.from_affine(cv, bx, by))
+    a = digit_pattern_operands()[::1093]
+    pp = np.tile(oracle.constants(cv)["p"], (len(a), 1))
+    red = lambda v: oracle.sub_if_above(v, pp)
+    cases = [(Rt, Put), ((red(a), red(np.roll(a, 5, axis=0)), red(np.roll(a, 11, axis=0))), (red(np.roll(a, 17, axis=0)), red(np.roll(a, 23, axis=0)), red(np.roll(a, 11, axis=0))))]
+    for P0, Q0 in cases:
+        for iters, swap in ((1, 0), (1, 1), (2, 0b10), (7, 0b1011001), (67, 0xdeadbeefcafef00d)):
+            P, Q = P0, Q0
+            for t in range(iters):
+                R, Qn = oracle.zdau(cv, P, Q)
+                P, Q = (Qn, R) if (swap >> (t & 63)) & 1 else (R, Qn)
+            exp = (P[0], P[1], Q[0], Q[1], P[2])
+            assert np.array_equal(P[2], Q[2])
+            for radix in (29, 32):
+                got = gpu.zdau_repeat(cv, P0, (Q0[0], Q0[1]), iters, swap, radix)
+                bad = [name for name, g, e in zip(("x1", "y1", "x2", "y2", "z"), got, exp) if not np.array_equal(g, e)]
+                assert not bad, (radix, iters, hex(swap), bad)
+
+
+@pytest.mark.parametrize("cv", CURVES)
 def test_point_formulas_on_digit_pattern_coordinates(gpu, oracle, cv):
     """DBLU / ZADDU / ZDAU / ADD_Z2_1 as expression DAGs over GF(p) (parity level J does not need curve points): coordinates from the
     carry-heavy digit-pattern family, every 7th operand (239 946 points), so that the formulas' add / subtract / double chains and

@@ -11,6 +11,11 @@ case "$name" in
     tail -5 "$out/pytest.txt"
     [ $rc -eq 0 ] && timeout -k 10 300 tools/ubench/valu_rates r4 > "$out/valu_rates_r4.txt" 2>&1 && cat "$out/valu_rates_r4.txt"
     exit $rc ;;
+  r4_radix)         # round 4: the reduced-radix ZDAU against the oracle, then the A/B of both loop representations
+    timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "reduced_radix or scalar_mult_vs_oracle or live_reference" > "$out/pytest.txt" 2>&1; rc=$?
+    tail -5 "$out/pytest.txt"
+    [ $rc -eq 0 ] && timeout -k 10 600 python tools/radix_ab.py ${1:-22} > "$out/radix_ab.txt" 2>&1; rc=$?; cat "$out/radix_ab.txt"
+    exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
     timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -15 "$out/pytest.txt"; exit $rc ;;
   *) echo "unknown step $name"; exit 2 ;;

@@ -1,0 +1,312 @@
+"""radix29_model.py -- big-int model and overflow proof of the reduced-radix field arithmetic of ecsimd_amd/csrc/fe29.cuh.
+
+A P-256 field element is nine SIGNED 32-bit limbs in radix 2^29 (value = sum l[i] * 2^(29 i)); the Montgomery radix is
+R' = 2^261.  Additions and subtractions are limb-wise 32-bit operations without carries, products accumulate in 64-bit
+columns (v_mad_i64_i32) without carries between the products of a column, and the Montgomery reduction -- q_k = column mod 2^29
+because p = -1 mod 2^29 -- is folded into the same column walk (finely integrated product scanning).
+
+This file is the CPU statement of that arithmetic, function for function (same names, same order of operations as fe29.cuh):
+
+  * `Exact`   -- executes on concrete integers with every machine limit asserted (int32 limbs, int64 columns);
+  * `Bounds`  -- executes on INTERVALS (per limb and for the value) and proves that no input inside the loop invariant of the
+                 ladder can overflow a limb or a column, and that one ZDAU maps the invariant into itself.
+
+tests/test_radix29_model.py runs both; the GPU tests compare the kernel with the oracle's ZDAU / ladder bit for bit.
+Reference formulas: /root/reference/include/ecsimd/curve_group.h:120-153 (ZDAU), mgry_mul.h:84-121 (Montgomery reduction).
+"""
+from fractions import Fraction
+
+W = 29
+NL = 9
+M29 = (1 << W) - 1
+RBITS = W * NL                      # 261
+P256 = 2**256 - 2**224 + 2**192 + 2**96 - 1
+SECP = 2**256 - 2**32 - 977
+I32 = (-(1 << 31), (1 << 31) - 1)
+I64 = (-(1 << 63), (1 << 63) - 1)
+
+
+class Curve:
+    """Sparse signed form of p in radix 2^29: p = sum c * 2^(29 off) over `terms`, with the term at offset 0 equal to -m0inv^-1."""
+    def __init__(self, name, p, terms, qmul):
+        self.name, self.p, self.terms, self.qmul = name, p, terms, qmul
+        assert sum(c << (W * o) for o, c in terms) == p, name
+        # q = (column * qmul) mod 2^29 makes column + q * (term at offset 0) vanish mod 2^29
+        c0 = dict(terms)[0]
+        assert (1 + qmul * c0) % (1 << W) == 0, name
+
+
+# p256 = 2^256 - 2^224 + 2^192 + 2^96 - 1: bit 96 = 3*29 + 9, 192 = 6*29 + 18, 224 = 7*29 + 21, 256 = 8*29 + 24
+CURVE_P256 = Curve("p256", P256, [(0, -1), (3, 1 << 9), (6, 1 << 18), (7, -(1 << 21)), (8, 1 << 24)], 1)
+# secp256k1 = 2^256 - 2^32 - 977: bit 32 = 29 + 3
+CURVE_SECP = Curve("secp256k1", SECP, [(0, -977), (1, -8), (8, 1 << 24)], pow(977, -1, 1 << W))
+
+
+def to_limbs(v):
+    """Tight limbs of an integer 0 <= v < 2^261 (limbs 0..7 in [0, 2^29), limb 8 the rest)."""
+    out = [(v >> (W * i)) & M29 for i in range(NL - 1)]
+    out.append(v >> (W * (NL - 1)))
+    return out
+
+
+def from_limbs(l):
+    return sum(int(x) << (W * i) for i, x in enumerate(l))
+
+
+# ---------------------------------------------------------------------------------------------------------------- exact execution
+class Exact:
+    """Concrete execution with the machine's limits asserted."""
+    def __init__(self, curve=CURVE_P256):
+        self.cv = curve
+
+    @staticmethod
+    def _i32(v):
+        assert I32[0] <= v <= I32[1], f"limb overflow: {v}"
+        return v
+
+    @staticmethod
+    def _i64(v):
+        assert I64[0] <= v <= I64[1], f"column overflow: {v}"
+        return v
+
+    def add(self, a, b): return [self._i32(x + y) for x, y in zip(a, b)]
+    def sub(self, a, b): return [self._i32(x - y) for x, y in zip(a, b)]
+    def dbl(self, a): return [self._i32(x + x) for x in a]
+
+    def norm(self, a, shift=0):
+        """One parallel carry pass over (a << shift): limbs 0..7 end in [c_min, 2^29 + c_max), the top limb takes its carry."""
+        x = [self._i32(v << shift) for v in a]
+        c = [v >> W for v in x]
+        out = [x[0] & M29] + [(x[i] & M29) + c[i - 1] for i in range(1, NL - 1)] + [self._i32(x[NL - 1] + c[NL - 2])]
+        return out
+
+    def _columns(self, prod):
+        """The FIPS column walk shared by mul and sqr: prod(k) -> list of (x, y) factors of column k."""
+        cv = self.cv
+        q = []
+        r = [0] * NL
+        acc = 0
+        for k in range(2 * NL - 1):
+            for x, y in prod(k):
+                acc = self._i64(acc + self._i32(x) * self._i32(y))
+            for off, c in cv.terms:
+                j = k - off
+                if off != 0 and 0 <= j < len(q) and j < NL:
+                    acc = self._i64(acc + q[j] * c)
+            if k < NL:
+                qk = (acc * cv.qmul) & M29
+                q.append(qk)
+                acc = self._i64(acc + qk * dict(cv.terms)[0])
+                assert acc & M29 == 0
+                acc >>= W
+            else:
+                r[k - NL] = acc & M29
+                acc >>= W
+        r[NL - 1] = self._i32(acc)
+        return r
+
+    def mul(self, a, b):
+        return self._columns(lambda k: [(a[i], b[k - i]) for i in range(max(0, k - NL + 1), min(k, NL - 1) + 1)])
+
+    def sqr(self, a):
+        a2 = self.dbl(a)
+        def prod(k):
+            t = [(a2[i], a[k - i]) for i in range(max(0, k - NL + 1), min(k, NL - 1) + 1) if i < k - i]
+            if k % 2 == 0:
+                t.append((a[k // 2], a[k // 2]))
+            return t
+        return self._columns(prod)
+
+    def cswap(self, m, a, b):
+        return (b, a) if m else (a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------- interval execution
+class Iv:
+    """An abstract field element: an interval per limb and an interval for the value."""
+    def __init__(self, limbs, val):
+        self.l = [tuple(x) for x in limbs]
+        self.v = tuple(val)
+
+    def __repr__(self):
+        f = lambda x: f"{x / 2**W:+.3f}"
+        return "Iv(limbs/2^29: " + " ".join(f"[{f(a)},{f(b)}]" for a, b in self.l) + f"; value/p: [{self.v[0] / P256:+.2f},{self.v[1] / P256:+.2f}])"
+
+    def within(self, other):
+        return all(o[0] <= s[0] and s[1] <= o[1] for s, o in zip(self.l, other.l)) and other.v[0] <= self.v[0] and self.v[1] <= other.v[1]
+
+
+def _iadd(a, b): return (a[0] + b[0], a[1] + b[1])
+def _isub(a, b): return (a[0] - b[1], a[1] - b[0])
+def _imul(a, b):
+    c = (a[0] * b[0], a[0] * b[1], a[1] * b[0], a[1] * b[1])
+    return (min(c), max(c))
+def _chk(iv, lim, what):
+    assert lim[0] <= iv[0] and iv[1] <= lim[1], f"{what} may overflow: [{iv[0]}, {iv[1]}] (2^{max(abs(iv[0]), abs(iv[1])).bit_length()})"
+    return iv
+
+
+class Bounds:
+    """Interval execution of the same functions: proves the absence of overflow for EVERY input inside the given intervals."""
+    def __init__(self, curve=CURVE_P256):
+        self.cv = curve
+        self.worst_col = 0
+        self.worst_limb = 0
+
+    def _limb(self, iv, what="limb"):
+        self.worst_limb = max(self.worst_limb, abs(iv[0]), abs(iv[1]))
+        return _chk(iv, I32, what)
+
+    def _col(self, iv, what="column"):
+        self.worst_col = max(self.worst_col, abs(iv[0]), abs(iv[1]))
+        return _chk(iv, I64, what)
+
+    def _tighten_top(self, x):
+        """The top limb is floor((value - low limbs) / 2^232): intersect its interval with what the value interval allows."""
+        lo = sum(x.l[i][0] << (W * i) for i in range(NL - 1)); hi = sum(x.l[i][1] << (W * i) for i in range(NL - 1))
+        sh = W * (NL - 1)
+        t = (-((-(x.v[0] - hi)) // (1 << sh)) if False else (x.v[0] - hi) >> sh, (x.v[1] - lo) >> sh)
+        top = (max(x.l[NL - 1][0], t[0]), min(x.l[NL - 1][1], t[1]))
+        assert top[0] <= top[1], (x, t)
+        x.l[NL - 1] = top
+        return x
+
+    def add(self, a, b): return self._tighten_top(Iv([self._limb(_iadd(x, y)) for x, y in zip(a.l, b.l)], _iadd(a.v, b.v)))
+    def sub(self, a, b): return self._tighten_top(Iv([self._limb(_isub(x, y)) for x, y in zip(a.l, b.l)], _isub(a.v, b.v)))
+    def dbl(self, a): return self._tighten_top(Iv([self._limb((2 * x[0], 2 * x[1])) for x in a.l], (2 * a.v[0], 2 * a.v[1])))
+
+    def norm(self, a, shift=0):
+        x = [self._limb((v[0] << shift, v[1] << shift), "shifted limb") for v in a.l]
+        c = [(v[0] >> W, v[1] >> W) for v in x]
+        low = lambda v: (0, M29) if (v[1] - v[0] >= M29 or (v[0] >> W) != (v[1] >> W)) else (v[0] & M29, v[1] & M29)
+        out = [low(x[0])] + [self._limb(_iadd(low(x[i]), c[i - 1])) for i in range(1, NL - 1)] + [self._limb(_iadd(x[NL - 1], c[NL - 2]))]
+        return self._tighten_top(Iv(out, (a.v[0] << shift, a.v[1] << shift)))
+
+    def _columns(self, prod, tval):
+        cv = self.cv
+        c0 = dict(cv.terms)[0]
+        acc = (0, 0)
+        for k in range(2 * NL - 1):
+            for x, y in prod(k):
+                acc = self._col(_iadd(acc, _imul(x, y)))
+            for off, c in cv.terms:
+                j = k - off
+                if off != 0 and 0 <= j < NL and j < k + 1:
+                    acc = self._col(_iadd(acc, _imul((0, M29), (c, c))))
+            if k < NL:
+                acc = self._col(_iadd(acc, _imul((0, M29), (c0, c0))))
+            acc = (acc[0] >> W, acc[1] >> W)
+        # value: (T + Q p) / R' with 0 <= Q < R'
+        R = 1 << RBITS
+        val = (tval[0] // R if tval[0] >= 0 else -((-tval[0] + R - 1) // R), (tval[1] + (R - 1) * cv.p) // R + 1)
+        out = Iv([(0, M29)] * (NL - 1) + [self._limb(acc, "top limb")], val)
+        return self._tighten_top(out)
+
+    def mul(self, a, b):
+        return self._columns(lambda k: [(a.l[i], b.l[k - i]) for i in range(max(0, k - NL + 1), min(k, NL - 1) + 1)], _imul(a.v, b.v))
+
+    def sqr(self, a):
+        a2 = [self._limb((2 * x[0], 2 * x[1]), "doubled limb") for x in a.l]
+        def prod(k):
+            t = [(a2[i], a.l[k - i]) for i in range(max(0, k - NL + 1), min(k, NL - 1) + 1) if i < k - i]
+            if k % 2 == 0:
+                s = a.l[k // 2]
+                m = max(abs(s[0]), abs(s[1]))
+                t.append(((0, m), (0, m)) if s[0] < 0 < s[1] else (s, s))        # a square is never negative
+            return t
+        m = max(abs(a.v[0]), abs(a.v[1]))
+        tv = (0 if a.v[0] < 0 < a.v[1] else min(a.v[0] ** 2, a.v[1] ** 2), m * m)
+        return self._columns(prod, tv)
+
+    def cswap(self, m, a, b):
+        j = lambda s, t: (min(s[0], t[0]), max(s[1], t[1]))
+        u = Iv([j(s, t) for s, t in zip(a.l, b.l)], j(a.v, b.v))
+        return u, Iv(u.l, u.v)
+
+
+# ---------------------------------------------------------------------------------------------------------------- the ZDAU iteration
+def zdau29(E, st, swap):
+    """One ladder iteration on the loop state st = dict(x1, x2, dx, y1, dy, z), with the output points exchanged where `swap`.
+    Same field values as point.cuh zdau<C> (curve_group.h:120-153): (x1, y1) <- 2 (x1, y1) + (x2, y2), (x2, y2) re-expressed with
+    the new z.  Loop-carried besides the coordinates: dx = x1 - x2 and dy = y1 - y2 (differences of tight values; y2 itself is
+    y1 - dy and is only materialised after the last iteration)."""
+    x1, x2, dx, y1, dy, z = st["x1"], st["x2"], st["dx"], st["y1"], st["dy"], st["z"]
+    Cp = E.sqr(dx)
+    W1p = E.mul(x1, Cp)
+    W2p = E.mul(x2, Cp)
+    Dp = E.sqr(dy)
+    A1p = E.mul(y1, E.sub(W1p, W2p))
+    X3 = E.sub(E.sub(Dp, W1p), W2p)
+    u = E.norm(E.sub(X3, W1p))
+    Cc = E.sqr(u)
+    s = E.norm(E.sub(dy, u))
+    yp = E.norm(E.sub(E.sub(E.sqr(s), Dp), Cc))               # Y3' + 2 A1'
+    A2 = E.dbl(A1p)
+    Y3p = E.sub(yp, A2)
+    ym = E.norm(E.sub(Y3p, A2))
+    C4 = E.norm(Cc, 2)                                        # 4 C, normalised in the same pass
+    W1 = E.mul(X3, C4)
+    W2 = E.mul(W1p, C4)
+    A1 = E.mul(Y3p, E.sub(W1, W2))
+    w = E.norm(E.add(dx, u))
+    zz = E.sub(E.sub(E.sqr(w), Cp), Cc)
+    z = E.mul(z, zz)
+    ym, yp = E.cswap(swap, ym, yp)
+    D = E.sqr(ym)
+    Dc = E.sqr(yp)
+    W12 = E.add(W1, W2)
+    nx1 = E.sub(D, W12)
+    nx2 = E.sub(Dc, W12)
+    P1 = E.mul(ym, E.sub(W1, nx1))
+    P2 = E.mul(yp, E.sub(W1, nx2))
+    return {"x1": nx1, "x2": nx2, "dx": E.sub(D, Dc), "y1": E.sub(P1, A1), "dy": E.sub(P1, P2), "z": z}
+
+
+def ladder_invariant(curve=CURVE_P256):
+    """The abstract loop state the ladder maintains (checked by `prove_invariant`): limb intervals in units of 1 and value intervals."""
+    p = curve.p
+    B = 1 << W
+    T8 = 1 << 27                                  # bound on the top limb of everything in the loop (values stay below 2^259)
+    lim = lambda lo, hi, vlo, vhi: Iv([(lo * B, hi * B - 1 if hi > 0 else hi * B)] * (NL - 1) + [(-T8, T8)], (vlo * p, vhi * p))
+    return {
+        "x1": lim(-2, 1, -8, 4), "x2": lim(-2, 1, -8, 4),       # D - (W1 + W2)
+        "dx": lim(-1, 1, -4, 4), "dy": lim(-1, 1, -4, 4),       # differences of two tight products
+        "y1": lim(-1, 1, -4, 4),                               # P1 - A1
+        "z": lim(0, 1, -3, 4),
+    }
+
+
+def prove_invariant(curve=CURVE_P256):
+    """One abstract ZDAU from the invariant: nothing overflows and the result lies inside the invariant again.  Returns the
+    worst column and limb magnitudes met (as bit lengths) for the record."""
+    E = Bounds(curve)
+    inv = ladder_invariant(curve)
+    out = zdau29(E, {k: Iv(v.l, v.v) for k, v in inv.items()}, True)
+    for k in inv:
+        assert out[k].within(inv[k]), (k, out[k], inv[k])
+    return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length(), "out": out}
+
+
+# ---------------------------------------------------------------------------------------------------------------- big-int ZDAU (field values)
+def zdau_field(p, x1, y1, x2, y2, z):
+    """curve_group.h:120-153 on integers mod p (the values, whatever the representation)."""
+    dx = (x1 - x2) % p; Cp = dx * dx % p; W1p = x1 * Cp % p; W2p = x2 * Cp % p
+    dy = (y1 - y2) % p; Dp = dy * dy % p; A1p = y1 * (W1p - W2p) % p
+    X3 = (Dp - W1p - W2p) % p; u = (X3 - W1p) % p; Cc = u * u % p
+    yp = ((dy - u) ** 2 - Dp - Cc) % p
+    Y3p = (yp - 2 * A1p) % p; ym = (Y3p - 2 * A1p) % p
+    W1 = 4 * X3 * Cc % p; W2 = 4 * W1p * Cc % p
+    A1 = Y3p * (W1 - W2) % p
+    zz = ((dx + u) ** 2 - Cp - Cc) % p
+    z3 = z * zz % p
+    D = ym * ym % p; nx1 = (D - W1 - W2) % p; ny1 = (ym * (W1 - nx1) - A1) % p
+    Dc = yp * yp % p; nx2 = (Dc - W1 - W2) % p; ny2 = (yp * (W1 - nx2) - A1) % p
+    return nx1, ny1, nx2, ny2, z3
+
+
+if __name__ == "__main__":
+    for cv in (CURVE_P256, CURVE_SECP):
+        r = prove_invariant(cv)
+        print(cv.name, "invariant holds; worst column 2^%d, worst limb 2^%d" % (r["worst_column_bits"], r["worst_limb_bits"]))
+        for k, v in r["out"].items():
+            print("  ", k, v)
