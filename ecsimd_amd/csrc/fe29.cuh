@@ -20,6 +20,7 @@
 // order) on intervals and shows that one zdau29 maps the loop invariant into itself with every limb inside int32 and every
 // column inside int64 (tests/test_radix29_model.py), and on concrete integers against the big-int ZDAU.
 #pragma once
+#include <utility>
 #include "field.cuh"
 
 namespace ecsimd_hip {
@@ -67,10 +68,54 @@ ECS_DEV void cswap29(uint32_t m, fe29& a, fe29& b) {
   for (int i = 0; i < R29_LIMBS; ++i) { const int32_t t = (a.l[i] ^ b.l[i]) & (int32_t)m; a.l[i] ^= t; b.l[i] ^= t; }
 }
 
+#include "fe29_cols.inc"
+
 // Montgomery product a * b / 2^261 (SQR: a * a / 2^261 with the 36 cross products taken once on a doubled operand), reduction
 // folded into the column walk.  Result: limbs 0..7 in [0, 2^29), the top limb signed and small; value in (T / R', T / R' + p).
-template <int C, bool SQR> ECS_DEV fe29 fips29(const fe29& a, const fe29& b) {
+// Column K is ONE asm statement (fe29_cols.inc, generated): its products and the quotient digits' contributions accumulate on top
+// of the carry; the compiler only extracts the digit (v_and_b32) and shifts the column down (v_ashrrev_i64) between two statements.
+struct r29_consts_sgpr { int32_t k9, k18, km21, k24, km8, km977; };
+template <int C, bool SQR, int K> ECS_DEV void fips29_column(int64_t& acc, const fe29& a, const int32_t (&a2)[R29_LIMBS], const fe29& b,
+                                                             int32_t (&q)[R29_LIMBS], fe29& r, const r29_consts_sgpr& k) {
   using PR = r29_prime<C>;
+  constexpr int lo = K > R29_LIMBS - 1 ? K - (R29_LIMBS - 1) : 0, hi = K < R29_LIMBS - 1 ? K : R29_LIMBS - 1;
+  constexpr int NCROSS = SQR ? ((K - 1) / 2 >= lo && K > 0 ? (K - 1) / 2 - lo + 1 : 0) : hi - lo + 1;
+  constexpr int NP = NCROSS + ((SQR && K % 2 == 0) ? 1 : 0);
+  int32_t x[NP > 0 ? NP : 1], y[NP > 0 ? NP : 1];
+#pragma unroll
+  for (int t = 0; t < NCROSS; ++t) { x[t] = SQR ? a2[lo + t] : a.l[lo + t]; y[t] = SQR ? a.l[K - lo - t] : b.l[K - lo - t]; }
+  if constexpr (SQR && K % 2 == 0) { x[NCROSS] = a.l[K / 2]; y[NCROSS] = a.l[K / 2]; }
+  constexpr auto in = [](int j) { return j >= 0 && j < R29_LIMBS; };
+  if constexpr (PR::p256) {
+    // + q 2^9 three limbs up, + q 2^18 six up, - q 2^21 seven up, + q 2^24 eight up; - q at its own column cancels the low 29 bits
+    constexpr int NR = (in(K - 3) ? 1 : 0) + (in(K - 6) ? 1 : 0) + (in(K - 7) ? 1 : 0) + (in(K - 8) ? 1 : 0);
+    int32_t qq[NR > 0 ? NR : 1], cc[NR > 0 ? NR : 1];
+    int n = 0;
+    if constexpr (in(K - 3)) { qq[n] = q[K - 3]; cc[n++] = k.k9; }
+    if constexpr (in(K - 6)) { qq[n] = q[K - 6]; cc[n++] = k.k18; }
+    if constexpr (in(K - 7)) { qq[n] = q[K - 7]; cc[n++] = k.km21; }
+    if constexpr (in(K - 8)) { qq[n] = q[K - 8]; cc[n++] = k.k24; }
+    r29_col<NP, NR>::run(acc, x, y, qq, cc);
+    if constexpr (K < R29_LIMBS) q[K] = (int32_t)acc & R29_MASK;          // acc - q[K] is a multiple of 2^29: the shift below drops it
+    else r.l[K - R29_LIMBS] = (int32_t)acc & R29_MASK;
+  } else {
+    // secp256k1: - 8 q one limb up, + q 2^24 eight up; - 977 q at its own column, after q = column * 977^-1 mod 2^29
+    constexpr int NR = (in(K - 1) ? 1 : 0) + (in(K - 8) ? 1 : 0);
+    int32_t qq[NR > 0 ? NR : 1], cc[NR > 0 ? NR : 1];
+    int n = 0;
+    if constexpr (in(K - 1)) { qq[n] = q[K - 1]; cc[n++] = k.km8; }
+    if constexpr (in(K - 8)) { qq[n] = q[K - 8]; cc[n++] = k.k24; }
+    r29_col<NP, NR>::run(acc, x, y, qq, cc);
+    if constexpr (K < R29_LIMBS) { q[K] = (int32_t)((uint32_t)acc * PR::QMUL) & R29_MASK; acc += (int64_t)q[K] * k.km977; }
+    else r.l[K - R29_LIMBS] = (int32_t)acc & R29_MASK;
+  }
+  acc >>= R29_BITS;
+}
+template <int C, bool SQR, int... K> ECS_DEV void fips29_columns(int64_t& acc, const fe29& a, const int32_t (&a2)[R29_LIMBS], const fe29& b,
+                                                                int32_t (&q)[R29_LIMBS], fe29& r, const r29_consts_sgpr& k, std::integer_sequence<int, K...>) {
+  (fips29_column<C, SQR, K>(acc, a, a2, b, q, r, k), ...);
+}
+template <int C, bool SQR> ECS_DEV fe29 fips29(const fe29& a, const fe29& b) {
   int32_t q[R29_LIMBS];
   int32_t a2[R29_LIMBS];
   fe29 r;
@@ -78,35 +123,9 @@ template <int C, bool SQR> ECS_DEV fe29 fips29(const fe29& a, const fe29& b) {
 #pragma unroll
     for (int i = 0; i < R29_LIMBS; ++i) a2[i] = r29_dbl32(a.l[i]);
   }
-  // p256: + q 2^9 (3 limbs up), + q 2^18 (6 up), - q 2^21 (7 up), + q 2^24 (8 up); - q at its own column cancels the low bits
-  // secp256k1: - 977 q at its own column, - 8 q one limb up, + q 2^24 eight limbs up
-  const int32_t k9 = r29_opaque(1 << 9), k18 = r29_opaque(1 << 18), km21 = r29_opaque(-(1 << 21)), k24 = r29_opaque(1 << 24);
-  const int32_t km977 = r29_opaque(-977), km8 = r29_opaque(-8);
+  const r29_consts_sgpr k{r29_opaque(1 << 9), r29_opaque(1 << 18), r29_opaque(-(1 << 21)), r29_opaque(1 << 24), r29_opaque(-8), r29_opaque(-977)};
   int64_t acc = 0;
-#pragma unroll
-  for (int k = 0; k < 2 * R29_LIMBS - 1; ++k) {
-#pragma unroll
-    for (int i = 0; i < R29_LIMBS; ++i) {
-      const int j = k - i;
-      if (j < 0 || j >= R29_LIMBS) continue;
-      if constexpr (!SQR) acc += (int64_t)a.l[i] * b.l[j];
-      else { if (i < j) acc += (int64_t)a2[i] * a.l[j]; else if (i == j) acc += (int64_t)a.l[i] * a.l[i]; }
-    }
-    if constexpr (PR::p256) {
-      if (k >= 3 && k - 3 < R29_LIMBS) acc += (int64_t)q[k - 3] * k9;
-      if (k >= 6 && k - 6 < R29_LIMBS) acc += (int64_t)q[k - 6] * k18;
-      if (k >= 7 && k - 7 < R29_LIMBS) acc += (int64_t)q[k - 7] * km21;
-      if (k >= 8 && k - 8 < R29_LIMBS) acc += (int64_t)q[k - 8] * k24;
-      if (k < R29_LIMBS) q[k] = (int32_t)acc & R29_MASK;            // acc - q[k] is a multiple of 2^29: the shift below drops it
-      else r.l[k - R29_LIMBS] = (int32_t)acc & R29_MASK;
-    } else {
-      if (k >= 1 && k - 1 < R29_LIMBS) acc += (int64_t)q[k - 1] * km8;
-      if (k >= 8 && k - 8 < R29_LIMBS) acc += (int64_t)q[k - 8] * k24;
-      if (k < R29_LIMBS) { q[k] = (int32_t)((uint32_t)acc * PR::QMUL) & R29_MASK; acc += (int64_t)q[k] * km977; }
-      else r.l[k - R29_LIMBS] = (int32_t)acc & R29_MASK;
-    }
-    acc >>= R29_BITS;
-  }
+  fips29_columns<C, SQR>(acc, a, a2, b, q, r, k, std::make_integer_sequence<int, 2 * R29_LIMBS - 1>{});
   r.l[R29_LIMBS - 1] = (int32_t)acc;
   return r;
 }
