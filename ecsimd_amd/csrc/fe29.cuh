@@ -95,7 +95,7 @@ template <int C, bool SQR, int K> ECS_DEV void fips29_column(int64_t& acc, const
     if constexpr (in(K - 6)) { qq[n] = q[K - 6]; cc[n++] = k.k18; }
     if constexpr (in(K - 7)) { qq[n] = q[K - 7]; cc[n++] = k.km21; }
     if constexpr (in(K - 8)) { qq[n] = q[K - 8]; cc[n++] = k.k24; }
-    r29_col<NP, NR>::run(acc, x, y, qq, cc);
+    if constexpr (K == 0) r29_col_first<NP>::run(acc, x, y); else r29_col<NP, NR>::run(acc, x, y, qq, cc);
     if constexpr (K < R29_LIMBS) q[K] = (int32_t)acc & R29_MASK;          // acc - q[K] is a multiple of 2^29: the shift below drops it
     else r.l[K - R29_LIMBS] = (int32_t)acc & R29_MASK;
   } else {
@@ -105,7 +105,7 @@ template <int C, bool SQR, int K> ECS_DEV void fips29_column(int64_t& acc, const
     int n = 0;
     if constexpr (in(K - 1)) { qq[n] = q[K - 1]; cc[n++] = k.km8; }
     if constexpr (in(K - 8)) { qq[n] = q[K - 8]; cc[n++] = k.k24; }
-    r29_col<NP, NR>::run(acc, x, y, qq, cc);
+    if constexpr (K == 0) r29_col_first<NP>::run(acc, x, y); else r29_col<NP, NR>::run(acc, x, y, qq, cc);
     if constexpr (K < R29_LIMBS) { q[K] = (int32_t)((uint32_t)acc * PR::QMUL) & R29_MASK; acc += (int64_t)q[K] * k.km977; }
     else r.l[K - R29_LIMBS] = (int32_t)acc & R29_MASK;
   }
@@ -124,7 +124,7 @@ template <int C, bool SQR> ECS_DEV fe29 fips29(const fe29& a, const fe29& b) {
     for (int i = 0; i < R29_LIMBS; ++i) a2[i] = r29_dbl32(a.l[i]);
   }
   const r29_consts_sgpr k{r29_opaque(1 << 9), r29_opaque(1 << 18), r29_opaque(-(1 << 21)), r29_opaque(1 << 24), r29_opaque(-8), r29_opaque(-977)};
-  int64_t acc = 0;
+  int64_t acc;
   fips29_columns<C, SQR>(acc, a, a2, b, q, r, k, std::make_integer_sequence<int, 2 * R29_LIMBS - 1>{});
   r.l[R29_LIMBS - 1] = (int32_t)acc;
   return r;

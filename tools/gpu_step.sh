@@ -16,6 +16,9 @@ case "$name" in
     tail -5 "$out/pytest.txt"
     [ $rc -eq 0 ] && timeout -k 10 600 python tools/radix_ab.py ${1:-22} > "$out/radix_ab.txt" 2>&1; rc=$?; cat "$out/radix_ab.txt"
     exit $rc ;;
+  ab)               # A/B of library builds: bash tools/gpu_step.sh ab "<bench args>" name=lib ...
+    args=$1; shift
+    timeout -k 10 900 python tools/ab_variants.py "$args" "$@" > "$out/ab.txt" 2>&1; rc=$?; cat "$out/ab.txt"; exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
     timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -15 "$out/pytest.txt"; exit $rc ;;
   *) echo "unknown step $name"; exit 2 ;;
