@@ -56,7 +56,9 @@ sys.path.insert(0, ROOT)
 
 MAD32_PER_SCALAR_MULT = 555968          # 4088 field mults x 136 mad32
 ALGO_BYTES_PER_SCALAR_MULT = 192        # 32 B scalar + 64 B point in, 96 B Jacobian out
-A_PRIORI_PEAK_TMAD32 = 256 * 4 * 16 * 2.4e9 / 1e12    # 39.32: one full-rate wave64 VALU instruction per 4 cycles per SIMD at the 2.4 GHz maximum clock
+# 39.32: the HALF-rate VALU class -- v_mad_u64_u32 / v_mad_i64_i32, the carry adds, 64-bit shifts -- issues one wave64 instruction per 4 cycles
+# per SIMD (MI355X_MICROARCH.md: SIMD-32, 2 cycles for a full-rate instruction such as v_add_u32 / v_and_b32 / v_mov_b32); at the 2.4 GHz maximum clock
+A_PRIORI_PEAK_TMAD32 = 256 * 4 * 16 * 2.4e9 / 1e12
 SEED = 0x5EEDEC51D0000001
 EXIT_PARITY = 3                         # a checker contradicts the GPU result
 
@@ -292,6 +294,10 @@ def main():
         result["roofline"] = roofline_object(args, eng, n, float(np.mean(kernel_ms)))
         if world == 1 and not args.no_cpu_baseline:
             attach_cpu_baseline(args, result, eng, curve, k, bx, by, [t[:n] for t in runner.last_result()], failures)
+            if args.workload == "ladder":
+                result["ref_compat"] = ref_compat_leg(args, result, eng, curve, k, xm, ym, n, result["roofline"]["peak"], failures)
+        if isinstance(result.get("cpu_baseline"), dict):
+            result["cpu_baseline"].pop("_sample", None)
         if (force_dist or rehearse) and not torch.equal(runner.gathered[0].to(eng.tdev), runner.last_result()):
             failures.append("the gathered shard differs from the computed one")
         if distributed and args.workload in ("ladder", "ladder-ref-compat"):
@@ -350,7 +356,10 @@ def base_line(args, world, total_units, n, value, elapsed):
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": names.get(args.workload) or (f"scalar_mult_{args.curve} fixed-base (G), {sizes}, random scalars, "
                                                              + fixed[args.workload] + " + simultaneous inversion, affine out"),
-                   "element": "256-bit integers: 8 x u32 words (= 4 x u64 limbs) in VGPRs, v_mad_u64_u32 carry chains",
+                   "element": ("256-bit integers, one per lane in VGPRs: canonical 8 x u32 words (= 4 x u64 limbs) at every kernel boundary; the ladder's 254 iterations run on nine "
+                               "signed 29-bit digits in 32-bit words (Montgomery radix 2^261, v_mad_i64_i32 into carry-free 64-bit columns, lazy carries: fe29.cuh) -- "
+                               "REF_SQUARE_COMPAT and LADDER_RADIX32 keep the 8 x u32 v_mad_u64_u32 carry chains") if args.workload == "ladder" else
+                              "256-bit integers: 8 x u32 words (= 4 x u64 limbs) in VGPRs, v_mad_u64_u32 carry chains",
                    "global_batch": total_units, "per_gpu_batch": n,
                    "parallelism": (f"group{world}" + ("+rccl_gather" if world > 1 else "") if args.multi == "group" else f"shard{world}" + ("+rccl_gather" if world > 1 else ""))},
     }
@@ -427,6 +436,48 @@ def attach_cpu_baseline(args, result, eng, curve, k, bx, by, out, failures):
     except (CheckerUnavailable, OSError) as exc:
         result["cpu_baseline"] = {"value": None, "unit": "scalar_mults/s", "cores": usable_cores(), "kind": "unavailable",
                                   "sample": "the CPU checkers could not be loaded here", "error": repr(exc)[:300]}
+
+
+def ref_compat_leg(args, result, eng, curve, k, xm, ym, n, peak, failures, steps=3):
+    """the default line also TIMES the mode that is bit-identical to the reference on every lane --
+    ECSIMD_HIP_REF_SQUARE_COMPAT (the reference's square() as written, mul.h:160-212, dropped carry included) -- at the same batch:
+    `steps` launches between HIP events on the launch stream, and the lanes the CPU leg already pushed through the compiled
+    reference compared bit for bit (X, Y, Z): not one may differ, else EXIT_PARITY.  With only the C restatement available the
+    bug-for-bug oracle stands in on a smaller sample."""
+    import numpy as np
+    import torch
+    from ecsimd_amd import BASE_MGRY, OUT_JACOBIAN, REF_SQUARE_COMPAT
+    from oracle import loader
+    out = [eng.empty(n) for _ in range(3)]
+    fl = BASE_MGRY | OUT_JACOBIAN | REF_SQUARE_COMPAT
+    eng.scalar_mult(curve, k, xm, ym, flags=fl, out=out)                      # warm-up
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    for a, b in evs:
+        a.record(); eng.scalar_mult(curve, k, xm, ym, flags=fl, out=out); b.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    sample = (result.get("cpu_baseline") or {}).get("_sample")
+    compared = differing = None
+    witness = None
+    if sample is not None:
+        m, kn, xn, yn, ref, kind, _ = sample
+        if kind == "reference":
+            witness = "the compiled reference (oracle/_ref), the lanes of cpu_baseline"
+        else:                                                                 # the exact port is no witness for this mode: the bug-for-bug restatement on a bounded sample
+            m = min(m, 4096)
+            ref = loader.Oracle(faithful=True).scalar_mult(curve, kn[:m], xn[:m], yn[:m], threads=usable_cores())
+            witness = "the bug-for-bug C restatement (oracle/ecsimd_oracle.c, faithful mode)"
+        got = [eng.to_numpy(t[:m]) for t in out]
+        differing = int(np.count_nonzero((got[0] != ref[0][:m]).any(axis=1) | (got[1] != ref[1][:m]).any(axis=1) | (got[2] != ref[2][:m]).any(axis=1)))
+        compared = int(m)
+        if differing:
+            failures.append(f"ref_compat: {differing} of {m} lanes of the reference-compatible ladder differ from the reference")
+    achieved = n / (ms * 1e-3) * MAD32_PER_SCALAR_MULT / 1e12
+    return {"what": "the same batch through ECSIMD_HIP_REF_SQUARE_COMPAT (the reference's square() as written: bit-identical to the reference on EVERY lane; "
+                    "radix-2^32 loop, the dropped carry depends on the 32-bit Montgomery digits)",
+            "value": n / (ms * 1e-3), "unit": "scalar_mults/s", "kernel_ms": ms, "steps": steps, "achieved": achieved, "frac": achieved / peak,
+            "frac_of_a_priori_peak": achieved / A_PRIORI_PEAK_TMAD32, "lanes_compared": compared, "lanes_differing": differing, "compared_with": witness}
 
 
 def group_leg(args, world, timeout_s=240):
@@ -548,6 +599,8 @@ def main_group(args):
     result["roofline"]["kernel_ms_per_member"] = member_ms
     if N == 1 and not args.no_cpu_baseline:
         attach_cpu_baseline(args, result, engs[0], curve, ks[0], bxs[0], bys[0], [t[:n0] for t in last] + [None] * (3 - len(last)), failures)
+        if isinstance(result.get("cpu_baseline"), dict):
+            result["cpu_baseline"].pop("_sample", None)
     if failures:
         result["parity_failures"] = failures
     emit(json.dumps(result))
@@ -805,7 +858,8 @@ def cpu_baseline(eng, curve, k, bx, by, gpu_out, target_s, failures, compat=Fals
             failures.append("config 1: the compiled reference and the restatement disagree on benchs/ops.cpp's operations")
     except (OSError, AttributeError) as exc:                # a prebuilt checker without bench_ops: a side figure, not a failure
         c1 = {"error": repr(exc)[:200]}
-    return {"value": m / dt, "unit": "scalar_mults/s", "cores": cores, "kind": kind,
+    return {"_sample": (m, kn, xn, yn, ref, kind, bool(compat)),          # for ref_compat_leg; removed before the line is printed
+            "value": m / dt, "unit": "scalar_mults/s", "cores": cores, "kind": kind,
             "per_core": (m / dt) / cores, "one_thread": one, "cpu_model": cpu_model(), "flags": build_flags(kind), "config1_ops8": c1,
             "sample": f"first {m} (scalar, point) pairs of the GPU batch, {dt:.1f} s wall, {cores} threads, "
                       + ("g++ -O2 -mavx2 build of the reference headers" if kind == "reference" else "gcc -O2 C restatement"),

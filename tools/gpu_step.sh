@@ -19,6 +19,11 @@ case "$name" in
   ab)               # A/B of library builds: bash tools/gpu_step.sh ab "<bench args>" name=lib ...
     args=$1; shift
     timeout -k 10 900 python tools/ab_variants.py "$args" "$@" > "$out/ab.txt" 2>&1; rc=$?; cat "$out/ab.txt"; exit $rc ;;
+  bench)            # the driver's default command, timed by the shell as the driver does
+    s0=$(date +%s); timeout -k 10 600 python bench.py "$@" > "$out/bench.json" 2> "$out/bench.err"; rc=$?; s1=$(date +%s)
+    echo "rc=$rc wall=$((s1 - s0)) s"; tail -3 "$out/bench.err"; python3 -c "
+import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value %.3f M/s  ms/step %.2f  frac %.3f (a priori %.3f)' % (d['value']/1e6, d['ms_per_step'], r['frac'], r['frac_of_a_priori_peak'])); print('ref_compat', {k: v for k, v in d.get('ref_compat', {}).items() if k != 'what'}); print('cpu', {k: d['cpu_baseline'][k] for k in ('value','cores','kind','lanes_compared','lanes_differing_from_gpu','lanes_differing_confirmed_by_openssl')})"
+    exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
     timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -15 "$out/pytest.txt"; exit $rc ;;
   *) echo "unknown step $name"; exit 2 ;;
