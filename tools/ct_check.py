@@ -107,7 +107,20 @@ def check(text, want, allow_global_loads=1, allow_lds_reads=False):
     if not sizes:
         raise Violation("no loop found")
     header = max(sizes, key=sizes.get)
-    loop = [(lab, insts) for lab, hdr, insts in blocks if hdr == header]
+    member = [n for n, (_, hdr, _) in enumerate(blocks) if hdr == header]
+    # A ROTATED loop (round 4, k_scalar_mult<29>): the blocks that reload the scalar word sit in FRONT of the annotated header and are
+    # entered by a branch from the loop's latch (`s_branch .LBB4_7` ... fall through into the header) -- the compiler's "in Loop" comments
+    # leave them out, but they run once per 32 iterations.  Every block from the earliest such branch target up to the header belongs to
+    # the cycle and is checked with it.
+    pos = {lab: n for n, (lab, _, _) in enumerate(blocks)}
+    first = member[0]
+    for n in member:
+        for inst in blocks[n][2]:
+            op, ops = split_ops(inst)
+            if (op == "s_branch" or op.startswith("s_cbranch")) and ops and ops[-1] in pos and pos[ops[-1]] < first:
+                first = min(first, pos[ops[-1]])
+    member = list(range(first, member[0])) + member
+    loop = [(blocks[n][0], blocks[n][2]) for n in member]
     flat = [i for _, insts in loop for i in insts]
     report = {"kernel": want, "loop_header": header, "instructions": len(flat), "branches": [], "global_loads": [], "scratch": 0, "lds_reads": 0}
 
