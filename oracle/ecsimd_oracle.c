@@ -43,8 +43,13 @@ typedef struct {
   uint32_t mprime;  /* -p^-1 mod 2^32                               mgry_mul.h:33-38 */
 } oracle_curve;
 
-enum { ORACLE_P256 = 0, ORACLE_SECP256K1 = 1, ORACLE_NCURVES = 2 };
-static oracle_curve g_curves[ORACLE_NCURVES];
+enum { ORACLE_P256 = 0, ORACLE_SECP256K1 = 1, ORACLE_NCURVES = 2, ORACLE_MAXFIELDS = 64 };
+/* ids 0, 1: the two curves.  ids >= 2: FIELDS ONLY -- any odd 256-bit modulus registered at run time with
+ * oracle_register_modulus (the reference's L3 layer is generic in P: mgry_mul.h:84-121 details::mgry_reduce<P>,
+ * mgry_csts.h:15-35 mgry_constants<WBN, P>, gfp.h:17-115 GFp<WBN, P>); a, b, gx, gy stay zero there. */
+static oracle_curve g_curves[ORACLE_MAXFIELDS];
+static int g_nfields = ORACLE_NCURVES;
+static pthread_mutex_t g_fields_lock = PTHREAD_MUTEX_INITIALIZER;
 static int g_init_done = 0;
 
 /* ---------------------------------------------------------------- bignum layer (L2) */
@@ -461,8 +466,14 @@ static void slow_dbl_mod(bn256 *a, const bn256 *p) {
   *a = t;
 }
 
+/* everything mgry_constants<WBN, P> (mgry_csts.h:15-35) and mgry_mul_constants (mgry_mul.h:25-50) derive from P,
+ * for the modulus already stored in c->p (any odd value; a, b, gx, gy as already stored) */
+static void field_init(oracle_curve *c);
 static void curve_init(oracle_curve *c, const char *p, const char *a, const char *b, const char *gx, const char *gy) {
   bn_from_hex(&c->p, p); bn_from_hex(&c->a, a); bn_from_hex(&c->b, b); bn_from_hex(&c->gx, gx); bn_from_hex(&c->gy, gy);
+  field_init(c);
+}
+static void field_init(oracle_curve *c) {
   /* m' = -p^-1 mod 2^32 by Newton iteration (mgry_mul.h:33-38 computes it with cbn::mod_inv) */
   uint32_t p0 = (uint32_t)c->p.l[0], inv = p0;
   for (int i = 0; i < 5; ++i) inv *= 2u - p0 * inv;
@@ -479,8 +490,8 @@ static void curve_init(oracle_curve *c, const char *p, const char *a, const char
   mgry_from_classical(&c->bm, &c->b, c);
   bn256 two; memset(&two, 0, sizeof two); two.l[0] = 2;
   bn_sub(&c->p_m2, &c->p, &two);
-  bn256 pp1; bn_add(&pp1, &c->p, &one);                               /* p+1 < 2^256 for both primes */
-  for (int i = 0; i < NL; ++i) c->p_sqrt.l[i] = (pp1.l[i] >> 2) | (i + 1 < NL ? pp1.l[i + 1] << 62 : 0);
+  bn256 pp1; const int pc = bn_add(&pp1, &c->p, &one);                /* p+1 < 2^256 except for p = 2^256 - 1 */
+  for (int i = 0; i < NL; ++i) c->p_sqrt.l[i] = (pp1.l[i] >> 2) | (i + 1 < NL ? pp1.l[i + 1] << 62 : (uint64_t)pc << 62);
 }
 
 static void oracle_init_once(void) {
@@ -502,7 +513,7 @@ static void oracle_init_once(void) {
 
 static const oracle_curve *curve_of(int id) {
   oracle_init_once();
-  return (id >= 0 && id < ORACLE_NCURVES) ? &g_curves[id] : NULL;
+  return (id >= 0 && id < __atomic_load_n(&g_nfields, __ATOMIC_ACQUIRE)) ? &g_curves[id] : NULL;
 }
 
 /* ---------------------------------------------------------------- exported batch API
@@ -512,6 +523,25 @@ static const oracle_curve *curve_of(int id) {
 typedef const uint64_t *cu64p;
 #define BN(p, i) ((bn256 *)((p) + 4 * (size_t)(i)))
 #define CBN(p, i) ((const bn256 *)((p) + 4 * (size_t)(i)))
+
+/* A field id for the odd modulus p (4 x u64 LE limbs): the same id for the same p; -1 if p is even or the table is full.
+ * The id is accepted by every oracle_mod_* / oracle_mgry_* / oracle_gfp_* function below (not by the point functions). */
+EXPORT int oracle_register_modulus(const uint64_t *p) {
+  oracle_init_once();
+  if (!(p[0] & 1)) return -1;
+  pthread_mutex_lock(&g_fields_lock);
+  int id = -1;
+  for (int i = 0; i < g_nfields; ++i) if (memcmp(g_curves[i].p.l, p, 32) == 0) { id = i; break; }
+  if (id < 0 && g_nfields < ORACLE_MAXFIELDS) {
+    oracle_curve *c = &g_curves[g_nfields];
+    memset(c, 0, sizeof *c); memcpy(c->p.l, p, 32);
+    field_init(c);
+    id = g_nfields;
+    __atomic_store_n(&g_nfields, g_nfields + 1, __ATOMIC_RELEASE);
+  }
+  pthread_mutex_unlock(&g_fields_lock);
+  return id;
+}
 
 EXPORT int oracle_get_constants(int curve, uint64_t *out /* 12 x 4 u64 */, uint32_t *mprime) {
   const oracle_curve *c = curve_of(curve); if (!c) return -1;

@@ -260,6 +260,13 @@ class Oracle(_Lib):
         self.lib.oracle_set_square_mode(C.c_int(1 if self.faithful else 0))   # one shared library: select per call
         return super()._f(name)
 
+    def register_modulus(self, p: int) -> int:
+        """Field id (>= 2) of the odd modulus p, for the mod_* / mgry_* / gfp_* methods (not the point methods)."""
+        limbs = np.array([(p >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+        fid = int(self.lib.oracle_register_modulus(_p(limbs)))
+        assert fid >= 2, (fid, hex(p))
+        return fid
+
     def dropped_carries(self) -> int:
         return int(self.lib.oracle_dropped_carries())
 
@@ -267,9 +274,28 @@ class Oracle(_Lib):
         self.lib.oracle_reset_dropped_carries()
 
 
+# The curve-less moduli oracle/ref_driver.cpp instantiates the reference's field layer for (field ids 2..6 there): the two group
+# orders, a prime below 2^255, the largest odd 256-bit value (composite) and a 192-bit prime.  Only the ones = 3 mod 4 have a
+# GFp<WBN, P> in the reference (gfp.h:84): sqrt / opposite exist for those alone.
+REF_MODULI = {
+    "n_p256": 0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551,
+    "n_secp256k1": 0xfffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364141,
+    "p25519": 2 ** 255 - 19,
+    "all_ones": 2 ** 256 - 1,
+    "p192": 2 ** 192 - 2 ** 64 - 1,
+}
+
+
 class Reference(_Lib):
     prefix = "ref_"
     path = os.path.join(HERE, "_ref", "libecsimd_ref.so")
+
+    def register_modulus(self, p: int) -> int:
+        """The reference is generic at COMPILE time: only the moduli of REF_MODULI have an instance (ids 2..6)."""
+        for fid in range(2, 2 + len(REF_MODULI)):
+            if sum(int(v) << (64 * i) for i, v in enumerate(self.constants(fid)["p"])) == p:
+                return fid
+        raise KeyError(hex(p))
 
     def scalar_mult_1s(self, curve, k1, x, y):
         k1 = _arr(np.asarray(k1, dtype=np.uint64).reshape(1, 4))

@@ -84,28 +84,19 @@ template <class M> void store_mask(uint8_t* out, size_t w, size_t n, M const& m)
 }
 inline size_t nwides(size_t n) { return (n + 3) / 4; }
 
-template <class Curve> struct ops {
-  using P    = typename Curve::P;
+// The reference's L3 layer instantiated for ONE modulus type P_ (P_::value): generic in P (mgry_mul.h:84-121,
+// mgry_csts.h:15-35, gfp.h:17-115).  ops<Curve> below adds the point layer for a curve over that field.
+template <class P_> struct fops {
+  using P    = P_;
   using WMBN = wide_mgry_bignum<WBN, P>;
   using gfp  = GFp<WBN, P>;
-  using CG   = curve_group<Curve>;
-  using WCP  = wide_curve_point<Curve>;
-  using WJCP = wide_jacobian_curve_point<Curve>;
   using csts = mgry_constants<WBN, P>;
 
-  static WJCP load_pt(const uint64_t* x, const uint64_t* y, const uint64_t* z, size_t w, size_t n) {
-    WJCP p; p.x() = gfp{WMBN{load_wide<BN>(x, w, n)}}; p.y() = gfp{WMBN{load_wide<BN>(y, w, n)}}; p.z() = gfp{WMBN{load_wide<BN>(z, w, n)}}; return p;
-  }
-  static void store_pt(uint64_t* x, uint64_t* y, uint64_t* z, size_t w, size_t n, WJCP const& p) {
-    store_wide(x, w, n, p.x().wbn()); store_wide(y, w, n, p.y().wbn()); store_wide(z, w, n, p.z().wbn());
-  }
-
-  static int constants(uint64_t* out, uint32_t* mprime) {
+  // field ids (moduli without a curve): p, R mod p, R^2 mod p, -R mod p; the curve slots stay zero
+  static int field_constants(uint64_t* out, uint32_t* mprime) {
     using half_P = remap_limb_t<P, uint32_t>;
-    const BN vals[12] = {P::value, Curve::A::value, Curve::B::value, Curve::Gx::value, Curve::Gy::value,
-                         csts::R_p, csts::Rsq_p, csts::Pm1_by_R_p, CG::Am, CG::Bm, BN{}, BN{}};
-    for (int i = 0; i < 10; ++i) store_bn<BN>(out + 4 * i, vals[i]);
-    std::memset(out + 40, 0, 64);   // p-2 and (p+1)/4 are private members of GFp (gfp.h:79-87): left zero
+    std::memset(out, 0, 12 * 32);
+    store_bn<BN>(out, P::value); store_bn<BN>(out + 4 * 5, csts::R_p); store_bn<BN>(out + 4 * 6, csts::Rsq_p); store_bn<BN>(out + 4 * 7, csts::Pm1_by_R_p);
     *mprime = details::mgry_mul_constants<half_P, eve::fixed<4>>::mprime;
     return 0;
   }
@@ -132,19 +123,60 @@ template <class Curve> struct ops {
   static int pow_(const uint64_t* a, const uint64_t* e, uint64_t* out, size_t n) {
     const BN M = load_bn<BN>(e);
     for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, mgry_pow(WMBN{load_wide<BN>(a, w, n)}, M).wbn()); return 0; }
+  // GFp<WBN, P> itself only instantiates for p = 3 mod 4 (static_assert at gfp.h:84, for its sqrt exponent); the layers below it take
+  // any odd P.  For the other moduli inverse() is spelled as what gfp.h:42-44 computes, mgry_pow(x, P - 2), and sqrt / opposite
+  // (GFp members) are not offered (-1).
+  static constexpr bool gfp_ok = (P::value.cbn()[0] & 3) == 3;
+  static BN p_minus_2() {
+    auto c = P::value.cbn(); uint64_t borrow = 2;
+    for (size_t i = 0; i < BN::nlimbs && borrow; ++i) { const uint64_t v = c[i]; c[i] = v - borrow; borrow = v < borrow ? 1 : 0; }
+    return BN::from(c);
+  }
   static int inverse_(const uint64_t* a, uint64_t* out, size_t n) {
-    for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, gfp{WMBN{load_wide<BN>(a, w, n)}}.inverse().wbn()); return 0; }
+    if constexpr (gfp_ok) { for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, gfp{WMBN{load_wide<BN>(a, w, n)}}.inverse().wbn()); }
+    else { const BN e = p_minus_2(); for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, mgry_pow(WMBN{load_wide<BN>(a, w, n)}, e).wbn()); }
+    return 0; }
   // sqrt: the reference returns nullopt if ANY lane of the wide fails (gfp.h:50); `ok` reports that
   // all-or-nothing flag per wide (replicated to its lanes); `out` is written only when it succeeded.
   static int sqrt_(const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n) {
-    for (size_t w = 0; w < nwides(n); ++w) {
-      const auto r = gfp{WMBN{load_wide<BN>(a, w, n)}}.sqrt();
-      for (size_t lane = 0; lane < 4; ++lane) { size_t i = 4 * w + lane; if (i < n && ok) ok[i] = r.has_value(); }
-      if (r) store_wide(out, w, n, r->wbn());
-    } return 0; }
+    if constexpr (gfp_ok) {
+      for (size_t w = 0; w < nwides(n); ++w) {
+        const auto r = gfp{WMBN{load_wide<BN>(a, w, n)}}.sqrt();
+        for (size_t lane = 0; lane < 4; ++lane) { size_t i = 4 * w + lane; if (i < n && ok) ok[i] = r.has_value(); }
+        if (r) store_wide(out, w, n, r->wbn());
+      } return 0;
+    } else return -1; }
   static int opposite_(const uint64_t* a, uint64_t* out, size_t n) {
-    for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, gfp{WMBN{load_wide<BN>(a, w, n)}}.opposite().wbn()); return 0; }
+    if constexpr (gfp_ok) { for (size_t w = 0; w < nwides(n); ++w) store_wide(out, w, n, gfp{WMBN{load_wide<BN>(a, w, n)}}.opposite().wbn()); return 0; }
+    else return -1; }
+};
 
+template <class Curve> struct ops : fops<typename Curve::P> {
+  using F    = fops<typename Curve::P>;
+  using P    = typename Curve::P;
+  using WMBN = wide_mgry_bignum<WBN, P>;
+  using gfp  = GFp<WBN, P>;
+  using CG   = curve_group<Curve>;
+  using WCP  = wide_curve_point<Curve>;
+  using WJCP = wide_jacobian_curve_point<Curve>;
+  using csts = mgry_constants<WBN, P>;
+
+  static WJCP load_pt(const uint64_t* x, const uint64_t* y, const uint64_t* z, size_t w, size_t n) {
+    WJCP p; p.x() = gfp{WMBN{load_wide<BN>(x, w, n)}}; p.y() = gfp{WMBN{load_wide<BN>(y, w, n)}}; p.z() = gfp{WMBN{load_wide<BN>(z, w, n)}}; return p;
+  }
+  static void store_pt(uint64_t* x, uint64_t* y, uint64_t* z, size_t w, size_t n, WJCP const& p) {
+    store_wide(x, w, n, p.x().wbn()); store_wide(y, w, n, p.y().wbn()); store_wide(z, w, n, p.z().wbn());
+  }
+
+  static int constants(uint64_t* out, uint32_t* mprime) {
+    using half_P = remap_limb_t<P, uint32_t>;
+    const BN vals[12] = {P::value, Curve::A::value, Curve::B::value, Curve::Gx::value, Curve::Gy::value,
+                         csts::R_p, csts::Rsq_p, csts::Pm1_by_R_p, CG::Am, CG::Bm, BN{}, BN{}};
+    for (int i = 0; i < 10; ++i) store_bn<BN>(out + 4 * i, vals[i]);
+    std::memset(out + 40, 0, 64);   // p-2 and (p+1)/4 are private members of GFp (gfp.h:79-87): left zero
+    *mprime = details::mgry_mul_constants<half_P, eve::fixed<4>>::mprime;
+    return 0;
+  }
   static int dblu_(uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
     for (size_t w = 0; w < nwides(n); ++w) { auto P_ = load_pt(px, py, pz, w, n); const auto R = CG::DBLU(P_); store_pt(px, py, pz, w, n, P_); store_pt(rx, ry, rz, w, n, R); } return 0; }
   static int zaddu_(uint64_t* px, uint64_t* py, uint64_t* pz, const uint64_t* ox, const uint64_t* oy, const uint64_t* oz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
@@ -201,6 +233,17 @@ template <class Curve> struct ops {
 using P256 = ops<curve_nist_p256>;
 using K256 = ops<curve_secp256k1>;
 
+// Moduli without a curve (field ids 2..6): the two group orders (SP 800-186 / SEC 2 public data), a prime below 2^255, the
+// largest odd 256-bit value (composite: Montgomery arithmetic needs p odd, not prime) and a 192-bit prime (p << R).
+#define MODULUS(NAME, HEX) struct NAME { static constexpr auto value = bn_from_bytes_BE<BN>(HEX##_hex); }
+MODULUS(mod_n_p256,      "ffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551");
+MODULUS(mod_n_secp256k1, "fffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364141");
+MODULUS(mod_25519,       "7fffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffed");
+MODULUS(mod_all_ones,    "ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff");
+MODULUS(mod_p192,        "0000000000000000fffffffffffffffffffffffffffffffeffffffffffffffff");
+#undef MODULUS
+using F2 = fops<mod_n_p256>; using F3 = fops<mod_n_secp256k1>; using F4 = fops<mod_25519>; using F5 = fops<mod_all_ones>; using F6 = fops<mod_p192>;
+
 // BASELINE.json configs[0]: benchs/ops.cpp restated as a timed loop (its harness, Google Benchmark, is not installed and
 // cannot be fetched: SURVEY.md 8(c)).  Like the benchmark, the operands are built before the timed region and every pass
 // makes one out-of-line call per wide; the result is kept from being optimised away by an empty asm that takes its
@@ -252,12 +295,16 @@ template <class Curve> double bench_ops(int op, const uint64_t* a, const uint64_
 } // namespace
 
 #define DISPATCH(fn, ...) (curve == 0 ? P256::fn(__VA_ARGS__) : curve == 1 ? K256::fn(__VA_ARGS__) : -1)
+// the field layer also takes the curve-less moduli
+#define FDISPATCH(fn, ...) (curve == 0 ? P256::fn(__VA_ARGS__) : curve == 1 ? K256::fn(__VA_ARGS__) : curve == 2 ? F2::fn(__VA_ARGS__) : curve == 3 ? F3::fn(__VA_ARGS__) : \
+                            curve == 4 ? F4::fn(__VA_ARGS__) : curve == 5 ? F5::fn(__VA_ARGS__) : curve == 6 ? F6::fn(__VA_ARGS__) : -1)
 
 extern "C" {
 #define EXPORT __attribute__((visibility("default")))
 typedef const uint64_t* cu64p;
 
-EXPORT int ref_get_constants(int curve, uint64_t* out, uint32_t* mprime) { return DISPATCH(constants, out, mprime); }
+EXPORT int ref_get_constants(int curve, uint64_t* out, uint32_t* mprime) {
+  return curve < 2 ? DISPATCH(constants, out, mprime) : FDISPATCH(field_constants, out, mprime); }
 
 // curve-independent bignum ops (add.h, sub.h, shift.h, mul.h)
 EXPORT int ref_add(cu64p a, cu64p b, uint64_t* out, uint8_t* carry, size_t n) {
@@ -273,18 +320,18 @@ EXPORT int ref_mul(cu64p a, cu64p b, uint64_t* out8, size_t n) {
 EXPORT int ref_square(cu64p a, uint64_t* out8, size_t n) {
   for (size_t w = 0; w < nwides(n); ++w) store_wide(out8, w, n, square(load_wide<BN>(a, w, n))); return 0; }
 
-EXPORT int ref_mod_add(int curve, cu64p a, cu64p b, uint64_t* out, size_t n) { return DISPATCH(mod_add_, a, b, out, n); }
-EXPORT int ref_mod_sub(int curve, cu64p a, cu64p b, uint64_t* out, size_t n) { return DISPATCH(mod_sub_, a, b, out, n); }
-EXPORT int ref_mod_shift_left(int curve, cu64p a, int count, uint64_t* out, size_t n) { return DISPATCH(mod_shl_, a, count, out, n); }
-EXPORT int ref_mgry_reduce(int curve, cu64p a8, uint64_t* out, size_t n) { return DISPATCH(reduce_, a8, out, n); }
-EXPORT int ref_mgry_mul(int curve, cu64p a, cu64p b, uint64_t* out, size_t n) { return DISPATCH(mgry_mul_, a, b, out, n); }
-EXPORT int ref_mgry_sqr(int curve, cu64p a, uint64_t* out, size_t n) { return DISPATCH(mgry_sqr_, a, out, n); }
-EXPORT int ref_mgry_from_classical(int curve, cu64p a, uint64_t* out, size_t n) { return DISPATCH(from_classical_, a, out, n); }
-EXPORT int ref_mgry_to_classical(int curve, cu64p a, uint64_t* out, size_t n) { return DISPATCH(to_classical_, a, out, n); }
-EXPORT int ref_mgry_pow(int curve, cu64p a, cu64p e, uint64_t* out, size_t n) { return DISPATCH(pow_, a, e, out, n); }
-EXPORT int ref_gfp_inverse(int curve, cu64p a, uint64_t* out, size_t n) { return DISPATCH(inverse_, a, out, n); }
-EXPORT int ref_gfp_sqrt(int curve, cu64p a, uint64_t* out, uint8_t* ok, size_t n) { return DISPATCH(sqrt_, a, out, ok, n); }
-EXPORT int ref_gfp_opposite(int curve, cu64p a, uint64_t* out, size_t n) { return DISPATCH(opposite_, a, out, n); }
+EXPORT int ref_mod_add(int curve, cu64p a, cu64p b, uint64_t* out, size_t n) { return FDISPATCH(mod_add_, a, b, out, n); }
+EXPORT int ref_mod_sub(int curve, cu64p a, cu64p b, uint64_t* out, size_t n) { return FDISPATCH(mod_sub_, a, b, out, n); }
+EXPORT int ref_mod_shift_left(int curve, cu64p a, int count, uint64_t* out, size_t n) { return FDISPATCH(mod_shl_, a, count, out, n); }
+EXPORT int ref_mgry_reduce(int curve, cu64p a8, uint64_t* out, size_t n) { return FDISPATCH(reduce_, a8, out, n); }
+EXPORT int ref_mgry_mul(int curve, cu64p a, cu64p b, uint64_t* out, size_t n) { return FDISPATCH(mgry_mul_, a, b, out, n); }
+EXPORT int ref_mgry_sqr(int curve, cu64p a, uint64_t* out, size_t n) { return FDISPATCH(mgry_sqr_, a, out, n); }
+EXPORT int ref_mgry_from_classical(int curve, cu64p a, uint64_t* out, size_t n) { return FDISPATCH(from_classical_, a, out, n); }
+EXPORT int ref_mgry_to_classical(int curve, cu64p a, uint64_t* out, size_t n) { return FDISPATCH(to_classical_, a, out, n); }
+EXPORT int ref_mgry_pow(int curve, cu64p a, cu64p e, uint64_t* out, size_t n) { return FDISPATCH(pow_, a, e, out, n); }
+EXPORT int ref_gfp_inverse(int curve, cu64p a, uint64_t* out, size_t n) { return FDISPATCH(inverse_, a, out, n); }
+EXPORT int ref_gfp_sqrt(int curve, cu64p a, uint64_t* out, uint8_t* ok, size_t n) { return FDISPATCH(sqrt_, a, out, ok, n); }
+EXPORT int ref_gfp_opposite(int curve, cu64p a, uint64_t* out, size_t n) { return FDISPATCH(opposite_, a, out, n); }
 EXPORT int ref_dblu(int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { return DISPATCH(dblu_, px, py, pz, rx, ry, rz, n); }
 EXPORT int ref_zaddu(int curve, uint64_t* px, uint64_t* py, uint64_t* pz, cu64p ox, cu64p oy, cu64p oz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { return DISPATCH(zaddu_, px, py, pz, ox, oy, oz, rx, ry, rz, n); }
 EXPORT int ref_zdau(int curve, cu64p px, cu64p py, cu64p pz, uint64_t* qx, uint64_t* qy, uint64_t* qz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) { return DISPATCH(zdau_, px, py, pz, qx, qy, qz, rx, ry, rz, n); }

@@ -31,7 +31,9 @@ def test_group_mode_matches_the_plain_line_at_one_gpu():
     assert abs(group["value"] - plain["value"]) / plain["value"] < 0.01, (plain["value"], group["value"])
     for d in (plain, group):
         assert d["n_gpus"] == 1 and d["steps"] == 8 and d["roofline"]["traffic"] is not None and "parity_failures" not in d
-        assert 0.6 < d["roofline"]["frac"] < 0.85
+        # algorithmic mad32 (136 per field multiplication) over the live v_mad_u64_u32 probe: 0.75 on 8 x 32-bit words
+        # (rounds 1-3), 0.90-0.91 since the loop runs on nine 29-bit limbs (81 multiplies per product instead of 64 + the reduction's)
+        assert 0.6 < d["roofline"]["frac"] < 1.0
 
 
 def test_two_ranks_rehearsed_on_one_gpu():
