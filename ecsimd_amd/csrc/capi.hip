@@ -9,12 +9,14 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <new>
 #include <vector>
 
 #include "../../include/ecsimd_hip.h"
 #include "kernels.h"
 #include "point.cuh"   // curve constants for ecsimd_hip_get_constant (host-side constexpr use only)
+#include "gfield.cuh"  // gmod: a run-time modulus as the generic field kernels take it
 
 using namespace ecsimd_hip;
 using launch::BLOCK;
@@ -349,6 +351,77 @@ int run_varwin(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, 
 }
 }  // namespace
 
+// ================================================================== run-time moduli
+// The reference's field layer is generic in the modulus type P (mgry_mul.h:84-121, mgry_csts.h:15-35, gfp.h:17-115): a caller
+// instantiates it for any odd 256-bit P at compile time.  Here the same genericity is a run-time registry: a field id names a
+// modulus, the host derives what mgry_constants<WBN, P> / mgry_mul_constants derive (R, R^2, -R mod p, m') plus the division-step
+// constants, and the generic kernels of k_gfield.hip take the record as a kernel argument.  Ids 0, 1 are the curve primes (their
+// special-form kernels, field.cuh); 2, 3 the two group orders; 4... whatever ecsimd_hip_register_modulus was given.  Process-wide,
+// append-only, guarded by one mutex (registration is rare; lookups copy 236 bytes).
+namespace {
+struct u256 { uint64_t l[4]; };
+bool u_geq(const u256& a, const u256& b) { for (int i = 3; i >= 0; --i) if (a.l[i] != b.l[i]) return a.l[i] > b.l[i]; return true; }
+uint64_t u_sub(u256& r, const u256& a, const u256& b) {
+  uint64_t bw = 0;
+  for (int i = 0; i < 4; ++i) { const unsigned __int128 d = (unsigned __int128)a.l[i] - b.l[i] - bw; r.l[i] = (uint64_t)d; bw = (uint64_t)(d >> 64) & 1u; }
+  return bw;
+}
+void u_dbl_mod(u256& a, const u256& p) {                       // a < p  ->  2a mod p
+  const uint64_t top = a.l[3] >> 63;
+  for (int i = 3; i > 0; --i) a.l[i] = (a.l[i] << 1) | (a.l[i - 1] >> 63);
+  a.l[0] <<= 1;
+  if (top || u_geq(a, p)) { u256 t; (void)u_sub(t, a, p); a = t; }
+}
+void u_words(uint32_t (&w)[8], const u256& v) { for (int i = 0; i < 4; ++i) { w[2 * i] = (uint32_t)v.l[i]; w[2 * i + 1] = (uint32_t)(v.l[i] >> 32); } }
+gmod make_gmod(const uint64_t pl[4], uint32_t flags) {
+  gmod M; memset(&M, 0, sizeof M);
+  u256 p; for (int i = 0; i < 4; ++i) p.l[i] = pl[i];
+  u_words(M.p, p);
+  u256 t = {{1, 0, 0, 0}};                                    // 1 < p (p >= 3)
+  for (int i = 0; i < 256; ++i) u_dbl_mod(t, p);
+  u_words(M.r, t);                                            // R mod p            mgry_csts.h:20 (cbn::div there)
+  { u256 nr; (void)u_sub(nr, p, t); u_words(M.negr, nr); }    // -R mod p = p - (R mod p), R mod p in [1, p)   mgry_csts.h:24
+  for (int i = 0; i < 256; ++i) u_dbl_mod(t, p);
+  u_words(M.rsq, t);                                          // R^2 mod p          mgry_csts.h:21
+  for (int i = 0; i < 256; ++i) u_dbl_mod(t, p);
+  u_words(M.r3, t);                                           // R^3 mod p
+  { u256 two = {{2, 0, 0, 0}}, e; (void)u_sub(e, p, two); u_words(M.pm2, e); }                                     // gfp.h:79-81
+  { unsigned __int128 c = 1; u256 q; for (int i = 0; i < 4; ++i) { c += p.l[i]; q.l[i] = (uint64_t)c; c >>= 64; }   // (p + 1) / 4, the carry of p + 1 kept
+    u256 h; for (int i = 0; i < 4; ++i) h.l[i] = (q.l[i] >> 2) | ((i < 3 ? q.l[i + 1] : (uint64_t)c) << 62); u_words(M.psqrt, h); }
+  for (int i = 0; i < 9; ++i) {                               // p in 30-bit limbs (the top one holds bits 240..255)
+    const int bit = 30 * i, limb = bit / 64, off = bit % 64;
+    uint64_t v = p.l[limb] >> off;
+    if (off > 34 && limb + 1 < 4) v |= p.l[limb + 1] << (64 - off);
+    M.p30[i] = (int32_t)(v & (i < 8 ? 0x3fffffffu : 0xffffu));
+  }
+  uint32_t p0 = (uint32_t)p.l[0], inv = p0;                   // p^-1 mod 2^32 by Newton iteration (mgry_mul.h:33-38 uses cbn::mod_inv)
+  for (int i = 0; i < 5; ++i) inv *= 2u - p0 * inv;
+  M.pinv30 = inv & 0x3fffffffu;
+  M.mprime = 0u - inv;
+  M.flags = (flags & GMOD_PRIME) | ((p0 & 3u) == 3u ? GMOD_3MOD4 : 0u);
+  return M;
+}
+struct modulus_registry {
+  std::mutex mu;
+  std::vector<gmod> mods;                                     // index = field id - 2
+  modulus_registry() {
+    uint64_t n[4];
+    words_to_limbs(curve_order<CURVE_P256>::N, n); mods.push_back(make_gmod(n, GMOD_PRIME));
+    words_to_limbs(curve_order<CURVE_SECP256K1>::N, n); mods.push_back(make_gmod(n, GMOD_PRIME));
+  }
+};
+modulus_registry& registry() { static modulus_registry r; return r; }
+constexpr int FIRST_FIELD_ID = 2, MAX_FIELDS = 4096;
+// the record of field id `id` (>= 2); false if there is none
+bool lookup_modulus(int id, gmod* out) {
+  modulus_registry& r = registry();
+  std::lock_guard<std::mutex> g(r.mu);
+  if (id < FIRST_FIELD_ID || (size_t)(id - FIRST_FIELD_ID) >= r.mods.size()) return false;
+  *out = r.mods[id - FIRST_FIELD_ID];
+  return true;
+}
+}  // namespace
+
 extern "C" {
 
 const char* ecsimd_hip_version(void) { return "ecsimd-hip 0.1 (gfx950)"; }
@@ -441,6 +514,27 @@ int ecsimd_hip_memcpy_d2d(ecsimd_hip_ctx* ctx, void* dst, const void* src, size_
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "hipMemcpy d2d");
 }
 
+
+int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id) {
+  if (!p || !field_id) return ECSIMD_HIP_ERR_BAD_ARG;
+  if (!(p[0] & 1u) || (p[0] < 3 && !(p[1] | p[2] | p[3]))) return ECSIMD_HIP_ERR_BAD_ARG;        // odd, >= 3 (Montgomery arithmetic needs gcd(p, 2^256) = 1)
+  if (flags & ~ECSIMD_HIP_MODULUS_PRIME) return ECSIMD_HIP_ERR_BAD_ARG;
+  // the curve primes keep their special-form kernels
+  { uint64_t c[4]; words_to_limbs(curve_consts<CURVE_P256>::P, c); if (!memcmp(c, p, 32)) { *field_id = ECSIMD_HIP_P256; return ECSIMD_HIP_OK; }
+    words_to_limbs(curve_consts<CURVE_SECP256K1>::P, c); if (!memcmp(c, p, 32)) { *field_id = ECSIMD_HIP_SECP256K1; return ECSIMD_HIP_OK; } }
+  try {
+    const gmod M = make_gmod(p, (flags & ECSIMD_HIP_MODULUS_PRIME) ? GMOD_PRIME : 0u);
+    modulus_registry& r = registry();
+    std::lock_guard<std::mutex> g(r.mu);
+    for (size_t i = 0; i < r.mods.size(); ++i)
+      if (!memcmp(r.mods[i].p, M.p, sizeof M.p)) { r.mods[i].flags |= M.flags; *field_id = FIRST_FIELD_ID + (int)i; return ECSIMD_HIP_OK; }   // the same id; a later "prime" sticks
+    if (r.mods.size() >= (size_t)MAX_FIELDS) return ECSIMD_HIP_ERR_BAD_ARG;
+    r.mods.push_back(M);
+    *field_id = FIRST_FIELD_ID + (int)r.mods.size() - 1;
+    return ECSIMD_HIP_OK;
+  } catch (...) { return ECSIMD_HIP_ERR_BAD_ARG; }             // nothing throws across the C ABI
+}
+
 int ecsimd_hip_get_constant(int curve, int which, uint64_t out[4]) {
   if (!out || which < 0 || which > 11) return ECSIMD_HIP_ERR_BAD_ARG;
 #define PICK(C) do { using K = curve_consts<C>; using E = curve_exps<C>; \
@@ -462,7 +556,21 @@ int ecsimd_hip_get_constant(int curve, int which, uint64_t out[4]) {
     } } while (0)
   if (curve == ECSIMD_HIP_P256) PICK(CURVE_P256);
   else if (curve == ECSIMD_HIP_SECP256K1) PICK(CURVE_SECP256K1);
-  else return ECSIMD_HIP_ERR_BAD_ARG;
+  else {
+    // a field id: p, R mod p, R^2 mod p, -R mod p, p - 2, (p + 1) / 4; the curve slots (a, b, Gx, Gy, a R, b R) read zero
+    gmod M;
+    if (!lookup_modulus(curve, &M)) return ECSIMD_HIP_ERR_BAD_ARG;
+    static const uint32_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    switch (which) {
+      case 0: words_to_limbs(M.p, out); break;
+      case 5: words_to_limbs(M.r, out); break;
+      case 6: words_to_limbs(M.rsq, out); break;
+      case 7: words_to_limbs(M.negr, out); break;
+      case 10: words_to_limbs(M.pm2, out); break;
+      case 11: words_to_limbs(M.psqrt, out); break;
+      default: words_to_limbs(zero, out); break;
+    }
+  }
 #undef PICK
   return ECSIMD_HIP_OK;
 }
@@ -524,39 +632,55 @@ int ecsimd_hip_sec1_encode(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, co
 int ecsimd_hip_sec1_decode(ecsimd_hip_ctx* ctx, int curve, const uint8_t* in, uint64_t* x, uint64_t* y, uint8_t* ok, size_t n, int compressed) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(in); REQUIRE_PTR(x); REQUIRE_PTR(y); RUN(launch::sec1_decode(s, curve, in, x, y, ok, n, compressed != 0)); }
 
-// ---- L3
+// ---- L3.  `curve` is a FIELD id here: a curve's prime (0, 1: the special-form kernels of field.cuh) or a run-time modulus (>= 2: k_gfield.hip).
+#define FIELD_OR_CURVE(generic_call) do { if (curve != ECSIMD_HIP_P256 && curve != ECSIMD_HIP_SECP256K1) { \
+    gmod M; if (!lookup_modulus(curve, &M)) return bad(ctx, "unknown curve / field id"); RUN(generic_call); } } while (0)
 int ecsimd_hip_mod_add(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, instance(ctx, curve), launch::F_MOD_ADD, a, b, out, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); FIELD_OR_CURVE(launch::gfield_binop(s, M, launch::F_MOD_ADD, a, b, out, n)); RUN(launch::field_binop(s, instance(ctx, curve), launch::F_MOD_ADD, a, b, out, n)); }
 int ecsimd_hip_mod_sub(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, instance(ctx, curve), launch::F_MOD_SUB, a, b, out, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); FIELD_OR_CURVE(launch::gfield_binop(s, M, launch::F_MOD_SUB, a, b, out, n)); RUN(launch::field_binop(s, instance(ctx, curve), launch::F_MOD_SUB, a, b, out, n)); }
 int ecsimd_hip_mod_mul(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::mod_mul(s, instance(ctx, curve), a, b, out, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); FIELD_OR_CURVE(launch::gfield_mod_mul(s, M, a, b, out, n)); RUN(launch::mod_mul(s, instance(ctx, curve), a, b, out, n)); }
 int ecsimd_hip_mod_shift_left(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, int count, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); if ((count & 0xff) < 1 || (count & ~0x1ff)) return bad(ctx, "count must be 1..255, optionally | ECSIMD_HIP_SHIFT_FUSED"); RUN(launch::mod_shift_left(s, instance(ctx, curve), a, count, out, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(out); if ((count & 0xff) < 1 || (count & ~0x1ff)) return bad(ctx, "count must be 1..255, optionally | ECSIMD_HIP_SHIFT_FUSED"); FIELD_OR_CURVE(launch::gfield_shift_left(s, M, a, count, out, n)); RUN(launch::mod_shift_left(s, instance(ctx, curve), a, count, out, n)); }
 int ecsimd_hip_mgry_reduce(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a8, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a8); REQUIRE_PTR(out); RUN(launch::mgry_reduce(s, instance(ctx, curve), a8, out, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(a8); REQUIRE_PTR(out); FIELD_OR_CURVE(launch::gfield_reduce(s, M, a8, out, n)); RUN(launch::mgry_reduce(s, instance(ctx, curve), a8, out, n)); }
 int ecsimd_hip_mgry_mul(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); RUN(launch::field_binop(s, instance(ctx, curve), launch::F_MGRY_MUL, a, b, out, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(b); REQUIRE_PTR(out); FIELD_OR_CURVE(launch::gfield_binop(s, M, launch::F_MGRY_MUL, a, b, out, n)); RUN(launch::field_binop(s, instance(ctx, curve), launch::F_MGRY_MUL, a, b, out, n)); }
 int ecsimd_hip_mgry_sqr(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, instance(ctx, curve), launch::F_MGRY_SQR, a, out, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(out); FIELD_OR_CURVE(launch::gfield_unop(s, M, launch::F_MGRY_SQR, a, out, n, ctx->ref_square != 0)); RUN(launch::field_unop(s, instance(ctx, curve), launch::F_MGRY_SQR, a, out, n)); }
 int ecsimd_hip_mgry_from_classical(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, instance(ctx, curve), launch::F_FROM_CLASSICAL, a, out, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(out); FIELD_OR_CURVE(launch::gfield_unop(s, M, launch::F_FROM_CLASSICAL, a, out, n, false)); RUN(launch::field_unop(s, instance(ctx, curve), launch::F_FROM_CLASSICAL, a, out, n)); }
 int ecsimd_hip_mgry_to_classical(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, instance(ctx, curve), launch::F_TO_CLASSICAL, a, out, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(out); FIELD_OR_CURVE(launch::gfield_unop(s, M, launch::F_TO_CLASSICAL, a, out, n, false)); RUN(launch::field_unop(s, instance(ctx, curve), launch::F_TO_CLASSICAL, a, out, n)); }
 int ecsimd_hip_mgry_pow(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, const uint64_t exponent[4], uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); if (!exponent) return bad(ctx, "exponent is null");
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(out); if (!exponent) return bad(ctx, "exponent is null");
   launch::words8 e; for (int i = 0; i < 4; ++i) { e.w[2 * i] = (uint32_t)exponent[i]; e.w[2 * i + 1] = (uint32_t)(exponent[i] >> 32); }
+  FIELD_OR_CURVE(launch::gfield_pow(s, M, a, e, out, n, ctx->ref_square != 0));
   RUN(launch::mgry_pow(s, instance(ctx, curve), a, e, out, n)); }
 int ecsimd_hip_gfp_inverse(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out);
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(out);
+  if (curve != ECSIMD_HIP_P256 && curve != ECSIMD_HIP_SECP256K1) {
+    // a run-time modulus.  Registered as PRIME: the shared division-step inversion below (the unique inverse = x^(p-2)); otherwise x^(p-2) bit by
+    // bit, which is what gfp.h:42-44 computes whatever p is (for a composite p it is not an inverse, and the reference returns it all the same).
+    gmod M; if (!lookup_modulus(curve, &M)) return bad(ctx, "unknown curve / field id");
+    if ((M.flags & GMOD_PRIME) && !ctx->ref_square && !overlaps(out, a)) RUN(launch::gfield_inverse_batched(s, M, a, out, n));
+    RUN(launch::gfield_unop(s, M, launch::F_INVERSE, a, out, n, ctx->ref_square != 0));
+  }
   // one inversion per ~64 elements (Montgomery's trick, out[] as scratch) unless the call is in place
   // (the reference-square instances raise to p - 2 per element, squaring by squaring as the reference does)
   if (overlaps(out, a) || ctx->ref_square) RUN(launch::field_unop(s, instance(ctx, curve), launch::F_INVERSE, a, out, n));
   RUN(launch::inverse_batched(s, curve, a, out, n)); }
 int ecsimd_hip_gfp_opposite(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::field_unop(s, instance(ctx, curve), launch::F_OPPOSITE, a, out, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(out); FIELD_OR_CURVE(launch::gfield_unop(s, M, launch::F_OPPOSITE, a, out, n, false)); RUN(launch::field_unop(s, instance(ctx, curve), launch::F_OPPOSITE, a, out, n)); }
 int ecsimd_hip_gfp_sqrt(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(a); REQUIRE_PTR(out); RUN(launch::gfp_sqrt(s, instance(ctx, curve), a, out, ok, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(a); REQUIRE_PTR(out);
+  if (curve != ECSIMD_HIP_P256 && curve != ECSIMD_HIP_SECP256K1) {
+    gmod M; if (!lookup_modulus(curve, &M)) return bad(ctx, "unknown curve / field id");
+    if (!(M.flags & GMOD_3MOD4)) return bad(ctx, "gfp_sqrt needs p = 3 mod 4 (the reference's GFp does not instantiate otherwise: gfp.h:84)");
+    RUN(launch::gfield_sqrt(s, M, a, out, ok, n, ctx->ref_square != 0));
+  }
+  RUN(launch::gfp_sqrt(s, instance(ctx, curve), a, out, ok, n)); }
 
 // ---- L4/L5
 int ecsimd_hip_from_affine(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n) {
@@ -707,28 +831,65 @@ int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t
   return double_scalar_mult_impl(ctx, curve, u1, u2, qx, qy, rx, ry, finite, n, 0); }
 
 // ECDSA's acceptance test on top of double_scalar_mult: ok[i] = Q[i] is a valid public key && u1*G + u2*Q is finite && its x mod n == r[i].
+// `extra` bytes are kept untouched at the end of the workspace for the caller (ecdsa_verify's u1, u2 and range flags).
+namespace {
+struct verify_layout { size_t front, behind; };
+verify_layout verify_sizes(size_t n) {
+  const size_t chunk = n < VARWIN_CHUNK ? n : VARWIN_CHUNK;
+  return {7 * chunk * 32 + launch::varwin_scratch_bytes(chunk), n * 32 + ((n + 15) / 16) * 16};
+}
+int ecdsa_verify_rx_impl(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
+                         const uint64_t* r, uint8_t* ok, size_t n, size_t extra) {
+  (void)hipSetDevice(ctx->device);
+  // x coordinates and the finite flags of the sums live behind double_scalar_mult's own workspace use
+  const verify_layout L = verify_sizes(n);
+  // sizes the workspace (and builds the table) first, so that the pointers taken below stay valid
+  int rc = ensure_window_table(ctx, curve, (ctx->window16_table[curve] != nullptr || n >= BIG_TABLE_WORTH_IT) ? launch::BIG_WINDOW_BITS : SIGNED_WBITS);
+  if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, L.front + L.behind + extra);
+  if (rc != ECSIMD_HIP_OK) return rc;
+  uint64_t* rx = ctx->workspace + L.front / 8;
+  uint8_t* fin = reinterpret_cast<uint8_t*>(rx + 4 * n);
+  rc = double_scalar_mult_impl(ctx, curve, u1, u2, qx, qy, rx, nullptr, fin, n, L.behind + extra);
+  if (rc != ECSIMD_HIP_OK) return rc;
+  launch::x_mod_n_equals(ctx->stream, curve, rx, fin, r, ok, n);       // fin is 0 for the lanes whose Q failed validation
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "ecdsa_verify_rx launch");
+}
+}  // namespace
+
 int ecsimd_hip_ecdsa_verify_rx(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                                const uint64_t* r, uint8_t* ok, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(u1); REQUIRE_PTR(u2); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(r);
   if (!ok && n) return bad(ctx, "ok is null");
   if (ctx->ref_square) return bad(ctx, "ecdsa_verify_rx is not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT form");
   if (n == 0) return ECSIMD_HIP_OK;
+  return ecdsa_verify_rx_impl(ctx, curve, u1, u2, qx, qy, r, ok, n, 0); }
+
+// The whole verification (SEC 1 v2 4.1.4, FIPS 186-5 6.4.2): range checks and u1 = e / s, u2 = r / s modulo the group order on the device
+// (k_gfield.hip k_ecdsa_scalars: one shared inversion per up to 128 signatures), then the acceptance test above.
+int ecsimd_hip_ecdsa_verify(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, const uint64_t* r, const uint64_t* s_, const uint64_t* qx, const uint64_t* qy,
+                            uint8_t* ok, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(e); REQUIRE_PTR(r); REQUIRE_PTR(s_); REQUIRE_PTR(qx); REQUIRE_PTR(qy);
+  if (!ok && n) return bad(ctx, "ok is null");
+  if (ctx->ref_square) return bad(ctx, "ecdsa_verify is not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT form");
+  if (n == 0) return ECSIMD_HIP_OK;
+  if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
   (void)hipSetDevice(ctx->device);
-  // x coordinates and the finite flags of the sums live behind double_scalar_mult's own workspace use
-  const size_t chunk = n < VARWIN_CHUNK ? n : VARWIN_CHUNK;
-  const size_t front = 7 * chunk * 32 + launch::varwin_scratch_bytes(chunk);
-  const size_t behind = n * 32 + ((n + 15) / 16) * 16;
-  // sizes the workspace (and builds the table) first, so that the pointers taken below stay valid
+  gmod N; if (!lookup_modulus(curve == ECSIMD_HIP_P256 ? ECSIMD_HIP_FIELD_P256_ORDER : ECSIMD_HIP_FIELD_SECP256K1_ORDER, &N)) return bad(ctx, "group order missing from the registry");
+  const verify_layout L = verify_sizes(n);
+  const size_t extra = 2 * n * 32 + ((n + 15) / 16) * 16;        // u1, u2, range flags
   int rc = ensure_window_table(ctx, curve, (ctx->window16_table[curve] != nullptr || n >= BIG_TABLE_WORTH_IT) ? launch::BIG_WINDOW_BITS : SIGNED_WBITS);
-  if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, front + behind);
+  if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, L.front + L.behind + extra);
   if (rc != ECSIMD_HIP_OK) return rc;
-  uint64_t* rx = ctx->workspace + front / 8;
-  uint8_t* fin = reinterpret_cast<uint8_t*>(rx + 4 * n);
-  rc = double_scalar_mult_impl(ctx, curve, u1, u2, qx, qy, rx, nullptr, fin, n, behind);
+  uint64_t* u1 = ctx->workspace + (L.front + L.behind) / 8;
+  uint64_t* u2 = u1 + 4 * n;
+  uint8_t* in_range = reinterpret_cast<uint8_t*>(u2 + 4 * n);
+  launch::ecdsa_scalars(ctx->stream, N, e, r, s_, u1, u2, in_range, n);
+  rc = ecdsa_verify_rx_impl(ctx, curve, u1, u2, qx, qy, r, ok, n, extra);     // the workspace is already this large: nothing moves
   if (rc != ECSIMD_HIP_OK) return rc;
-  launch::x_mod_n_equals(ctx->stream, curve, rx, fin, r, ok, n);       // fin is 0 for the lanes whose Q failed validation
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "ecdsa_verify_rx launch"); }
+  launch::mask_op(ctx->stream, ECSIMD_HIP_MASK_AND, ok, in_range, ok, n);      // u1 = u2 = 0 already fails (the sum is infinite); the flag says why
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, err, "ecdsa_verify launch"); }
 
 int ecsimd_hip_scalar_mult_p256(ecsimd_hip_ctx* ctx, const uint64_t* k, const uint64_t* xm, const uint64_t* ym, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) {
   return ecsimd_hip_scalar_mult(ctx, ECSIMD_HIP_P256, k, xm, ym, ox, oy, oz, n, ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN); }

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 namespace ecsimd_hip {
+struct gmod;                 // gfield.cuh: a run-time modulus and what the field layer derives from it
 namespace launch {
 
 constexpr int BLOCK = 256;   // one wave per SIMD of a CU; several workgroups resident per CU
@@ -46,6 +47,19 @@ void mod_mul(hipStream_t, int curve, const uint64_t* a, const uint64_t* b, uint6
 void mgry_reduce(hipStream_t, int curve, const uint64_t* a8, uint64_t* out, size_t n);
 void mgry_pow(hipStream_t, int curve, const uint64_t* a, const words8& e, uint64_t* out, size_t n);
 void gfp_sqrt(hipStream_t, int curve, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n);
+
+// k_gfield.hip: the same layer for a RUN-TIME modulus (any odd 256-bit value: the group orders, a caller's own prime); ref_square =
+// the reference's square() as written.  F_INVERSE: division steps for a prime modulus, x^(p-2) bit by bit otherwise (gfp.h:42-44).
+void gfield_binop(hipStream_t, const gmod&, field_op op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+void gfield_unop(hipStream_t, const gmod&, field_op op, const uint64_t* a, uint64_t* out, size_t n, bool ref_square);
+void gfield_mod_mul(hipStream_t, const gmod&, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+void gfield_shift_left(hipStream_t, const gmod&, const uint64_t* a, int count, uint64_t* out, size_t n);
+void gfield_reduce(hipStream_t, const gmod&, const uint64_t* a8, uint64_t* out, size_t n);
+void gfield_pow(hipStream_t, const gmod&, const uint64_t* a, const words8& e, uint64_t* out, size_t n, bool ref_square);
+void gfield_sqrt(hipStream_t, const gmod&, const uint64_t* a, uint64_t* out, uint8_t* ok, size_t n, bool ref_square);
+void gfield_inverse_batched(hipStream_t, const gmod&, const uint64_t* a, uint64_t* out, size_t n);   // prime modulus; out must not alias a
+// ECDSA verification's arithmetic modulo the group order (gmod of n): valid = 1 <= r, s < n; u1 = e / s, u2 = r / s (0, 0 where invalid)
+void ecdsa_scalars(hipStream_t, const gmod& order, const uint64_t* e, const uint64_t* r, const uint64_t* s, uint64_t* u1, uint64_t* u2, uint8_t* valid, size_t n);
 
 // k_point_<curve>.hip
 void from_affine(hipStream_t, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n);

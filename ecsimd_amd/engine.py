@@ -13,6 +13,10 @@ import numpy as np
 
 P256, SECP256K1 = 0, 1
 CURVES = {"p256": P256, "secp256k1": SECP256K1}
+# field ids of the two group orders (include/ecsimd_hip.h enum ecsimd_hip_field): accepted wherever a method below takes a field's `curve`
+P256_ORDER, SECP256K1_ORDER = 2, 3
+ORDER_FIELD = {P256: P256_ORDER, SECP256K1: SECP256K1_ORDER}
+MODULUS_PRIME = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -343,6 +347,12 @@ class Engine:
         self._call("ecdsa_verify_rx", C.c_int(curve), self._ptr(u1), self._ptr(u2), self._ptr(qx), self._ptr(qy), self._ptr(r), self._ptr(ok, 0), C.c_size_t(n))
         return ok
 
+    def ecdsa_verify(self, curve, e, r, s, qx, qy):
+        """ecsimd_hip_ecdsa_verify: the whole verification, u1 = e/s and u2 = r/s modulo the group order computed on the device."""
+        n = e.shape[0]; ok = self.flags(n)
+        self._call("ecdsa_verify", C.c_int(curve), self._ptr(e), self._ptr(r), self._ptr(s), self._ptr(qx), self._ptr(qy), self._ptr(ok, 0), C.c_size_t(n))
+        return ok
+
     def scalar_mult_p256(self, k, xm, ym, out=None):
         n = k.shape[0]
         r = out if out is not None else [self.empty(n) for _ in range(3)]
@@ -364,6 +374,17 @@ class Engine:
             if best is None or mads.value / ms.value > best[0] / best[1]:
                 best = (mads.value, ms.value)
         return best
+
+
+def register_modulus(p: int, prime: bool = False) -> int:
+    """ecsimd_hip_register_modulus: the field id of the odd modulus p (process-wide; no GPU needed)."""
+    lib = load_library()
+    limbs = (C.c_uint64 * 4)(*[(p >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)])
+    fid = C.c_int(-1)
+    rc = lib.ecsimd_hip_register_modulus(limbs, C.c_int(MODULUS_PRIME if prime else 0), C.byref(fid))
+    if rc != 0:
+        raise EcsimdHipError(f"ecsimd_hip_register_modulus({p:#x}) failed with {rc} (the modulus must be odd and >= 3)")
+    return fid.value
 
 
 def shard_range_c(n_total: int, member: int, members: int):

@@ -42,6 +42,18 @@ enum ecsimd_hip_curve {
   ECSIMD_HIP_SECP256K1 = 1  /* prime of tests/mgry.cpp:25-27 with a=0, b=7 (SEC 2) */
 };
 
+/* FIELD ids: what the element-wise field entry points (mod_*, mgry_*, gfp_*, get_constant) take as `curve`.  The reference's field layer is
+ * generic in the modulus type P (mgry_mul.h:84-121 details::mgry_reduce<P>, mgry_csts.h:15-35 mgry_constants<WBN, P>, gfp.h:17-115 GFp<WBN, P>);
+ * here a modulus is a run-time value with an id.  0, 1: the curve primes above (hand-laid special-form kernels); 2, 3: the two group orders n
+ * (what ECDSA computes modulo); 4...: moduli registered with ecsimd_hip_register_modulus.  Points, ladders and tables exist for the two curves only. */
+enum ecsimd_hip_field {
+  ECSIMD_HIP_FIELD_P256_ORDER = 2,      /* n of P-256 (SP 800-186 3.2.1.3) */
+  ECSIMD_HIP_FIELD_SECP256K1_ORDER = 3  /* n of secp256k1 (SEC 2 v2 2.4.1) */
+};
+enum { ECSIMD_HIP_MODULUS_PRIME = 1 };  /* register_modulus: the caller vouches that p is PRIME; gfp_inverse then uses the constant-time division-step
+                                           inversion with one shared inversion per up to 128 elements (the unique inverse = x^(p-2)).  Without it
+                                           gfp_inverse raises to p - 2 bit by bit -- gfp.h:42-44 as written, the reference's value for ANY odd p */
+
 enum ecsimd_hip_status {
   ECSIMD_HIP_OK = 0,
   ECSIMD_HIP_ERR_BAD_ARG = -1,     /* null pointer, unknown curve, misaligned pointer */
@@ -145,6 +157,11 @@ int ecsimd_hip_memcpy_d2d(ecsimd_hip_ctx* ctx, void* dst, const void* src, size_
  * which = 0 p, 1 a, 2 b, 3 Gx, 4 Gy, 5 R mod p, 6 R^2 mod p, 7 -R mod p, 8 a*R, 9 b*R, 10 p-2, 11 (p+1)/4
  * (mgry_csts.h:15-24, curve_group.h:31-32, gfp.h:79-87). */
 int ecsimd_hip_get_constant(int curve, int which, uint64_t out[4]);
+/* A field id for the odd modulus p >= 3 (host pointer, 4 x u64 little-endian limbs): the host derives R mod p, R^2 mod p, -R mod p and m' = -p^-1 mod 2^32
+ * (mgry_csts.h:15-35, mgry_mul.h:33-38) once; the element-wise field entry points then accept the id as `curve` (for a field id get_constant
+ * reads zero in the curve slots 1-4, 8, 9).  The same p gives the same id (the two curve primes give 0 / 1); ids live as long as the
+ * process; thread-safe.  flags: 0 or ECSIMD_HIP_MODULUS_PRIME.  gfp_sqrt needs p = 3 mod 4, as the reference's GFp does (gfp.h:84). */
+int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id);
 
 /* ---- L2: bignum ops (curve independent) ----------------------------------------------- */
 /* add.h:11-34  add: out = a + b mod 2^256, carry[i] = carry-out (carry may be NULL) */
@@ -189,7 +206,8 @@ int ecsimd_hip_sec1_encode(ecsimd_hip_ctx*, int curve, const uint64_t* x, const 
  * (single byte 00) has no fixed-size record and is not representable here. */
 int ecsimd_hip_sec1_decode(ecsimd_hip_ctx*, int curve, const uint8_t* in, uint64_t* x, uint64_t* y, uint8_t* ok, size_t n, int compressed);
 
-/* ---- L3: GF(p) ------------------------------------------------------------------------ */
+/* ---- L3: GF(p) ------------------------------------------------------------------------
+ * `curve` is a FIELD id in this section (enum ecsimd_hip_field): a curve's prime or any registered modulus. */
 /* modular.h:10-15 mod_add, :24-41 mod_sub, mgry_ops.h:14-22 mgry_shift_left<count> (1 <= count <= 255).
  * count | ECSIMD_HIP_SHIFT_FUSED runs pairs of doublings as one quadrupling with a single conditional subtraction (what the point
  * formulas use on their own intermediates): the same canonical residue for every a < p; for a >= p only the plain form is
@@ -281,11 +299,19 @@ int ecsimd_hip_on_curve(ecsimd_hip_ctx*, int curve, const uint64_t* x, const uin
  * exists in this context or n >= 2^16 (which builds it); smaller batches use the 148 KiB table in LDS and keep nothing that size. */
 int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx*, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                                   uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
-/* (ok[i] is also 0 when Q[i] fails the validation above.)  The acceptance test of an ECDSA verification for precomputed u1 = e/s, u2 = r/s (mod n; computing them is the caller's:
- * this library has no arithmetic modulo the group order): ok[i] = 1 iff u1[i]*G + u2[i]*Q[i] is a finite point whose
+/* (ok[i] is also 0 when Q[i] fails the validation above.)  The acceptance test of an ECDSA verification for precomputed u1 = e/s, u2 = r/s (mod n; ecsimd_hip_ecdsa_verify
+ * below computes them on the device): ok[i] = 1 iff u1[i]*G + u2[i]*Q[i] is a finite point whose
  * x coordinate, reduced mod n, equals r[i].  Same workspace as double_scalar_mult plus 33 B per element. */
 int ecsimd_hip_ecdsa_verify_rx(ecsimd_hip_ctx*, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                                const uint64_t* r, uint8_t* ok, size_t n);
+/* ECDSA verification of n signatures (SEC 1 v2 4.1.4, FIPS 186-5 6.4.2; not in the reference -- SURVEY.md 8(f) rank 4, "the first real application of the
+ * engine").  Per element, all classical 4 x u64 LE limbs in device memory: e = the message digest as an integer (its leftmost 256 bits; ANY 256-bit value is
+ * taken and reduced mod n), (r, s) = the signature, (qx, qy) = the public key.  ok[i] = 1 iff 1 <= r, s < n, Q is a valid public key (on_curve), and
+ * R = (e/s) G + (r/s) Q is a finite point with x(R) mod n == r.  The arithmetic modulo the group order n runs on the device (field id
+ * ECSIMD_HIP_FIELD_*_ORDER: generic Montgomery multiplication, one constant-time division-step inversion shared by up to 128 signatures), then
+ * ecdsa_verify_rx's kernels.  Public data only (the window kernels index tables by scalar digits).  Workspace: ecdsa_verify_rx's plus 65 B per element. */
+int ecsimd_hip_ecdsa_verify(ecsimd_hip_ctx*, int curve, const uint64_t* e, const uint64_t* r, const uint64_t* s, const uint64_t* qx, const uint64_t* qy,
+                            uint8_t* ok, size_t n);
 /* lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P) -- P-256, base in Montgomery form with
  * Z = mgry(1), Jacobian Montgomery output. */
 int ecsimd_hip_scalar_mult_p256(ecsimd_hip_ctx*, const uint64_t* k, const uint64_t* xm, const uint64_t* ym,

@@ -346,6 +346,22 @@ class OpenSSLCheck:
         assert rc == 0, rc
         return ox, oy, inf
 
+    def ecdsa_sign(self, curve, d, e, threads=1):
+        """Key pairs from the private keys d and signatures of the digests e (as integers): returns r, s, qx, qy."""
+        d, e = _arr(d), _arr(e)
+        r, s, qx, qy = (np.empty_like(d) for _ in range(4))
+        rc = self.lib.ossl_ecdsa_sign(C.c_int(curve), _p(d), _p(e), _p(r), _p(s), _p(qx), _p(qy), C.c_size_t(len(d)), C.c_int(threads))
+        assert rc == 0, rc
+        return r, s, qx, qy
+
+    def ecdsa_verify(self, curve, e, r, s, qx, qy, threads=1):
+        """ECDSA_do_verify per element: 1 = accepted; bad signatures, invalid public keys, out-of-range r / s give 0."""
+        e, r, s, qx, qy = _arr(e), _arr(r), _arr(s), _arr(qx), _arr(qy)
+        ok = np.zeros(len(e), dtype=np.uint8)
+        rc = self.lib.ossl_ecdsa_verify(C.c_int(curve), _p(e), _p(r), _p(s), _p(qx), _p(qy), _p8(ok), C.c_size_t(len(e)), C.c_int(threads))
+        assert rc == 0, rc
+        return ok
+
     def time_scalar_mult(self, curve, k, x, y, threads=1) -> float:
         """Seconds for len(k) variable-base multiplications on `threads` threads (benchs/p256_ref.cpp:55-91)."""
         k, x, y = _arr(k), _arr(x), _arr(y)

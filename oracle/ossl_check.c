@@ -13,6 +13,7 @@
  */
 #include <openssl/bn.h>
 #include <openssl/ec.h>
+#include <openssl/ecdsa.h>
 #include <openssl/obj_mac.h>
 #include <pthread.h>
 #include <stdint.h>
@@ -123,5 +124,90 @@ API double ossl_time_scalar_mult(int curve, const uint64_t* k, const uint64_t* x
   clock_gettime(CLOCK_MONOTONIC, &b);
   if (rc) return (double)rc;
   return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+}
+/* ---- ECDSA through libcrypto: the independent checker of ecsimd_hip_ecdsa_verify (tests/test_gpu_parity.py).
+ * e = the digest as an integer (4 x u64 LE limbs; libcrypto receives it as 32 big-endian bytes), d = private keys. */
+typedef struct {
+  int curve, sign;
+  const uint64_t *d, *e;
+  uint64_t *r, *s, *qx, *qy;      /* sign: outputs; verify: inputs */
+  uint8_t* ok;
+  size_t begin, end;
+  int rc;
+} ecdsa_job_t;
+
+static void le_to_be32(unsigned char* out, const uint64_t* limbs) {
+  for (int i = 0; i < 32; ++i) out[i] = (unsigned char)(limbs[(31 - i) / 8] >> (8 * ((31 - i) % 8)));
+}
+
+static void* ecdsa_worker(void* arg) {
+  ecdsa_job_t* j = (ecdsa_job_t*)arg;
+  j->rc = -1;
+  EC_GROUP* g = EC_GROUP_new_by_curve_name(nid_of(j->curve));
+  BN_CTX* ctx = BN_CTX_new();
+  BIGNUM *a = BN_new(), *b = BN_new();
+  EC_POINT* Q = g ? EC_POINT_new(g) : NULL;
+  if (!g || !ctx || !a || !b || !Q) goto done;
+  for (size_t i = j->begin; i < j->end; ++i) {
+    unsigned char dig[32];
+    le_to_be32(dig, j->e + 4 * i);
+    EC_KEY* key = EC_KEY_new();
+    if (!key || !EC_KEY_set_group(key, g)) { EC_KEY_free(key); goto done; }
+    if (j->sign) {
+      if (!BN_lebin2bn((const unsigned char*)(j->d + 4 * i), 32, a)) { EC_KEY_free(key); goto done; }
+      if (!EC_POINT_mul(g, Q, a, NULL, NULL, ctx) || !EC_KEY_set_private_key(key, a) || !EC_KEY_set_public_key(key, Q)) { EC_KEY_free(key); goto done; }
+      if (!EC_POINT_get_affine_coordinates(g, Q, a, b, ctx)) { EC_KEY_free(key); goto done; }
+      BN_bn2lebinpad(a, (unsigned char*)(j->qx + 4 * i), 32); BN_bn2lebinpad(b, (unsigned char*)(j->qy + 4 * i), 32);
+      ECDSA_SIG* sig = ECDSA_do_sign(dig, 32, key);
+      if (!sig) { EC_KEY_free(key); goto done; }
+      const BIGNUM *r, *s_;
+      ECDSA_SIG_get0(sig, &r, &s_);
+      BN_bn2lebinpad(r, (unsigned char*)(j->r + 4 * i), 32); BN_bn2lebinpad(s_, (unsigned char*)(j->s + 4 * i), 32);
+      ECDSA_SIG_free(sig);
+    } else {
+      int ok = 0;
+      if (BN_lebin2bn((const unsigned char*)(j->qx + 4 * i), 32, a) && BN_lebin2bn((const unsigned char*)(j->qy + 4 * i), 32, b) &&
+          EC_KEY_set_public_key_affine_coordinates(key, a, b)) {                   /* rejects points off the curve and coordinates >= p */
+        ECDSA_SIG* sig = ECDSA_SIG_new();
+        BIGNUM *r = BN_lebin2bn((const unsigned char*)(j->r + 4 * i), 32, NULL), *s_ = BN_lebin2bn((const unsigned char*)(j->s + 4 * i), 32, NULL);
+        if (sig && r && s_ && ECDSA_SIG_set0(sig, r, s_)) ok = (ECDSA_do_verify(dig, 32, sig, key) == 1);     /* 0: bad signature, -1: r or s out of range */
+        else { BN_free(r); BN_free(s_); }
+        ECDSA_SIG_free(sig);
+      }
+      j->ok[i] = (uint8_t)ok;
+    }
+    EC_KEY_free(key);
+  }
+  j->rc = 0;
+done:
+  EC_POINT_free(Q); BN_free(a); BN_free(b); BN_CTX_free(ctx); EC_GROUP_free(g);
+  return NULL;
+}
+
+static int ecdsa_run(ecdsa_job_t proto, size_t n, int threads) {
+  if (nid_of(proto.curve) < 0) return -2;
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  if ((size_t)threads > n) threads = n ? (int)n : 1;
+  ecdsa_job_t jobs[256];
+  pthread_t tid[256];
+  for (int t = 0; t < threads; ++t) {
+    jobs[t] = proto; jobs[t].begin = n * t / threads; jobs[t].end = n * (t + 1) / threads;
+    if (threads == 1) ecdsa_worker(&jobs[t]);
+    else if (pthread_create(&tid[t], NULL, ecdsa_worker, &jobs[t])) return -3;
+  }
+  int rc = 0;
+  for (int t = 0; t < threads; ++t) { if (threads > 1) pthread_join(tid[t], NULL); if (jobs[t].rc) rc = jobs[t].rc; }
+  return rc;
+}
+/* key pair from the private key d[i] (1 <= d < n), signature of the digest e[i]: (qx, qy) = d G, (r, s) = ECDSA_do_sign */
+API int ossl_ecdsa_sign(int curve, const uint64_t* d, const uint64_t* e, uint64_t* r, uint64_t* s, uint64_t* qx, uint64_t* qy, size_t n, int threads) {
+  ecdsa_job_t j = {curve, 1, d, e, r, s, qx, qy, NULL, 0, 0, 0};
+  return ecdsa_run(j, n, threads);
+}
+/* ok[i] = ECDSA_do_verify(e[i], (r[i], s[i]), Q[i]) == 1; an invalid public key or an out-of-range r / s gives 0 */
+API int ossl_ecdsa_verify(int curve, const uint64_t* e, const uint64_t* r, const uint64_t* s, const uint64_t* qx, const uint64_t* qy, uint8_t* ok, size_t n, int threads) {
+  ecdsa_job_t j = {curve, 0, NULL, e, (uint64_t*)r, (uint64_t*)s, (uint64_t*)qx, (uint64_t*)qy, ok, 0, 0, 0};
+  return ecdsa_run(j, n, threads);
 }
 API const char* ossl_version(void) { return OpenSSL_version(OPENSSL_VERSION); }

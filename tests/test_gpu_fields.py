@@ -1,0 +1,235 @@
+"""GPU suite: the field layer for RUN-TIME moduli (k_gfield.hip) and the ECDSA verification built on it.
+
+The reference's field layer is generic in the modulus type P (mgry_mul.h:84-121, mgry_csts.h:15-35, gfp.h:17-115).  Checked here:
+  * every element-wise field entry point on a field id, against the oracle registered with the same modulus -- the five moduli the REAL
+    reference is compiled for (oracle/ref_driver.cpp: both group orders, 2^255 - 19, 2^256 - 1, P-192's prime; the oracle is pinned to
+    the reference on them by tests/test_oracle.py) and random odd moduli of every size;
+  * the same against the compiled reference directly, where oracle/_ref exists;
+  * the reference-square option on a run-time modulus against the compiled reference's own mgry_sqr;
+  * ecsimd_hip_ecdsa_verify against libcrypto's ECDSA_do_verify on valid, tampered and malformed signatures, and its mod-n half
+    against Python big-int arithmetic.
+"""
+import numpy as np
+import pytest
+
+from helpers import CURVE_PARAMS, P256, SECP256K1, R, from_int, to_int, ints_to_arr, arr_to_ints
+from oracle.loader import REF_MODULI
+
+pytestmark = pytest.mark.gpu
+CURVES = [P256, SECP256K1]
+THREADS = 16
+PRIME_MODULI = {"n_p256", "n_secp256k1", "p25519", "p192"}
+
+
+@pytest.fixture(scope="module")
+def gpu(engine):
+    from gpu_adapter import EngineNP
+    return EngineNP(engine)
+
+
+def field_id(p, prime=False):
+    from ecsimd_amd.engine import register_modulus
+    return register_modulus(p, prime=prime)
+
+
+def operands(p, n, seed):
+    rng = np.random.default_rng(seed)
+    a = ints_to_arr([to_int(x) % p for x in rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)])
+    b = ints_to_arr([to_int(x) % p for x in rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)])
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 2**32 - 1, 2**64 - 1, 2**128 - 1, 2**192 - 1, 2**255 - 1, 2**224, 2**96 - 1]
+    edge = [v % p for v in edge]
+    for i, v in enumerate(edge):
+        a[i] = from_int(v); b[len(edge) - 1 - i] = from_int(v)
+    a[20:40] = ints_to_arr([(p - 1 - j) % p for j in range(20)]); b[20:40] = ints_to_arr([(p - 1 - 3 * j) % p for j in range(20)])
+    return a, b
+
+
+def check_field(gpu, chk, fg, fc, p, n=4096, seed=1, prime=True, sqrt=True):
+    """Every element-wise entry point on field id fg (HIP) against the checker `chk` on its id fc."""
+    a, b = operands(p, n, seed)
+    for name in ("mod_add", "mod_sub", "mgry_mul"):
+        assert np.array_equal(getattr(gpu, name)(fg, a, b), getattr(chk, name)(fc, a, b)), (hex(p), name)
+    assert np.array_equal(gpu.mgry_sqr(fg, a), chk.mgry_mul(fc, a, a)), hex(p)                      # the exact square (the reference's own defect: below)
+    for name in ("mgry_from_classical", "mgry_to_classical"):
+        assert np.array_equal(getattr(gpu, name)(fg, a), getattr(chk, name)(fc, a)), (hex(p), name)
+    for cnt in (1, 2, 3, 9):
+        assert np.array_equal(gpu.mod_shift_left(fg, a, cnt), chk.mod_shift_left(fc, a, cnt)), (hex(p), cnt)
+    rng = np.random.default_rng(seed + 99)
+    t8 = ints_to_arr([(to_int(x) % p) * (to_int(y) % 2**256) for x, y in zip(rng.integers(0, 2**64, size=(256, 4), dtype=np.uint64),
+                                                                            rng.integers(0, 2**64, size=(256, 4), dtype=np.uint64))], 8)   # < p * 2^256
+    t8[0] = 0; t8[1] = ints_to_arr([p * 2**256 - 1], 8)[0]; t8[2] = ints_to_arr([(p - 1) * (p - 1)], 8)[0]
+    assert np.array_equal(gpu.mgry_reduce(fg, t8), chk.mgry_reduce(fc, t8)), hex(p)
+    # classical product (an extension): against big-int arithmetic
+    assert arr_to_ints(gpu.mod_mul(fg, a[:512], b[:512])) == [x * y % p for x, y in zip(arr_to_ints(a[:512]), arr_to_ints(b[:512]))]
+    m = 300                                                                                          # > 256: the batched form takes more than one workgroup's lanes at m = 1
+    assert np.array_equal(gpu.gfp_inverse(fg, a[:m]), chk.gfp_inverse(fc, a[:m])), hex(p)              # x^(p-2) in the checker; division steps here when prime
+    if prime:
+        am = arr_to_ints(a[:m]); Rm = R % p
+        assert arr_to_ints(gpu.gfp_inverse(fg, a[:m])) == [(pow(v * pow(Rm, -1, p) % p, -1, p) * Rm % p) if v else 0 for v in am]
+    e = from_int(0x1234567890abcdef_0fedcba987654321_00000000ffffffff_8000000000000001)
+    assert np.array_equal(gpu.mgry_pow(fg, a[:64], e), chk.mgry_pow(fc, a[:64], e)), hex(p)
+    for e in (from_int(0), from_int(1), from_int(2**255)):
+        assert np.array_equal(gpu.mgry_pow(fg, a[:16], e), chk.mgry_pow(fc, a[:16], e))
+    if sqrt and p % 4 == 3:
+        sq = chk.mgry_mul(fc, a[:64], a[:64])
+        s, ok = gpu.gfp_sqrt(fg, np.concatenate([sq, a[64:128]]))
+        so, oko = chk.gfp_sqrt(fc, np.concatenate([sq, a[64:128]]))
+        assert np.array_equal(ok, oko) and np.array_equal(s, so)
+        assert np.array_equal(gpu.gfp_opposite(fg, a), chk.gfp_opposite(fc, a))
+
+
+@pytest.mark.parametrize("name", sorted(REF_MODULI))
+def test_runtime_modulus_vs_oracle(gpu, oracle, name):
+    p = REF_MODULI[name]
+    check_field(gpu, oracle, field_id(p, prime=name in PRIME_MODULI), oracle.register_modulus(p), p, prime=name in PRIME_MODULI, seed=len(name))
+
+
+def test_group_order_ids_are_built_in(engine, oracle):
+    from ecsimd_amd.engine import P256_ORDER, SECP256K1_ORDER
+    for cv, fid in ((P256, P256_ORDER), (SECP256K1, SECP256K1_ORDER)):
+        n = CURVE_PARAMS[cv]["n"]
+        assert field_id(n) == fid and to_int(engine.constant(fid, 0)) == n
+        c = oracle.constants(oracle.register_modulus(n))
+        for which, key in ((5, "r_p"), (6, "rsq_p"), (7, "pm1_r_p"), (10, "p_m2")):
+            assert np.array_equal(engine.constant(fid, which), c[key])
+    assert field_id(CURVE_PARAMS[P256]["p"]) == P256 and field_id(CURVE_PARAMS[SECP256K1]["p"]) == SECP256K1     # the curve primes keep their kernels
+
+
+def test_random_odd_moduli_of_every_size(gpu, oracle):
+    """Moduli nobody compiled anything for: random odd values of 2 .. 256 bits (composite almost surely -- Montgomery arithmetic needs
+    p odd, not prime), registered WITHOUT the prime flag, so gfp_inverse is x^(p-2) bit by bit as gfp.h:42-44 writes it."""
+    rng = np.random.default_rng(77)
+    sizes = [2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 192, 193, 224, 254, 255, 256, 256, 256]
+    for bits in sizes:
+        p = (int.from_bytes(rng.bytes(32), "big") >> (256 - bits)) | (1 << (bits - 1)) | 1
+        check_field(gpu, oracle, field_id(p), oracle.register_modulus(p), p, n=1024, seed=bits, prime=False, sqrt=(bits > 8))
+
+
+@pytest.mark.parametrize("name", sorted(REF_MODULI))
+def test_runtime_modulus_vs_the_live_reference(gpu, reference, name):
+    """The compiled reference itself, instantiated for the same modulus (oracle/ref_driver.cpp fops<P>)."""
+    p = REF_MODULI[name]
+    fg, fr = field_id(p, prime=name in PRIME_MODULI), reference.register_modulus(p)
+    a, b = operands(p, 2048, 5)
+    for f in ("mod_add", "mod_sub", "mgry_mul"):
+        assert np.array_equal(getattr(gpu, f)(fg, a, b), getattr(reference, f)(fr, a, b)), (name, f)
+    for f in ("mgry_from_classical", "mgry_to_classical"):
+        assert np.array_equal(getattr(gpu, f)(fg, a), getattr(reference, f)(fr, a)), (name, f)
+    assert np.array_equal(gpu.mod_shift_left(fg, a, 5), reference.mod_shift_left(fr, a, 5))
+    # random operands only: on the carry-heavy edge values the reference's x^(p-2) runs into its own square() defect (checked below in
+    # compatibility mode, where the HIP path reproduces it)
+    assert np.array_equal(gpu.gfp_inverse(fg, a[64:192]), reference.gfp_inverse(fr, a[64:192]))
+    # the reference-square option: mgry_sqr with the reference's square() as written -- on carry-heavy operands, where it drops a carry
+    pat = np.array([0, 0xffffffff, 0x80000000, 0x7fffffff, 1, 0xfffffffe], dtype=np.uint64)
+    w = pat[np.random.default_rng(3).integers(0, len(pat), size=(4096, 8))]
+    x = (w[:, 0::2] | (w[:, 1::2] << np.uint64(32))).astype(np.uint64)
+    x = ints_to_arr([v % p for v in arr_to_ints(x)])
+    ref_sq = reference.mgry_sqr(fr, x)
+    gpu.e.set_ref_square_compat(True)
+    try:
+        got = gpu.mgry_sqr(fg, x)
+        inv_c = gpu.gfp_inverse(fg, x[:64])
+    finally:
+        gpu.e.set_ref_square_compat(False)
+    assert np.array_equal(got, ref_sq), name
+    assert np.array_equal(inv_c, reference.gfp_inverse(fr, x[:64])), name
+    if p > 2**200:
+        assert (ref_sq != reference.mgry_mul(fr, x, x)).any(axis=1).sum() > 0, "the sample never hit the reference's dropped carry"
+
+
+def test_unknown_field_ids_are_refused(engine):
+    import ctypes as C
+    a = engine.to_device(ints_to_arr([1, 2, 3, 4]))
+    out = engine.empty(4)
+    for fid in (-1, 4096 + 2, 1 << 20):
+        rc = engine.lib.ecsimd_hip_mgry_mul(engine.ctx, C.c_int(fid), C.c_void_p(a.data_ptr()), C.c_void_p(a.data_ptr()), C.c_void_p(out.data_ptr()), C.c_size_t(4))
+        assert rc == -1
+    p1 = field_id(2**255 - 19)                                       # = 1 mod 4: no GFp in the reference (gfp.h:84), no sqrt here
+    ok = engine.flags(4)
+    assert engine.lib.ecsimd_hip_gfp_sqrt(engine.ctx, C.c_int(p1), C.c_void_p(a.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(ok.data_ptr()), C.c_size_t(4)) == -1
+
+
+# ---------------------------------------------------------------- ECDSA
+def signatures(openssl, cv, n, seed):
+    order = CURVE_PARAMS[cv]["n"]
+    rng = np.random.default_rng(seed)
+    d = ints_to_arr([to_int(x) % (order - 1) + 1 for x in rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)])
+    e = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)          # digests: any 256-bit value (most exceed neither n nor not)
+    e[:8] = ints_to_arr([0, 1, order - 1, order, order + 1, 2**256 - 1, 2**255, 2**256 - order])
+    r, s, qx, qy = openssl.ecdsa_sign(cv, d, e, threads=THREADS)
+    return e, r, s, qx, qy
+
+
+@pytest.mark.parametrize("cv", CURVES)
+def test_ecdsa_verify_vs_libcrypto(engine, openssl, cv):
+    """4 096 valid signatures made by libcrypto, then the same with each input tampered in turn, malformed (r, s) and invalid public keys:
+    lane for lane the verdict of ECDSA_do_verify."""
+    order = CURVE_PARAMS[cv]["n"]; p = CURVE_PARAMS[cv]["p"]
+    n = 4096
+    e, r, s, qx, qy = signatures(openssl, cv, n, 2024 + cv)
+    up = engine.to_device
+    run = lambda e_, r_, s_, x_, y_: engine.to_numpy(engine.ecdsa_verify(cv, up(e_), up(r_), up(s_), up(x_), up(y_)))
+    assert run(e, r, s, qx, qy).all()
+    rng = np.random.default_rng(9)
+    # a mixed batch: every lane picks one way of being wrong (or none)
+    kind = rng.integers(0, 12, size=n)
+    e2, r2, s2, x2, y2 = (v.copy() for v in (e, r, s, qx, qy))
+    for i in range(n):
+        k = kind[i]
+        if k == 1: e2[i, 0] ^= np.uint64(1)                                       # another message
+        elif k == 2: r2[i] = from_int((to_int(r[i]) + 1) % order)                  # another r
+        elif k == 3: s2[i] = from_int((to_int(s[i]) + 1) % order)                  # another s
+        elif k == 4: x2[i], y2[i] = qx[(i + 1) % n], qy[(i + 1) % n]               # somebody else's key
+        elif k == 5: r2[i] = from_int(0)                                           # r = 0
+        elif k == 6: s2[i] = from_int(0)                                           # s = 0
+        elif k == 7: r2[i] = from_int(to_int(r[i]) + order) if to_int(r[i]) + order < 2**256 else from_int(order)      # r >= n (r + n would verify without the range check)
+        elif k == 8: s2[i] = from_int(order)                                       # s = n
+        elif k == 9: y2[i] = from_int((to_int(qy[i]) + 1) % p)                     # a point off the curve
+        elif k == 10: x2[i], y2[i] = from_int(0), from_int(0)                      # the point at infinity
+        elif k == 11: s2[i] = from_int(order - to_int(s[i]))                       # (r, n - s): the other valid signature of the same message
+    got = run(e2, r2, s2, x2, y2)
+    exp = openssl.ecdsa_verify(cv, e2, r2, s2, x2, y2, threads=THREADS)
+    assert np.array_equal(got, exp), np.flatnonzero(got != exp)[:8]
+    assert exp[kind == 0].all() and exp[kind == 11].all() and not exp[(kind != 0) & (kind != 11)].any()
+    # ragged sizes (one lane, one wave + 1, a workgroup + 1) and the empty batch
+    for m in (0, 1, 65, 257):
+        assert np.array_equal(run(e2[:m], r2[:m], s2[:m], x2[:m], y2[:m]), exp[:m])
+
+
+@pytest.mark.parametrize("cv", CURVES)
+def test_ecdsa_scalars_at_the_shared_inversion_sizes(engine, openssl, cv):
+    """2^18 + 3 signatures: three elements share an inversion (one lane's strided slice), with invalid lanes among them --
+    valid ones accepted, the tampered ones rejected; a libcrypto sample of 2 048 lanes agrees."""
+    n = (1 << 18) + 3
+    base = 4096
+    e, r, s, qx, qy = signatures(openssl, cv, base, 31 + cv)
+    rep = (n + base - 1) // base
+    tile = lambda v: np.tile(v, (rep, 1))[:n].copy()
+    E, Rr, S, X, Y = (tile(v) for v in (e, r, s, qx, qy))
+    bad = np.arange(n) % 7 == 3
+    S[bad] = 0                                                          # s = 0 inside shared-inversion groups
+    worse = np.arange(n) % 11 == 5
+    E[worse, 1] ^= np.uint64(0x10)
+    up = engine.to_device
+    got = engine.to_numpy(engine.ecdsa_verify(cv, up(E), up(Rr), up(S), up(X), up(Y)))
+    assert np.array_equal(got == 1, ~(bad | worse))
+    idx = np.random.default_rng(1).choice(n, 2048, replace=False)
+    assert np.array_equal(got[idx], openssl.ecdsa_verify(cv, E[idx], Rr[idx], S[idx], X[idx], Y[idx], threads=THREADS))
+
+
+@pytest.mark.parametrize("cv", CURVES)
+def test_scalar_field_arithmetic_against_big_ints(gpu, cv):
+    """u1 = e / s, u2 = r / s mod n by the public field entry points on the group-order field id: what ecdsa_verify computes inside."""
+    from ecsimd_amd.engine import ORDER_FIELD
+    order = CURVE_PARAMS[cv]["n"]; fid = ORDER_FIELD[cv]
+    rng = np.random.default_rng(4 + cv)
+    n = 1000
+    ev = [int.from_bytes(rng.bytes(32), "big") % order for _ in range(n)]
+    rv = [int.from_bytes(rng.bytes(32), "big") % order for _ in range(n)]
+    sv = [int.from_bytes(rng.bytes(32), "big") % (order - 1) + 1 for _ in range(n)]
+    sm = gpu.mgry_from_classical(fid, ints_to_arr(sv))
+    wm = gpu.gfp_inverse(fid, sm)                                       # s^-1 R
+    u1 = gpu.mgry_mul(fid, ints_to_arr(ev), wm)                         # e * (s^-1 R) / R
+    u2 = gpu.mgry_mul(fid, ints_to_arr(rv), wm)
+    assert arr_to_ints(u1) == [e * pow(s, -1, order) % order for e, s in zip(ev, sv)]
+    assert arr_to_ints(u2) == [r * pow(s, -1, order) % order for r, s in zip(rv, sv)]
