@@ -79,6 +79,7 @@ struct ecsimd_hip_ctx {
   uint32_t* window16_table[2]; // per curve: signed BIG_WINDOW_BITS-bit windows in device memory (20 bits: 13 x 524 288 entries, 436 MB)
   uint64_t* workspace;         // grow-only scratch for the windowed path's Jacobian intermediates
   size_t workspace_bytes;
+  uint64_t* base_special[2];   // per curve: the reference ladder's 3 degenerate scalars and its affine results for them on G (small-batch route of scalar_mult_base)
   uint8_t* valid;              // grow-only: per-lane public-key validity of double_scalar_mult / ecdsa_verify_rx
   size_t valid_bytes;
   int ref_square;              // ecsimd_hip_set_ref_square_compat: the reference's square() as written (mul.h:160-212)
@@ -351,6 +352,42 @@ int run_varwin(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, 
 }
 }  // namespace
 
+// ---- the small-batch route of scalar_mult_base (see ecsimd_hip_scalar_mult_base)
+namespace {
+constexpr size_t SMALL_BASE_MAX = (size_t)1 << 16;
+// A stream under capture can neither build the comb's table nor the record below: such a call keeps the ladder (and stays capturable).
+bool capturing_needs_build(ecsimd_hip_ctx* ctx, int curve) {
+  return capturing(ctx) && (!ctx->windowct_table[curve] || !ctx->base_special[curve]);
+}
+int ensure_base_special(ecsimd_hip_ctx* ctx, int curve) {
+  if (ctx->base_special[curve]) return ECSIMD_HIP_OK;
+  uint64_t nn[4], host[12];
+  words_to_limbs(curve == ECSIMD_HIP_P256 ? curve_order<CURVE_P256>::N : curve_order<CURVE_SECP256K1>::N, nn);
+  uint64_t b = 1;                                                // n - 1
+  for (int l = 0; l < 4; ++l) { const unsigned __int128 d = (unsigned __int128)nn[l] - b; host[l] = (uint64_t)d; b = (uint64_t)(d >> 64) & 1u; }
+  b = 0;                                                         // 2^256 - n
+  for (int l = 0; l < 4; ++l) { const unsigned __int128 d = (unsigned __int128)0 - nn[l] - b; host[8 + l] = (uint64_t)d; b = (uint64_t)(d >> 64) & 1u; }
+  b = 1;                                                         // 2^256 - n - 1
+  for (int l = 0; l < 4; ++l) { const unsigned __int128 d = (unsigned __int128)host[8 + l] - b; host[4 + l] = (uint64_t)d; b = (uint64_t)(d >> 64) & 1u; }
+  for (int j = 0; j < 3; ++j) if (!ladder_degenerate(nn, host + 4 * j)) return bad(ctx, "base_special: not a degenerate scalar");
+  uint64_t* rec = nullptr; uint64_t* tmp = nullptr;
+  hipError_t e = hipMalloc(&rec, 9 * 32);
+  if (e == hipSuccess) e = hipMalloc(&tmp, 9 * 32);               // Jacobian scratch of the three ladders
+  if (e == hipSuccess) e = hipMemcpyAsync(rec, host, 3 * 32, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     // `host` is on this stack frame
+  if (e == hipSuccess) {
+    launch::scalar_mult(ctx->stream, curve, rec, 4, nullptr, nullptr, tmp, tmp + 12, tmp + 24, 3, ECSIMD_HIP_OUT_AFFINE);    // the ladder, fast domain
+    launch::to_affine_batched(ctx->stream, curve, tmp, tmp + 12, tmp + 24, rec + 12, rec + 24, 3, true);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  (void)hipFree(tmp);
+  if (e != hipSuccess) { (void)hipFree(rec); return fail(ctx, e, "base_special build"); }
+  ctx->base_special[curve] = rec;
+  return ECSIMD_HIP_OK;
+}
+}  // namespace
+
 // ================================================================== run-time moduli
 // The reference's field layer is generic in the modulus type P (mgry_mul.h:84-121, mgry_csts.h:15-35, gfp.h:17-115): a caller
 // instantiates it for any odd 256-bit P at compile time.  Here the same genericity is a run-time registry: a field id names a
@@ -437,7 +474,7 @@ int ecsimd_hip_init(int device, ecsimd_hip_ctx** out) {
   ecsimd_hip_ctx* ctx = new (std::nothrow) ecsimd_hip_ctx();
   if (!ctx) return ECSIMD_HIP_ERR_HIP;
   ctx->device = device; ctx->cus = prop.multiProcessorCount; ctx->err[0] = 0; ctx->sink = nullptr;
-  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->window6_table[0] = ctx->window6_table[1] = nullptr; ctx->windowct_table[0] = ctx->windowct_table[1] = nullptr; ctx->window16_table[0] = ctx->window16_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0; ctx->ref_square = 0; ctx->valid = nullptr; ctx->valid_bytes = 0;
+  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->window6_table[0] = ctx->window6_table[1] = nullptr; ctx->windowct_table[0] = ctx->windowct_table[1] = nullptr; ctx->window16_table[0] = ctx->window16_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0; ctx->ref_square = 0; ctx->valid = nullptr; ctx->valid_bytes = 0; ctx->base_special[0] = ctx->base_special[1] = nullptr;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ECSIMD_HIP_ERR_HIP; }
   ctx->stream = ctx->own_stream;
   if (hipEventCreateWithFlags(&ctx->handoff, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ECSIMD_HIP_ERR_HIP; }
@@ -450,7 +487,7 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->sink);
-  (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->windowct_table[0]); (void)hipFree(ctx->windowct_table[1]); (void)hipFree(ctx->window16_table[0]); (void)hipFree(ctx->window16_table[1]); (void)hipFree(ctx->workspace); (void)hipFree(ctx->valid);
+  (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->windowct_table[0]); (void)hipFree(ctx->windowct_table[1]); (void)hipFree(ctx->window16_table[0]); (void)hipFree(ctx->window16_table[1]); (void)hipFree(ctx->workspace); (void)hipFree(ctx->valid); (void)hipFree(ctx->base_special[0]); (void)hipFree(ctx->base_special[1]);
   (void)hipEventDestroy(ctx->handoff);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -720,7 +757,9 @@ int ecsimd_hip_trplu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py,
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz); RUN(launch::trplu(s, instance(ctx, curve), px, py, pz, rx, ry, rz, n)); }
 
 int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy);
+  REQUIRE_CTX();
+  if (x == nullptr && y == nullptr && n) return ecsimd_hip_scalar_mult_base(ctx, curve, k, ox, oy, oz, n, flags & ~ECSIMD_HIP_BASE_MGRY);   // no base point: the generator
+  REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy);
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED)) {
     // per-lane window tables (8 multiples of P) in HBM + signed 4-bit windows (k_varwin.inc): a different algorithm from
@@ -774,6 +813,30 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* 
          launch::to_affine_batched(s, curve, jx, jy, jz, ox, oy, n, true)));
   }
   if (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED (the ladder is constant-time as it is)");
+  // Small batches, affine output, no algorithm asked for: a launch of the ladder costs its 254 iterations however few lanes it has (1.3 ms), the
+  // constant-time comb 51 additions (0.2 ms) -- and every reference test and benchmark multiplies G (benchs/curve_group.cpp:23-35).  The comb is as
+  // safe for secret scalars as the ladder; its affine result is the true k*G, which is the ladder's everywhere but at the ladder's three degenerate
+  // scalars, and there the lanes take the ladder's own (meaningless, but the reference's) coordinates from a 288-byte record: the same bits out.
+  if ((flags & ECSIMD_HIP_OUT_AFFINE) && n <= SMALL_BASE_MAX && !(flags & (ECSIMD_HIP_REF_SQUARE_COMPAT | ECSIMD_HIP_LADDER_RADIX32)) && !ctx->ref_square &&
+      ECS_FIXED4_ODD && ECS_SIGNED_ODD && !capturing_needs_build(ctx, curve)) {
+    if (n == 0) return ECSIMD_HIP_OK;
+    (void)hipSetDevice(ctx->device);
+    const int ctbits = curve == ECSIMD_HIP_P256 ? CT_WBITS : CT_WBITS_SECP;
+    if (ctbits) {
+      int rc = ensure_window_table(ctx, curve, ctbits);
+      const bool x_is_exact = (oy == nullptr && curve == ECSIMD_HIP_P256);    // the P-256 x-only ladder returns the true x for every k already
+      if (rc == ECSIMD_HIP_OK && !x_is_exact) rc = ensure_base_special(ctx, curve);
+      if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 3 * n * 32);
+      if (rc != ECSIMD_HIP_OK) return rc;
+      uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
+      hipStream_t s = ctx->stream;
+      launch::base_windowed_signed(s, curve, ctbits, k, ctx->windowct_table[curve], jx, jy, jz, n, true);
+      launch::to_affine_batched(s, curve, jx, jy, jz, ox, oy, n, true);
+      if (!x_is_exact) launch::patch_special(s, k, ctx->base_special[curve], ox, oy, n);
+      hipError_t e = hipGetLastError();
+      return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult_base (small batch) launch");
+    }
+  }
   return run_ladder(ctx, curve, k, 4, nullptr, nullptr, ox, oy, oz, n, flags); }
 int ecsimd_hip_affine_add(ecsimd_hip_ctx* ctx, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by,
                           uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) {

@@ -102,6 +102,23 @@ __global__ void __launch_bounds__(BLOCK) k_if_else(const uint8_t* mask, const ui
   GID; fe_store(out, i, fe_select(0u - (uint32_t)(mask[i] != 0), fe_load(a, i), fe_load(b, i)));      // ifelse.h:15-22
 }
 
+// The small-batch route of scalar_mult_base (capi.hip): the comb's affine result is the true k*G, the reference ladder's differs from it at its
+// three degenerate scalars (curve_group.h:189-218 as written).  `special` = 3 scalars, then the ladder's affine x and y for each (9 elements):
+// a lane whose k equals one of the scalars takes the ladder's coordinates -- by selects, no branch on k.
+__global__ void __launch_bounds__(BLOCK) k_patch_special(const uint64_t* k, const uint64_t* special, uint64_t* ox, uint64_t* oy, size_t n) {
+  GID; const fe v = fe_load(k, i);
+  fe x = fe_load(ox, i), y;
+  if (oy) y = fe_load(oy, i);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const uint32_t m = 0u - (uint32_t)fe_eq(v, fe_load(special, j));
+    x = fe_select(m, fe_load(special, 3 + j), x);
+    if (oy) y = fe_select(m, fe_load(special, 6 + j), y);
+  }
+  fe_store(ox, i, x);
+  if (oy) fe_store(oy, i, y);
+}
+
 namespace launch {
 static_assert(PEAK_MADS_PER_LANE_PER_ITER == 4 * 16, "keep in sync with k_peak_mad32");
 #define GO(kern, ...) hipLaunchKernelGGL(kern, grid_for(n), dim3(BLOCK), 0, s, __VA_ARGS__)
@@ -113,6 +130,7 @@ void mul(hipStream_t s, const uint64_t* a, const uint64_t* b, uint64_t* out8, si
 void square(hipStream_t s, const uint64_t* a, uint64_t* out8, size_t n, bool ref_compat) { if (ref_compat) GO(k_square<true>, a, out8, n); else GO(k_square<false>, a, out8, n); }
 void swap_if(hipStream_t s, const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n) { GO(k_swap_if, mask, a, b, n); }
 void if_else(hipStream_t s, const uint8_t* mask, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { GO(k_if_else, mask, a, b, out, n); }
+void patch_special(hipStream_t s, const uint64_t* k, const uint64_t* special, uint64_t* ox, uint64_t* oy, size_t n) { GO(k_patch_special, k, special, ox, oy, n); }
 void cmp_eq(hipStream_t s, const uint64_t* a, const uint64_t* b, int limbs, uint8_t* flag, size_t n) { GO(k_cmp_eq, a, b, limbs, flag, n); }
 void mask_op(hipStream_t s, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) { GO(k_mask_op, op, a, b, out, n); }
 void mask_count(hipStream_t s, const uint8_t* a, size_t n, unsigned long long* count) { GO(k_mask_count, a, n, count); }

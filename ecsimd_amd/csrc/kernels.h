@@ -23,6 +23,7 @@ void mul(hipStream_t, const uint64_t* a, const uint64_t* b, uint64_t* out8, size
 void square(hipStream_t, const uint64_t* a, uint64_t* out8, size_t n, bool ref_compat = false);   // ref_compat: mul.h:160-212 as written
 void swap_if(hipStream_t, const uint8_t* mask, uint64_t* a, uint64_t* b, size_t n);
 void if_else(hipStream_t, const uint8_t* mask, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+void patch_special(hipStream_t, const uint64_t* k, const uint64_t* special /* 3 scalars, 3 x, 3 y */, uint64_t* ox, uint64_t* oy, size_t n);   // oy may be null
 void cmp_eq(hipStream_t, const uint64_t* a, const uint64_t* b, int limbs, uint8_t* flag, size_t n);
 void mask_op(hipStream_t, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);     // 0 not, 1 and, 2 or, 3 equal
 void mask_count(hipStream_t, const uint8_t* a, size_t n, unsigned long long* count);

@@ -1,5 +1,5 @@
-// ecsimd/curve.h -- curve description (reference curve.h:12-30) and the map from a curve's prime
-// to the engine's curve id.  Only the two primes with hand-written kernels are accepted.
+// ecsimd/curve.h -- curve description (reference curve.h:12-30), the map from a curve's prime to the engine's curve id (the two
+// curves with hand-written kernels) and from ANY odd modulus type to a field id (the field layer is as generic in P as the reference's).
 #ifndef ECSIMD_CURVE_H
 #define ECSIMD_CURVE_H
 #include <ecsimd/bignum.h>
@@ -21,7 +21,26 @@ using secp256k1_prime = bn256_constant<0xffffffffffffffffull, 0xffffffffffffffff
 template <class P> constexpr int hip_curve_id() {
   if (P::value == detail::p256_prime::value) return ECSIMD_HIP_P256;
   if (P::value == detail::secp256k1_prime::value) return ECSIMD_HIP_SECP256K1;
-  throw "ecsimd: no HIP kernels for this prime (P-256 and secp256k1 only)";
+  throw "ecsimd: no HIP point kernels for this prime (P-256 and secp256k1 only)";
 }
+// Field id of a modulus type P for the element-wise field layer (mod_add ... mgry_pow, GFp<WBN, P>): any odd 256-bit P::value, as in the
+// reference (mgry_mul.h:84-121 details::mgry_reduce<P>, mgry_csts.h:15-35, gfp.h:17-115).  The two curve primes map to their special-form
+// kernels; every other modulus is registered with the engine on first use (ecsimd_hip_register_modulus: host arithmetic only, once per type).
+// Prime = the caller's word that P is prime: GFp::inverse then shares one division-step inversion among the lanes instead of raising to P - 2.
+template <class P, bool Prime = false> inline int hip_field_id() {
+  if constexpr (P::value == detail::p256_prime::value) return ECSIMD_HIP_P256;
+  else if constexpr (P::value == detail::secp256k1_prime::value) return ECSIMD_HIP_SECP256K1;
+  else {
+    static const int id = [] {
+      int fid = -1;
+      hip::check(ecsimd_hip_register_modulus(P::value.limbs.data(), Prime ? ECSIMD_HIP_MODULUS_PRIME : 0, &fid), "ecsimd_hip_register_modulus");
+      return fid;
+    }();
+    return id;
+  }
+}
+// The group orders (SP 800-186 3.2.1.3, SEC 2 v2 2.4.1) as modulus types: GFp<WBN, p256_order> is arithmetic modulo n (built-in field ids).
+using p256_order = bn256_constant<0xffffffff00000000ull, 0xffffffffffffffffull, 0xbce6faada7179e84ull, 0xf3b9cac2fc632551ull>;
+using secp256k1_order = bn256_constant<0xffffffffffffffffull, 0xfffffffffffffffeull, 0xbaaedce6af48a03bull, 0xbfd25e8cd0364141ull>;
 }  // namespace ecsimd
 #endif

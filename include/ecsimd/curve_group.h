@@ -124,6 +124,15 @@ struct curve_group {
     hip::check(ecsimd_hip_ecdsa_verify_rx(hip::context(), curve_id, u1.data(), u2.data(), Q.x().data(), Q.y().data(), r.data(), ok.data(), Q.size()), "ecsimd_hip_ecdsa_verify_rx");
     return ok;
   }
+  // The whole ECDSA verification (SEC 1 v2 4.1.4): e = the digest as an integer (any 256-bit value), (r, s) the signature, Q the public key.
+  // Lane i is set iff 1 <= r, s < n, Q is a valid public key and x((e/s) G + (r/s) Q) mod n == r.  The arithmetic modulo the group order
+  // runs on the device (the field layer on the order's field id; GFp<WBN, p256_order> / GFp<WBN, secp256k1_order> is the same arithmetic).
+  static hip::mask ecdsa_verify(WBN const& e, WBN const& r, WBN const& s, WCP const& Q) {
+    same_length(e.size(), Q.size(), "ecdsa_verify"); same_length(r.size(), Q.size(), "ecdsa_verify"); same_length(s.size(), Q.size(), "ecdsa_verify");
+    hip::mask ok(Q.size());
+    hip::check(ecsimd_hip_ecdsa_verify(hip::context(), curve_id, e.data(), r.data(), s.data(), Q.x().data(), Q.y().data(), ok.data(), Q.size()), "ecsimd_hip_ecdsa_verify");
+    return ok;
+  }
   // ---- several GPUs: k[i] * P[i] for HOST arrays, sharded over a device group.  P affine classical (x, y);
   // the result is what scalar_mult(x, from_affine(P)) returns lane by lane -- Jacobian, Montgomery form -- or, with
   // affine_out, what .to_affine() of it returns.  Member m computes the slice device_group::shard_range(n, m, size());

@@ -19,7 +19,7 @@ struct GFp {
   WBN to_classical() const { return n_.to_classical(); }
   GFp inverse() const {                                                       // gfp.h:42-44: x^(p-2)
     auto r = WBN::uninitialized(n_.size());
-    hip::check(ecsimd_hip_gfp_inverse(hip::context(), hip_curve_id<P>(), wbn().data(), r.data(), r.size()), "ecsimd_hip_gfp_inverse");
+    hip::check(ecsimd_hip_gfp_inverse(hip::context(), hip_field_id<P>(), wbn().data(), r.data(), r.size()), "ecsimd_hip_gfp_inverse");
     return GFp{WMBN{r}};
   }
   // gfp.h:46-54: x^((p+1)/4); like the reference, nullopt if ANY lane has no square root.
@@ -27,13 +27,13 @@ struct GFp {
   std::optional<GFp> sqrt() const { hip::mask ok; GFp r = sqrt_lanes(ok); if (!all(ok)) return {}; return {r}; }
   GFp sqrt_lanes(hip::mask& ok) const {
     auto r = WBN::uninitialized(n_.size()); ok = hip::mask(n_.size());
-    hip::check(ecsimd_hip_gfp_sqrt(hip::context(), hip_curve_id<P>(), wbn().data(), r.data(), ok.data(), r.size()), "ecsimd_hip_gfp_sqrt");
+    hip::check(ecsimd_hip_gfp_sqrt(hip::context(), hip_field_id<P>(), wbn().data(), r.data(), ok.data(), r.size()), "ecsimd_hip_gfp_sqrt");
     return GFp{WMBN{r}};
   }
   GFp sqr() const { return {mgry_sqr(n_)}; }
   GFp opposite() const {                                                      // gfp.h:60-64
     auto r = WBN::uninitialized(n_.size());
-    hip::check(ecsimd_hip_gfp_opposite(hip::context(), hip_curve_id<P>(), wbn().data(), r.data(), r.size()), "ecsimd_hip_gfp_opposite");
+    hip::check(ecsimd_hip_gfp_opposite(hip::context(), hip_field_id<P>(), wbn().data(), r.data(), r.size()), "ecsimd_hip_gfp_opposite");
     return GFp{WMBN{r}};
   }
   auto const& wbn() const { return n_.wbn(); }

@@ -10,19 +10,19 @@ namespace details {
 // T * 2^-256 mod p for a batch of 512-bit values (mgry_mul.h:84-121)
 template <class P> wide_bignum<bignum_256> mgry_reduce(wide_bignum<bignum_512> const& a) {
   auto r = wide_bignum<bignum_256>::uninitialized(a.size());
-  hip::check(ecsimd_hip_mgry_reduce(hip::context(), hip_curve_id<P>(), a.data(), r.data(), a.size()), "ecsimd_hip_mgry_reduce"); return r;
+  hip::check(ecsimd_hip_mgry_reduce(hip::context(), hip_field_id<P>(), a.data(), r.data(), a.size()), "ecsimd_hip_mgry_reduce"); return r;
 }
 }  // namespace details
 
 template <class P> struct mgry_constants {            // mgry_csts.h:15-24, values from the engine
-  static bignum_256 get(int which) { bignum_256 r; hip::check(ecsimd_hip_get_constant(hip_curve_id<P>(), which, r.limbs.data()), "ecsimd_hip_get_constant"); return r; }
+  static bignum_256 get(int which) { bignum_256 r; hip::check(ecsimd_hip_get_constant(hip_field_id<P>(), which, r.limbs.data()), "ecsimd_hip_get_constant"); return r; }
   static bignum_256 R_p() { return get(5); }
   static bignum_256 Rsq_p() { return get(6); }
   static bignum_256 Pm1_by_R_p() { return get(7); }
 };
 
-// mgry.h:18-26 to_mgry<P>(v): v * R mod p at COMPILE TIME (the reference divides with ctbignum; here 256 modular
-// doublings of v mod p -- the same residue).  p must exceed 2^255 (both supported primes), so v < 2^256 < 2p.
+// mgry.h:18-26 to_mgry<P>(v): v * R mod p at COMPILE TIME (the reference divides with ctbignum; here v mod p bit by bit, then 256 modular
+// doublings -- the same residue), for any modulus p >= 2.
 namespace details {
 constexpr bool bn_geq(bignum_256 const& a, bignum_256 const& b) {
   for (int i = 3; i >= 0; --i) { if (a.limbs[i] != b.limbs[i]) return a.limbs[i] > b.limbs[i]; }
@@ -33,17 +33,19 @@ constexpr bignum_256 bn_sub_wrap(bignum_256 const& a, bignum_256 const& b) {
   for (int i = 0; i < 4; ++i) { const uint64_t d = a.limbs[i] - b.limbs[i], d2 = d - borrow; borrow = (a.limbs[i] < b.limbs[i]) || (d < borrow); r.limbs[i] = d2; }
   return r;
 }
+// (2 r + bit) mod p for r < p: 2r + bit < 2p, one subtraction (mod 2^256 when the top bit fell off)
+constexpr bignum_256 bn_dbl_mod(bignum_256 const& r, bool bit, bignum_256 const& p) {
+  const bool top = r.limbs[3] >> 63;
+  bignum_256 d; for (int i = 3; i > 0; --i) d.limbs[i] = (r.limbs[i] << 1) | (r.limbs[i - 1] >> 63);
+  d.limbs[0] = (r.limbs[0] << 1) | (bit ? 1u : 0u);
+  return (top || bn_geq(d, p)) ? bn_sub_wrap(d, p) : d;
+}
 }  // namespace details
 template <class P> constexpr bignum_256 to_mgry(bignum_256 const& v) {
   constexpr bignum_256 p = P::value;
-  static_assert(p.limbs[3] >> 63, "to_mgry: p > 2^255");
-  bignum_256 r = details::bn_geq(v, p) ? details::bn_sub_wrap(v, p) : v;
-  for (int k = 0; k < 256; ++k) {
-    const bool top = r.limbs[3] >> 63;
-    bignum_256 d; for (int i = 3; i > 0; --i) d.limbs[i] = (r.limbs[i] << 1) | (r.limbs[i - 1] >> 63);
-    d.limbs[0] = r.limbs[0] << 1;
-    r = (top || details::bn_geq(d, p)) ? details::bn_sub_wrap(d, p) : d;          // 2r < 2p: one subtraction (mod 2^256 when the top bit fell off)
-  }
+  bignum_256 r{};
+  for (int k = 255; k >= 0; --k) r = details::bn_dbl_mod(r, (v.limbs[k / 64] >> (k % 64)) & 1u, p);      // v mod p
+  for (int k = 0; k < 256; ++k) r = details::bn_dbl_mod(r, false, p);                                       // * 2^256
   return r;
 }
 
@@ -59,12 +61,12 @@ struct wide_mgry_bignum {
   static wide_mgry_bignum R(size_t lanes = default_lanes) { return wide_mgry_bignum{WBN(lanes, constants_type::R_p())}; }
   static wide_mgry_bignum from_classical(WBN const& n) {                                   // mgry.h:47-50
     auto r = WBN::uninitialized(n.size());
-    hip::check(ecsimd_hip_mgry_from_classical(hip::context(), hip_curve_id<P>(), n.data(), r.data(), n.size()), "ecsimd_hip_mgry_from_classical");
+    hip::check(ecsimd_hip_mgry_from_classical(hip::context(), hip_field_id<P>(), n.data(), r.data(), n.size()), "ecsimd_hip_mgry_from_classical");
     return wide_mgry_bignum{r};
   }
   WBN to_classical() const {                                                               // mgry.h:52-55
     auto r = WBN::uninitialized(n_.size());
-    hip::check(ecsimd_hip_mgry_to_classical(hip::context(), hip_curve_id<P>(), n_.data(), r.data(), n_.size()), "ecsimd_hip_mgry_to_classical");
+    hip::check(ecsimd_hip_mgry_to_classical(hip::context(), hip_field_id<P>(), n_.data(), r.data(), n_.size()), "ecsimd_hip_mgry_to_classical");
     return r;
   }
   WBN const& wbn() const { return n_; }

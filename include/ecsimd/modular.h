@@ -7,15 +7,15 @@
 namespace ecsimd {
 template <class P, class BN> wide_bignum<BN> mod_add(wide_bignum<BN> const& a, wide_bignum<BN> const& b) {
   auto r = wide_bignum<BN>::uninitialized(a.size());
-  hip::check(ecsimd_hip_mod_add(hip::context(), hip_curve_id<P>(), a.data(), b.data(), r.data(), a.size()), "ecsimd_hip_mod_add"); return r;
+  hip::check(ecsimd_hip_mod_add(hip::context(), hip_field_id<P>(), a.data(), b.data(), r.data(), a.size()), "ecsimd_hip_mod_add"); return r;
 }
 template <class P, class BN> wide_bignum<BN> mod_sub(wide_bignum<BN> const& a, wide_bignum<BN> const& b) {
   auto r = wide_bignum<BN>::uninitialized(a.size());
-  hip::check(ecsimd_hip_mod_sub(hip::context(), hip_curve_id<P>(), a.data(), b.data(), r.data(), a.size()), "ecsimd_hip_mod_sub"); return r;
+  hip::check(ecsimd_hip_mod_sub(hip::context(), hip_field_id<P>(), a.data(), b.data(), r.data(), a.size()), "ecsimd_hip_mod_sub"); return r;
 }
 template <class P, class BN> wide_bignum<BN> mod_shift_left(wide_bignum<BN> const& a, int count) {
   auto r = wide_bignum<BN>::uninitialized(a.size());
-  hip::check(ecsimd_hip_mod_shift_left(hip::context(), hip_curve_id<P>(), a.data(), count, r.data(), a.size()), "ecsimd_hip_mod_shift_left"); return r;
+  hip::check(ecsimd_hip_mod_shift_left(hip::context(), hip_field_id<P>(), a.data(), count, r.data(), a.size()), "ecsimd_hip_mod_shift_left"); return r;
 }
 template <class P, class BN> wide_bignum<BN> mod_shift_left_one(wide_bignum<BN> const& a) { return mod_shift_left<P>(a, 1); }
 // reference-shaped overloads: the modulus is passed as a wide and must be one of the two primes

@@ -75,3 +75,10 @@ def kats():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_moduli():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "ref_moduli_vectors.json")) as f:
+        return json.load(f)

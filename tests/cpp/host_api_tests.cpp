@@ -174,6 +174,53 @@ TEST(Mgry, Gfp) {                                                               
   EXPECT_TRUE(all(Z.wbn() == W256{bignum_256{}}));
 }
 
+// ------------------------------------------------------------------ the field layer is generic in P (mgry_mul.h:84-121, gfp.h:17-115)
+namespace {
+struct P192 { static constexpr auto value = bn_from_bytes_BE<bignum_256>("0000000000000000FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFFFFFFFFFFFF"_hex); };   // P-192's prime: a modulus of no curve here
+}
+TEST(Mgry, AnyModulus) {
+  using GFP = GFp<W256, P192>;                                                                  // = 3 mod 4, as gfp.h:84 wants
+  const auto a = GFP::from_classical(splat<W256>("0000000000000000123456789abcdef0fedcba9876543210aabbccddeeff0011"_hex));
+  const auto b = GFP::from_classical(splat<W256>("00000000000000000f1e2d3c4b5a69788796a5b4c3d2e1f00112233445566778"_hex));
+  EXPECT_TRUE(all((a * b).to_classical() == splat<W256>("00000000000000002caf945261384f2410d8a623fcdc6a3f7a4f03ba95b7c40c"_hex)));
+  EXPECT_TRUE(all(a.inverse().to_classical() == splat<W256>("00000000000000001145f09c0965e40d3a322db8613aa048e7e16376a1b07a1e"_hex)));
+  EXPECT_TRUE(all(a.opposite().to_classical() == splat<W256>("0000000000000000edcba9876543210f0123456789abcdee554433221100ffee"_hex)));
+  const auto root = a.sqr().sqrt();
+  EXPECT_TRUE(root.has_value());
+  if (root) EXPECT_TRUE(all(root->sqr().wbn() == a.sqr().wbn()));
+  EXPECT_TRUE(all((a + a.opposite()).wbn() == W256{bignum_256{}}));
+  // compile-time to_mgry for a modulus below 2^255, against the engine's from_classical
+  constexpr auto am = to_mgry<P192>(bn_from_bytes_BE<bignum_256>("0000000000000000123456789abcdef0fedcba9876543210aabbccddeeff0011"_hex));
+  EXPECT_TRUE(all(a.wbn() == W256{am}));
+  EXPECT_TRUE((mgry_constants<P192>::R_p() == to_mgry<P192>(bignum_256::from(1))));
+}
+TEST(Mgry, GroupOrderArithmetic) {
+  // u1 = e / s, u2 = r / s modulo the order of P-256 with the reference's own vocabulary (RFC 6979 A.2.5, SHA-256, "sample")
+  using Fn = GFp<W256, p256_order>;
+  const auto e = splat<W256>("AF2BDBE1AA9B6EC1E2ADE1D694F41FC71A831D0268E9891562113D8A62ADD1BF"_hex);
+  const auto r = splat<W256>("EFD48B2AACB6A8FD1140DD9CD45E81D69D2C877B56AAF991C34D0EA84EAF3716"_hex);
+  const auto s = splat<W256>("F7CB1C942D657C41D436C7A1B6E29F65F3E900DBB9AFF4064DC4AB2F843ACDA8"_hex);
+  const auto w = Fn::from_classical(s).inverse();
+  EXPECT_TRUE(all((Fn::from_classical(e) * w).to_classical() == splat<W256>("a9cceaf9beeb5f3ef17670f8eb7f810b486952f78536ee77f31cff76caae5841"_hex)));
+  EXPECT_TRUE(all((Fn::from_classical(r) * w).to_classical() == splat<W256>("48dc5acda3b1ad61b01f62f0ec7e692d6b6ca086e80a10b4241298ec71e7211d"_hex)));
+}
+TEST(Ecdsa, Rfc6979Vectors) {
+  // RFC 6979 A.2.5 (P-256, SHA-256): "sample" and "test" under one key; then each input disturbed in turn
+  using Curve = curve_nist_p256; using CG = curve_group<Curve>; using WCP = wide_curve_point<Curve>;
+  const auto qx = "60FED4BA255A9D31C961EB74C6356D68C049B8923B61FA6CE669622E60F29FB6"_hex, qy = "7903FE1008B8BC99A41AE9E95628BC64F2F1B20C2D7E9F5177A3C294D4462299"_hex;
+  const auto e1 = "AF2BDBE1AA9B6EC1E2ADE1D694F41FC71A831D0268E9891562113D8A62ADD1BF"_hex, e2 = "9F86D081884C7D659A2FEAA0C55AD015A3BF4F1B2B0B822CD15D6C15B0F00A08"_hex;
+  const auto r1 = "EFD48B2AACB6A8FD1140DD9CD45E81D69D2C877B56AAF991C34D0EA84EAF3716"_hex, s1 = "F7CB1C942D657C41D436C7A1B6E29F65F3E900DBB9AFF4064DC4AB2F843ACDA8"_hex;
+  const auto r2 = "F1ABB023518351CD71D881567B1EA663ED3EFCF6C5132B354F28D3B0B7D38367"_hex, s2 = "019F4113742A2B14BD25926B49C649155F267E60D3814B4C0CC84250E46F0083"_hex;
+  const auto zero = "0000000000000000000000000000000000000000000000000000000000000000"_hex;
+  const WCP Q{splat<W256>(qx), splat<W256>(qy)};
+  //                                  valid  valid  wrong message  r of the other  s = 0
+  const auto e = lanes<W256>(e1, e2, e2, e1), r = lanes<W256>(r1, r2, r1, r2), s = lanes<W256>(s1, s2, s1, zero);
+  const auto ok = CG::ecdsa_verify(e, r, s, Q).host();
+  EXPECT_TRUE(ok[0] == 1 && ok[1] == 1 && ok[2] == 0 && ok[3] == 0);
+  const WCP off{splat<W256>(qx), splat<W256>(qx)};                                              // not a curve point
+  EXPECT_TRUE(CG::ecdsa_verify(e, r, s, off).count() == 0);
+}
+
 // ------------------------------------------------------------------ tests/curve_point.cpp
 TEST(CurvePoint, FromXAndRoundTrip) {
   using Curve = curve_nist_p256; using WCP = wide_curve_point<Curve>; using WJCP = wide_jacobian_curve_point<Curve>;

@@ -47,8 +47,38 @@ def test_constants_without_a_gpu(lib, oracle):
             out = (C.c_uint64 * 4)()
             assert lib.ecsimd_hip_get_constant(C.c_int(cv), C.c_int(i), out) == 0
             assert list(out) == [int(v) for v in c[nm]], (cv, nm)
-    assert lib.ecsimd_hip_get_constant(C.c_int(2), C.c_int(0), (C.c_uint64 * 4)()) == -1
+    assert lib.ecsimd_hip_get_constant(C.c_int(-1), C.c_int(0), (C.c_uint64 * 4)()) == -1
+    assert lib.ecsimd_hip_get_constant(C.c_int(1 << 20), C.c_int(0), (C.c_uint64 * 4)()) == -1      # no such field id
     assert lib.ecsimd_hip_get_constant(C.c_int(0), C.c_int(12), (C.c_uint64 * 4)()) == -1
+
+
+def test_modulus_registry_without_a_gpu(lib, oracle):
+    """ecsimd_hip_register_modulus is host-only: what it derives from a modulus (R, R^2, -R mod p, p - 2, (p + 1)/4 -- mgry_csts.h:15-35)
+    equals the oracle's for the same modulus; the same p gives the same id, the curve primes their curve ids, even values are refused."""
+    import numpy as np
+    from ecsimd_amd.engine import register_modulus, EcsimdHipError, P256_ORDER, SECP256K1_ORDER
+    from oracle.loader import REF_MODULI, to_int
+    rng = np.random.default_rng(8)
+    moduli = list(REF_MODULI.values()) + [3, 5, 2**64 + 13, 2**256 - 189] + [int.from_bytes(rng.bytes(32), "big") | 1 for _ in range(8)]
+    for p in moduli:
+        fid = register_modulus(p)
+        assert fid >= 2 and register_modulus(p, prime=True) == fid
+        c = oracle.constants(oracle.register_modulus(p))
+        for which, key in ((0, "p"), (5, "r_p"), (6, "rsq_p"), (7, "pm1_r_p"), (10, "p_m2"), (11, "p_sqrt")):
+            out = (C.c_uint64 * 4)()
+            assert lib.ecsimd_hip_get_constant(C.c_int(fid), C.c_int(which), out) == 0
+            assert list(out) == [int(v) for v in c[key]], (hex(p), key)
+        for which in (1, 2, 3, 4, 8, 9):                                                   # no curve behind a field id
+            out = (C.c_uint64 * 4)(1, 1, 1, 1)
+            assert lib.ecsimd_hip_get_constant(C.c_int(fid), C.c_int(which), out) == 0 and list(out) == [0, 0, 0, 0]
+    assert register_modulus(REF_MODULI["n_p256"]) == P256_ORDER and register_modulus(REF_MODULI["n_secp256k1"]) == SECP256K1_ORDER
+    assert register_modulus(0xffffffff00000001000000000000000000000000ffffffffffffffffffffffff) == 0 and register_modulus(2**256 - 2**32 - 977) == 1
+    for bad in (0, 1, 2, 2**255, 2**256 - 2):
+        with pytest.raises(EcsimdHipError):
+            register_modulus(bad)
+    fid = C.c_int()
+    assert lib.ecsimd_hip_register_modulus(None, C.c_int(0), C.byref(fid)) == -1
+    assert lib.ecsimd_hip_register_modulus((C.c_uint64 * 4)(7, 0, 0, 0), C.c_int(2), C.byref(fid)) == -1      # unknown flag
 
 
 def test_no_cpu_fallback():

@@ -84,6 +84,12 @@ def test_runtime_modulus_vs_oracle(gpu, oracle, name):
     check_field(gpu, oracle, field_id(p, prime=name in PRIME_MODULI), oracle.register_modulus(p), p, prime=name in PRIME_MODULI, seed=len(name))
 
 
+def test_runtime_moduli_vs_the_reference_fixtures(gpu, golden_moduli):
+    """tests/golden/ref_moduli_vectors.json: vectors minted from the compiled reference for its five curve-less instances."""
+    from test_oracle import check_moduli_fixtures
+    check_moduli_fixtures(gpu, lambda p: field_id(p, prime=p != 2**256 - 1), golden_moduli)
+
+
 def test_group_order_ids_are_built_in(engine, oracle):
     from ecsimd_amd.engine import P256_ORDER, SECP256K1_ORDER
     for cv, fid in ((P256, P256_ORDER), (SECP256K1, SECP256K1_ORDER)):

@@ -212,6 +212,59 @@ def test_oracle_scalar_mult_1s_fixture(oracle, golden):
         assert [arr_to_hexes(v) for v in J] == [g["X"], g["Y"], g["Z"]]
 
 
+def check_moduli_fixtures(impl, register, data):
+    """tests/golden/ref_moduli_vectors.json (the reference's field layer instantiated for curve-less moduli) against `impl`."""
+    for name, g in data["moduli"].items():
+        p = int(g["p"], 16); fid = register(p); f = g["field"]
+        a, b, t8 = hexes_to_arr(f["a"]), hexes_to_arr(f["b"]), hexes_to_arr(f["t8"], 8)
+        eq = lambda got, key: np.array_equal(got, hexes_to_arr(f[key])) or pytest.fail(f"{name}: {key}")
+        eq(impl.mod_add(fid, a, b), "mod_add"); eq(impl.mod_sub(fid, a, b), "mod_sub")
+        eq(impl.mod_shift_left(fid, a, 1), "shl1"); eq(impl.mod_shift_left(fid, a, 3), "shl3")
+        eq(impl.mgry_mul(fid, a, b), "mgry_mul"); eq(impl.mgry_sqr(fid, a), "mgry_sqr"); eq(impl.mgry_reduce(fid, t8), "mgry_reduce")
+        eq(impl.mgry_from_classical(fid, a), "from_classical"); eq(impl.mgry_to_classical(fid, a), "to_classical")
+        eq(impl.gfp_inverse(fid, a), "inverse"); eq(impl.mgry_pow(fid, a, from_hex(f["pow_exponent"])), "pow")
+        if "opposite" in f:
+            eq(impl.gfp_opposite(fid, a), "opposite")
+            s, ok = impl.gfp_sqrt(fid, hexes_to_arr(f["mgry_sqr"]))
+            wide_ok = np.array(f["sqrt_ok"], dtype=bool)                       # the reference reports all-or-nothing per wide of 4
+            assert np.array_equal(ok.astype(bool).reshape(-1, 4).all(axis=1).repeat(4), wide_ok), name
+            assert np.array_equal(s[wide_ok], hexes_to_arr(f["sqrt_of_sqr"])[wide_ok]), name
+
+
+def test_oracle_matches_the_moduli_fixtures(oracle, golden_moduli):
+    """The restatement is as generic in the modulus as the reference (mgry_mul.h:84-121 mgry_reduce<P>, mgry_csts.h:15-35): both group orders,
+    2^255 - 19, 2^256 - 1 (composite) and P-192's prime, on vectors minted from the compiled reference."""
+    check_moduli_fixtures(oracle, oracle.register_modulus, golden_moduli)
+    for name, g in golden_moduli["moduli"].items():
+        c = oracle.constants(oracle.register_modulus(int(g["p"], 16)))
+        for k, v in g["constants"].items():
+            assert (format(c[k], "08x") if k == "mprime" else format(to_int(c[k]), "064x")) == v, (name, k)
+
+
+def test_oracle_moduli_vs_live_reference(oracle, oracle_faithful, reference):
+    """Random and structured operands, every field op, every modulus the reference is compiled for -- and the square defect with it."""
+    from oracle.loader import REF_MODULI
+    rng = np.random.default_rng(21)
+    pat = np.array([0, 0xffffffff, 0x80000000, 0x7fffffff, 1, 0xfffffffe], dtype=np.uint64)
+    for name, p in REF_MODULI.items():
+        fo, fr = oracle.register_modulus(p), reference.register_modulus(p)
+        n = 2000
+        a = ints_to_arr([to_int(x) % p for x in rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)])
+        b = ints_to_arr([to_int(x) % p for x in rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)])
+        w = pat[rng.integers(0, len(pat), size=(n // 2, 8))]
+        a[: n // 2] = ints_to_arr([v % p for v in arr_to_ints((w[:, 0::2] | (w[:, 1::2] << np.uint64(32))).astype(np.uint64))])
+        for f in ("mod_add", "mod_sub", "mgry_mul"):
+            assert np.array_equal(getattr(oracle, f)(fo, a, b), getattr(reference, f)(fr, a, b)), (name, f)
+        for f in ("mgry_from_classical", "mgry_to_classical"):
+            assert np.array_equal(getattr(oracle, f)(fo, a), getattr(reference, f)(fr, a)), (name, f)
+        assert np.array_equal(oracle_faithful.mgry_sqr(fo, a), reference.mgry_sqr(fr, a)), name          # bug for bug
+        assert np.array_equal(oracle_faithful.gfp_inverse(fo, a[:64]), reference.gfp_inverse(fr, a[:64])), name
+        t8 = ints_to_arr([x * y for x, y in zip(arr_to_ints(a), arr_to_ints(rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)))], 8)
+        assert np.array_equal(oracle.mgry_reduce(fo, t8), reference.mgry_reduce(fr, t8)), name
+        # and the arithmetic itself, against big ints
+        assert arr_to_ints(oracle.mgry_mul(fo, a, b)) == [x * y * pow(R, -1, p) % p for x, y in zip(arr_to_ints(a), arr_to_ints(b))]
+
+
 # ---------------------------------------------------------------- (3) live reference, random inputs
 def structured_words(n, seed=1):
     """Carry-heavy operands: each 32-bit digit is 0 / ff..f / 80..0 / 7f..f / 1 / ff..e, or random (1 in 4)."""

@@ -82,7 +82,17 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     u1 = e.fill_random(n2, SEED, 21)
     row(f"double_scalar_mult<{nm}> u1*G + u2*Q (ECDSA-verify shape)", n2, timeit(lambda: e.double_scalar_mult(cv, u1, k, b2x, b2y), 5),
         vw + int((12 * 11 + (7 + inv_m / 32) + 6 + inv_m / 32) * 136), 160, "verifications")
-    del u1
+    # the whole verification: + the arithmetic modulo the group order (k_gfield.hip k_ecdsa_scalars: 6 generic Montgomery products per signature and
+    # one division-step inversion per 32 at this size) and the final x mod n == r; (e, r, s, Qx, Qy) in = 160 B
+    dsm = vw + int((12 * 11 + (7 + inv_m / 32) + 6 + inv_m / 32) * 136)
+    row(f"ecdsa_verify_rx<{nm}> (u1, u2 given)", n2, timeit(lambda: e.ecdsa_verify_rx(cv, u1, k, b2x, b2y, u1), 5), dsm, 161, "verifications")
+    rr = e.fill_random(n2, SEED, 22, clear_top_bits=1); ss = e.fill_random(n2, SEED, 23, clear_top_bits=1)
+    row(f"ecdsa_verify<{nm}> (e, r, s, Q -> ok: mod-n arithmetic on the device)", n2, timeit(lambda: e.ecdsa_verify(cv, u1, rr, ss, b2x, b2y), 5), dsm + 6 * 136, 161, "verifications")
+    from ecsimd_amd.engine import ORDER_FIELD
+    fo = ORDER_FIELD[cv]
+    row(f"mgry_mul<order of {nm}> (run-time modulus, generic reduction)", n2, timeit(lambda: e.mgry_mul(fo, rr, ss)), 136, 96, "field mults")
+    row(f"gfp_inverse<order of {nm}> (division steps, shared by 32)", n2, timeit(lambda: e.gfp_inverse(fo, rr)), int((3 + 88 / 32) * 136), 128, "elements")   # ~12 000 instructions of division steps ~ 88 field multiplications, shared by 32
+    del u1, rr, ss
     row(f"scalar_mult_base<{nm}> 20-bit windows, odd digits (table in device memory), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 32, out=outj)), int((12 * 11 + 7 + inv_m / 32) * 136), 96, "scalar mults")
     row(f"scalar_mult_base<{nm}> signed 7-bit windows, affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 8, out=outj)), int((37 * 11 + 7 + inv_m / 32) * 136), 96, "scalar mults")
     wire = e.sec1_encode(cv, b2x, b2y, True)

@@ -69,6 +69,13 @@ def parse_function(text, want):
                 hdr = m.group(1)[2:]               # the header belongs to its own loop
             blocks.append([m.group(1) or f"bb.{m.group(2)}", hdr, []])
             continue
+        if t.startswith(";") and blocks[-1][1] is None and not blocks[-1][2]:
+            # the loop annotation of a block whose label line already carries a comment (an IR block name) sits on the NEXT line
+            mh = re.search(r"in Loop: Header=(BB\w+)", t)
+            if mh:
+                blocks[-1][1] = mh.group(1)
+            elif "Loop Header" in t and blocks[-1][0].startswith(".LBB"):
+                blocks[-1][1] = blocks[-1][0][2:]
         if not t or t.startswith(";") or t.startswith("."):
             continue
         blocks[-1][2].append(t.split(";")[0].strip())
@@ -161,28 +168,38 @@ def check(text, want, allow_global_loads=1, allow_lds_reads=False):
             succs[n].add(n + 1)
     preds = {n: {m for m in succs if n in succs[m]} for n in range(len(loop))}
 
-    def def_is_clean(insts, k, visiting):
+    # One query = one walk: any dirty definition on any path makes the whole query dirty (every level returns False at once), so a
+    # (block, register) pair that the walk has already entered may be taken as clean wherever it is met again -- the greatest fixed point,
+    # and each pair is expanded ONCE per query (a path-by-path walk is exponential in the diamonds of a loop with data-dependent branches).
+    def def_is_clean(insts, k, seen):
         op, ops = split_ops(insts[k])
         if not op.startswith("s_") or "saveexec" in op:
             return False
         nd = dest_count(op)
-        return all(clean_scalar_at(insts, k, s_, visiting) for o in ops[nd:] for s_ in regs_of(o) if s_ != "scc")
+        return all(clean_scalar_at(insts, k, s_, seen) for o in ops[nd:] for s_ in regs_of(o) if s_ != "scc")
 
-    def clean_scalar_at(block_insts, idx, reg, visiting=frozenset()):
+    def clean_scalar_at(block_insts, idx, reg, seen=None):
         """Is scalar `reg`, read by instruction idx of this block, made of clean values on every path that reaches it?"""
+        if seen is None:
+            seen = set()
         if (isinstance(reg, tuple) and reg[0] == "v") or reg in ("vcc", "exec"):
             return False
         for k in range(idx - 1, -1, -1):
             op, ops = split_ops(block_insts[k])
             if reg in [r for o in ops[:dest_count(op)] for r in regs_of(o)]:
-                return def_is_clean(block_insts, k, visiting)
+                dkey = (block_of[id(block_insts)], k, reg)
+                if dkey in seen:
+                    return True
+                seen.add(dkey)
+                return def_is_clean(block_insts, k, seen)
         n = block_of[id(block_insts)]
         key = (n, reg)
-        if key in visiting:
+        if key in seen:
             return True
+        seen.add(key)
         for m in preds[n]:                                    # (the header's entry edge from outside the loop: a loop-invariant value)
             pin = loop[m][1]
-            if not clean_scalar_at(pin, len(pin), reg, visiting | {key}):
+            if not clean_scalar_at(pin, len(pin), reg, seen):
                 return False
         return True
 
