@@ -24,6 +24,11 @@ case "$name" in
     echo "rc=$rc wall=$((s1 - s0)) s"; tail -3 "$out/bench.err"; python3 -c "
 import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value %.3f M/s  ms/step %.2f  frac %.3f (a priori %.3f)' % (d['value']/1e6, d['ms_per_step'], r['frac'], r['frac_of_a_priori_peak'])); print('ref_compat', {k: v for k, v in d.get('ref_compat', {}).items() if k != 'what'}); print('cpu', {k: d['cpu_baseline'][k] for k in ('value','cores','kind','lanes_compared','lanes_differing_from_gpu','lanes_differing_confirmed_by_openssl')})"
     exit $rc ;;
+  small_batch)      # round 4: the small-batch route of scalar_mult_base (test), then the latency table against the compiled reference
+    timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_cpp_host_api.py -x -q -m gpu -k "small_base or scalar_mult_vs_oracle or cpp_api or fixtures_from" > "$out/pytest.txt" 2>&1; rc=$?
+    tail -5 "$out/pytest.txt"
+    [ $rc -eq 0 ] && for c in p256 secp256k1; do timeout -k 10 500 python tools/small_batch.py $c > "$out/small_batch_$c.txt" 2>&1 || rc=$?; cat "$out/small_batch_$c.txt"; done
+    exit $rc ;;
   secondary)        # tools/bench_kernels.py -> profiles/rNN/secondary_kernels.{json,txt}
     timeout -k 10 900 python tools/bench_kernels.py > "$out/secondary_kernels.json" 2> "$out/secondary_kernels.txt"; rc=$?; tail -70 "$out/secondary_kernels.txt"; exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
