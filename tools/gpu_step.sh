@@ -29,6 +29,10 @@ import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value
     tail -5 "$out/pytest.txt"
     [ $rc -eq 0 ] && for c in p256 secp256k1; do timeout -k 10 500 python tools/small_batch.py $c > "$out/small_batch_$c.txt" 2>&1 || rc=$?; cat "$out/small_batch_$c.txt"; done
     exit $rc ;;
+  traffic)          # round 4: where the window kernels' bytes come from -- the re-read probe of the calibration, then FETCH_SIZE / WRITE_SIZE / RDREQ_DRAM per kernel
+    bash tools/profile_calib.sh r04 > "$out/calib.txt" 2>&1; rc=$?; tail -12 "$out/calib.txt"
+    [ $rc -eq 0 ] && TRAFFIC_EXTRA_COUNTERS="TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_sum" bash tools/profile_traffic.sh r04 ${@:-windowed windowed-ct} > "$out/traffic.txt" 2>&1; rc=$?; tail -8 "$out/traffic.txt"
+    exit $rc ;;
   secondary)        # tools/bench_kernels.py -> profiles/rNN/secondary_kernels.{json,txt}
     timeout -k 10 900 python tools/bench_kernels.py > "$out/secondary_kernels.json" 2> "$out/secondary_kernels.txt"; rc=$?; tail -70 "$out/secondary_kernels.txt"; exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it

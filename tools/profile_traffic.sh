@@ -15,7 +15,8 @@ export ECSIMD_BENCH_STEP_MARKER=1      # a one-element k_fill_random launch in f
 for W in $WORKLOADS; do
   for CV in p256 secp256k1; do
     D="$OUT/${W}_${CV}"; mkdir -p "$D"
-    for C in FETCH_SIZE WRITE_SIZE; do
+    # TRAFFIC_EXTRA_COUNTERS (r4): further single-counter passes, e.g. TCC_EA0_RDREQ_DRAM_sum (the requests "destined for DRAM (MC)")
+    for C in FETCH_SIZE WRITE_SIZE $TRAFFIC_EXTRA_COUNTERS; do
       rocprofv3 --pmc $C --output-format csv -d "$D/pmc_$C" -- python3 "$REPO/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --workload $W --curve $CV > "$D/pmc_$C.log" 2>&1 \
         || { echo "FAILED $W $CV $C"; tail -3 "$D/pmc_$C.log"; }
     done

@@ -72,18 +72,29 @@ def main():
         fs, ws = last_step(rows(f[0])), last_step(rows(w[0]))
         if [r[1:3] for r in fs] != [r[1:3] for r in ws]:
             raise SystemExit(f"{base}: the two passes dispatched different kernel sequences")
+        extra = {}                                        # r4: further counters of the same step, kernel by kernel (TRAFFIC_EXTRA_COUNTERS)
+        for xd in sorted(glob.glob(os.path.join(d, "pmc_*"))):
+            cname = os.path.basename(xd)[4:]
+            xf = glob.glob(os.path.join(xd, "*", "*_counter_collection.csv"))
+            if cname in ("FETCH_SIZE", "WRITE_SIZE") or not os.path.isdir(xd) or not xf:
+                continue
+            xs = last_step(rows(xf[0]))
+            if [r[1:3] for r in xs] == [r[1:3] for r in fs]:
+                extra[cname] = [r[3] for r in xs]
         kernels, total = [], 0.0
-        for (did, name, grid, fv), (_, _, _, wv) in zip(fs, ws):
+        for idx, ((did, name, grid, fv), (_, _, _, wv)) in enumerate(zip(fs, ws)):
             read = fv * 1024 * f_stream
             how = f"FETCH_SIZE x 1024 x {f_stream:.3f} (128-byte requests tallied at 64)" + ("; includes the unused halves of the lines its 64-byte table reads fetch" if name in GATHERS else "")
             kernels.append({"kernel": name, "grid": grid, "FETCH_SIZE_KB": fv, "WRITE_SIZE_KB": wv, "read_bytes": read, "write_bytes": wv * 1024, "pricing": how})
+            for cname, vals in extra.items():
+                kernels[-1][cname] = vals[idx]
             total += read + wv * 1024
         lanes = max(k["grid"] for k in kernels)
         json.dump({"_about": f"one timed step of `bench.py --workload {wl} --curve {curve}` (2^24 units) under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)",
                    "hbm_bytes_per_step": total, "kernels": kernels}, open(os.path.join(dst, base + ".json"), "w"), indent=1)
         table[f"{KEY[wl]}_{curve}_2^24"] = total
         print(f"{base:34s} {len(kernels):3d} kernels  {total / 1e6:10.1f} MB per step  ({total / (1 << 24):7.1f} B per unit)")
-    table["_source"] = ("profiles/r03/traffic/<workload>_<curve>.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel of ONE timed step (every kernel of the step, "
+    table["_source"] = (f"profiles/{rnd}/traffic/ (keys not re-measured this round keep the earlier round's figure) -- profiles/r03/traffic/<workload>_<curve>.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel of ONE timed step (every kernel of the step, "
                         "workspace round trips included), FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 with the factor 2 established by profiles/r03/hbm_counter_calibration.json "
                         "(tools/summarize_traffic.py); the 2^22 keys are round 2's")
     json.dump(table, open(tpath, "w"), indent=1)

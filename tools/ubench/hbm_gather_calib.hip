@@ -13,6 +13,11 @@
 //   calib_gather64_ic   calib_gather64 over a 32 MiB table, 32 rounds: the table stays in the Infinity Cache / L2
 //   calib_own512        lane i reads ONE of the eight 64-byte entries of ITS OWN 512-byte block (the per-element window
 //                       tables of k_varwin_mult_*: neighbouring lanes read from neighbouring blocks), 2^22 lanes over 2 GiB
+//   calib_own512_reread (r4) lane i reads ALL EIGHT entries of its own 512-byte block, 63 times over (the constant-time window loop of
+//                       k_varwin_mult_odd<true>: one table per lane, re-read in every window), at 3 workgroups per CU like that
+//                       kernel (dynamic LDS caps the occupancy): the blocks of the resident lanes -- 256 CUs x 768 lanes x 512 B =
+//                       100 MB -- exceed the L2s (4 MiB per XCD) and fit the 256 MB Infinity Cache.  If this pattern sustains more
+//                       than HBM's 8 TB/s, the re-reads are served by the Infinity Cache -- and the counters count them all the same.
 //
 // Run plainly it prints requested bytes and GB/s per kernel (HIP events); under `rocprofv3 --pmc FETCH_SIZE` (and, in
 // separate passes, WRITE_SIZE, TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum) the counters per kernel divided by the
@@ -69,6 +74,26 @@ __global__ void __launch_bounds__(256) calib_own512(const uint4* t, uint32_t* s,
   const uint4* e = t + i * 32 + d * 4;
   const uint32_t v = fold(e[0]) ^ fold(e[1]) ^ fold(e[2]) ^ fold(e[3]); if (v == 0x12345678u) s[0] = v; }
 
+// 63 rounds x 8 entries x 64 B per lane; asm volatile loads: the compiler must not keep the block in registers
+__global__ void __launch_bounds__(256) calib_own512_reread(const uint4* t, uint32_t* s, size_t n, int rounds) {
+  extern __shared__ uint32_t occupancy_cap[];
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  const uint4* e = t + i * 32;
+  uint32_t v = 0;
+  for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+      uint4 a0, a1, a2, a3, a4, a5, a6, a7;
+      asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:16\n\tglobal_load_dwordx4 %2, %8, off offset:32\n\t"
+                   "global_load_dwordx4 %3, %8, off offset:48\n\tglobal_load_dwordx4 %4, %8, off offset:64\n\tglobal_load_dwordx4 %5, %8, off offset:80\n\t"
+                   "global_load_dwordx4 %6, %8, off offset:96\n\tglobal_load_dwordx4 %7, %8, off offset:112\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), "=&v"(a7) : "v"(e + k) : "memory");
+      v ^= fold(a0) ^ fold(a1) ^ fold(a2) ^ fold(a3) ^ fold(a4) ^ fold(a5) ^ fold(a6) ^ fold(a7);
+    }
+  }
+  if (v == 0x12345678u) { s[0] = v; occupancy_cap[threadIdx.x] = v; }
+}
+
 int main() {
   const size_t n = (size_t)1 << 24;                 // lanes per launch
   const size_t bytes = (size_t)2 << 30;             // 2 GiB: 8x the Infinity Cache
@@ -115,6 +140,16 @@ int main() {
   CHECK(hipEventRecord(e0));
   hipLaunchKernelGGL(calib_own512, dim3((unsigned)((n / 4) / 256)), block, 0, 0, buf, sink, n / 4, 3u);
   CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize()); report("calib_own512", (double)(n / 4) * 64, 1);
+  // the constant-time window loop's pattern: 2^22 lanes, 63 rounds over each lane's own 512-byte block, 3 workgroups per CU
+  {
+    const size_t lanes = n / 4; const int rounds = 63;
+    const size_t lds = 52 * 1024;                                   // 160 KB per CU / 52 KB = 3 workgroups of 4 waves
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(calib_own512_reread), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    flush(); CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(calib_own512_reread, dim3((unsigned)(lanes / 256)), block, lds, 0, buf, sink, lanes, rounds);
+    CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize()); report("calib_own512_reread", (double)lanes * 512 * rounds, 1);
+  }
   CHECK(hipFree(buf)); CHECK(hipFree(sink));
   return 0;
 }
