@@ -83,7 +83,7 @@ def parse_args(argv=None):
                          "ladder-ref-compat: the same with ECSIMD_HIP_REF_SQUARE_COMPAT (the reference's square() as written, dropped carry included); "
                          "ladder-x: x(k*P) only, the constant-time ladder without its Z coordinate (P-256; ECDH's shared secret; affine-level parity); "
                          "windowed: variable base with per-element tables of 8 multiples of P and signed 4-bit windows, affine out (ALG_WINDOWED; affine-level parity); "
-                         "windowed-ct: the same with ALG_CONSTANT_TIME (every entry of the lane's table read in every window; no GLV split): secret scalars; "
+                         "windowed-ct: the same with ALG_CONSTANT_TIME (every entry of the lane's table read in every window; secp256k1 keeps the GLV split, on the complete addition law): secret scalars; "
                          "fixed-base: k*G with the 4-bit-window LDS table + simultaneous inversion, affine out (BASELINE configs[2]); "
                          "fixed-base-ct: the same kernel with ALG_CONSTANT_TIME (every table entry read, kept under lane masks: safe for secret scalars); "
                          "fixed-base-signed: the same with signed 7-bit windows (36 additions instead of 63); "

@@ -765,10 +765,11 @@ int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, co
     // per-lane window tables (8 multiples of P) in HBM + signed 4-bit windows (k_varwin.inc): a different algorithm from
     // the reference ladder, so affine output only (SURVEY.md 8(a) level A)
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
-    if ((flags & ECSIMD_HIP_ALG_CONSTANT_TIME) && (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED)) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED");
+    if ((flags & ECSIMD_HIP_ALG_CONSTANT_TIME) && (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED)) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED only, not ALG_WINDOWED_SIGNED");
     NO_COMPAT("ALG_WINDOWED");
     return run_varwin(ctx, curve, k, 4, x, y, ox, oy, n, flags, 0);
   }
+  if (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED (the ladder is constant-time as it is)");
   return run_ladder(ctx, curve, k, 4, x, y, ox, oy, oz, n, flags); }
 int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[4], const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy); if (!k1) return bad(ctx, "k1 is null");
@@ -780,10 +781,11 @@ int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[
   store_words(ctx->stream, w, kdev);
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED)) {
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
-    if ((flags & ECSIMD_HIP_ALG_CONSTANT_TIME) && (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED)) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED");
+    if ((flags & ECSIMD_HIP_ALG_CONSTANT_TIME) && (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED)) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED only, not ALG_WINDOWED_SIGNED");
     NO_COMPAT("ALG_WINDOWED");
     return run_varwin(ctx, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, n, flags, 0);
   }
+  if (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED (the ladder is constant-time as it is)");
   return run_ladder(ctx, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, oz, n, flags); }
 int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy);
@@ -796,7 +798,7 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* 
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
     const bool ct = (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) != 0;
     if (ct && !(ECS_FIXED4_ODD && ECS_SIGNED_ODD)) return bad(ctx, "this build (-DECS_FIXED4_ODD=0 / -DECS_SIGNED_ODD=0) has no constant-time comb");
-    if (ct && (big || six)) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED (the 4-bit table in LDS) only");
+    if (ct && (big || six)) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED only (its own 5-bit comb in LDS), not ALG_WINDOWED_SIGNED / ALG_WINDOWED_BIG");
     NO_COMPAT("ALG_WINDOWED");
     if (n == 0) return ECSIMD_HIP_OK;
     (void)hipSetDevice(ctx->device);

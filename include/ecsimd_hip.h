@@ -111,8 +111,10 @@ enum {
                                       scalar_mult / scalar_mult_1s: the per-element window tables with all 8 entries of the lane's own table (512
                                       contiguous bytes) read in every window; on secp256k1 the GLV split stays, run on the COMPLETE addition law of
                                       a = 0 curves (no exceptional case to branch on; ALG_NO_ENDOMORPHISM: the plain odd-digit loop).  ECDH with a
-                                      secret scalar at 1.45x (P-256: 70.4 M/s) / 1.74x (secp256k1: 84.4 M/s) the ladder's rate, 1.28x the P-256
-                                      ladder without Z (oy = NULL works here too).  Not with ALG_WINDOWED_SIGNED / ALG_WINDOWED_BIG (64 or 2^19 entries per window to read) */
+                                      secret scalar at 1.26x (P-256: 71.8 M/s) / 1.49x (secp256k1: 86.0 M/s) the round-4 ladder's rate
+                                      (oy = NULL works here too).  Not with ALG_WINDOWED_SIGNED / ALG_WINDOWED_BIG (64 or 2^19 entries per window to read).
+                                      Without ALG_WINDOWED the flag is refused by every entry point (the ladder is constant-time as it is);
+                                      double_scalar_mult / ecdsa_verify* take no flags: they are for public data */
   ECSIMD_HIP_LADDER_RADIX32 = 256, /* ladder only (r4): run the 254 iterations on 8 x 32-bit canonical words (the kernel of rounds 1-3) instead of the
                                       reduced-radix loop (nine signed 29-bit limbs, carry-free columns: fe29.cuh) that is the default since round 4.
                                       The field values of every iteration are the same, so X, Y, Z are bit-identical; kept for A/B measurements.

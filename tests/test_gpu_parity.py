@@ -513,8 +513,12 @@ def test_constant_time_fixed_base(engine, oracle, cv):
     for flags in (OUT_AFFINE | ALG_WINDOWED_SIGNED | ALG_CONSTANT_TIME, OUT_AFFINE | ALG_WINDOWED_BIG | ALG_CONSTANT_TIME, OUT_AFFINE | ALG_CONSTANT_TIME):
         with pytest.raises(EcsimdHipError, match="ALG_CONSTANT_TIME"):
             engine.scalar_mult_base(cv, k[:64].contiguous(), flags=flags)
-    with pytest.raises(EcsimdHipError, match="ALG_CONSTANT_TIME"):
-        engine.scalar_mult(cv, k[:64].contiguous(), ct[0][:64].contiguous(), ct[1][:64].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED_SIGNED | ALG_CONSTANT_TIME)
+    # the same rule at every entry point: the flag modifies ALG_WINDOWED and nothing else -- not the signed / big tables, not the ladder
+    for flags in (OUT_AFFINE | ALG_WINDOWED_SIGNED | ALG_CONSTANT_TIME, OUT_AFFINE | ALG_CONSTANT_TIME, ALG_CONSTANT_TIME):
+        with pytest.raises(EcsimdHipError, match="ALG_CONSTANT_TIME"):
+            engine.scalar_mult(cv, k[:64].contiguous(), ct[0][:64].contiguous(), ct[1][:64].contiguous(), flags=flags)
+        with pytest.raises(EcsimdHipError, match="ALG_CONSTANT_TIME"):
+            engine.scalar_mult_1s(cv, from_int(12345), ct[0][:64].contiguous(), ct[1][:64].contiguous(), flags=flags)
 
 
 @pytest.mark.parametrize("cv", CURVES)
