@@ -956,6 +956,30 @@ int ecsimd_hip_ecdsa_verify(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, c
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, err, "ecdsa_verify launch"); }
 
+// Signing: R = k G on the constant-time comb (the kernel behind ALG_WINDOWED | ALG_CONSTANT_TIME), x only; then the scalar-field half.
+int ecsimd_hip_ecdsa_sign(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, const uint64_t* d, const uint64_t* k, uint64_t* r, uint64_t* s_, uint8_t* ok, size_t n) {
+  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(e); REQUIRE_PTR(d); REQUIRE_PTR(k); REQUIRE_PTR(r); REQUIRE_PTR(s_);
+  if (!ok && n) return bad(ctx, "ok is null");
+  if (ctx->ref_square) return bad(ctx, "ecdsa_sign is not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT form");
+  if (!(ECS_FIXED4_ODD && ECS_SIGNED_ODD)) return bad(ctx, "this build (-DECS_FIXED4_ODD=0 / -DECS_SIGNED_ODD=0) has no constant-time comb");
+  if (overlaps(r, e) || overlaps(r, d) || overlaps(r, k) || overlaps(s_, e) || overlaps(s_, d) || overlaps(s_, k) || overlaps(r, s_)) return bad(ctx, "r and s must not alias an input or each other");
+  if (n == 0) return ECSIMD_HIP_OK;
+  if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
+  (void)hipSetDevice(ctx->device);
+  gmod N; if (!lookup_modulus(curve == ECSIMD_HIP_P256 ? ECSIMD_HIP_FIELD_P256_ORDER : ECSIMD_HIP_FIELD_SECP256K1_ORDER, &N)) return bad(ctx, "group order missing from the registry");
+  const int ctbits = curve == ECSIMD_HIP_P256 ? CT_WBITS : CT_WBITS_SECP;
+  if (!ctbits) return bad(ctx, "this build has no 5- / 6-bit constant-time comb");
+  int rc = ensure_window_table(ctx, curve, ctbits);
+  if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 4 * n * 32);
+  if (rc != ECSIMD_HIP_OK) return rc;
+  uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n; uint64_t* rx = jz + 4 * n;
+  hipStream_t st = ctx->stream;
+  launch::base_windowed_signed(st, curve, ctbits, k, ctx->windowct_table[curve], jx, jy, jz, n, true);      // k >= n is reduced by the comb; the lane is refused below
+  launch::to_affine_batched(st, curve, jx, jy, jz, rx, nullptr, n, true);
+  launch::ecdsa_sign_scalars(st, N, e, d, k, rx, r, s_, ok, n);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, err, "ecdsa_sign launch"); }
+
 int ecsimd_hip_scalar_mult_p256(ecsimd_hip_ctx* ctx, const uint64_t* k, const uint64_t* xm, const uint64_t* ym, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) {
   return ecsimd_hip_scalar_mult(ctx, ECSIMD_HIP_P256, k, xm, ym, ox, oy, oz, n, ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN); }
 

@@ -164,12 +164,14 @@ template <> struct r29_consts<CURVE_P256> {
   static constexpr int32_t P[9]   = {0x1fffffff, 0x1fffffff, 0x1fffffff, 0x000001ff, 0x00000000, 0x00000000, 0x00040000, 0x1fe00000, 0x00ffffff};
   static constexpr int32_t IN[9]  = {0x00000400, 0x00000000, 0x00000000, 0x1ff80000, 0x1fffffff, 0x1fffffff, 0x0fffffff, 0x1fffffff, 0x00000003};
   static constexpr int32_t OUT[9] = {0x00000001, 0x00000000, 0x00000000, 0x1ffffe00, 0x1fffffff, 0x1fffffff, 0x1ffbffff, 0x001fffff, 0x00000000};
+  static constexpr int32_t ONE[9] = {0x00000020, 0x00000000, 0x00000000, 0x1fffc000, 0x1fffffff, 0x1fffffff, 0x1f7fffff, 0x03ffffff, 0x00000000};   // 2^261 mod p: the field's 1
 };
 template <> struct r29_consts<CURVE_SECP256K1_CLASSICAL> {
   // the secp256k1 loops run in the CLASSICAL domain of field.cuh: in = 2^522 mod p (x -> x * 2^261), out = 1
   static constexpr int32_t P[9]   = {0x1ffffc2f, 0x1ffffff7, 0x1fffffff, 0x1fffffff, 0x1fffffff, 0x1fffffff, 0x1fffffff, 0x1fffffff, 0x00ffffff};
   static constexpr int32_t IN[9]  = {0x1a428400, 0x00f44001, 0x00010000, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000};
   static constexpr int32_t OUT[9] = {0x00000001, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000};
+  static constexpr int32_t ONE[9] = {0x00007a20, 0x00000100, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000, 0x00000000};   // 2^261 mod p = 32 (2^32 + 977)
 };
 template <const int32_t (&ARR)[9]> ECS_DEV fe29 fe29_const() { fe29 r;
 #pragma unroll
@@ -180,9 +182,8 @@ template <int C> ECS_DEV fe29 enter29(const fe& v) { return mul29<C>(to29(v), fe
 // ... and back: the canonical residue of field.cuh's domain.  `v` is anything the loop holds (|value| < 8 p): the product with a
 // tight constant < p lies in (-p/4, 9p/8), + p makes it positive, a sequential carry pass makes the limbs tight, and two
 // conditional subtractions of p (sign of the top limb after a borrow pass) land in [0, p).
-template <int C> ECS_DEV fe leave29(const fe29& v) {
+template <int C> ECS_DEV fe canon29(fe29 t) {                        // a value in (-p, 9p/8): + p, carry pass, two conditional subtractions
   using K = r29_consts<C>;
-  fe29 t = mul29<C>(v, fe29_const<K::OUT>());
 #pragma unroll
   for (int i = 0; i < R29_LIMBS; ++i) t.l[i] += K::P[i];
 #pragma unroll
@@ -200,6 +201,7 @@ template <int C> ECS_DEV fe leave29(const fe29& v) {
   }
   return from29(t);
 }
+template <int C> ECS_DEV fe leave29(const fe29& v) { return canon29<C>(mul29<C>(v, fe29_const<r29_consts<C>::OUT>())); }
 
 // ---------------------------------------------------------------- the ladder iteration
 // Loop state: the co-Z pair (x1, y1), (x2, y2) with y2 kept as dy = y1 - y2 and dx = x1 - x2 carried beside x1, x2 -- differences of
@@ -241,5 +243,39 @@ template <int C> ECS_DEV void zdau29(coz29& s, uint32_t oswap) {
   s.y1 = sub29(P1, A1);
   s.dy = sub29(P1, P2);
 }
+
+
+// ---------------------------------------------------------------- the combs' mixed addition (round 4)
+// A Jacobian accumulator (X, Y, Z) + an affine table point (x2, y2), Hankerson-Menezes-Vanstone Alg. 3.22 as point.cuh madd_hmv<C> (8M + 3S),
+// on the reduced-radix representation.  Invariant of the accumulator (tools/radix29_model.py comb_invariant, proven by prove_comb_invariant:
+// one madd29 maps it into itself with every limb inside int32 and every column inside int64): X limbs in [-3, 1] x 2^29, Y in [-1, 1] x 2^29,
+// Z tight; table coordinates tight, y possibly negated.  Three carry passes: H and r feed squares, V - X3 is 31 bits wide before its product.
+struct jpoint29 { fe29 x, y, z; };
+template <int C> ECS_DEV jpoint29 madd29(const jpoint29& P, const fe29& x2, const fe29& y2) {
+  const fe29 Z1Z1 = sqr29<C>(P.z);
+  const fe29 U2 = mul29<C>(x2, Z1Z1);
+  const fe29 S2 = mul29<C>(y2, mul29<C>(Z1Z1, P.z));
+  const fe29 H = norm29(sub29(U2, P.x));
+  const fe29 r = norm29(sub29(S2, P.y));
+  const fe29 HH = sqr29<C>(H);
+  const fe29 HHH = mul29<C>(H, HH);
+  const fe29 V = mul29<C>(P.x, HH);
+  jpoint29 R;
+  R.z = mul29<C>(P.z, H);
+  R.x = sub29(sub29(sqr29<C>(r), HHH), dbl29(V));
+  R.y = sub29(mul29<C>(r, norm29(sub29(V, R.x))), mul29<C>(P.y, HHH));
+  return R;
+}
+// -a where m is all ones, a where it is zero: (a ^ m) - m, two full-rate instructions per limb
+ECS_DEV fe29 cneg29(uint32_t m, const fe29& a) { fe29 r;
+#pragma unroll
+  for (int i = 0; i < R29_LIMBS; ++i) r.l[i] = (a.l[i] ^ (int32_t)m) - (int32_t)m;
+  return r; }
+ECS_DEV fe29 select29(uint32_t m, const fe29& a, const fe29& b) { fe29 r;                 // m ? a : b
+#pragma unroll
+  for (int i = 0; i < R29_LIMBS; ++i) r.l[i] = b.l[i] ^ ((a.l[i] ^ b.l[i]) & (int32_t)m);
+  return r; }
+// a table coordinate: the canonical fast-domain element v  ->  the canonical residue of v * 2^261 as 8 words; to29 gives tight limbs back at the read
+template <int C> ECS_DEV fe pack29(const fe& v) { return canon29<C>(enter29<C>(v)); }     // enter29 returns a value in [0, 1.04 p): canonicalised, it fits 8 words
 
 }  // namespace ecsimd_hip

@@ -139,6 +139,60 @@ __global__ void __launch_bounds__(256) k_ecdsa_scalars(gmod M, const uint64_t* _
     fe_store(u2, e, b);
   }
 }
+
+// ECDSA signing, the arithmetic modulo the group order (SEC 1 v2 4.1.3 steps 3-6; M = n's gmod): given the digest e, the private key d, the
+// nonce k and x = x(k G) (classical, < p < 2n),
+//   r = x mod n,   s = k^-1 (e + r d) mod n,   ok = 1 <= d, k < n  and  r != 0  and  s != 0      (r = s = 0 where not ok: a new nonce is the caller's).
+// d and k are SECRETS: everything here is selects and the branch-free generic field functions (g_mul, g_add, the division-step inversion, whose
+// control flow and addresses do not depend on their operands); the shared inversion multiplies the nonces of one lane's m elements together, which
+// reveals nothing outside the lane.  Seven generic Montgomery products per signature + 1/m inversion; s[] carries the prefix products on the way up.
+__global__ void __launch_bounds__(256) k_ecdsa_sign_scalars(gmod M, const uint64_t* __restrict__ ev, const uint64_t* __restrict__ dv, const uint64_t* __restrict__ kv,
+                                                            const uint64_t* __restrict__ xv, uint64_t* __restrict__ rv, uint64_t* __restrict__ sv,
+                                                            uint8_t* __restrict__ okv, size_t n, size_t lanes, int m) {
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= lanes) return;
+  const fe N = g_words(M.p);
+  fe one;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) one.w[j] = (j == 0) ? 1u : 0u;
+  auto in_range = [&](const fe& v) { return (uint32_t)(!g_is_zero(v)) & (uint32_t)g_less(v, N); };
+  fe acc = one;
+  for (int j = 0; j < m; ++j) {
+    const size_t e = (size_t)j * lanes + g;
+    if (e >= n) break;                                     // (a bound on the public batch length)
+    const fe k = fe_load(kv, e);
+    const uint32_t good = 0u - in_range(k);
+    const fe kk = fe_select(good, k, one);
+    acc = (j == 0) ? kk : g_mul(acc, kk, M);               // acc_0 = k_0, acc_j = acc_(j-1) k_j / R  (k_ecdsa_scalars has the algebra)
+    fe_store(sv, e, acc);
+  }
+  fe inv = g_inverse_plain(acc, M);
+  int last = m - 1;
+  while (last >= 0 && (size_t)last * lanes + g >= n) --last;
+  const fe rsq = g_words(M.rsq);
+  for (int j = last; j >= 0; --j) {
+    const size_t e = (size_t)j * lanes + g;
+    const fe k = fe_load(kv, e), d = fe_load(dv, e);
+    const uint32_t good = in_range(k) & in_range(d);
+    const fe kk = fe_select(0u - in_range(k), k, one);
+    fe w;
+    if (j > 0) { w = g_mul(inv, fe_load(sv, (size_t)(j - 1) * lanes + g), M); inv = g_mul(inv, kk, M); }
+    else w = inv;                                          // k^-1, plain
+    fe r = fe_load(xv, e);
+    g_cond_sub(r, 0, M);                                   // x < p < 2n: one conditional subtraction reduces it
+    fe em = fe_load(ev, e);
+    g_cond_sub(em, 0, M);                                  // e < 2^256 < 2n
+    const fe rd = g_mul(g_mul(r, d, M), rsq, M);           // r d mod n
+    const fe t = g_add(em, rd, M);
+    fe s = g_mul(g_mul(w, rsq, M), t, M);                  // (k^-1 R) t / R
+    const uint32_t ok = good & (uint32_t)(!g_is_zero(r)) & (uint32_t)(!g_is_zero(s));
+    const uint32_t keep = 0u - ok;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { r.w[q] &= keep; s.w[q] &= keep; }
+    fe_store(rv, e, r); fe_store(sv, e, s);
+    okv[e] = (uint8_t)ok;
+  }
+}
 }  // namespace
 
 namespace launch {
@@ -184,6 +238,10 @@ void gfield_inverse_batched(hipStream_t s, const gmod& M, const uint64_t* a, uin
 void ecdsa_scalars(hipStream_t s, const gmod& M, const uint64_t* e, const uint64_t* r, const uint64_t* sg, uint64_t* u1, uint64_t* u2, uint8_t* valid, size_t n) {
   size_t lanes, m; batch_shape(n, lanes, m);
   hipLaunchKernelGGL(k_ecdsa_scalars, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, M, e, r, sg, u1, u2, valid, n, lanes, (int)m);
+}
+void ecdsa_sign_scalars(hipStream_t s, const gmod& M, const uint64_t* e, const uint64_t* d, const uint64_t* k, const uint64_t* x, uint64_t* r, uint64_t* sg, uint8_t* ok, size_t n) {
+  size_t lanes, m; batch_shape(n, lanes, m);
+  hipLaunchKernelGGL(k_ecdsa_sign_scalars, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, M, e, d, k, x, r, sg, ok, n, lanes, (int)m);
 }
 }  // namespace launch
 }  // namespace ecsimd_hip

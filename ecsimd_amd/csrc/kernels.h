@@ -61,6 +61,8 @@ void gfield_sqrt(hipStream_t, const gmod&, const uint64_t* a, uint64_t* out, uin
 void gfield_inverse_batched(hipStream_t, const gmod&, const uint64_t* a, uint64_t* out, size_t n);   // prime modulus; out must not alias a
 // ECDSA verification's arithmetic modulo the group order (gmod of n): valid = 1 <= r, s < n; u1 = e / s, u2 = r / s (0, 0 where invalid)
 void ecdsa_scalars(hipStream_t, const gmod& order, const uint64_t* e, const uint64_t* r, const uint64_t* s, uint64_t* u1, uint64_t* u2, uint8_t* valid, size_t n);
+// ECDSA signing's arithmetic modulo the group order: r = x mod n, s = (e + r d) / k; ok = the inputs are in range and r, s != 0 (secret d, k: selects only)
+void ecdsa_sign_scalars(hipStream_t, const gmod& order, const uint64_t* e, const uint64_t* d, const uint64_t* k, const uint64_t* x, uint64_t* r, uint64_t* s, uint8_t* ok, size_t n);
 
 // k_point_<curve>.hip
 void from_affine(hipStream_t, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n);

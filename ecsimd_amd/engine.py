@@ -353,6 +353,12 @@ class Engine:
         self._call("ecdsa_verify", C.c_int(curve), self._ptr(e), self._ptr(r), self._ptr(s), self._ptr(qx), self._ptr(qy), self._ptr(ok, 0), C.c_size_t(n))
         return ok
 
+    def ecdsa_sign(self, curve, e, d, k):
+        """ecsimd_hip_ecdsa_sign: (r, s, ok) for digests e, private keys d and caller-supplied nonces k."""
+        n = e.shape[0]; r, s, ok = self.empty(n), self.empty(n), self.flags(n)
+        self._call("ecdsa_sign", C.c_int(curve), self._ptr(e), self._ptr(d), self._ptr(k), self._ptr(r), self._ptr(s), self._ptr(ok, 0), C.c_size_t(n))
+        return r, s, ok
+
     def scalar_mult_p256(self, k, xm, ym, out=None):
         n = k.shape[0]
         r = out if out is not None else [self.empty(n) for _ in range(3)]

@@ -133,6 +133,15 @@ struct curve_group {
     hip::check(ecsimd_hip_ecdsa_verify(hip::context(), curve_id, e.data(), r.data(), s.data(), Q.x().data(), Q.y().data(), ok.data(), Q.size()), "ecsimd_hip_ecdsa_verify");
     return ok;
   }
+  // ECDSA signing (SEC 1 v2 4.1.3): digests e, private keys d, the CALLER's nonces k (RFC 6979 or a DRBG).  Returns (r, s); ok[i] is false -- and
+  // r = s = 0 -- where d or k is not in [1, n) or r or s came out zero.  k G runs on the constant-time comb; no branch or address depends on d or k.
+  static std::pair<WBN, WBN> ecdsa_sign(WBN const& e, WBN const& d, WBN const& k, hip::mask& ok) {
+    same_length(e.size(), d.size(), "ecdsa_sign"); same_length(k.size(), d.size(), "ecdsa_sign");
+    auto r = WBN::uninitialized(d.size()), s = WBN::uninitialized(d.size());
+    ok = hip::mask(d.size());
+    hip::check(ecsimd_hip_ecdsa_sign(hip::context(), curve_id, e.data(), d.data(), k.data(), r.data(), s.data(), ok.data(), d.size()), "ecsimd_hip_ecdsa_sign");
+    return {r, s};
+  }
   // ---- several GPUs: k[i] * P[i] for HOST arrays, sharded over a device group.  P affine classical (x, y);
   // the result is what scalar_mult(x, from_affine(P)) returns lane by lane -- Jacobian, Montgomery form -- or, with
   // affine_out, what .to_affine() of it returns.  Member m computes the slice device_group::shard_range(n, m, size());

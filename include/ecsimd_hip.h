@@ -318,6 +318,14 @@ int ecsimd_hip_ecdsa_verify_rx(ecsimd_hip_ctx*, int curve, const uint64_t* u1, c
  * ecdsa_verify_rx's kernels.  Public data only (the window kernels index tables by scalar digits).  Workspace: ecdsa_verify_rx's plus 65 B per element. */
 int ecsimd_hip_ecdsa_verify(ecsimd_hip_ctx*, int curve, const uint64_t* e, const uint64_t* r, const uint64_t* s, const uint64_t* qx, const uint64_t* qy,
                             uint8_t* ok, size_t n);
+/* ECDSA signing of n digests (SEC 1 v2 4.1.3; not in the reference): e = the digest as an integer, d = the private key, k = the per-signature nonce --
+ * the CALLER's (RFC 6979 or a DRBG: this library has no hash and no random source), 1 <= d, k < n.  R = k G comes from the constant-time comb (the kernel
+ * of ALG_WINDOWED | ALG_CONSTANT_TIME), r = x(R) mod n, s = k^-1 (e + r d) mod n on the device (generic Montgomery products on the order's field id, one
+ * constant-time division-step inversion shared by up to 128 signatures).  ok[i] = 1 and (r, s) a valid signature, or ok[i] = 0 and r = s = 0 where d or k is
+ * out of range or r or s came out 0 (probability ~2^-255: sign again with another nonce).  d and k are treated as SECRETS: no branch or address depends on
+ * them (the comb's window loop is checked on the ISA, the scalar-field kernel is selects and branch-free field functions; not pinned on the ISA).
+ * r, s must not alias an input.  Workspace: 128 B per element. */
+int ecsimd_hip_ecdsa_sign(ecsimd_hip_ctx*, int curve, const uint64_t* e, const uint64_t* d, const uint64_t* k, uint64_t* r, uint64_t* s, uint8_t* ok, size_t n);
 /* lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P) -- P-256, base in Montgomery form with
  * Z = mgry(1), Jacobian Montgomery output. */
 int ecsimd_hip_scalar_mult_p256(ecsimd_hip_ctx*, const uint64_t* k, const uint64_t* xm, const uint64_t* ym,

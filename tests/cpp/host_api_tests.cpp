@@ -219,6 +219,18 @@ TEST(Ecdsa, Rfc6979Vectors) {
   EXPECT_TRUE(ok[0] == 1 && ok[1] == 1 && ok[2] == 0 && ok[3] == 0);
   const WCP off{splat<W256>(qx), splat<W256>(qx)};                                              // not a curve point
   EXPECT_TRUE(CG::ecdsa_verify(e, r, s, off).count() == 0);
+  // signing with the RFC's own nonces (A.2.5: k for "sample" and "test") reproduces its signatures; a zero nonce is refused
+  const auto x = "C9AFA9D845BA75166B5C215767B1D6934E50C3DB36E89B127B8A622B120F6721"_hex;
+  const auto k1 = "A6E3C57DD01ABE90086538398355DD4C3B17AA873382B0F24D6129493D8AAD60"_hex, k2 = "D16B6AE827F17175E040871A1C7EC3500192C4C92677336EC2537ACAEE0008E0"_hex;
+  hip::mask signed_ok;
+  const auto sig = CG::ecdsa_sign(lanes<W256>(e1, e2, e1, e2), splat<W256>(x), lanes<W256>(k1, k2, zero, k1), signed_ok);
+  const auto so = signed_ok.host();
+  EXPECT_TRUE(so[0] == 1 && so[1] == 1 && so[2] == 0 && so[3] == 1);
+  EXPECT_TRUE(sig.first.get(0) == bn_from_bytes_BE<bignum_256>(r1) && sig.second.get(0) == bn_from_bytes_BE<bignum_256>(s1));
+  EXPECT_TRUE(sig.first.get(1) == bn_from_bytes_BE<bignum_256>(r2) && sig.second.get(1) == bn_from_bytes_BE<bignum_256>(s2));
+  EXPECT_TRUE(sig.first.get(2) == bignum_256{} && sig.second.get(2) == bignum_256{});
+  const auto again = CG::ecdsa_verify(lanes<W256>(e1, e2, e1, e2), sig.first, sig.second, Q).host();
+  EXPECT_TRUE(again[0] == 1 && again[1] == 1 && again[2] == 0 && again[3] == 1);                // lane 3: "test" signed with the other nonce: valid all the same
 }
 
 // ------------------------------------------------------------------ tests/curve_point.cpp

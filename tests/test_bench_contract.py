@@ -206,10 +206,10 @@ def test_native_chatter_cannot_reach_stdout(tmp_path):
 
 
 def test_designs_results_table_is_the_committed_json():
-    """VERDICT r2 "record drift": DESIGN.md section 4's table is generated from profiles/r03/bench_n1_*.json."""
+    """VERDICT r2 "record drift": DESIGN.md section 4's table is generated from profiles/r04/bench_n1_*.json."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "results_table.py"), "r03", "--check"], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "results_table.py"), "r04", "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
 
 

@@ -224,6 +224,47 @@ def test_ecdsa_scalars_at_the_shared_inversion_sizes(engine, openssl, cv):
 
 
 @pytest.mark.parametrize("cv", CURVES)
+def test_ecdsa_sign_vs_big_ints_and_libcrypto(engine, openssl, cv):
+    """ecsimd_hip_ecdsa_sign (k G on the constant-time comb, r and s on the order's field id): (r, s) equal the textbook formulas on Python
+    integers with libcrypto's k G, libcrypto's ECDSA_do_verify and this library's own ecdsa_verify accept every one of them, out-of-range
+    d / k are refused with r = s = 0 -- at a size where several signatures share an inversion too."""
+    order = CURVE_PARAMS[cv]["n"]
+    up = engine.to_device
+    for n, seed in ((3001, 5), ((1 << 18) + 9, 6)):
+        rng = np.random.default_rng(seed + cv)
+        rnd = lambda: ints_to_arr([to_int(x) % (order - 1) + 1 for x in rng.integers(0, 2**64, size=(min(n, 4096), 4), dtype=np.uint64)])
+        tile = lambda v: np.tile(v, ((n + len(v) - 1) // len(v), 1))[:n].copy()
+        d, k = tile(rnd()), tile(rnd())
+        e = tile(rng.integers(0, 2**64, size=(min(n, 4096), 4), dtype=np.uint64))
+        e[:6] = ints_to_arr([0, 1, order - 1, order, 2**256 - 1, 2**255])
+        bad = {10: ("d", 0), 11: ("d", order), 12: ("k", 0), 13: ("k", order), 14: ("k", order + 5), 15: ("d", 2**256 - 1)}
+        for i, (which, v) in bad.items():
+            (d if which == "d" else k)[i] = from_int(v)
+        r, s, ok = (engine.to_numpy(t) for t in engine.ecdsa_sign(cv, up(e), up(d), up(k)))
+        good = np.ones(n, dtype=bool); good[list(bad)] = False
+        assert np.array_equal(ok == 1, good)
+        assert not r[~good].any() and not s[~good].any()
+        m = 2048                                                    # the textbook formulas on a sample, with libcrypto's k G
+        idx = np.concatenate([np.arange(64), rng.choice(n, m - 64, replace=False)]); idx = idx[good[idx]]
+        kx, _, inf = openssl.scalar_mult_base(cv, k[idx], threads=THREADS)
+        assert not inf.any()
+        for j, i in enumerate(idx):
+            rr = to_int(kx[j]) % order
+            ss = pow(to_int(k[i]), -1, order) * (to_int(e[i]) + rr * to_int(d[i])) % order
+            assert (to_int(r[i]), to_int(s[i])) == (rr, ss), i
+        qx, qy, _ = openssl.scalar_mult_base(cv, d[idx], threads=THREADS)
+        assert openssl.ecdsa_verify(cv, e[idx], r[idx], s[idx], qx, qy, threads=THREADS).all()
+        assert engine.to_numpy(engine.ecdsa_verify(cv, up(e[idx]), up(r[idx]), up(s[idx]), up(qx), up(qy))).all()
+    if cv == P256:                                                  # RFC 6979 A.2.5, SHA-256, "sample": the nonce is the RFC's k
+        x = 0xC9AFA9D845BA75166B5C215767B1D6934E50C3DB36E89B127B8A622B120F6721
+        kk = 0xA6E3C57DD01ABE90086538398355DD4C3B17AA873382B0F24D6129493D8AAD60
+        ee = 0xAF2BDBE1AA9B6EC1E2ADE1D694F41FC71A831D0268E9891562113D8A62ADD1BF
+        r, s, ok = (engine.to_numpy(t) for t in engine.ecdsa_sign(cv, up(ints_to_arr([ee])), up(ints_to_arr([x])), up(ints_to_arr([kk]))))
+        assert ok[0] == 1 and to_int(r[0]) == 0xEFD48B2AACB6A8FD1140DD9CD45E81D69D2C877B56AAF991C34D0EA84EAF3716
+        assert to_int(s[0]) == 0xF7CB1C942D657C41D436C7A1B6E29F65F3E900DBB9AFF4064DC4AB2F843ACDA8
+
+
+@pytest.mark.parametrize("cv", CURVES)
 def test_scalar_field_arithmetic_against_big_ints(gpu, cv):
     """u1 = e / s, u2 = r / s mod n by the public field entry points on the group-order field id: what ecdsa_verify computes inside."""
     from ecsimd_amd.engine import ORDER_FIELD

@@ -84,3 +84,55 @@ def test_montgomery_product_and_square_on_extreme_limbs(cv):
         assert all(0 <= x <= m.M29 for x in r[:8])
         s = E.sqr(b)
         assert (m.from_limbs(s) * R - m.from_limbs(b) ** 2) % p == 0
+
+
+# ---------------------------------------------------------------- the combs' mixed addition (fe29.cuh madd29)
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_one_comb_addition_maps_its_invariant_into_itself_without_overflow(cv):
+    r = m.prove_comb_invariant(cv)
+    assert r["worst_column_bits"] <= 63 and r["worst_limb_bits"] <= 31
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_comb_addition_needs_all_three_carry_passes(cv):
+    """Dropping the pass on H overflows a doubled limb on both curves; on P-256 dropping either of the other two overflows a column -- so the
+    device function keeps all three on both curves."""
+    def variant(nH, nr, nv):
+        def f(E, X1, Y1, Z1, x2, y2):
+            N = lambda on, v: E.norm(v) if on else v
+            Z1Z1 = E.sqr(Z1); U2 = E.mul(x2, Z1Z1); S2 = E.mul(y2, E.mul(Z1Z1, Z1))
+            H = N(nH, E.sub(U2, X1)); r = N(nr, E.sub(S2, Y1))
+            HH = E.sqr(H); HHH = E.mul(H, HH); V = E.mul(X1, HH)
+            X3 = E.sub(E.sub(E.sqr(r), HHH), E.dbl(V))
+            return X3, E.sub(E.mul(r, N(nv, E.sub(V, X3))), E.mul(Y1, HHH)), E.mul(Z1, H)
+        return f
+    inv = m.comb_invariant(cv)
+    c = lambda k: m.Iv(inv[k].l, inv[k].v)
+    for flags in ((0, 1, 1), (1, 0, 0)) + (((1, 0, 1), (1, 1, 0)) if cv is m.CURVE_P256 else ()):
+        with pytest.raises(AssertionError, match="overflow"):
+            variant(*flags)(m.Bounds(cv), c("X"), c("Y"), c("Z"), c("tx"), c("ty"))
+    variant(1, 1, 1)(m.Bounds(cv), c("X"), c("Y"), c("Z"), c("tx"), c("ty"))
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_exact_comb_additions_equal_the_big_int_formulas(cv):
+    """A comb's life on concrete integers with the machine limits asserted: start from a table entry, 64 additions of tight (x, +-y) in a row
+    (extreme and random coordinates: they need not be curve points, the formulas are a DAG over GF(p)), against the formulas mod p."""
+    rng = random.Random(61)
+    p = cv.p; R = 1 << m.RBITS; Rinv = pow(R, -1, p)
+    E = m.Exact(cv)
+    tight = lambda v: m.to_limbs(v * R % p)
+    val = lambda l: m.from_limbs(l) * Rinv % p
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (1 << 255) % p, (1 << 232) - 1, 1 << 232, m.M29]
+    for trial in range(40):
+        pick = (lambda: rng.choice(edge)) if trial < 10 else (lambda: rng.randrange(p))
+        x, y = pick(), pick()
+        X, Y, Z = tight(x), tight(y), tight(1)
+        fx, fy, fz = x, y, 1
+        for _ in range(64):
+            x2, y2 = pick(), pick()
+            neg = rng.getrandbits(1)
+            ty = [-v for v in tight(y2)] if neg else tight(y2)
+            X, Y, Z = m.madd29(E, X, Y, Z, tight(x2), ty)
+            fx, fy, fz = m.madd_field(p, fx, fy, fz, x2, (-y2) % p if neg else y2)
+            assert (val(X), val(Y), val(Z)) == (fx, fy, fz)

@@ -88,6 +88,8 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     row(f"ecdsa_verify_rx<{nm}> (u1, u2 given)", n2, timeit(lambda: e.ecdsa_verify_rx(cv, u1, k, b2x, b2y, u1), 5), dsm, 161, "verifications")
     rr = e.fill_random(n2, SEED, 22, clear_top_bits=1); ss = e.fill_random(n2, SEED, 23, clear_top_bits=1)
     row(f"ecdsa_verify<{nm}> (e, r, s, Q -> ok: mod-n arithmetic on the device)", n2, timeit(lambda: e.ecdsa_verify(cv, u1, rr, ss, b2x, b2y), 5), dsm + 6 * 136, 161, "verifications")
+    row(f"ecdsa_sign<{nm}> (e, d, k -> r, s: k G on the constant-time comb + mod-n arithmetic on the device)", n2, timeit(lambda: e.ecdsa_sign(cv, u1, rr, ss), 5),
+        int((51 * 11 + 9 + 7) * 136), 160, "signatures")
     from ecsimd_amd.engine import ORDER_FIELD
     fo = ORDER_FIELD[cv]
     row(f"mgry_mul<order of {nm}> (run-time modulus, generic reduction)", n2, timeit(lambda: e.mgry_mul(fo, rr, ss)), 136, 96, "field mults")

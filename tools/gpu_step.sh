@@ -33,6 +33,19 @@ import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value
     bash tools/profile_calib.sh r04 > "$out/calib.txt" 2>&1; rc=$?; tail -12 "$out/calib.txt"
     [ $rc -eq 0 ] && TRAFFIC_EXTRA_COUNTERS="TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_sum" bash tools/profile_traffic.sh r04 ${@:-windowed windowed-ct} > "$out/traffic.txt" 2>&1; rc=$?; tail -8 "$out/traffic.txt"
     exit $rc ;;
+  soak)             # the ladder (default: radix 29; and REF_SQUARE_COMPAT) against the compiled reference: tools/soak.py <log2 lanes> <batches>
+    timeout -k 10 1000 python tools/soak.py ${1:-23} ${2:-4} > "$out/soak.txt" 2>&1; rc=$?; tail -12 "$out/soak.txt"; exit $rc ;;
+  bench_all)        # every bench line profiles/rNN keeps
+    bash tools/bench_all.sh ${1:-r04} > "$out/bench_all.txt" 2>&1; rc=$?; cat "$out/bench_all.txt" | head -30; exit $rc ;;
+  comb29)           # round 4: the combs' additions on 29-bit limbs -- every test that runs a comb, then A/B against the radix-32 build (build/ab_comb32)
+    timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fields.py tests/test_openssl_crosscheck.py -x -q -m gpu \
+      -k "fixed_base or config3 or comb or exceptional or digit_pattern or small_base or openssl or ecdsa or double_scalar or constant_time or x_coordinate" > "$out/pytest.txt" 2>&1; rc=$?
+    tail -5 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
+    for w in fixed-base fixed-base-ct fixed-base-signed fixed-base-big; do for c in p256 secp256k1; do
+      echo "== $w $c" >> "$out/ab.txt"
+      timeout -k 10 300 python tools/ab_variants.py "--workload $w --curve $c --global-log2-batch 22 --steps 10 --warmup 2" radix29=base radix32=build/ab_comb32/libecsimd_hip.so >> "$out/ab.txt" 2>&1 || rc=$?
+    done; done
+    cat "$out/ab.txt"; exit $rc ;;
   secondary)        # tools/bench_kernels.py -> profiles/rNN/secondary_kernels.{json,txt}
     timeout -k 10 900 python tools/bench_kernels.py > "$out/secondary_kernels.json" 2> "$out/secondary_kernels.txt"; rc=$?; tail -70 "$out/secondary_kernels.txt"; exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it

@@ -287,6 +287,54 @@ def prove_invariant(curve=CURVE_P256):
     return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length(), "out": out}
 
 
+# ---------------------------------------------------------------------------------------------------------------- the combs' mixed addition
+def madd29(E, X1, Y1, Z1, x2, y2):
+    """fe29.cuh madd29<C>: Jacobian (X1, Y1, Z1) + affine (x2, y2), Hankerson-Menezes-Vanstone Alg. 3.22 as point.cuh madd_hmv (8M + 3S);
+    statement for statement the device function."""
+    Z1Z1 = E.sqr(Z1)
+    U2 = E.mul(x2, Z1Z1)
+    S2 = E.mul(y2, E.mul(Z1Z1, Z1))
+    H = E.norm(E.sub(U2, X1))
+    r = E.norm(E.sub(S2, Y1))
+    HH = E.sqr(H)
+    HHH = E.mul(H, HH)
+    V = E.mul(X1, HH)
+    Z3 = E.mul(Z1, H)
+    X3 = E.sub(E.sub(E.sqr(r), HHH), E.dbl(V))
+    Y3 = E.sub(E.mul(r, E.norm(E.sub(V, X3))), E.mul(Y1, HHH))
+    return X3, Y3, Z3
+
+
+def comb_invariant(curve=CURVE_P256):
+    """The accumulator of the fixed-base combs between two additions, and what a table read hands madd29: X = r^2 - HHH - 2V, Y a difference of
+    two products, Z a product; a table coordinate is to29 of a canonical residue (tight, value in [0, p)), its y possibly negated."""
+    p = curve.p
+    B = 1 << W
+    T8 = 1 << 27
+    lim = lambda lo, hi, vlo, vhi: Iv([(lo * B, hi * B)] * (NL - 1) + [(-T8, T8)], (vlo * p, vhi * p))
+    return {"X": lim(-3, 1, -8, 5), "Y": lim(-1, 1, -4, 4), "Z": lim(0, 1, -3, 4), "tx": lim(0, 1, 0, 1), "ty": lim(-1, 1, -1, 1)}
+
+
+def prove_comb_invariant(curve=CURVE_P256):
+    """One abstract madd29 from the invariant: no limb or column overflows, the sum lies inside the invariant again.  (The first entry -- tight
+    x, +-y, Z = the constant 2^261 mod p -- lies inside it trivially.)  All three carry passes are needed: without any one of them the proof fails."""
+    E = Bounds(curve)
+    inv = comb_invariant(curve)
+    c = lambda k: Iv(inv[k].l, inv[k].v)
+    X3, Y3, Z3 = madd29(E, c("X"), c("Y"), c("Z"), c("tx"), c("ty"))
+    assert X3.within(inv["X"]) and Y3.within(inv["Y"]) and Z3.within(inv["Z"]), (X3, Y3, Z3)
+    return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length()}
+
+
+def madd_field(p, X1, Y1, Z1, x2, y2):
+    """The same formulas on integers mod p (Jacobian x = X / Z^2, y = Y / Z^3)."""
+    Z1Z1 = Z1 * Z1 % p; U2 = x2 * Z1Z1 % p; S2 = y2 * Z1Z1 * Z1 % p
+    H = (U2 - X1) % p; r = (S2 - Y1) % p
+    HH = H * H % p; HHH = H * HH % p; V = X1 * HH % p
+    X3 = (r * r - HHH - 2 * V) % p
+    return X3, (r * (V - X3) - Y1 * HHH) % p, Z1 * H % p
+
+
 # ---------------------------------------------------------------------------------------------------------------- big-int ZDAU (field values)
 def zdau_field(p, x1, y1, x2, y2, z):
     """curve_group.h:120-153 on integers mod p (the values, whatever the representation)."""
@@ -310,3 +358,5 @@ if __name__ == "__main__":
         print(cv.name, "invariant holds; worst column 2^%d, worst limb 2^%d" % (r["worst_column_bits"], r["worst_limb_bits"]))
         for k, v in r["out"].items():
             print("  ", k, v)
+        c = prove_comb_invariant(cv)
+        print(cv.name, "comb invariant holds; worst column 2^%d, worst limb 2^%d" % (c["worst_column_bits"], c["worst_limb_bits"]))
