@@ -266,6 +266,71 @@ template <int C> ECS_DEV jpoint29 madd29(const jpoint29& P, const fe29& x2, cons
   R.y = sub29(mul29<C>(r, norm29(sub29(V, R.x))), mul29<C>(P.y, HHH));
   return R;
 }
+// ---------------------------------------------------------------- the variable-base window loop (round 4)
+// Doublings multiply by 3, 4 and 8, and on lazy limbs nothing ever takes a multiple of p away: a Montgomery product only divides by 2^261 ~ 32 p,
+// so values above ~10 p GROW from one doubling to the next.  vred29 is the missing piece: v -> v - k p with k = round(top limb / 2^24) -- the top
+// limb IS the value in units of 2^232, p is 2^24 of them -- through p's sparse signed form: five (secp256k1: three) full-rate limb updates, after
+// which |v| < p/2 + a few 2^232.  Applied to X3 and Y3 of every doubling and of the double-add, it closes the loop's invariant
+// (tools/radix29_model.py prove_window_invariant: limbs in [-2.25, 1.25] x 2^29, |value| <= 0.6 p, Z tight).
+template <int C> ECS_DEV fe29 vred29(fe29 a) {
+  const int32_t k = (a.l[8] + (1 << 23)) >> 24;
+  if constexpr (r29_prime<C>::p256) { a.l[0] += k; a.l[3] -= k << 9; a.l[6] -= k << 18; a.l[7] += k << 21; }
+  else { a.l[0] += 977 * k; a.l[1] += k << 3; }
+  a.l[8] -= k << 24;
+  return a;
+}
+// Jacobian doubling (a = -3: 4M + 4S, a = 0: 3M + 5S... the formulas of k_varwin.inc jdbl): YY = Y^2, G = 4 YY, B = X G, alpha = 3 (X - Z^2)(X + Z^2) | 3 X^2,
+// X3 = alpha^2 - 2 B, Y3 = alpha (B - X3) - 8 YY^2, Z3 = 2 Y Z.  (No halving here: 8 Y^4 is formed as 2 x (4 YY^2) by a shifting carry pass.)
+template <int C> ECS_DEV jpoint29 jdbl29(const jpoint29& P) {
+  const fe29 Yn = norm29(P.y);
+  const fe29 YY = sqr29<C>(Yn);
+  const fe29 G = norm29<2>(YY);
+  const fe29 B = mul29<C>(P.x, G);
+  fe29 t;
+  if constexpr (r29_prime<C>::p256) {
+    const fe29 delta = sqr29<C>(P.z);
+    t = mul29<C>(norm29(sub29(P.x, delta)), norm29(add29(P.x, delta)));
+  } else {
+    t = sqr29<C>(norm29(P.x));
+  }
+  const fe29 alpha = norm29(add29(dbl29(t), t));
+  jpoint29 R;
+  R.z = mul29<C>(dbl29(Yn), P.z);
+  const fe29 X3 = sub29(sqr29<C>(alpha), dbl29(B));
+  const fe29 E8 = dbl29(norm29<2>(sqr29<C>(YY)));
+  R.y = vred29<C>(sub29(mul29<C>(alpha, norm29(sub29(B, X3))), E8));
+  R.x = vred29<C>(X3);
+  return R;
+}
+// 2R + T for an affine T = (x2, y2) as (R + T) + R: the mixed addition's by-products X1 H^2, Y1 H^3 are R in the coordinates of R + T, so the second
+// addition is a co-Z one (k_varwin.inc dbl_add: 13M + 5S).
+template <int C> ECS_DEV jpoint29 dbl_add29(const jpoint29& P, const fe29& x2, const fe29& y2) {
+  const fe29 Z1Z1 = sqr29<C>(P.z);
+  const fe29 U2 = mul29<C>(x2, Z1Z1);
+  const fe29 S2 = mul29<C>(y2, mul29<C>(Z1Z1, P.z));
+  const fe29 H = norm29(sub29(U2, P.x));
+  const fe29 r = norm29(sub29(S2, P.y));
+  const fe29 HH = sqr29<C>(H);
+  const fe29 HHH = mul29<C>(H, HH);
+  const fe29 V = mul29<C>(P.x, HH);
+  const fe29 Yh = mul29<C>(P.y, HHH);
+  const fe29 X3 = sub29(sub29(sqr29<C>(r), HHH), dbl29(V));
+  const fe29 Y3 = sub29(mul29<C>(r, norm29(sub29(V, X3))), Yh);
+  const fe29 Z3 = mul29<C>(P.z, H);
+  const fe29 dx = norm29(sub29(X3, V));
+  const fe29 dy = norm29(sub29(Y3, Yh));
+  const fe29 Cc = sqr29<C>(dx);
+  const fe29 W1 = mul29<C>(X3, Cc);
+  const fe29 W2 = mul29<C>(V, Cc);
+  const fe29 A1 = mul29<C>(Y3, sub29(W1, W2));
+  jpoint29 Q;
+  const fe29 Qx = sub29(sub29(sqr29<C>(dy), W1), W2);
+  Q.y = vred29<C>(sub29(mul29<C>(dy, norm29(sub29(W1, Qx))), A1));
+  Q.x = vred29<C>(Qx);
+  Q.z = mul29<C>(Z3, dx);
+  return Q;
+}
+
 // -a where m is all ones, a where it is zero: (a ^ m) - m, two full-rate instructions per limb
 ECS_DEV fe29 cneg29(uint32_t m, const fe29& a) { fe29 r;
 #pragma unroll

@@ -231,6 +231,25 @@ def test_round3_lines_carry_traffic_and_the_full_cpu_baseline():
                 assert all(o["equals_the_restatement"] for o in c["config1_ops8"]["ops"].values())
 
 
+def test_round4_lines_carry_the_reference_compatible_rate_and_the_new_fractions():
+    """the default line times ECSIMD_HIP_REF_SQUARE_COMPAT at the same batch and compares it with the compiled reference on the
+    CPU leg's lanes -- 0 differing, or the run would have exited with EXIT_PARITY.  Round 4's ladder runs on 29-bit limbs: its algorithmic rate is
+    0.78-0.85 of the a-priori multiply peak (rounds 1-3: 0.68); the combs' additions do too."""
+    r4 = {os.path.basename(p)[len("bench_n1_"):-len(".json")]: json.load(open(p)) for p in LINES if os.sep + "r04" + os.sep in p}
+    assert len(r4) >= 19
+    rc = r4["ladder"]["ref_compat"]
+    assert rc["lanes_compared"] > 10 ** 6 and rc["lanes_differing"] == 0 and rc["steps"] >= 3
+    assert 40e6 < rc["value"] < r4["ladder"]["value"] and 0.55 < rc["frac_of_a_priori_peak"] < 0.7
+    assert "variable-base" in r4["ladder"]["config"]["workload"] and "2^24" in r4["ladder"]["config"]["workload"]
+    for name in ("ladder", "ladder_secp256k1", "group_mode"):
+        assert 54e6 < r4[name]["value"] < 64e6 and 0.75 < r4[name]["roofline"]["frac_of_a_priori_peak"] < 0.9, name
+    for name, d in r4.items():
+        assert d["roofline"]["traffic"] is not None and d["roofline"]["traffic"] > 0, name
+        assert d.get("parity_failures") is None, name
+    assert r4["fixed_base"]["value"] > 320e6 and r4["fixed_base_secp256k1"]["value"] > 320e6           # BASELINE configs[2] on the reduced radix (r3: 295)
+    assert r4["fixed_base_constant_time"]["value"] > 350e6 and r4["fixed_base_signed7"]["value"] > 530e6
+
+
 def test_the_group_leg_child_is_not_a_rank():
     """At N > 1 rank 0 starts `bench.py --multi group` in a child process; the child must not inherit RANK / WORLD_SIZE (it
     would refuse to run as "one of several ranks").  Without GPUs here it has to get as far as counting devices."""

@@ -113,7 +113,7 @@ def test_constant_time_fixed_base_kernel_reads_every_entry_and_branches_on_nothi
     entries of the window -- are addressed by loop-invariant registers and the counter; around the loop (first window, the
     exceptional scalar k*, k = 0 mod n) nothing branches on a lane mask once the scalar has been loaded."""
     rep = ct_check.check(affine_asm, "15k_base_windowedILb1E", allow_global_loads=0, allow_lds_reads=True)
-    assert rep["instructions"] > 2000 and rep["lds_reads"] == 32 and rep["scratch"] == 0 and rep["global_loads"] == []
+    assert rep["instructions"] > 1800 and rep["lds_reads"] == 32 and rep["scratch"] == 0 and rep["global_loads"] == []
     assert len(rep["branches"]) == 1 and re.match(r"s_cmpk?_(lg|eq)_[iu]32 s\d+, \S+ ; s_cbranch_scc[01] ", rep["branches"][0]), rep["branches"]
     assert ct_check.check_after_secret_load(affine_asm, "15k_base_windowedILb1E") > 2500
 
@@ -122,7 +122,7 @@ def test_constant_time_five_bit_comb(affine_asm):
     """What ALG_CONSTANT_TIME runs on a fixed base, both curves: k_base_windowed_s<5, true, 256> -- 16 entries x 4 reads per window, one branch,
     nothing else; the same template without the flag (a digit addresses the one read) is refused."""
     rep = ct_check.check(affine_asm, "k_base_windowed_sILi5ELb1ELi256E", allow_global_loads=0, allow_lds_reads=True)
-    assert rep["instructions"] > 2300 and rep["lds_reads"] == 64 and rep["scratch"] == 0 and rep["global_loads"] == []
+    assert rep["instructions"] > 1900 and rep["lds_reads"] == 64 and rep["scratch"] == 0 and rep["global_loads"] == []
     assert len(rep["branches"]) == 1 and re.match(r"s_cmpk?_(lg|eq|lt|gt|le|ge)_[iu]32 s\d+, \S+ ; s_cbranch_scc[01] ", rep["branches"][0]), rep["branches"]
     assert ct_check.check_after_secret_load(affine_asm, "k_base_windowed_sILi5ELb1ELi256E") > 2800
     with pytest.raises(ct_check.Violation, match="LDS address"):
