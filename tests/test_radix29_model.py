@@ -136,3 +136,54 @@ def test_exact_comb_additions_equal_the_big_int_formulas(cv):
             X, Y, Z = m.madd29(E, X, Y, Z, tight(x2), ty)
             fx, fy, fz = m.madd_field(p, fx, fy, fz, x2, (-y2) % p if neg else y2)
             assert (val(X), val(Y), val(Z)) == (fx, fy, fz)
+
+
+# ---------------------------------------------------------------- the variable-base window loop (fe29.cuh jdbl29, dbl_add29, vred29)
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_one_window_of_the_variable_base_loop_maps_its_invariant_into_itself(cv):
+    r = m.prove_window_invariant(cv)
+    assert r["worst_column_bits"] <= 63 and r["worst_limb_bits"] <= 31
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_exact_window_loop_equals_the_big_int_formulas(cv):
+    """63 windows in a row (three doublings and a double-add each) on concrete integers with the machine limits asserted, against the
+    Jacobian formulas mod p; coordinates are arbitrary field elements (the formulas are a DAG over GF(p))."""
+    rng = random.Random(97)
+    p = cv.p; R = 1 << m.RBITS; Rinv = pow(R, -1, p)
+    a = -3 if cv is m.CURVE_P256 else 0
+    E = m.Exact(cv)
+    tight = lambda v: m.to_limbs(v * R % p)
+    val = lambda l: m.from_limbs(l) * Rinv % p
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (1 << 255) % p, (1 << 232) - 1, 1 << 232, m.M29]
+    for trial in range(12):
+        pick = (lambda: rng.choice(edge)) if trial < 4 else (lambda: rng.randrange(p))
+        fx, fy, fz = pick(), pick(), 1
+        X, Y, Z = tight(fx), tight(fy), tight(1)
+        for _ in range(63):
+            for _ in range(3):
+                X, Y, Z = m.jdbl29(E, X, Y, Z)
+                fx, fy, fz = m.jdbl_field(p, a, fx, fy, fz)
+                assert (val(X), val(Y), val(Z)) == (fx, fy, fz)
+            x2, y2 = pick(), pick()
+            neg = rng.getrandbits(1)
+            ty = [-v for v in tight(y2)] if neg else tight(y2)
+            X, Y, Z = m.dbl_add29(E, X, Y, Z, tight(x2), ty)
+            fx, fy, fz = m.dbl_add_field(p, fx, fy, fz, x2, (-y2) % p if neg else y2)
+            assert (val(X), val(Y), val(Z)) == (fx, fy, fz)
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_without_the_value_reduction_the_doublings_grow(cv):
+    """Why vred29 exists: on lazy limbs no doubling ever takes a multiple of p away, and the constants 3, 4, 8 push values past the point
+    (~10 p) where a Montgomery product stops shrinking them -- the interval run overflows within a window."""
+    class NoRed(m.Bounds):
+        def vred(self, a):
+            return a
+    E = NoRed(cv)
+    inv = m.window_invariant(cv)
+    X, Y, Z = (m.Iv(inv[k].l, inv[k].v) for k in "XYZ")
+    with pytest.raises(AssertionError):
+        for _ in range(6):
+            X, Y, Z = m.jdbl29(E, X, Y, Z)
+            assert abs(X.v[0]) < 8 * cv.p and abs(X.v[1]) < 8 * cv.p, "value escapes"

@@ -46,6 +46,15 @@ import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value
       timeout -k 10 300 python tools/ab_variants.py "--workload $w --curve $c --global-log2-batch 22 --steps 10 --warmup 2" radix29=base radix32=build/ab_comb32/libecsimd_hip.so >> "$out/ab.txt" 2>&1 || rc=$?
     done; done
     cat "$out/ab.txt"; exit $rc ;;
+  varwin29)         # round 4: the odd-digit window loop on 29-bit limbs -- every test that runs it, then A/B against the radix-32 build (build/ab_vw32)
+    timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fields.py tests/test_openssl_crosscheck.py tests/test_gpu_large.py -x -q -m gpu \
+      -k "windowed or varwin or digit_pattern or openssl or ecdsa or double_scalar or constant_time or x_coordinate or exceptional or maximum or large or invalid" > "$out/pytest.txt" 2>&1; rc=$?
+    tail -5 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
+    for w in windowed windowed-ct; do for c in p256; do
+      echo "== $w $c" >> "$out/ab.txt"
+      timeout -k 10 300 python tools/ab_variants.py "--workload $w --curve $c --global-log2-batch 22 --steps 5 --warmup 1" radix29=base radix32=build/ab_vw32/libecsimd_hip.so >> "$out/ab.txt" 2>&1 || rc=$?
+    done; done
+    cat "$out/ab.txt"; exit $rc ;;
   secondary)        # tools/bench_kernels.py -> profiles/rNN/secondary_kernels.{json,txt}
     timeout -k 10 900 python tools/bench_kernels.py > "$out/secondary_kernels.json" 2> "$out/secondary_kernels.txt"; rc=$?; tail -70 "$out/secondary_kernels.txt"; exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it

@@ -120,6 +120,14 @@ class Exact:
     def cswap(self, m, a, b):
         return (b, a) if m else (a, b)
 
+    def vred(self, a):
+        """fe29.cuh vred29: v - k p with k = round(top limb / 2^24), through p's sparse signed form."""
+        k = (a[NL - 1] + (1 << 23)) >> 24
+        out = list(a)
+        for off, c in self.cv.terms:
+            out[off] = self._i32(out[off] - k * c)
+        return out
+
 
 # ---------------------------------------------------------------------------------------------------------------- interval execution
 class Iv:
@@ -217,6 +225,17 @@ class Bounds:
         m = max(abs(a.v[0]), abs(a.v[1]))
         tv = (0 if a.v[0] < 0 < a.v[1] else min(a.v[0] ** 2, a.v[1] ** 2), m * m)
         return self._columns(prod, tv)
+
+    def vred(self, a):
+        """k ranges over what the top limb's interval allows; the new top limb is the rounding remainder, within [-2^23, 2^23]; the value follows
+        from the new limbs (the low limbs are whatever they were, moved by k times p's small terms)."""
+        assert dict(self.cv.terms)[NL - 1] == 1 << 24
+        kr = ((a.l[NL - 1][0] + (1 << 23)) >> 24, (a.l[NL - 1][1] + (1 << 23)) >> 24)
+        l = list(a.l)
+        for off, c in self.cv.terms:
+            l[off] = self._limb((-(1 << 23), 1 << 23)) if off == NL - 1 else self._limb(_isub(l[off], _imul(kr, (c, c))))
+        lo = sum(l[i][0] << (W * i) for i in range(NL)); hi = sum(l[i][1] << (W * i) for i in range(NL))
+        return Iv(l, (lo, hi))
 
     def cswap(self, m, a, b):
         j = lambda s, t: (min(s[0], t[0]), max(s[1], t[1]))
@@ -335,6 +354,85 @@ def madd_field(p, X1, Y1, Z1, x2, y2):
     return X3, (r * (V - X3) - Y1 * HHH) % p, Z1 * H % p
 
 
+# ---------------------------------------------------------------------------------------------------------------- the variable-base window loop
+def jdbl29(E, X, Y, Z):
+    """fe29.cuh jdbl29<C> (a = -3 for P-256, a = 0 for secp256k1), statement for statement."""
+    Yn = E.norm(Y)
+    YY = E.sqr(Yn)
+    G = E.norm(YY, 2)
+    B = E.mul(X, G)
+    if E.cv is CURVE_P256:
+        delta = E.sqr(Z)
+        t = E.mul(E.norm(E.sub(X, delta)), E.norm(E.add(X, delta)))
+    else:
+        t = E.sqr(E.norm(X))
+    alpha = E.norm(E.add(E.dbl(t), t))
+    Z3 = E.mul(E.dbl(Yn), Z)
+    X3 = E.sub(E.sqr(alpha), E.dbl(B))
+    E8 = E.dbl(E.norm(E.sqr(YY), 2))
+    Y3 = E.vred(E.sub(E.mul(alpha, E.norm(E.sub(B, X3))), E8))
+    return E.vred(X3), Y3, Z3
+
+
+def dbl_add29(E, X, Y, Z, x2, y2):
+    """fe29.cuh dbl_add29<C>: 2 (X, Y, Z) + (x2, y2) as (R + T) + R, the second addition co-Z."""
+    Z1Z1 = E.sqr(Z); U2 = E.mul(x2, Z1Z1); S2 = E.mul(y2, E.mul(Z1Z1, Z))
+    H = E.norm(E.sub(U2, X)); r = E.norm(E.sub(S2, Y))
+    HH = E.sqr(H); HHH = E.mul(H, HH); V = E.mul(X, HH); Yh = E.mul(Y, HHH)
+    X3 = E.sub(E.sub(E.sqr(r), HHH), E.dbl(V))
+    Y3 = E.sub(E.mul(r, E.norm(E.sub(V, X3))), Yh)
+    Z3 = E.mul(Z, H)
+    dx = E.norm(E.sub(X3, V)); dy = E.norm(E.sub(Y3, Yh))
+    Cc = E.sqr(dx); W1 = E.mul(X3, Cc); W2 = E.mul(V, Cc)
+    A1 = E.mul(Y3, E.sub(W1, W2))
+    Qx = E.sub(E.sub(E.sqr(dy), W1), W2)
+    Qy = E.vred(E.sub(E.mul(dy, E.norm(E.sub(W1, Qx))), A1))
+    return E.vred(Qx), Qy, E.mul(Z3, dx)
+
+
+def window_invariant(curve=CURVE_P256):
+    """The accumulator of k_varwin_mult_odd between two point operations: X and Y fresh from vred29 (|value| <= 0.6 p; limbs of a difference of
+    products, moved by at most a few 2^21 by the reduction), Z a product."""
+    p = curve.p
+    B = 1 << W
+    lim = lambda lo, hi, top, vlo, vhi: Iv([(int(lo * B), int(hi * B))] * (NL - 1) + [(-top, top)], (int(vlo * p), int(vhi * p)))
+    return {"X": lim(-2.25, 1.25, 1 << 25, -1.05, 1.05), "Y": lim(-2.25, 1.25, 1 << 25, -1.05, 1.05), "Z": lim(0, 1, 1 << 27, -3, 4),
+            "tx": lim(0, 1, 1 << 27, 0, 1), "ty": lim(-1, 1, 1 << 27, -1, 1)}
+
+
+def prove_window_invariant(curve=CURVE_P256):
+    """One window of the loop -- three jdbl29 and one dbl_add29 -- on intervals: no overflow, and after EVERY one of the four operations the
+    accumulator lies inside the invariant again (so any mix of doublings and additions is covered, the table-entry start included)."""
+    E = Bounds(curve)
+    inv = window_invariant(curve)
+    c = lambda k: Iv(inv[k].l, inv[k].v)
+    inside = lambda X, Y, Z: X.within(inv["X"]) and Y.within(inv["Y"]) and Z.within(inv["Z"])
+    X, Y, Z = c("X"), c("Y"), c("Z")
+    for _ in range(3):
+        X, Y, Z = jdbl29(E, X, Y, Z)
+        assert inside(X, Y, Z), (X, Y, Z)
+    X, Y, Z = dbl_add29(E, c("X"), c("Y"), c("Z"), c("tx"), c("ty"))
+    assert inside(X, Y, Z), (X, Y, Z)
+    return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length()}
+
+
+def jdbl_field(p, a, X, Y, Z):
+    YY = Y * Y % p; B = 4 * X * YY % p
+    alpha = (3 * X * X + a * pow(Z, 4, p)) % p
+    X3 = (alpha * alpha - 2 * B) % p
+    return X3, (alpha * (B - X3) - 8 * YY * YY) % p, 2 * Y * Z % p
+
+
+def dbl_add_field(p, X, Y, Z, x2, y2):
+    X3, Y3, Z3 = madd_field(p, X, Y, Z, x2, y2)                   # R + T
+    H = (x2 * Z * Z - X) % p
+    V, Yh = X * H * H % p, Y * pow(H, 3, p) % p                     # R over Z3
+    dx, dy = (X3 - V) % p, (Y3 - Yh) % p
+    Cc = dx * dx % p; W1 = X3 * Cc % p; W2 = V * Cc % p
+    Qx = (dy * dy - W1 - W2) % p
+    return Qx, (dy * (W1 - Qx) - Y3 * (W1 - W2)) % p, Z3 * dx % p
+
+
 # ---------------------------------------------------------------------------------------------------------------- big-int ZDAU (field values)
 def zdau_field(p, x1, y1, x2, y2, z):
     """curve_group.h:120-153 on integers mod p (the values, whatever the representation)."""
@@ -360,3 +458,5 @@ if __name__ == "__main__":
             print("  ", k, v)
         c = prove_comb_invariant(cv)
         print(cv.name, "comb invariant holds; worst column 2^%d, worst limb 2^%d" % (c["worst_column_bits"], c["worst_limb_bits"]))
+        c = prove_window_invariant(cv)
+        print(cv.name, "window-loop invariant holds; worst column 2^%d, worst limb 2^%d" % (c["worst_column_bits"], c["worst_limb_bits"]))
