@@ -55,6 +55,9 @@ import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value
       timeout -k 10 300 python tools/ab_variants.py "--workload $w --curve $c --global-log2-batch 22 --steps 5 --warmup 1" radix29=base radix32=build/ab_vw32/libecsimd_hip.so >> "$out/ab.txt" 2>&1 || rc=$?
     done; done
     cat "$out/ab.txt"; exit $rc ;;
+  profile)          # rocprofv3 --kernel-trace --stats + separate --pmc passes around bench.py: tools/profile.sh <tag> [bench args] (summaries: tools/summarize_profiles.py)
+    tag=${1:-r04_ladder}; shift || true
+    bash tools/profile.sh "$tag" "$@" > "$out/profile_$tag.txt" 2>&1; rc=$?; tail -8 "$out/profile_$tag.txt"; exit $rc ;;
   secondary)        # tools/bench_kernels.py -> profiles/rNN/secondary_kernels.{json,txt}
     timeout -k 10 900 python tools/bench_kernels.py > "$out/secondary_kernels.json" 2> "$out/secondary_kernels.txt"; rc=$?; tail -70 "$out/secondary_kernels.txt"; exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
