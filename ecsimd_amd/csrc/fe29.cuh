@@ -331,6 +331,46 @@ template <int C> ECS_DEV jpoint29 dbl_add29(const jpoint29& P, const fe29& x2, c
   return Q;
 }
 
+// ---------------------------------------------------------------- the complete addition law of a = 0 curves (round 4; k_varwin.inc k_varwin_mult_glv_ct)
+// Homogeneous projective (X : Y : Z), Renes-Costello-Batina 2016 as k_varwin.inc pdbl_complete / padd_mixed_complete, for b = 7 (3b = 21).
+// 21 x = 4x + 16x + x by two shifting carry passes, then vred29 and a carry pass (the result feeds products and triplings).  Carry passes
+// where the interval proof needs them (tools/radix29_model.py prove_complete_invariant: every coordinate with limbs in [-2.25, 3.25] x 2^29 and
+// |value| <= 1.05 p between two operations), vred29 on every output.
+template <int C> ECS_DEV fe29 mul21_29(const fe29& x) {
+  const fe29 a = norm29<2>(x);
+  const fe29 b = norm29<2>(a);
+  return vred29<C>(add29(add29(a, b), x));
+}
+template <int C> ECS_DEV jpoint29 pdbl29(const jpoint29& P) {
+  const fe29 Yn = norm29(P.y), Zn = norm29(P.z);
+  const fe29 yy = sqr29<C>(Yn), zz = sqr29<C>(Zn);
+  const fe29 xy = mul29<C>(P.x, Yn), yz = mul29<C>(Yn, Zn);
+  const fe29 t = norm29(mul21_29<C>(zz));
+  const fe29 m = sub29(yy, add29(dbl29(t), t));
+  const fe29 q = norm29(add29(yy, t));
+  jpoint29 R;
+  R.x = vred29<C>(dbl29(mul29<C>(xy, m)));
+  R.y = vred29<C>(add29(mul29<C>(m, q), dbl29(norm29<2>(mul29<C>(yy, t)))));
+  R.z = vred29<C>(dbl29(norm29<2>(mul29<C>(yy, yz))));
+  return R;
+}
+template <int C> ECS_DEV jpoint29 padd29(const jpoint29& P, const fe29& x2, const fe29& y2) {
+  const fe29 Xn = norm29(P.x), Yn = norm29(P.y), Zn = norm29(P.z);
+  const fe29 t0 = mul29<C>(Xn, x2), t1 = mul29<C>(Yn, y2);
+  const fe29 t3 = sub29(sub29(mul29<C>(add29(Xn, Yn), norm29(add29(x2, y2))), t0), t1);
+  const fe29 t4 = norm29(add29(mul29<C>(y2, Zn), Yn));
+  const fe29 t5 = norm29(add29(mul29<C>(x2, Zn), Xn));
+  const fe29 z3b = norm29(mul21_29<C>(Zn));
+  const fe29 A = sub29(t1, z3b), B = add29(t1, z3b);
+  const fe29 Cc = mul21_29<C>(t5);
+  const fe29 t03 = norm29(add29(dbl29(t0), t0));
+  jpoint29 R;
+  R.x = vred29<C>(sub29(mul29<C>(t3, A), mul29<C>(Cc, t4)));
+  R.y = vred29<C>(add29(mul29<C>(t03, Cc), mul29<C>(B, A)));
+  R.z = vred29<C>(add29(mul29<C>(t4, B), mul29<C>(t03, t3)));
+  return R;
+}
+
 // -a where m is all ones, a where it is zero: (a ^ m) - m, two full-rate instructions per limb
 ECS_DEV fe29 cneg29(uint32_t m, const fe29& a) { fe29 r;
 #pragma unroll

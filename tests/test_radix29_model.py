@@ -187,3 +187,59 @@ def test_without_the_value_reduction_the_doublings_grow(cv):
         for _ in range(6):
             X, Y, Z = m.jdbl29(E, X, Y, Z)
             assert abs(X.v[0]) < 8 * cv.p and abs(X.v[1]) < 8 * cv.p, "value escapes"
+
+
+# ---------------------------------------------------------------- the complete addition law of secp256k1 (fe29.cuh pdbl29, padd29)
+def test_complete_addition_law_keeps_its_invariant_without_overflow():
+    r = m.prove_complete_invariant(m.CURVE_SECP)
+    assert r["worst_column_bits"] <= 63 and r["worst_limb_bits"] <= 31
+
+
+def test_exact_complete_addition_law_equals_the_big_int_formulas_and_the_affine_law():
+    """33 windows of four doublings and two additions from the neutral element (0 : 1 : 0), on integers with the machine limits asserted:
+    the projective triple equals the formulas mod p at every step, and -- with real curve points -- the affine group law, P + P, P + (-P) = O
+    and O + T included (the completeness the constant-time GLV loop relies on)."""
+    cv = m.CURVE_SECP
+    rng = random.Random(21)
+    p = cv.p; R = 1 << m.RBITS; Rinv = pow(R, -1, p)
+    E = m.Exact(cv)
+    tight = lambda v: m.to_limbs(v * R % p)
+    val = lambda l: m.from_limbs(l) * Rinv % p
+    X, Y, Z = tight(0), tight(1), tight(0)
+    f = (0, 1, 0)
+    for w in range(33):
+        for _ in range(4):
+            X, Y, Z = m.pdbl29(E, X, Y, Z); f = m.pdbl_field(p, *f)
+            assert (val(X), val(Y), val(Z)) == f
+        for _ in range(2):
+            x2, y2 = rng.randrange(p), rng.randrange(p)
+            neg = rng.getrandbits(1)
+            ty = [-v for v in tight(y2)] if neg else tight(y2)
+            X, Y, Z = m.padd29(E, X, Y, Z, tight(x2), ty); f = m.padd_field(p, *f, x2, (-y2) % p if neg else y2)
+            assert (val(X), val(Y), val(Z)) == f
+    # the group law on real points of y^2 = x^3 + 7
+    G = (0x79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798, 0x483ada7726a3c4655da4fbfc0e1108a8fd17b448a68554199c47d08ffb10d4b8)
+    def aff(P):
+        x, y, z = (val(c) for c in P)
+        return None if z == 0 else (x * pow(z, -1, p) % p, y * pow(z, -1, p) % p)
+    def add_aff(P, Q):
+        if P is None: return Q
+        if Q is None: return P
+        if P[0] == Q[0]:
+            if (P[1] + Q[1]) % p == 0: return None
+            lam = 3 * P[0] * P[0] * pow(2 * P[1], -1, p) % p
+        else:
+            lam = (Q[1] - P[1]) * pow(Q[0] - P[0], -1, p) % p
+        x3 = (lam * lam - P[0] - Q[0]) % p
+        return x3, (lam * (P[0] - x3) - P[1]) % p
+    O = (tight(0), tight(1), tight(0))
+    P1 = m.padd29(E, *O, tight(G[0]), tight(G[1]))                                  # O + G
+    assert aff(P1) == G
+    P2 = m.padd29(E, *P1, tight(G[0]), tight(G[1]))                                 # G + G through the ADDITION formula
+    assert aff(P2) == add_aff(G, G) == aff(m.pdbl29(E, *P1))
+    assert aff(m.padd29(E, *P1, tight(G[0]), [-v for v in tight(G[1])])) is None    # G + (-G) = O
+    assert aff(m.pdbl29(E, *O)) is None                                             # 2 O = O
+    acc, ref = P2, add_aff(G, G)
+    for _ in range(20):
+        acc = m.padd29(E, *m.pdbl29(E, *acc), tight(G[0]), tight(G[1])); ref = add_aff(add_aff(ref, ref), G)
+        assert aff(acc) == ref

@@ -75,7 +75,10 @@ class Exact:
 
     def norm(self, a, shift=0):
         """One parallel carry pass over (a << shift): limbs 0..7 end in [c_min, 2^29 + c_max), the top limb takes its carry."""
-        x = [self._i32(v << shift) for v in a]
+        # the device forms (v << shift) in a wrapping 32-bit register and uses only its low 29 bits; the carry comes from the unshifted limb
+        # (v >> (29 - shift)): only the TOP limb's shifted value has to fit
+        x = [v << shift for v in a]
+        self._i32(x[NL - 1])
         c = [v >> W for v in x]
         out = [x[0] & M29] + [(x[i] & M29) + c[i - 1] for i in range(1, NL - 1)] + [self._i32(x[NL - 1] + c[NL - 2])]
         return out
@@ -184,7 +187,8 @@ class Bounds:
     def dbl(self, a): return self._tighten_top(Iv([self._limb((2 * x[0], 2 * x[1])) for x in a.l], (2 * a.v[0], 2 * a.v[1])))
 
     def norm(self, a, shift=0):
-        x = [self._limb((v[0] << shift, v[1] << shift), "shifted limb") for v in a.l]
+        x = [(v[0] << shift, v[1] << shift) for v in a.l]          # (see Exact.norm: only the top limb's shifted value is materialised)
+        self._limb(x[NL - 1], "shifted top limb")
         c = [(v[0] >> W, v[1] >> W) for v in x]
         low = lambda v: (0, M29) if (v[1] - v[0] >= M29 or (v[0] >> W) != (v[1] >> W)) else (v[0] & M29, v[1] & M29)
         out = [low(x[0])] + [self._limb(_iadd(low(x[i]), c[i - 1])) for i in range(1, NL - 1)] + [self._limb(_iadd(x[NL - 1], c[NL - 2]))]
@@ -433,6 +437,76 @@ def dbl_add_field(p, X, Y, Z, x2, y2):
     return Qx, (dy * (W1 - Qx) - Y3 * (W1 - W2)) % p, Z3 * dx % p
 
 
+# ---------------------------------------------------------------------------------------------------------------- the complete addition law (a = 0, b = 7)
+def mul21_29(E, x):
+    a = E.norm(x, 2)
+    b = E.norm(a, 2)
+    return E.vred(E.add(E.add(a, b), x))
+
+
+def pdbl29(E, X, Y, Z):
+    """fe29.cuh pdbl29<C>: homogeneous projective doubling of Renes-Costello-Batina for a = 0, 3b = 21 (6M + 2S)."""
+    Yn = E.norm(Y); Zn = E.norm(Z)
+    yy = E.sqr(Yn); zz = E.sqr(Zn)
+    xy = E.mul(X, Yn); yz = E.mul(Yn, Zn)
+    t = E.norm(mul21_29(E, zz))
+    m = E.sub(yy, E.add(E.dbl(t), t))
+    q = E.norm(E.add(yy, t))
+    X3 = E.vred(E.dbl(E.mul(xy, m)))
+    Y3 = E.vred(E.add(E.mul(m, q), E.dbl(E.norm(E.mul(yy, t), 2))))
+    Z3 = E.vred(E.dbl(E.norm(E.mul(yy, yz), 2)))
+    return X3, Y3, Z3
+
+
+def padd29(E, X, Y, Z, x2, y2):
+    """fe29.cuh padd29<C>: (X : Y : Z) + affine (x2, y2), the complete mixed addition (11M)."""
+    Xn = E.norm(X); Yn = E.norm(Y); Zn = E.norm(Z)
+    t0 = E.mul(Xn, x2); t1 = E.mul(Yn, y2)
+    t3 = E.sub(E.sub(E.mul(E.add(Xn, Yn), E.norm(E.add(x2, y2))), t0), t1)
+    t4 = E.norm(E.add(E.mul(y2, Zn), Yn))
+    t5 = E.norm(E.add(E.mul(x2, Zn), Xn))
+    z3b = E.norm(mul21_29(E, Zn))
+    A = E.sub(t1, z3b); B = E.add(t1, z3b)
+    Cc = mul21_29(E, t5)
+    t03 = E.norm(E.add(E.dbl(t0), t0))
+    X3 = E.vred(E.sub(E.mul(t3, A), E.mul(Cc, t4)))
+    Y3 = E.vred(E.add(E.mul(t03, Cc), E.mul(B, A)))
+    Z3 = E.vred(E.add(E.mul(t4, B), E.mul(t03, t3)))
+    return X3, Y3, Z3
+
+
+def complete_invariant(curve=CURVE_SECP):
+    p = curve.p
+    B = 1 << W
+    lim = lambda lo, hi, top, vlo, vhi: Iv([(int(lo * B), int(hi * B))] * (NL - 1) + [(-top, top)], (int(vlo * p), int(vhi * p)))
+    inv = {k: lim(-2.25, 3.25, 1 << 25, -1.05, 1.05) for k in "XYZ"}
+    inv.update({"tx": lim(0, 1, 1 << 27, 0, 1), "ty": lim(-1, 1, 1 << 27, -1, 1)})
+    return inv
+
+
+def prove_complete_invariant(curve=CURVE_SECP):
+    """pdbl29 and padd29 from the invariant (the neutral element (0 : 1 : 0) in tight limbs lies inside it): no overflow, closed."""
+    E = Bounds(curve)
+    inv = complete_invariant(curve)
+    c = lambda k: Iv(inv[k].l, inv[k].v)
+    inside = lambda P: all(P[i].within(inv[k]) for i, k in enumerate("XYZ"))
+    assert inside(pdbl29(E, c("X"), c("Y"), c("Z")))
+    assert inside(padd29(E, c("X"), c("Y"), c("Z"), c("tx"), c("ty")))
+    return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length()}
+
+
+def pdbl_field(p, X, Y, Z):
+    yy = Y * Y % p; t = 21 * Z * Z % p; m = (yy - 3 * t) % p; q = (yy + t) % p
+    return 2 * X * Y * m % p, (m * q + 8 * yy * t) % p, 8 * yy * Y * Z % p
+
+
+def padd_field(p, X, Y, Z, x2, y2):
+    t0 = X * x2 % p; t1 = Y * y2 % p; t3 = ((X + Y) * (x2 + y2) - t0 - t1) % p
+    t4 = (y2 * Z + Y) % p; t5 = (x2 * Z + X) % p
+    A = (t1 - 21 * Z) % p; B = (t1 + 21 * Z) % p; Cc = 21 * t5 % p
+    return (t3 * A - Cc * t4) % p, (3 * t0 * Cc + B * A) % p, (t4 * B + 3 * t0 * t3) % p
+
+
 # ---------------------------------------------------------------------------------------------------------------- big-int ZDAU (field values)
 def zdau_field(p, x1, y1, x2, y2, z):
     """curve_group.h:120-153 on integers mod p (the values, whatever the representation)."""
@@ -460,3 +534,5 @@ if __name__ == "__main__":
         print(cv.name, "comb invariant holds; worst column 2^%d, worst limb 2^%d" % (c["worst_column_bits"], c["worst_limb_bits"]))
         c = prove_window_invariant(cv)
         print(cv.name, "window-loop invariant holds; worst column 2^%d, worst limb 2^%d" % (c["worst_column_bits"], c["worst_limb_bits"]))
+    c = prove_complete_invariant(CURVE_SECP)
+    print("secp256k1 complete-addition invariant holds; worst column 2^%d, worst limb 2^%d" % (c["worst_column_bits"], c["worst_limb_bits"]))
