@@ -251,12 +251,13 @@ template <int C> ECS_DEV void zdau29(coz29& s, uint32_t oswap) {
 // one madd29 maps it into itself with every limb inside int32 and every column inside int64): X limbs in [-3, 1] x 2^29, Y in [-1, 1] x 2^29,
 // Z tight; table coordinates tight, y possibly negated.  Three carry passes: H and r feed squares, V - X3 is 31 bits wide before its product.
 struct jpoint29 { fe29 x, y, z; };
-template <int C> ECS_DEV jpoint29 madd29(const jpoint29& P, const fe29& x2, const fe29& y2) {
+// (H and r are handed out for the caller that has to recognise R = +-T -- H = 0 as a field element, then r = 0: is_zero29 below)
+template <int C> ECS_DEV jpoint29 madd29(const jpoint29& P, const fe29& x2, const fe29& y2, fe29& H, fe29& r) {
   const fe29 Z1Z1 = sqr29<C>(P.z);
   const fe29 U2 = mul29<C>(x2, Z1Z1);
   const fe29 S2 = mul29<C>(y2, mul29<C>(Z1Z1, P.z));
-  const fe29 H = norm29(sub29(U2, P.x));
-  const fe29 r = norm29(sub29(S2, P.y));
+  H = norm29(sub29(U2, P.x));
+  r = norm29(sub29(S2, P.y));
   const fe29 HH = sqr29<C>(H);
   const fe29 HHH = mul29<C>(H, HH);
   const fe29 V = mul29<C>(P.x, HH);
@@ -266,6 +267,7 @@ template <int C> ECS_DEV jpoint29 madd29(const jpoint29& P, const fe29& x2, cons
   R.y = sub29(mul29<C>(r, norm29(sub29(V, R.x))), mul29<C>(P.y, HHH));
   return R;
 }
+template <int C> ECS_DEV jpoint29 madd29(const jpoint29& P, const fe29& x2, const fe29& y2) { fe29 H, r; return madd29<C>(P, x2, y2, H, r); }
 // ---------------------------------------------------------------- the variable-base window loop (round 4)
 // Doublings multiply by 3, 4 and 8, and on lazy limbs nothing ever takes a multiple of p away: a Montgomery product only divides by 2^261 ~ 32 p,
 // so values above ~10 p GROW from one doubling to the next.  vred29 is the missing piece: v -> v - k p with k = round(top limb / 2^24) -- the top
@@ -329,6 +331,24 @@ template <int C> ECS_DEV jpoint29 dbl_add29(const jpoint29& P, const fe29& x2, c
   Q.x = vred29<C>(Qx);
   Q.z = mul29<C>(Z3, dx);
   return Q;
+}
+// The mixed addition BETWEEN DOUBLINGS (the default GLV loop, k_varwin.inc k_varwin_mult_glv): X3 takes one more carry pass, X3 and Y3 the value
+// reduction -- then the sum lies inside the window loop's invariant again (tools/radix29_model.py prove_glv_invariant).
+template <int C> ECS_DEV jpoint29 madd29v(const jpoint29& P, const fe29& x2, const fe29& y2, fe29& H, fe29& r) {
+  jpoint29 R = madd29<C>(P, x2, y2, H, r);
+  R.x = vred29<C>(norm29(R.x)); R.y = vred29<C>(R.y);
+  return R;
+}
+// v = 0 as a FIELD element, for |value| < 2^260: the value reduction leaves |v| < p, where the only multiple of p is the integer 0; a sequential
+// carry pass makes the limbs below the top one canonical, so the integer 0 is nine zero limbs.  Its caller branches on the result: public scalars only.
+template <int C> ECS_DEV bool is_zero29(fe29 v) {
+  v = vred29<C>(v);
+#pragma unroll
+  for (int i = 0; i < R29_LIMBS - 1; ++i) { v.l[i + 1] += v.l[i] >> R29_BITS; v.l[i] &= R29_MASK; }
+  int32_t d = 0;
+#pragma unroll
+  for (int i = 0; i < R29_LIMBS; ++i) d |= v.l[i];
+  return d == 0;
 }
 
 // ---------------------------------------------------------------- the complete addition law of a = 0 curves (round 4; k_varwin.inc k_varwin_mult_glv_ct)

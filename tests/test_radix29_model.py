@@ -243,3 +243,57 @@ def test_exact_complete_addition_law_equals_the_big_int_formulas_and_the_affine_
     for _ in range(20):
         acc = m.padd29(E, *m.pdbl29(E, *acc), tight(G[0]), tight(G[1])); ref = add_aff(add_aff(ref, ref), G)
         assert aff(acc) == ref
+
+
+# ---------------------------------------------------------------- the default GLV loop of secp256k1 (fe29.cuh madd29v, is_zero29)
+def test_default_glv_loop_keeps_the_window_invariant_without_overflow():
+    r = m.prove_glv_invariant(m.CURVE_SECP)
+    assert r["worst_column_bits"] <= 63 and r["worst_limb_bits"] <= 31
+
+
+def test_the_extra_carry_pass_of_madd29v_is_needed():
+    """Without the carry pass on X3 the sum leaves the window invariant (X3's limbs reach -3.x 2^29), which jdbl29 was proven on."""
+    cv = m.CURVE_SECP
+    inv = m.window_invariant(cv)
+    E = m.Bounds(cv)
+    X3, Y3, Z3 = m.madd29(E, *(m.Iv(inv[k].l, inv[k].v) for k in ("X", "Y", "Z", "tx", "ty")))
+    assert not E.vred(X3).within(inv["X"]) and E.vred(E.norm(X3)).within(inv["X"])
+
+
+def test_exact_default_glv_loop_equals_the_big_int_formulas_and_is_zero29_decides_field_zero():
+    """33 windows of four jdbl29 and two madd29v on integers with the machine limits asserted, against the formulas mod p; then is_zero29 on
+    the H and r of additions that DO meet R = +-T (lazy accumulator against the tight table point of the same field value) and of ones that do not."""
+    cv = m.CURVE_SECP
+    rng = random.Random(33)
+    p = cv.p; R = 1 << m.RBITS; Rinv = pow(R, -1, p)
+    E = m.Exact(cv)
+    tight = lambda v: m.to_limbs(v * R % p)
+    val = lambda l: m.from_limbs(l) * Rinv % p
+    beta = 0x7ae96a2b657c07106e64479eac3434e99cf0497512f58995c1396c28719501ee
+    fx, fy, fz = rng.randrange(p), rng.randrange(p), 1
+    X, Y, Z = tight(fx), tight(fy), tight(1)
+    zeros = 0
+    for w in range(33):
+        for _ in range(4):
+            X, Y, Z = m.jdbl29(E, X, Y, Z); fx, fy, fz = m.jdbl_field(p, 0, fx, fy, fz)
+            assert (val(X), val(Y), val(Z)) == (fx, fy, fz)
+        for lam in (False, True):
+            zi = pow(fz, -1, p)
+            case = rng.randrange(4) if fz else 3
+            if case == 0:   x2, y2 = fx * zi * zi % p, fy * zi ** 3 % p                  # T = R: H = 0, r = 0
+            elif case == 1: x2, y2 = fx * zi * zi % p, (-fy * zi ** 3) % p               # T = -R: H = 0, r != 0
+            else:           x2, y2 = rng.randrange(p), rng.randrange(p)
+            tx = E.mul(tight(x2 * pow(beta, -1, p) % p), tight(beta)) if lam else tight(x2)
+            assert val(tx) == x2
+            neg = rng.getrandbits(1)
+            ty = [-v for v in tight((-y2) % p)] if neg else tight(y2)
+            X3, Y3, Z3, H, r = m.madd29v(E, X, Y, Z, tx, ty, with_hr=True)
+            hz, rz = m.is_zero29(E, list(H)), m.is_zero29(E, list(r))
+            assert hz == (case in (0, 1)) and rz == (case == 0 or (y2 * fz ** 3 - fy) % p == 0), (w, case)
+            zeros += hz
+            if hz:                                                                        # the kernel takes the tangent / infinity instead; go on from T's double
+                X, Y, Z = m.jdbl29(E, tx, ty, tight(1)); fx, fy, fz = m.jdbl_field(p, 0, x2, y2, 1)
+            else:
+                X, Y, Z = X3, Y3, Z3; fx, fy, fz = m.madd_field(p, fx, fy, fz, x2, y2)
+            assert (val(X), val(Y), val(Z)) == (fx, fy, fz)
+    assert zeros >= 10

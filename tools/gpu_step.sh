@@ -55,6 +55,15 @@ import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value
       timeout -k 10 300 python tools/ab_variants.py "--workload $w --curve $c --global-log2-batch 22 --steps 5 --warmup 1" radix29=base radix32=build/ab_vw32/libecsimd_hip.so >> "$out/ab.txt" 2>&1 || rc=$?
     done; done
     cat "$out/ab.txt"; exit $rc ;;
+  glv29)            # round 4: the default GLV loop + the checked mixed addition on 29-bit limbs -- the tests that run them, then A/B against build/ab_glv32
+    timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fields.py tests/test_openssl_crosscheck.py tests/test_gpu_large.py tests/test_cpp_host_api.py -x -q -m gpu \
+      -k "windowed or varwin or digit_pattern or openssl or ecdsa or double_scalar or add or complete or x_coordinate or exceptional or maximum or large or invalid or cpp_api or glv or endomorphism" > "$out/pytest.txt" 2>&1; rc=$?
+    tail -5 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
+    for w in windowed; do
+      echo "== $w secp256k1" >> "$out/ab.txt"
+      timeout -k 10 300 python tools/ab_variants.py "--workload $w --curve secp256k1 --global-log2-batch 22 --steps 5 --warmup 1" radix29=base radix32=build/ab_glv32/libecsimd_hip.so >> "$out/ab.txt" 2>&1 || rc=$?
+    done
+    cat "$out/ab.txt"; exit $rc ;;
   profile)          # rocprofv3 --kernel-trace --stats + separate --pmc passes around bench.py: tools/profile.sh <tag> [bench args] (summaries: tools/summarize_profiles.py)
     tag=${1:-r04_ladder}; shift || true
     bash tools/profile.sh "$tag" "$@" > "$out/profile_$tag.txt" 2>&1; rc=$?; tail -8 "$out/profile_$tag.txt"; exit $rc ;;

@@ -420,6 +420,49 @@ def prove_window_invariant(curve=CURVE_P256):
     return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length()}
 
 
+# ---------------------------------------------------------------------------------------------------------------- the default GLV loop (secp256k1)
+def madd29v(E, X1, Y1, Z1, x2, y2, with_hr=False):
+    """fe29.cuh madd29v<C>: madd29, then one more carry pass on X3 and the value reduction on X3 and Y3."""
+    Z1Z1 = E.sqr(Z1); U2 = E.mul(x2, Z1Z1); S2 = E.mul(y2, E.mul(Z1Z1, Z1))
+    H = E.norm(E.sub(U2, X1)); r = E.norm(E.sub(S2, Y1))
+    HH = E.sqr(H); HHH = E.mul(H, HH); V = E.mul(X1, HH)
+    Z3 = E.mul(Z1, H)
+    X3 = E.sub(E.sub(E.sqr(r), HHH), E.dbl(V))
+    Y3 = E.sub(E.mul(r, E.norm(E.sub(V, X3))), E.mul(Y1, HHH))
+    out = (E.vred(E.norm(X3)), E.vred(Y3), Z3)
+    return out + (H, r) if with_hr else out
+
+
+def is_zero29(E, v):
+    """fe29.cuh is_zero29<C> on the Exact machine: vred29, a sequential carry pass over limbs 0..7, all nine limbs zero."""
+    v = E.vred(v)
+    for i in range(NL - 1):
+        v[i + 1] = E._i32(v[i + 1] + (v[i] >> W)); v[i] &= M29
+    return not any(v)
+
+
+def prove_glv_invariant(curve=CURVE_SECP):
+    """k_varwin_mult_glv on 29-bit limbs: jdbl29 and madd29v in any order (four doublings, two additions per window; the accumulator may also be
+    replaced by a table entry with Z = 2^261 mod p, or by jdbl29 of one) keep the window loop's invariant; x2 may be a table coordinate or its
+    product with beta (value up to 1.05 p).  And the operands of is_zero29, H and r, are small enough for its argument: after vred29 |v| < p."""
+    E = Bounds(curve)
+    inv = window_invariant(curve)
+    p = curve.p
+    c = lambda k: Iv(inv[k].l, inv[k].v)
+    inside = lambda P: all(P[i].within(inv[k]) for i, k in enumerate("XYZ"))
+    tx = Iv(inv["tx"].l, (0, int(1.05 * p)))
+    assert inside(jdbl29(E, c("X"), c("Y"), c("Z")))
+    X3, Y3, Z3, H, r = madd29v(E, c("X"), c("Y"), c("Z"), tx, c("ty"), with_hr=True)
+    assert inside((X3, Y3, Z3)), (X3, Y3, Z3)
+    assert inside(jdbl29(E, tx, c("ty"), Iv(inv["Z"].l, (0, p))))                           # the tangent at a table point (R = T)
+    for v in (H, r):
+        w = E.vred(v)
+        assert -p < w.v[0] and w.v[1] < p, w
+        t = w.l[NL - 1]                                                                      # the sequential pass: the carries stay small
+        assert all(abs(b) < (1 << 31) - (1 << 3) for iv in w.l for b in iv) and abs(t[0]) < 1 << 30 and abs(t[1]) < 1 << 30
+    return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length()}
+
+
 def jdbl_field(p, a, X, Y, Z):
     YY = Y * Y % p; B = 4 * X * YY % p
     alpha = (3 * X * X + a * pow(Z, 4, p)) % p
