@@ -251,13 +251,15 @@ template <int C> ECS_DEV void zdau29(coz29& s, uint32_t oswap) {
 // one madd29 maps it into itself with every limb inside int32 and every column inside int64): X limbs in [-3, 1] x 2^29, Y in [-1, 1] x 2^29,
 // Z tight; table coordinates tight, y possibly negated.  Three carry passes: H and r feed squares, V - X3 is 31 bits wide before its product.
 struct jpoint29 { fe29 x, y, z; };
-// (H and r are handed out for the caller that has to recognise R = +-T -- H = 0 as a field element, then r = 0: is_zero29 below)
-template <int C> ECS_DEV jpoint29 madd29(const jpoint29& P, const fe29& x2, const fe29& y2, fe29& H, fe29& r) {
+// (Two halves, so that a caller can look at H and r -- R = +-T is H = 0, then r = 0: is_zero29 below -- before paying for the rest.)
+template <int C> ECS_DEV void madd29_hr(const jpoint29& P, const fe29& x2, const fe29& y2, fe29& H, fe29& r) {
   const fe29 Z1Z1 = sqr29<C>(P.z);
   const fe29 U2 = mul29<C>(x2, Z1Z1);
   const fe29 S2 = mul29<C>(y2, mul29<C>(Z1Z1, P.z));
   H = norm29(sub29(U2, P.x));
   r = norm29(sub29(S2, P.y));
+}
+template <int C> ECS_DEV jpoint29 madd29_finish(const jpoint29& P, const fe29& H, const fe29& r) {
   const fe29 HH = sqr29<C>(H);
   const fe29 HHH = mul29<C>(H, HH);
   const fe29 V = mul29<C>(P.x, HH);
@@ -267,7 +269,7 @@ template <int C> ECS_DEV jpoint29 madd29(const jpoint29& P, const fe29& x2, cons
   R.y = sub29(mul29<C>(r, norm29(sub29(V, R.x))), mul29<C>(P.y, HHH));
   return R;
 }
-template <int C> ECS_DEV jpoint29 madd29(const jpoint29& P, const fe29& x2, const fe29& y2) { fe29 H, r; return madd29<C>(P, x2, y2, H, r); }
+template <int C> ECS_DEV jpoint29 madd29(const jpoint29& P, const fe29& x2, const fe29& y2) { fe29 H, r; madd29_hr<C>(P, x2, y2, H, r); return madd29_finish<C>(P, H, r); }
 // ---------------------------------------------------------------- the variable-base window loop (round 4)
 // Doublings multiply by 3, 4 and 8, and on lazy limbs nothing ever takes a multiple of p away: a Montgomery product only divides by 2^261 ~ 32 p,
 // so values above ~10 p GROW from one doubling to the next.  vred29 is the missing piece: v -> v - k p with k = round(top limb / 2^24) -- the top
@@ -334,8 +336,8 @@ template <int C> ECS_DEV jpoint29 dbl_add29(const jpoint29& P, const fe29& x2, c
 }
 // The mixed addition BETWEEN DOUBLINGS (the default GLV loop, k_varwin.inc k_varwin_mult_glv): X3 takes one more carry pass, X3 and Y3 the value
 // reduction -- then the sum lies inside the window loop's invariant again (tools/radix29_model.py prove_glv_invariant).
-template <int C> ECS_DEV jpoint29 madd29v(const jpoint29& P, const fe29& x2, const fe29& y2, fe29& H, fe29& r) {
-  jpoint29 R = madd29<C>(P, x2, y2, H, r);
+template <int C> ECS_DEV jpoint29 madd29v_finish(const jpoint29& P, const fe29& H, const fe29& r) {
+  jpoint29 R = madd29_finish<C>(P, H, r);
   R.x = vred29<C>(norm29(R.x)); R.y = vred29<C>(R.y);
   return R;
 }

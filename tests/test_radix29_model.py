@@ -245,7 +245,7 @@ def test_exact_complete_addition_law_equals_the_big_int_formulas_and_the_affine_
         assert aff(acc) == ref
 
 
-# ---------------------------------------------------------------- the default GLV loop of secp256k1 (fe29.cuh madd29v, is_zero29)
+# ---------------------------------------------------------------- the default GLV loop of secp256k1 (fe29.cuh madd29_hr, madd29v_finish, is_zero29)
 def test_default_glv_loop_keeps_the_window_invariant_without_overflow():
     r = m.prove_glv_invariant(m.CURVE_SECP)
     assert r["worst_column_bits"] <= 63 and r["worst_limb_bits"] <= 31
@@ -297,3 +297,15 @@ def test_exact_default_glv_loop_equals_the_big_int_formulas_and_is_zero29_decide
                 X, Y, Z = X3, Y3, Z3; fx, fy, fz = m.madd_field(p, fx, fy, fz, x2, y2)
             assert (val(X), val(Y), val(Z)) == (fx, fy, fz)
     assert zeros >= 10
+
+
+def test_beta_constant_of_the_glv_loops():
+    """k_varwin.inc glv_consts::BETA29 is beta * 2^261 mod p in tight limbs, beta the cube root of unity of BETA (same file)."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ecsimd_amd", "csrc", "k_varwin.inc")).read()
+    words = [int(w, 16) for w in re.findall(r"0x[0-9a-f]+", re.search(r"BETA\[8\] = \{([^}]*)\}", src).group(1))]
+    limbs = [int(w, 16) for w in re.findall(r"0x[0-9a-f]+", re.search(r"BETA29\[9\] = \{([^}]*)\}", src).group(1))]
+    beta = sum(w << (32 * i) for i, w in enumerate(words))
+    p = m.CURVE_SECP.p
+    assert pow(beta, 3, p) == 1 and beta != 1
+    assert limbs == m.to_limbs(beta * (1 << m.RBITS) % p)

@@ -312,8 +312,8 @@ def prove_invariant(curve=CURVE_P256):
 
 # ---------------------------------------------------------------------------------------------------------------- the combs' mixed addition
 def madd29(E, X1, Y1, Z1, x2, y2):
-    """fe29.cuh madd29<C>: Jacobian (X1, Y1, Z1) + affine (x2, y2), Hankerson-Menezes-Vanstone Alg. 3.22 as point.cuh madd_hmv (8M + 3S);
-    statement for statement the device function."""
+    """fe29.cuh madd29<C> (= madd29_hr + madd29_finish): Jacobian (X1, Y1, Z1) + affine (x2, y2), Hankerson-Menezes-Vanstone Alg. 3.22 as
+    point.cuh madd_hmv (8M + 3S); statement for statement the device function."""
     Z1Z1 = E.sqr(Z1)
     U2 = E.mul(x2, Z1Z1)
     S2 = E.mul(y2, E.mul(Z1Z1, Z1))
@@ -422,7 +422,7 @@ def prove_window_invariant(curve=CURVE_P256):
 
 # ---------------------------------------------------------------------------------------------------------------- the default GLV loop (secp256k1)
 def madd29v(E, X1, Y1, Z1, x2, y2, with_hr=False):
-    """fe29.cuh madd29v<C>: madd29, then one more carry pass on X3 and the value reduction on X3 and Y3."""
+    """fe29.cuh madd29_hr<C> + madd29v_finish<C>: madd29, then one more carry pass on X3 and the value reduction on X3 and Y3."""
     Z1Z1 = E.sqr(Z1); U2 = E.mul(x2, Z1Z1); S2 = E.mul(y2, E.mul(Z1Z1, Z1))
     H = E.norm(E.sub(U2, X1)); r = E.norm(E.sub(S2, Y1))
     HH = E.sqr(H); HHH = E.mul(H, HH); V = E.mul(X1, HH)
