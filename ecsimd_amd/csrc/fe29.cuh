@@ -212,7 +212,8 @@ struct coz29 { fe29 x1, x2, dx, y1, dy, z; };
 // The field VALUES are point.cuh zdau<C>'s (curve_group.h:120-153), statement for statement in tools/radix29_model.py zdau29.
 // Differences from the 8-word form: the factor 4 of W1 = 4 X3' C, W2 = 4 W1' C rides in on a normalised 4C (one pass makes both
 // products tight and true-valued); A1 is an ordinary product (a shared 18-column product is dearer than the reduction it saves here).
-template <int C> ECS_DEV void zdau29(coz29& s, uint32_t oswap) {
+// NOZ: the x-only ladder's iteration (point.cuh scalar_mult_ladder_x) -- the same without the Z update, 8M + 6S.
+template <int C, bool NOZ = false> ECS_DEV void zdau29(coz29& s, uint32_t oswap) {
   const fe29 Cp = sqr29<C>(s.dx);
   const fe29 W1p = mul29<C>(s.x1, Cp);
   const fe29 W2p = mul29<C>(s.x2, Cp);
@@ -229,8 +230,10 @@ template <int C> ECS_DEV void zdau29(coz29& s, uint32_t oswap) {
   const fe29 W1 = mul29<C>(X3, C4);
   const fe29 W2 = mul29<C>(W1p, C4);
   const fe29 A1 = mul29<C>(Y3p, sub29(W1, W2));
-  const fe29 zz = sub29(sub29(sqr29<C>(norm29(add29(s.dx, u))), Cp), Cc);
-  s.z = mul29<C>(s.z, zz);
+  if constexpr (!NOZ) {
+    const fe29 zz = sub29(sub29(sqr29<C>(norm29(add29(s.dx, u))), Cp), Cc);
+    s.z = mul29<C>(s.z, zz);
+  }
   cswap29(oswap, ym, yp);
   const fe29 D = sqr29<C>(ym);
   const fe29 Dc = sqr29<C>(yp);

@@ -452,8 +452,7 @@ template <int C, bool NOZ> ECS_DEV uint32_t ladder_core(const uint32_t* __restri
 // every iteration are the same, so the result is bit-identical (the representation of an intermediate is nobody's business).
 // Which instances have it: every one whose squaring is exact (the reference-square twins depend on the 32-bit Montgomery digits).
 template <int C> struct ladder_has_radix29 { static constexpr bool value = (C == CURVE_P256 || C == CURVE_SECP256K1_CLASSICAL); };
-template <int C> ECS_DEV uint32_t ladder_core29(const uint32_t* __restrict__ kwords, const fe& xm, const fe& ym, fe& px, fe& py, fe& z) {
-  fe bx, by;
+template <int C, bool NOZ = false> ECS_DEV uint32_t ladder_core29(const uint32_t* __restrict__ kwords, const fe& xm, const fe& ym, fe& px, fe& py, fe& bx, fe& by, fe& z) {
   px = xm; py = ym;
   {
     fe dx2, dy2;
@@ -477,17 +476,19 @@ template <int C> ECS_DEV uint32_t ladder_core29(const uint32_t* __restrict__ kwo
     const int nb = b + 1;
     if ((nb & 31) == 0) kw = (nb < 256) ? kwords[nb >> 5] : 0u;
     const uint32_t next = 0u - ((kw >> (nb & 31)) & 1u);
-    zdau29<C>(s, cur ^ next);
+    zdau29<C, NOZ>(s, cur ^ next);
     cur = next;
   }
-  px = leave29<C>(s.x2); py = leave29<C>(sub29(s.y1, s.dy)); z = leave29<C>(s.z);
+  px = leave29<C>(s.x2); py = leave29<C>(sub29(s.y1, s.dy));
+  if constexpr (NOZ) { bx = leave29<C>(s.x1); by = leave29<C>(s.y1); }       // the x-only ladder reads both registers; Z was not carried
+  else z = leave29<C>(s.z);
   return k0;
 }
 
 template <int C, int RADIX = 32> ECS_DEV jpoint scalar_mult_ladder(const uint32_t* __restrict__ kwords, const fe& xm, const fe& ym) {
   fe px, py, bx, by, z;
   uint32_t k0;
-  if constexpr (RADIX == 29) k0 = ladder_core29<C>(kwords, xm, ym, px, py, z);
+  if constexpr (RADIX == 29) k0 = ladder_core29<C>(kwords, xm, ym, px, py, bx, by, z);
   else k0 = ladder_core<C, false>(kwords, xm, ym, px, py, bx, by, z);
   // even k: subtract the original point once (curve_group.h:214-217)
   const fe oppy = fe_opposite<C>(ym);                    // jacobian_curve_point.h:48-54 via gfp.h:60-64
@@ -509,10 +510,17 @@ template <int C, int RADIX = 32> ECS_DEV jpoint scalar_mult_ladder(const uint32_
 // batch follows).  Only Z^2 is determined by this -- the sign of Z, hence y, is not (both are consistent with everything but the
 // input point), which is why the reference-identical Jacobian result cannot be had this way.
 // With a = 0 (secp256k1) only w^3 is determined and x keeps a cube-root ambiguity: not offered there.
+#ifndef ECS_LADDER_X_RADIX
+#define ECS_LADDER_X_RADIX 29
+#endif
 template <int C> ECS_DEV void scalar_mult_ladder_x(const uint32_t* __restrict__ kwords_odd, const fe& xm, const fe& ym, fe& num, fe& den) {
   static_assert(curve_prime<C>::is_p256, "a = -3");
   fe x0, y0, x1, y1, z;
+#if ECS_LADDER_X_RADIX == 29
+  (void)ladder_core29<C, true>(kwords_odd, xm, ym, x0, y0, x1, y1, z);      // round 4: the 254 iterations on 29-bit limbs, like the reference ladder's
+#else
   (void)ladder_core<C, true>(kwords_odd, xm, ym, x0, y0, x1, y1, z);
+#endif
   const fe e0 = fe_sub<C>(fe_sqr<C>(y0), fe_mul<C>(fe_sqr<C>(x0), x0));
   const fe e1 = fe_sub<C>(fe_sqr<C>(y1), fe_mul<C>(fe_sqr<C>(x1), x1));
   const fe D = fe_sub<C>(e0, e1);

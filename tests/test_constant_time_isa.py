@@ -51,11 +51,11 @@ def test_the_shipped_build_uses_the_branch_free_conditional_subtraction():
 
 
 # k_scalar_mult<29>: the reduced-radix loop every default call runs since round 4 (fe29.cuh: multiply-adds into carry-free columns, limb-wise adds, shifts
-# and masks -- no compare at all); k_scalar_mult<32>: the 8-word loop behind ECSIMD_HIP_LADDER_RADIX32 / REF_SQUARE_COMPAT; k_scalar_mult_x: the ladder without Z
+# and masks -- no compare at all); k_scalar_mult<32>: the 8-word loop behind ECSIMD_HIP_LADDER_RADIX32 / REF_SQUARE_COMPAT; k_scalar_mult_x: the ladder without Z (on 29-bit limbs too, later in round 4)
 @pytest.mark.parametrize("kernel", ["13k_scalar_multILi29E", "13k_scalar_multILi32E", "15k_scalar_mult_xE"])
 def test_p256_bit_loop_is_constant_time(p256_asm, kernel):
     rep = ct_check.check(p256_asm, kernel)
-    assert rep["instructions"] > 2500                               # it IS the ZDAU loop, not some small one
+    assert rep["instructions"] > (2200 if "mult_x" in kernel else 2500)    # it IS the ZDAU loop, not some small one (without Z on 29-bit limbs: 2 426)
     # the loop's branches: the exit test on the bit counter and the test(s) that gate the scalar-word reload (one or two, as the compiler
     # arranges `(nb & 31) == 0` and `nb < 256`) -- nothing else, and every one a scalar compare of the counter with a constant
     assert len(rep["branches"]) in (2, 3) and all(re.match(r"s_cmpk?_(lg|eq)_[iu]32 s\d+, (0x101|0x100|0) ; s_cbranch_scc[01] ", b) for b in rep["branches"]), rep["branches"]
