@@ -182,7 +182,7 @@ template <int C> ECS_DEV fe29 enter29(const fe& v) { return mul29<C>(to29(v), fe
 // ... and back: the canonical residue of field.cuh's domain.  `v` is anything the loop holds (|value| < 8 p): the product with a
 // tight constant < p lies in (-p/4, 9p/8), + p makes it positive, a sequential carry pass makes the limbs tight, and two
 // conditional subtractions of p (sign of the top limb after a borrow pass) land in [0, p).
-template <int C> ECS_DEV fe canon29(fe29 t) {                        // a value in (-p, 9p/8): + p, carry pass, two conditional subtractions
+template <int C> ECS_DEV fe canon29(fe29 t) {                        // a value in (-p, 2p) (leave29 needs (-p, 9p/8)): + p, carry pass, two conditional subtractions
   using K = r29_consts<C>;
 #pragma unroll
   for (int i = 0; i < R29_LIMBS; ++i) t.l[i] += K::P[i];

@@ -309,3 +309,70 @@ def test_beta_constant_of_the_glv_loops():
     p = m.CURVE_SECP.p
     assert pow(beta, 3, p) == 1 and beta != 1
     assert limbs == m.to_limbs(beta * (1 << m.RBITS) % p)
+
+
+def test_exact_isomorphic_table_of_the_glv_loop():
+    """k_varwin.inc k_varwin_table_iso on integers with the machine limits asserted: 2P by jdbl29, (k + 1)P = kP + P by madd29_hr / madd29v_finish,
+    then the backward walk with f_k = H_k .. H_7.  Every entry must be (x_k Zg^2, y_k Zg^3) for the AFFINE k P = (x_k, y_k) of the curve and
+    Zg = Z_8; and a window of the loop run on those entries must give, with Z' Zg, the point the same window gives on the curve itself."""
+    cv = m.CURVE_SECP
+    p = cv.p; R = 1 << m.RBITS; Rinv = pow(R, -1, p)
+    E = m.Exact(cv)
+    tight = lambda v: m.to_limbs(v * R % p)
+    val = lambda l: m.from_limbs(l) * Rinv % p
+    canon = lambda l: m.to_limbs(m.from_limbs(l) % p)                                     # canon29 + to29: the canonical residue, tight limbs
+    G = (0x79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798, 0x483ada7726a3c4655da4fbfc0e1108a8fd17b448a68554199c47d08ffb10d4b8)
+
+    def add_aff(P, Q):
+        if P[0] == Q[0]:
+            lam = 3 * P[0] * P[0] * pow(2 * P[1], -1, p) % p
+        else:
+            lam = (Q[1] - P[1]) * pow(Q[0] - P[0], -1, p) % p
+        x3 = (lam * lam - P[0] - Q[0]) % p
+        return x3, (lam * (P[0] - x3) - P[1]) % p
+    rng = random.Random(5)
+    P = G
+    for trial in range(6):
+        for _ in range(rng.randrange(1, 40)):
+            P = add_aff(P, G) if P != G else add_aff(G, G)
+        x1, y1 = tight(P[0]), tight(P[1])
+        slots = {}
+        h = [None] * 7
+        X, Y, Z = m.jdbl29(E, x1, y1, tight(1))
+        h[0] = Z
+        for k in range(2, 8):
+            slots[k] = (X, Y)                                                             # as born (scratch), lazy limbs and all
+            X, Y, Z, H, r = m.madd29v(E, X, Y, Z, x1, y1, with_hr=True)
+            h[k - 1] = H
+        slots[8] = (canon(X), canon(Y))
+        zg = canon(Z)
+        f = h[6]
+        for k in range(7, 0, -1):
+            Xk, Yk = (x1, y1) if k == 1 else slots[k]
+            f2 = E.sqr(f)
+            slots[k] = (canon(E.mul(Xk, f2)), canon(E.mul(Yk, E.mul(f2, f))))
+            if k > 1:
+                f = E.mul(f, h[k - 2])
+        Zg = val(zg)
+        assert Zg != 0
+        kP = P
+        for k in range(1, 9):
+            if k > 1:
+                kP = add_aff(kP, P)
+            assert (val(slots[k][0]), val(slots[k][1])) == (kP[0] * Zg * Zg % p, kP[1] * pow(Zg, 3, p) % p), k
+        # one window on the isomorphic curve: R = 16 (3P) + 5P - beta-free -- against the affine law
+        X, Y, Z = slots[3][0], slots[3][1], tight(1)
+        for _ in range(4):
+            X, Y, Z = m.jdbl29(E, X, Y, Z)
+        X, Y, Z = m.madd29v(E, X, Y, Z, slots[5][0], [-v for v in slots[5][1]])        # - 5P
+        zt = val(Z) * Zg % p                                                              # Z' Zg: the point on the curve itself
+        aff = (val(X) * pow(zt, -2, p) % p, val(Y) * pow(zt, -3, p) % p)
+        want = P
+        for _ in range(42):                                                               # 16 * 3 - 5 = 43
+            want = add_aff(want, P)
+        assert aff == want
+
+
+def test_isomorphic_table_walk_stays_inside_the_machine_and_canon29s_domain():
+    r = m.prove_iso_table(m.CURVE_SECP)
+    assert r["worst_column_bits"] <= 63 and r["worst_limb_bits"] <= 31

@@ -463,6 +463,27 @@ def prove_glv_invariant(curve=CURVE_SECP):
     return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length()}
 
 
+def prove_iso_table(curve=CURVE_SECP):
+    """k_varwin.inc k_varwin_table_iso: the forward chain is jdbl29 / madd29v inside the window invariant (prove_glv_invariant); here the rest --
+    everything handed to canon29 (an X, Y or Z of the chain; a product of the backward walk) has a value in canon29's domain (-p, 2p), and the walk's
+    products (tight f, f^2, f^3, a carry-passed H, the lazy X_k, Y_k of the chain) stay inside the machine."""
+    E = Bounds(curve)
+    inv = window_invariant(curve)
+    p = curve.p
+    c = lambda k: Iv(inv[k].l, inv[k].v)
+    ok = lambda v: -p < v.v[0] and v.v[1] < 2 * p                     # + p, then two conditional subtractions of p: [0, p) for anything in (-p, 2p)
+    X3, Y3, Z3, H, r = madd29v(E, c("X"), c("Y"), c("Z"), c("tx"), c("ty"), with_hr=True)
+    Xd, Yd, Zd = jdbl29(E, c("tx"), c("ty"), Iv(inv["Z"].l, (0, p)))
+    assert all(ok(v) for v in (X3, Y3, Z3, Xd, Yd, Zd))
+    tight = lambda: Iv(inv["tx"].l, (-p // 8, 9 * p // 8))            # a product (of a factor that may be negative), or to29 of canonical words
+    f = E.mul(tight(), H)                                             # f_k = f_(k+1) H_k
+    f2 = E.sqr(tight())
+    f3 = E.mul(tight(), tight())
+    for v in (f, f2, f3, E.mul(c("X"), tight()), E.mul(c("Y"), tight())):          # kP waits in scratch as it was born: lazy limbs times f^2, f^3
+        assert ok(v) and v.within(tight()), v
+    return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length()}
+
+
 def jdbl_field(p, a, X, Y, Z):
     YY = Y * Y % p; B = 4 * X * YY % p
     alpha = (3 * X * X + a * pow(Z, 4, p)) % p
