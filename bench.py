@@ -480,7 +480,7 @@ def ref_compat_leg(args, result, eng, curve, k, xm, ym, n, peak, failures, steps
             "frac_of_a_priori_peak": achieved / A_PRIORI_PEAK_TMAD32, "lanes_compared": compared, "lanes_differing": differing, "compared_with": witness}
 
 
-def group_leg(args, world, timeout_s=240):
+def group_leg(args, world, timeout_s=120):
     """N > 1, one process per GPU: after the timed loops rank 0 runs `bench.py --multi group` over the same N devices in a
     CHILD process (the ranks idle at a barrier meanwhile) -- the C ABI's device group, whose RCCL branch (ncclCommInitAll
     communicators, grouped ncclSend / ncclRecv) only a multi-GPU node can execute.  A side figure: a failure here is

@@ -222,7 +222,10 @@ template <int C, bool NOZ = false> ECS_DEV void zdau29(coz29& s, uint32_t oswap)
   const fe29 X3 = sub29(sub29(Dp, W1p), W2p);
   const fe29 u = norm29(sub29(X3, W1p));
   const fe29 Cc = sqr29<C>(u);
-  fe29 yp = norm29(sub29(sub29(sqr29<C>(norm29(sub29(s.dy, u))), Dp), Cc));      // Y3' + 2 A1'
+  // (two of the carry passes are P-256's alone: with secp256k1's sparser reduction the interval proof holds with dy - u and dx + u squared as they are)
+  constexpr bool TIGHT_SQ = r29_prime<C>::p256;
+  const fe29 dyu = sub29(s.dy, u);
+  fe29 yp = norm29(sub29(sub29(sqr29<C>(TIGHT_SQ ? norm29(dyu) : dyu), Dp), Cc));      // Y3' + 2 A1'
   const fe29 A2 = dbl29(A1p);
   const fe29 Y3p = sub29(yp, A2);
   fe29 ym = norm29(sub29(Y3p, A2));
@@ -231,7 +234,8 @@ template <int C, bool NOZ = false> ECS_DEV void zdau29(coz29& s, uint32_t oswap)
   const fe29 W2 = mul29<C>(W1p, C4);
   const fe29 A1 = mul29<C>(Y3p, sub29(W1, W2));
   if constexpr (!NOZ) {
-    const fe29 zz = sub29(sub29(sqr29<C>(norm29(add29(s.dx, u))), Cp), Cc);
+    const fe29 dxu = add29(s.dx, u);
+    const fe29 zz = sub29(sub29(sqr29<C>(TIGHT_SQ ? norm29(dxu) : dxu), Cp), Cc);
     s.z = mul29<C>(s.z, zz);
   }
   cswap29(oswap, ym, yp);
@@ -296,7 +300,7 @@ template <int C> ECS_DEV jpoint29 jdbl29(const jpoint29& P) {
   fe29 t;
   if constexpr (r29_prime<C>::p256) {
     const fe29 delta = sqr29<C>(P.z);
-    t = mul29<C>(norm29(sub29(P.x, delta)), norm29(add29(P.x, delta)));
+    t = mul29<C>(sub29(P.x, delta), norm29(add29(P.x, delta)));          // (one carry pass is enough: the interval proof holds with X - delta as it is)
   } else {
     t = sqr29<C>(norm29(P.x));
   }
@@ -305,7 +309,7 @@ template <int C> ECS_DEV jpoint29 jdbl29(const jpoint29& P) {
   R.z = mul29<C>(dbl29(Yn), P.z);
   const fe29 X3 = sub29(sqr29<C>(alpha), dbl29(B));
   const fe29 E8 = dbl29(norm29<2>(sqr29<C>(YY)));
-  R.y = vred29<C>(sub29(mul29<C>(alpha, norm29(sub29(B, X3))), E8));
+  R.y = vred29<C>(sub29(mul29<C>(alpha, sub29(B, X3)), E8));              // (B - X3 needs no carry pass beside the carry-passed alpha)
   R.x = vred29<C>(X3);
   return R;
 }
@@ -332,7 +336,7 @@ template <int C> ECS_DEV jpoint29 dbl_add29(const jpoint29& P, const fe29& x2, c
   const fe29 A1 = mul29<C>(Y3, sub29(W1, W2));
   jpoint29 Q;
   const fe29 Qx = sub29(sub29(sqr29<C>(dy), W1), W2);
-  Q.y = vred29<C>(sub29(mul29<C>(dy, norm29(sub29(W1, Qx))), A1));
+  Q.y = vred29<C>(sub29(mul29<C>(dy, sub29(W1, Qx)), A1));               // (nor W1 - Qx beside the carry-passed dy)
   Q.x = vred29<C>(Qx);
   Q.z = mul29<C>(Z3, dx);
   return Q;

@@ -262,7 +262,9 @@ def zdau29(E, st, swap):
     X3 = E.sub(E.sub(Dp, W1p), W2p)
     u = E.norm(E.sub(X3, W1p))
     Cc = E.sqr(u)
-    s = E.norm(E.sub(dy, u))
+    s = E.sub(dy, u)
+    if E.cv is CURVE_P256:                                    # (secp256k1's sparser reduction leaves room: both squares take their operand as it is)
+        s = E.norm(s)
     yp = E.norm(E.sub(E.sub(E.sqr(s), Dp), Cc))               # Y3' + 2 A1'
     A2 = E.dbl(A1p)
     Y3p = E.sub(yp, A2)
@@ -271,7 +273,9 @@ def zdau29(E, st, swap):
     W1 = E.mul(X3, C4)
     W2 = E.mul(W1p, C4)
     A1 = E.mul(Y3p, E.sub(W1, W2))
-    w = E.norm(E.add(dx, u))
+    w = E.add(dx, u)
+    if E.cv is CURVE_P256:
+        w = E.norm(w)
     zz = E.sub(E.sub(E.sqr(w), Cp), Cc)
     z = E.mul(z, zz)
     ym, yp = E.cswap(swap, ym, yp)
@@ -367,14 +371,14 @@ def jdbl29(E, X, Y, Z):
     B = E.mul(X, G)
     if E.cv is CURVE_P256:
         delta = E.sqr(Z)
-        t = E.mul(E.norm(E.sub(X, delta)), E.norm(E.add(X, delta)))
+        t = E.mul(E.sub(X, delta), E.norm(E.add(X, delta)))
     else:
         t = E.sqr(E.norm(X))
     alpha = E.norm(E.add(E.dbl(t), t))
     Z3 = E.mul(E.dbl(Yn), Z)
     X3 = E.sub(E.sqr(alpha), E.dbl(B))
     E8 = E.dbl(E.norm(E.sqr(YY), 2))
-    Y3 = E.vred(E.sub(E.mul(alpha, E.norm(E.sub(B, X3))), E8))
+    Y3 = E.vred(E.sub(E.mul(alpha, E.sub(B, X3)), E8))
     return E.vred(X3), Y3, Z3
 
 
@@ -390,7 +394,7 @@ def dbl_add29(E, X, Y, Z, x2, y2):
     Cc = E.sqr(dx); W1 = E.mul(X3, Cc); W2 = E.mul(V, Cc)
     A1 = E.mul(Y3, E.sub(W1, W2))
     Qx = E.sub(E.sub(E.sqr(dy), W1), W2)
-    Qy = E.vred(E.sub(E.mul(dy, E.norm(E.sub(W1, Qx))), A1))
+    Qy = E.vred(E.sub(E.mul(dy, E.sub(W1, Qx)), A1))
     return E.vred(Qx), Qy, E.mul(Z3, dx)
 
 
