@@ -340,7 +340,7 @@ def base_line(args, world, total_units, n, value, elapsed):
         "ladder-x": f"scalar_mult_{args.curve} variable-base, x coordinate only: " + ("the co-Z ladder without Z (8M + 6S per bit), x from the curve equation + simultaneous inversion"
                     if args.curve == "p256" else "the co-Z ladder + x-only simultaneous inversion") + f", batch {sizes}, affine x out",
         "windowed": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 multiples of P) + signed 4-bit windows + simultaneous "
-                    f"inversion{' + GLV split k = k1 + k2*lambda' if args.curve == 'secp256k1' else ''}, batch {sizes}, affine out",
+                    f"inversion{' + GLV split k = k1 + k2*lambda, the table over one Z and the loop on the isomorphic curve' if args.curve == 'secp256k1' else ''}, batch {sizes}, affine out",
         "windowed-ct": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 odd multiples of P) + signed 4-bit windows (odd digits), ALG_CONSTANT_TIME: "
                        f"all 8 entries of the lane's table read in every window, kept under lane masks"
                        + (" (secp256k1: GLV split k = k1 + k2*lambda on the complete addition law of a = 0 curves)" if args.curve == "secp256k1" else "") + f"; + simultaneous inversion, batch {sizes}, affine out",
@@ -390,11 +390,13 @@ def roofline_object(args, eng, n, avg_ms):
         if args.curve == "secp256k1" and args.workload == "windowed-ct":  # GLV split on the complete addition law: 32 windows x (4 doublings of 6M + 2S, two mixed additions of 11M, beta),
             fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / min(256, 7 * share)) + 32 * (4 * 8 + 2 * 11 + 1) + (2 * 11 + 1) + 3 + (7 + inv / share)   # the top window's two additions, (X Z, Y Z^2, Z)
         if args.curve == "secp256k1" and args.workload == "windowed":     # GLV split: 32 windows x (4 doublings + 2 mixed additions + beta) + the top window's two additions
-            fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / min(256, 7 * share)) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + (7 + inv / share)   # table {1..8}P
+            # table {1..8}P over ONE Z (k_varwin_table_iso: a doubling, six mixed additions, the backward walk of 5 products per entry -- no inversion), the
+            # loop on the isomorphic curve, one product by the common Z at the end
+            fm = (dbl + 6 * 11 + 7 * 5) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + 1 + (7 + inv / share)
         mad32_unit, bytes_unit = int(fm * 136), 160
         kname = ("k_varwin_mult_glv_ct + k_varwin_multiples" if (args.workload == "windowed-ct" and args.curve == "secp256k1") else
                  "k_varwin_mult_odd<true> + k_varwin_odd_multiples" if args.workload == "windowed-ct" else "k_varwin_mult_odd<false> + k_varwin_odd_multiples" if args.curve == "p256"
-                 else "k_varwin_mult_glv + k_varwin_multiples") + " + k_varwin_to_table + k_to_affine_batched"
+                 else "k_varwin_mult_glv + k_varwin_table_iso") + ("" if (args.workload == "windowed" and args.curve == "secp256k1") else " + k_varwin_to_table") + " + k_to_affine_batched"
     else:
         # what THIS algorithm needs per scalar: 63 / 36 / 12 mixed additions x 11 field mults,
         # 7 mults of the simultaneous-inversion walk and 267/m (secp256k1: 270/m) of the inversion m = min(128, n / 2^17) points share; 32 B in, 64 B out.
