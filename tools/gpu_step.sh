@@ -52,6 +52,7 @@ import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value
     timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fields.py tests/test_openssl_crosscheck.py tests/test_gpu_large.py -x -q -m gpu \
       -k "windowed or varwin or digit_pattern or openssl or ecdsa or double_scalar or constant_time or x_coordinate or exceptional or maximum or large or invalid" > "$out/pytest.txt" 2>&1; rc=$?
     tail -5 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
+    [ -f build/ab_vw32/libecsimd_hip.so ] || exit 0           # the A/B needs the radix-32 build (-DECS_VARWIN_RADIX=32) beside the tree
     for w in windowed windowed-ct; do for c in p256; do
       echo "== $w $c" >> "$out/ab.txt"
       timeout -k 10 300 python tools/ab_variants.py "--workload $w --curve $c --global-log2-batch 22 --steps 5 --warmup 1" radix29=base radix32=build/ab_vw32/libecsimd_hip.so >> "$out/ab.txt" 2>&1 || rc=$?
@@ -61,6 +62,7 @@ import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value
     timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fields.py tests/test_openssl_crosscheck.py tests/test_gpu_large.py tests/test_cpp_host_api.py -x -q -m gpu \
       -k "windowed or varwin or digit_pattern or openssl or ecdsa or double_scalar or add or complete or x_coordinate or exceptional or maximum or large or invalid or cpp_api or glv or endomorphism" > "$out/pytest.txt" 2>&1; rc=$?
     tail -5 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
+    [ -f build/ab_glv32/libecsimd_hip.so ] || exit 0          # (-DECS_GLV_RADIX=32)
     for w in windowed; do
       echo "== $w secp256k1" >> "$out/ab.txt"
       timeout -k 10 300 python tools/ab_variants.py "--workload $w --curve secp256k1 --global-log2-batch 22 --steps 5 --warmup 1" radix29=base radix32=build/ab_glv32/libecsimd_hip.so >> "$out/ab.txt" 2>&1 || rc=$?
