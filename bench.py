@@ -380,23 +380,24 @@ def roofline_object(args, eng, n, avg_ms):
         kname = ("k_scalar_mult_x + k_inverse_batched" if args.curve == "p256" else "k_scalar_mult + k_to_affine_batched")
     elif args.workload in ("windowed", "windowed-ct"):
         # what THIS algorithm needs per scalar.  P-256: table {1,3,..,15}P = DBLU + 7 co-Z additions
-        # (6 + 7 x 7), its inversion 7 x (7 + 267/224) (224 points share one inversion at 2^22), 63 windows x (3 doublings
+        # (6 + 7 x 7), made affine by one inversion per lane and a walk back (7 x 5 + 3 + 267/32 at 2^22), 63 windows x (3 doublings
         # + one fused double-add of 13M + 5S), the final inversion walk; a doubling is 4M + 4S (P-256) / 3M + 4S
         # (secp256k1), a mixed addition 8M + 3S; 96 B in, 64 B out.
         dbl = 8 if args.curve == "p256" else 7
         inv = 267 if args.curve == "p256" else 270                  # addition-chain inversion (point.cuh fe_inverse)
         share = min(128, max(1, min(n, 1 << 22) >> 17))            # elements per shared inversion (k_affine.inc; the windowed path works in chunks of 2^22)
-        fm = (6 + 7 * 7) + 7 * (7 + inv / min(256, 7 * share)) + 63 * (3 * dbl + 18) + (7 + inv / share)
+        chain = 7 * 5 + 3 + inv / share                            # the table's entries made affine: ONE inversion per lane (the chain's last Z, shared by `share` lanes), 5 products per entry on the walk back
+        fm = (6 + 7 * 7) + chain + 63 * (3 * dbl + 18) + (7 + inv / share)
         if args.curve == "secp256k1" and args.workload == "windowed-ct":  # GLV split on the complete addition law: 32 windows x (4 doublings of 6M + 2S, two mixed additions of 11M, beta),
-            fm = (4 * dbl + 3 * 11) + 7 * (7 + inv / min(256, 7 * share)) + 32 * (4 * 8 + 2 * 11 + 1) + (2 * 11 + 1) + 3 + (7 + inv / share)   # the top window's two additions, (X Z, Y Z^2, Z)
+            fm = (dbl + 6 * 11) + chain + 32 * (4 * 8 + 2 * 11 + 1) + (2 * 11 + 1) + 3 + (7 + inv / share)   # table {1..8}P as a chain; the top window's two additions; (X Z, Y Z^2, Z)
         if args.curve == "secp256k1" and args.workload == "windowed":     # GLV split: 32 windows x (4 doublings + 2 mixed additions + beta) + the top window's two additions
             # table {1..8}P over ONE Z (k_varwin_table_iso: a doubling, six mixed additions, the backward walk of 5 products per entry -- no inversion), the
             # loop on the isomorphic curve, one product by the common Z at the end
             fm = (dbl + 6 * 11 + 7 * 5) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + 1 + (7 + inv / share)
         mad32_unit, bytes_unit = int(fm * 136), 160
-        kname = ("k_varwin_mult_glv_ct + k_varwin_multiples" if (args.workload == "windowed-ct" and args.curve == "secp256k1") else
+        kname = ("k_varwin_mult_glv_ct + k_varwin_multiples_chain" if (args.workload == "windowed-ct" and args.curve == "secp256k1") else
                  "k_varwin_mult_odd<true> + k_varwin_odd_multiples" if args.workload == "windowed-ct" else "k_varwin_mult_odd<false> + k_varwin_odd_multiples" if args.curve == "p256"
-                 else "k_varwin_mult_glv + k_varwin_table_iso") + ("" if (args.workload == "windowed" and args.curve == "secp256k1") else " + k_varwin_to_table") + " + k_to_affine_batched"
+                 else "k_varwin_mult_glv + k_varwin_table_iso") + ("" if (args.workload == "windowed" and args.curve == "secp256k1") else " + k_varwin_invert_last + k_varwin_chain_to_table") + " + k_to_affine_batched"
     else:
         # what THIS algorithm needs per scalar: 63 / 36 / 12 mixed additions x 11 field mults,
         # 7 mults of the simultaneous-inversion walk and 267/m (secp256k1: 270/m) of the inversion m = min(128, n / 2^17) points share; 32 B in, 64 B out.
