@@ -389,7 +389,7 @@ def roofline_object(args, eng, n, avg_ms):
         chain = 7 * 5 + 3 + inv / share                            # the table's entries made affine: ONE inversion per lane (the chain's last Z, shared by `share` lanes), 5 products per entry on the walk back
         fm = (6 + 7 * 7) + chain + 63 * (3 * dbl + 18) + (7 + inv / share)
         if args.curve == "secp256k1" and args.workload == "windowed-ct":  # GLV split on the complete addition law: 32 windows x (4 doublings of 6M + 2S, two mixed additions of 11M, beta),
-            fm = (dbl + 6 * 11) + chain + 32 * (4 * 8 + 2 * 11 + 1) + (2 * 11 + 1) + 3 + (7 + inv / share)   # table {1..8}P as a chain; the top window's two additions; (X Z, Y Z^2, Z)
+            fm = (6 + 6 * 7) + chain + 32 * (4 * 8 + 2 * 11 + 1) + (2 * 11 + 1) + 3 + (7 + inv / share)   # table {1..8}P as a chain; the top window's two additions; (X Z, Y Z^2, Z)
         if args.curve == "secp256k1" and args.workload == "windowed":     # GLV split: 32 windows x (4 doublings + 2 mixed additions + beta) + the top window's two additions
             # table {1..8}P over ONE Z (k_varwin_table_iso: a doubling, six mixed additions, the backward walk of 5 products per entry -- no inversion), the
             # loop on the isomorphic curve, one product by the common Z at the end

@@ -150,12 +150,11 @@ template <int C> ECS_DEV jpoint add_z2_1(const fe& X1, const fe& Y1, const fe& Z
 // windowed fixed-base kernels: there the Jacobian representative is free (affine-level parity), and the
 // linear operations -- canonical, ~20 VALU instructions each -- are what ADD_Z2_1's 15 of them cost.
 // Z3 = Z1 * H (ADD_Z2_1 returns 2 * Z1 * H): a different representative of the same point.
-// (H = Z3 / Z1 is handed out for callers that chain additions and invert only the last Z: k_varwin.inc k_varwin_multiples_chain)
-template <int C> ECS_DEV jpoint madd_hmv(const fe& X1, const fe& Y1, const fe& Z1, const fe& x2, const fe& y2, fe& H) {
+template <int C> ECS_DEV jpoint madd_hmv(const fe& X1, const fe& Y1, const fe& Z1, const fe& x2, const fe& y2) {
   const fe Z1Z1 = fe_sqr<C>(Z1);
   const fe U2 = fe_mul<C>(x2, Z1Z1);
   const fe S2 = fe_mul<C>(y2, fe_mul<C>(Z1Z1, Z1));
-  H = fe_sub<C>(U2, X1);
+  const fe H = fe_sub<C>(U2, X1);
   const fe r = fe_sub<C>(S2, Y1);
   const fe HH = fe_sqr<C>(H);
   const fe HHH = fe_mul<C>(H, HH);
@@ -166,7 +165,6 @@ template <int C> ECS_DEV jpoint madd_hmv(const fe& X1, const fe& Y1, const fe& Z
   R.y = fe_mul_sub_product<C>(r, fe_sub<C>(V, R.x), mul8x8(Y1, HHH));               // one reduction for the difference of two products
   return R;
 }
-template <int C> ECS_DEV jpoint madd_hmv(const fe& X1, const fe& Y1, const fe& Z1, const fe& x2, const fe& y2) { fe H; return madd_hmv<C>(X1, Y1, Z1, x2, y2, H); }
 
 // group order n (curve_nist_p256.h has no order: the reference never reduces scalars; SEC 2 values)
 template <int CURVE> struct curve_order;
