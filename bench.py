@@ -391,9 +391,9 @@ def roofline_object(args, eng, n, avg_ms):
         if args.curve == "secp256k1" and args.workload == "windowed-ct":  # GLV split on the complete addition law: 32 windows x (4 doublings of 6M + 2S, two mixed additions of 11M, beta),
             fm = (6 + 6 * 7) + chain + 32 * (4 * 8 + 2 * 11 + 1) + (2 * 11 + 1) + 3 + (7 + inv / share)   # table {1..8}P as a chain; the top window's two additions; (X Z, Y Z^2, Z)
         if args.curve == "secp256k1" and args.workload == "windowed":     # GLV split: 32 windows x (4 doublings + 2 mixed additions + beta) + the top window's two additions
-            # table {1..8}P over ONE Z (k_varwin_table_iso: a doubling, six mixed additions, the backward walk of 5 products per entry -- no inversion), the
+            # table {1..8}P over ONE Z (k_varwin_table_iso: a doubling, P over its Z, six co-Z additions, the backward walk of 5 products per entry -- no inversion), the
             # loop on the isomorphic curve, one product by the common Z at the end
-            fm = (dbl + 6 * 11 + 7 * 5) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + 1 + (7 + inv / share)
+            fm = (dbl + 4 + 6 * 7 + 7 * 5) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + 1 + (7 + inv / share)
         mad32_unit, bytes_unit = int(fm * 136), 160
         kname = ("k_varwin_mult_glv_ct + k_varwin_multiples_chain" if (args.workload == "windowed-ct" and args.curve == "secp256k1") else
                  "k_varwin_mult_odd<true> + k_varwin_odd_multiples" if args.workload == "windowed-ct" else "k_varwin_mult_odd<false> + k_varwin_odd_multiples" if args.curve == "p256"

@@ -348,6 +348,22 @@ template <int C> ECS_DEV jpoint29 madd29v_finish(const jpoint29& P, const fe29& 
   R.x = vred29<C>(norm29(R.x)); R.y = vred29<C>(R.y);
   return R;
 }
+// The co-Z addition with update (curve_group.h:91-116 ZADDU, 5M + 2S): (x1, y1) + (x2, y2) over their common z -> (rx, ry); (x1, y1) is re-expressed
+// over the new z = z dx; dx = x1 - x2 (carry-passed) is handed out -- the ratio of the two Z (k_varwin.inc k_varwin_table_iso walks back through them).
+// (x1, y1) tight products, (x2, y2) a jdbl29 output or a sum of this function: tools/radix29_model.py iso_chain_invariant, prove_iso_table.
+template <int C> ECS_DEV void zaddu29(fe29& x1, fe29& y1, const fe29& x2, const fe29& y2, fe29& z, fe29& rx, fe29& ry, fe29& dx) {
+  dx = norm29(sub29(x1, x2));
+  const fe29 Cc = sqr29<C>(dx);
+  const fe29 W1 = mul29<C>(x1, Cc);
+  const fe29 W2 = mul29<C>(x2, Cc);
+  const fe29 dy = norm29(sub29(y1, y2));
+  const fe29 D = sqr29<C>(dy);
+  const fe29 A1 = mul29<C>(y1, sub29(W1, W2));
+  rx = sub29(sub29(D, W1), W2);
+  ry = sub29(mul29<C>(dy, sub29(W1, rx)), A1);
+  z = mul29<C>(z, dx);
+  x1 = W1; y1 = A1;
+}
 // v = 0 as a FIELD element, for |value| < 2^260: the value reduction leaves |v| < p, where the only multiple of p is the integer 0; a sequential
 // carry pass makes the limbs below the top one canonical, so the integer 0 is nine zero limbs.  Its caller branches on the result: public scalars only.
 template <int C> ECS_DEV bool is_zero29(fe29 v) {

@@ -312,8 +312,8 @@ def test_beta_constant_of_the_glv_loops():
 
 
 def test_exact_isomorphic_table_of_the_glv_loop():
-    """k_varwin.inc k_varwin_table_iso on integers with the machine limits asserted: 2P by jdbl29, (k + 1)P = kP + P by madd29_hr / madd29v_finish,
-    then the backward walk with f_k = H_k .. H_7.  Every entry must be (x_k Zg^2, y_k Zg^3) for the AFFINE k P = (x_k, y_k) of the curve and
+    """k_varwin.inc k_varwin_table_iso on integers with the machine limits asserted: 2P by jdbl29, (k + 1)P = P + kP by zaddu29 (co-Z),
+    then the backward walk with f_k = dx_k .. dx_7.  Every entry must be (x_k Zg^2, y_k Zg^3) for the AFFINE k P = (x_k, y_k) of the curve and
     Zg = Z_8; and a window of the loop run on those entries must give, with Z' Zg, the point the same window gives on the curve itself."""
     cv = m.CURVE_SECP
     p = cv.p; R = 1 << m.RBITS; Rinv = pow(R, -1, p)
@@ -332,7 +332,8 @@ def test_exact_isomorphic_table_of_the_glv_loop():
         return x3, (lam * (P[0] - x3) - P[1]) % p
     rng = random.Random(5)
     P = G
-    for trial in range(6):
+    below = False
+    for trial in range(24):
         for _ in range(rng.randrange(1, 40)):
             P = add_aff(P, G) if P != G else add_aff(G, G)
         x1, y1 = tight(P[0]), tight(P[1])
@@ -340,10 +341,15 @@ def test_exact_isomorphic_table_of_the_glv_loop():
         h = [None] * 7
         X, Y, Z = m.jdbl29(E, x1, y1, tight(1))
         h[0] = Z
+        zz = E.sqr(Z)
+        qx, qy = E.mul(x1, zz), E.mul(y1, E.mul(zz, Z))                                   # P over Z_2
         for k in range(2, 8):
             slots[k] = (X, Y)                                                             # as born (scratch), lazy limbs and all
-            X, Y, Z, H, r = m.madd29v(E, X, Y, Z, x1, y1, with_hr=True)
-            h[k - 1] = H
+            X, Y, qx, qy, Z, dx = m.zaddu29(E, qx, qy, X, Y, Z)
+            h[k - 1] = dx
+        for v in (E.vred(X), E.vred(Y), Z):                                              # what the kernel hands canon29 (its domain: (-p, 2p))
+            assert -p < m.from_limbs(v) < 2 * p
+        below |= m.from_limbs(X) <= -p
         slots[8] = (canon(X), canon(Y))
         zg = canon(Z)
         f = h[6]
@@ -371,6 +377,7 @@ def test_exact_isomorphic_table_of_the_glv_loop():
         for _ in range(42):                                                               # 16 * 3 - 5 = 43
             want = add_aff(want, P)
         assert aff == want
+    assert below                                                                          # the case vred29 is there for did occur
 
 
 def test_isomorphic_table_walk_stays_inside_the_machine_and_canon29s_domain():

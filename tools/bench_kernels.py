@@ -74,7 +74,7 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     dblm = 8 if cv == 0 else 7
     vw = int((55 + (7 * 5 + 3 + inv_m / 32) + 63 * (3 * dblm + 18) + (7 + inv_m / 32)) * 136)          # odd digits, fused double-add; the table by one inversion per lane + the walk back
     if cv == 1:                                      # secp256k1: GLV split (k_varwin.inc)
-        vw = int(((dblm + 6 * 11 + 7 * 5) + 32 * (4 * dblm + 23) + 23 + 1 + (7 + inv_m / 32)) * 136)       # the table over one Z (k_varwin_table_iso), the loop on the isomorphic curve
+        vw = int(((dblm + 4 + 6 * 7 + 7 * 5) + 32 * (4 * dblm + 23) + 23 + 1 + (7 + inv_m / 32)) * 136)       # the table over one Z (k_varwin_table_iso), the loop on the isomorphic curve
     row(f"scalar_mult<{nm}> windowed variable base (per-element tables), affine out", n2,
         timeit(lambda: e.scalar_mult(cv, k, b2x, b2y, flags=2 | 4, out=outj), 5), vw, 160, "scalar mults")
     row(f"to_affine<{nm}> (simultaneous inversion)", n2, timeit(lambda: e.to_affine(cv, outj)), int((7 + inv_m / 32) * 136), 256, "points")

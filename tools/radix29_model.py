@@ -467,23 +467,53 @@ def prove_glv_invariant(curve=CURVE_SECP):
     return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length()}
 
 
+def zaddu29(E, x1, y1, x2, y2, z):
+    """fe29.cuh zaddu29<C>: the co-Z addition with update (curve_group.h:91-116 ZADDU, 5M + 2S) -- (x1, y1) + (x2, y2) over the common z; returns the
+    sum, (x1, y1) re-expressed over the new z = z dx, and dx (the ratio of the two Z)."""
+    dx = E.norm(E.sub(x1, x2))
+    Cc = E.sqr(dx)
+    W1 = E.mul(x1, Cc)
+    W2 = E.mul(x2, Cc)
+    dy = E.norm(E.sub(y1, y2))
+    D = E.sqr(dy)
+    A1 = E.mul(y1, E.sub(W1, W2))
+    rx = E.sub(E.sub(D, W1), W2)
+    ry = E.sub(E.mul(dy, E.sub(W1, rx)), A1)
+    return rx, ry, W1, A1, E.mul(z, dx), dx
+
+
+def iso_chain_invariant(curve=CURVE_SECP):
+    """k_varwin_table_iso's forward chain: the running P is a pair of products (tight), the last multiple is jdbl29's output or a zaddu29 sum."""
+    p = curve.p
+    B = 1 << W
+    lim = lambda lo, hi, top, vlo, vhi: Iv([(int(lo * B), int(hi * B))] * (NL - 1) + [(-top, top)], (int(vlo * p), int(vhi * p)))
+    return {"px": lim(0, 1, 1 << 27, -0.25, 1.25), "py": lim(0, 1, 1 << 27, -0.25, 1.25), "z": lim(0, 1, 1 << 27, -0.25, 1.25),
+            "mx": lim(-2.25, 1.25, 1 << 27, -2.5, 1.5), "my": lim(-2.25, 1.25, 1 << 27, -1.5, 1.5)}
+
+
 def prove_iso_table(curve=CURVE_SECP):
-    """k_varwin.inc k_varwin_table_iso: the forward chain is jdbl29 / madd29v inside the window invariant (prove_glv_invariant); here the rest --
-    everything handed to canon29 (an X, Y or Z of the chain; a product of the backward walk) has a value in canon29's domain (-p, 2p), and the walk's
-    products (tight f, f^2, f^3, a carry-passed H, the lazy X_k, Y_k of the chain) stay inside the machine."""
+    """k_varwin.inc k_varwin_table_iso on intervals.  Forward: 2P = jdbl29(P), P re-expressed over its Z (three products), then zaddu29 six times -- the
+    chain's invariant (iso_chain_invariant) holds from the start and maps into itself.  Backward: everything handed to canon29 has a value in its
+    domain (-p, 2p), and the walk's products (tight f, f^2, f^3, a carry-passed dx, the lazy X_k, Y_k of the chain) stay inside the machine."""
     E = Bounds(curve)
-    inv = window_invariant(curve)
+    winv = window_invariant(curve)
+    inv = iso_chain_invariant(curve)
     p = curve.p
     c = lambda k: Iv(inv[k].l, inv[k].v)
     ok = lambda v: -p < v.v[0] and v.v[1] < 2 * p                     # + p, then two conditional subtractions of p: [0, p) for anything in (-p, 2p)
-    X3, Y3, Z3, H, r = madd29v(E, c("X"), c("Y"), c("Z"), c("tx"), c("ty"), with_hr=True)
-    Xd, Yd, Zd = jdbl29(E, c("tx"), c("ty"), Iv(inv["Z"].l, (0, p)))
-    assert all(ok(v) for v in (X3, Y3, Z3, Xd, Yd, Zd))
-    tight = lambda: Iv(inv["tx"].l, (-p // 8, 9 * p // 8))            # a product (of a factor that may be negative), or to29 of canonical words
-    f = E.mul(tight(), H)                                             # f_k = f_(k+1) H_k
+    tx, ty = Iv(winv["tx"].l, winv["tx"].v), Iv(winv["ty"].l, (0, p))
+    X2, Y2, Z2 = jdbl29(E, tx, ty, Iv(winv["Z"].l, (0, p)))                                # 2P from the tight input point, Z = 1
+    ZZ = E.sqr(Z2)
+    px, py = E.mul(tx, ZZ), E.mul(ty, E.mul(ZZ, Z2))                                       # P over Z_2
+    assert X2.within(inv["mx"]) and Y2.within(inv["my"]) and Z2.within(inv["z"]) and px.within(inv["px"]) and py.within(inv["py"])
+    rx, ry, W1, A1, z, dx = zaddu29(E, c("px"), c("py"), c("mx"), c("my"), c("z"))
+    assert rx.within(inv["mx"]) and ry.within(inv["my"]) and W1.within(inv["px"]) and A1.within(inv["py"]) and z.within(inv["z"])
+    assert not ok(rx) and ok(E.vred(rx)) and ok(E.vred(ry)) and ok(z)   # 8P goes to canon29: its X = D - W1 - W2 reaches below -p, so vred29 first
+    tight = lambda: Iv(winv["tx"].l, (-p // 4, 5 * p // 4))           # a product (of a factor that may be negative, or as wide as dx)
+    f = E.mul(tight(), dx)                                            # f_k = f_(k+1) dx_k
     f2 = E.sqr(tight())
     f3 = E.mul(tight(), tight())
-    for v in (f, f2, f3, E.mul(c("X"), tight()), E.mul(c("Y"), tight())):          # kP waits in scratch as it was born: lazy limbs times f^2, f^3
+    for v in (f, f2, f3, E.mul(c("mx"), tight()), E.mul(c("my"), tight()), E.mul(tx, tight())):      # kP waits in scratch as it was born: lazy limbs times f^2, f^3
         assert ok(v) and v.within(tight()), v
     return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length()}
 
