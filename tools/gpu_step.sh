@@ -19,6 +19,14 @@ case "$name" in
   ab)               # A/B of library builds: bash tools/gpu_step.sh ab "<bench args>" name=lib ...
     args=$1; shift
     timeout -k 10 900 python tools/ab_variants.py "$args" "$@" > "$out/ab.txt" 2>&1; rc=$?; cat "$out/ab.txt"; exit $rc ;;
+  ab_multi)         # several A/B pairs on one box against ONE other library: bash tools/gpu_step.sh ab_multi <other .so> "<workload> <curve>" ...
+    other=$1; shift; : > "$out/ab.txt"
+    for spec in "$@"; do
+      set -- $spec
+      echo "== $1 $2" >> "$out/ab.txt"
+      timeout -k 10 300 python tools/ab_variants.py "--workload $1 --curve $2 --global-log2-batch 22 --steps 5 --warmup 1" new=base other=$other >> "$out/ab.txt" 2>&1 || { cat "$out/ab.txt"; exit 1; }
+    done
+    cat "$out/ab.txt"; exit 0 ;;
   bench)            # the driver's default command, timed by the shell as the driver does
     s0=$(date +%s); timeout -k 10 600 python bench.py "$@" > "$out/bench.json" 2> "$out/bench.err"; rc=$?; s1=$(date +%s)
     echo "rc=$rc wall=$((s1 - s0)) s"; tail -3 "$out/bench.err"; python3 -c "
