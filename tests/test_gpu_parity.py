@@ -681,6 +681,30 @@ def test_windowed_variable_base_matches_the_ladder_at_affine_level(engine, oracl
 
 
 @pytest.mark.parametrize("cv", CURVES)
+def test_invalid_base_points_do_not_poison_their_neighbours_in_the_windowed_paths(engine, cv):
+    """scalar_mult does not validate its base points (the reference does not either), but the windowed paths SHARE inversions between lanes --
+    the table step (one inversion per lane's chain of multiples, k_varwin_invert_last, taken over many lanes at once) and the final to_affine --
+    so a lane whose "point" is (0, 0), off the curve, or has a coordinate >= p must cost its neighbours nothing: every other lane equals the ladder,
+    in every windowed form (default, constant time, the plain loop on secp256k1), for small and chunk-sized batches."""
+    import torch
+    from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, ALG_CONSTANT_TIME, ALG_NO_ENDOMORPHISM
+    for n in (5, 300, (1 << 18) + 3):
+        k = engine.fill_random(n, SEED, 91); s = engine.fill_random(n, SEED, 92)
+        bx, by = engine.scalar_mult_base(cv, s, flags=OUT_AFFINE)
+        lx, ly = engine.scalar_mult(cv, k, bx, by, flags=OUT_AFFINE)
+        bad = sorted({0, 3, n - 1, n // 2, min(n - 1, 64), min(n - 1, 255), min(n - 1, 256)})
+        px, py = bx.clone(), by.clone()
+        for j, i in enumerate(bad):
+            if j % 3 == 0:   px[i] = 0; py[i] = 0                                  # "infinity"
+            elif j % 3 == 1: py[i] = px[i]                                         # off the curve
+            else:            px[i] = -1; py[i] = -1                                # 2^256 - 1 >= p
+        good = torch.ones(n, dtype=torch.bool, device=bx.device); good[bad] = False
+        for flags in (ALG_WINDOWED, ALG_WINDOWED | ALG_CONSTANT_TIME, ALG_WINDOWED | ALG_NO_ENDOMORPHISM):
+            wx, wy = engine.scalar_mult(cv, k, px, py, flags=OUT_AFFINE | flags)
+            assert torch.equal(wx[good], lx[good]) and torch.equal(wy[good], ly[good]), (n, flags)
+
+
+@pytest.mark.parametrize("cv", CURVES)
 def test_simultaneous_inversion_to_affine(engine, oracle, cv):
     """to_affine with Montgomery's trick (non-aliasing outputs) == one inversion per element (aliasing
     outputs force the per-element kernel) == the oracle; Z = 0 elements give (0, 0) and do not poison
