@@ -365,9 +365,48 @@ template <int C, bool SQRT> ECS_DEV fe secp256k1_pow_chain(const fe& x) {
     return fe_mul<C>(fe_sqr_n<C>(t, 2), x);
   }
 }
+// The same two chains on fe29.cuh's 29-bit limbs (round 4, ECS_SQRT_RADIX): 253 squarings in a row are what the carry-free columns are best at; every
+// operand is a product (tight), the value is the canonical one at the end (leave29), so the bits are the chains' above.
+#ifndef ECS_SQRT_RADIX
+#define ECS_SQRT_RADIX 29
+#endif
+template <int C> ECS_DEV fe29 sqr29_n(fe29 a, int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) a = sqr29<C>(a);
+  return a;
+}
+template <int C> ECS_DEV fe fe_sqrt_candidate29(const fe& xin) {
+  const fe29 x = enter29<C>(xin);
+  const fe29 x2 = mul29<C>(sqr29<C>(x), x);
+  if constexpr (C == CURVE_P256) {
+    const fe29 x4 = mul29<C>(sqr29_n<C>(x2, 2), x2);
+    const fe29 x8 = mul29<C>(sqr29_n<C>(x4, 4), x4);
+    const fe29 x16 = mul29<C>(sqr29_n<C>(x8, 8), x8);
+    const fe29 x32 = mul29<C>(sqr29_n<C>(x16, 16), x16);
+    fe29 t = mul29<C>(sqr29_n<C>(x32, 32), x);
+    t = mul29<C>(sqr29_n<C>(t, 96), x);
+    return leave29<C>(sqr29_n<C>(t, 94));
+  } else {
+    const fe29 x3 = mul29<C>(sqr29<C>(x2), x);
+    const fe29 x6 = mul29<C>(sqr29_n<C>(x3, 3), x3);
+    const fe29 x9 = mul29<C>(sqr29_n<C>(x6, 3), x3);
+    const fe29 x11 = mul29<C>(sqr29_n<C>(x9, 2), x2);
+    const fe29 x22 = mul29<C>(sqr29_n<C>(x11, 11), x11);
+    const fe29 x44 = mul29<C>(sqr29_n<C>(x22, 22), x22);
+    const fe29 x88 = mul29<C>(sqr29_n<C>(x44, 44), x44);
+    const fe29 x176 = mul29<C>(sqr29_n<C>(x88, 88), x88);
+    const fe29 x220 = mul29<C>(sqr29_n<C>(x176, 44), x44);
+    const fe29 x223 = mul29<C>(sqr29_n<C>(x220, 3), x3);
+    fe29 t = mul29<C>(sqr29_n<C>(x223, 23), x22);
+    t = mul29<C>(sqr29_n<C>(t, 6), x2);
+    return leave29<C>(sqr29_n<C>(t, 2));
+  }
+}
 template <int C> ECS_DEV fe fe_sqrt_candidate(const fe& x) {        // a^((p+1)/4): a square root if there is one (p = 3 mod 4)
   if constexpr (curve_prime<C>::ref_square) {
     return fe_pow<C>(x, curve_exps<C>::P_SQRT);            // the reference's own sequence of squarings (mgry_ops.h:44-86)
+  } else if constexpr (ECS_SQRT_RADIX == 29 && (C == CURVE_P256 || C == CURVE_SECP256K1_CLASSICAL)) {
+    return fe_sqrt_candidate29<C>(x);
   } else if constexpr (C == CURVE_P256) {
     // (p + 1)/4 = (2^32 - 1) 2^222 + 2^190 + 2^94: 253 S + 7 M (bit by bit it is 253 S + 33 M; the power does not depend on the walk)
     const fe x2 = fe_mul<C>(fe_sqr<C>(x), x);

@@ -383,3 +383,29 @@ def test_exact_isomorphic_table_of_the_glv_loop():
 def test_isomorphic_table_walk_stays_inside_the_machine_and_canon29s_domain():
     r = m.prove_iso_table(m.CURVE_SECP)
     assert r["worst_column_bits"] <= 63 and r["worst_limb_bits"] <= 31
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_exact_square_root_chains_on_29_bit_limbs(cv):
+    """point.cuh fe_sqrt_candidate29: the addition chains for a^((p+1)/4) with sqr29 / mul29 on tight operands, machine limits asserted, against pow()."""
+    p = cv.p; R = 1 << m.RBITS; Rinv = pow(R, -1, p)
+    E = m.Exact(cv)
+    tight = lambda v: m.to_limbs(v * R % p)
+    val = lambda l: m.from_limbs(l) * Rinv % p
+    def sqr_n(a, n):
+        for _ in range(n):
+            a = E.sqr(a)
+        return a
+    rng = random.Random(77)
+    for xv in [0, 1, 2, p - 1, p - 2, (p - 1) // 2, m.M29, (1 << 232) - 1] + [rng.randrange(p) for _ in range(6)]:
+        x = tight(xv)
+        x2 = E.mul(E.sqr(x), x)
+        if cv is m.CURVE_P256:
+            x4 = E.mul(sqr_n(x2, 2), x2); x8 = E.mul(sqr_n(x4, 4), x4); x16 = E.mul(sqr_n(x8, 8), x8); x32 = E.mul(sqr_n(x16, 16), x16)
+            t = E.mul(sqr_n(x32, 32), x); t = E.mul(sqr_n(t, 96), x); t = sqr_n(t, 94)
+        else:
+            x3 = E.mul(E.sqr(x2), x); x6 = E.mul(sqr_n(x3, 3), x3); x9 = E.mul(sqr_n(x6, 3), x3); x11 = E.mul(sqr_n(x9, 2), x2)
+            x22 = E.mul(sqr_n(x11, 11), x11); x44 = E.mul(sqr_n(x22, 22), x22); x88 = E.mul(sqr_n(x44, 44), x44); x176 = E.mul(sqr_n(x88, 88), x88)
+            x220 = E.mul(sqr_n(x176, 44), x44); x223 = E.mul(sqr_n(x220, 3), x3)
+            t = E.mul(sqr_n(x223, 23), x22); t = E.mul(sqr_n(t, 6), x2); t = sqr_n(t, 2)
+        assert val(t) == pow(xv, (p + 1) // 4, p), hex(xv)
