@@ -162,4 +162,4 @@ def test_constant_time_glv_loop_of_secp256k1(tmp_path_factory):
     assert 1 <= len(rep["branches"]) <= 3 and all(re.match(r"s_cmpk?_(lg|eq|lt|gt|le|ge)_[iu]32 s\d+, \S+ ; s_cbranch_scc[01] ", b) for b in rep["branches"]), rep["branches"]
     assert ct_check.check_after_secret_load(asm, "k_varwin_mult_glv_ctILi0E") > 8000
     with pytest.raises(ct_check.Violation):
-        ct_check.check(asm, "17k_varwin_mult_glvILi0E", allow_global_loads=32)
+        ct_check.check(asm, "17k_varwin_mult_glvILi4E", allow_global_loads=32)

@@ -117,20 +117,29 @@ def test_glv_split_of_secp256k1():
         k1 = signed256(k - ((c1 * a1) & M256) - ((c2 * a2) & M256))
         k2 = signed256(((c1 * mb1) & M256) - ((c2 * a1) & M256))
         assert (k1 + k2 * lam - k) % n == 0 and abs(k1) < 1 << 128 and abs(k2) < 1 << 128
-        both = []
-        for v in (abs(k1), abs(k2)):
-            u = v + off
-            digits = [((u >> (4 * j)) & 15) - 8 for j in range(32)] + [u >> 128]
-            assert digits[32] in (0, 1) and sum(d << (4 * j) for j, d in enumerate(digits)) == v
-            both.append(digits)
-        # the window loop never adds a point to itself or to its opposite (add_checked's branches stay cold)
         s1, s2 = (-1 if k1 < 0 else 1), (-1 if k2 < 0 else 1)
-        acc = 0                                                                     # discrete log of R
-        for j in range(32, -1, -1):
-            acc = (16 * acc) % n if j != 32 else 0
-            for t in (s1 * both[0][j], s2 * both[1][j] * lam):
-                t %= n
-                if t and acc:
-                    assert (acc - t) % n and (acc + t) % n
-                acc = (acc + t) % n
-        assert acc == k % n
+        # k_varwin_mult_glv<WB>: 4-bit windows (8-entry tables) and the 5-bit windows of the 16-entry table over one Z (k_varwin_table_iso)
+        for wb, windows in ((4, 33), (5, 26)):
+            half = 1 << (wb - 1)
+            offw = sum(half << (wb * j) for j in range(windows - 1))
+            assert offw == (off if wb == 4 else sum(1 << (5 * t + 4) for t in range(25)))
+            both = []
+            for v in (abs(k1), abs(k2)):
+                u = v + offw
+                digits = [((u >> (wb * j)) & (2 * half - 1)) - half for j in range(windows - 1)] + [u >> (wb * (windows - 1))]
+                assert 0 <= digits[-1] <= (1 if wb == 4 else 8) and all(-half <= d < half for d in digits[:-1])      # table entries 1 .. half cover every magnitude
+                assert sum(d << (wb * j) for j, d in enumerate(digits)) == v
+                if wb == 5:                                                         # the kernel moves u up 3 bits and reads bits 128..132: the same digits
+                    us = u << 3
+                    assert [((us >> (5 * j + 3)) & 31) - 16 for j in range(25)] + [(us >> 128) & 31] == digits and us < 1 << 160
+                both.append(digits)
+            # the window loop never adds a point to itself or to its opposite (add_checked's branches stay cold)
+            acc = 0                                                                 # discrete log of R
+            for j in range(windows - 1, -1, -1):
+                acc = ((1 << wb) * acc) % n if j != windows - 1 else 0
+                for t in (s1 * both[0][j], s2 * both[1][j] * lam):
+                    t %= n
+                    if t and acc:
+                        assert (acc - t) % n and (acc + t) % n
+                    acc = (acc + t) % n
+            assert acc == k % n
