@@ -107,11 +107,11 @@ enum {
                                       loops, tests/test_constant_time_isa.py).  SAFE for secret scalars; same results as ALG_WINDOWED.
                                       scalar_mult_base: an odd-digit comb over an LDS table -- one address per wave, an LDS broadcast (52 five-bit
                                       windows x 16 entries, 51 additions, three 256-thread workgroups per CU): k*G for key generation and ECDSA
-                                      nonces at 6.3x the ladder's rate (P-256 364 M/s, secp256k1 365 M/s).
+                                      nonces at 6.3x the ladder's rate (P-256 368 M/s, secp256k1 365 M/s).
                                       scalar_mult / scalar_mult_1s: the per-element window tables with all 8 entries of the lane's own table (512
                                       contiguous bytes) read in every window; on secp256k1 the GLV split stays, run on the COMPLETE addition law of
                                       a = 0 curves (no exceptional case to branch on; ALG_NO_ENDOMORPHISM: the plain odd-digit loop).  ECDH with a
-                                      secret scalar at 1.32x (P-256: 75.9 M/s) / 1.67x (secp256k1: 98.2 M/s) the round-4 ladder's rate
+                                      secret scalar at 1.33x (P-256: 78.2 M/s) / 1.67x (secp256k1: 99.8 M/s) the round-4 ladder's rate
                                       (oy = NULL works here too).  Not with ALG_WINDOWED_SIGNED / ALG_WINDOWED_BIG (64 or 2^19 entries per window to read).
                                       Without ALG_WINDOWED the flag is refused by every entry point (the ladder is constant-time as it is);
                                       double_scalar_mult / ecdsa_verify* take no flags: they are for public data */
