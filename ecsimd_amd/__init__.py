@@ -7,7 +7,7 @@ passes device pointers of torch tensors (torch is plumbing: device memory, strea
 ``Engine`` fails loudly when the library or a gfx950 device is missing.
 """
 from .engine import Engine, DeviceGroup, shard_range_c, EcsimdHipError, CURVES, P256, SECP256K1, lib_path, load_library  # noqa: F401
-from .flags import BASE_CLASSICAL, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_NO_ENDOMORPHISM, ALG_WINDOWED_BIG, REF_SQUARE_COMPAT, ALG_CONSTANT_TIME, LADDER_RADIX32, GROUP_NO_GATHER  # noqa: F401
+from .flags import BASE_CLASSICAL, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_NO_ENDOMORPHISM, ALG_WINDOWED_BIG, REF_SQUARE_COMPAT, ALG_CONSTANT_TIME, LADDER_RADIX32, BASE_GENERATOR, GROUP_NO_GATHER  # noqa: F401
 
 __all__ = ["Engine", "DeviceGroup", "shard_range_c", "EcsimdHipError", "CURVES", "P256", "SECP256K1", "lib_path", "load_library",
-           "BASE_CLASSICAL", "BASE_MGRY", "OUT_JACOBIAN", "OUT_AFFINE", "ALG_WINDOWED", "ALG_WINDOWED_SIGNED", "ALG_NO_ENDOMORPHISM", "ALG_WINDOWED_BIG", "REF_SQUARE_COMPAT", "ALG_CONSTANT_TIME", "LADDER_RADIX32", "GROUP_NO_GATHER"]
+           "BASE_CLASSICAL", "BASE_MGRY", "OUT_JACOBIAN", "OUT_AFFINE", "ALG_WINDOWED", "ALG_WINDOWED_SIGNED", "ALG_NO_ENDOMORPHISM", "ALG_WINDOWED_BIG", "REF_SQUARE_COMPAT", "ALG_CONSTANT_TIME", "LADDER_RADIX32", "BASE_GENERATOR", "GROUP_NO_GATHER"]

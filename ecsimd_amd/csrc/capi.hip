@@ -563,8 +563,10 @@ int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id) {
     const gmod M = make_gmod(p, (flags & ECSIMD_HIP_MODULUS_PRIME) ? GMOD_PRIME : 0u);
     modulus_registry& r = registry();
     std::lock_guard<std::mutex> g(r.mu);
+    // Entries are keyed on (p, PRIME): the flag changes what gfp_inverse computes (the shared division-step inversion against gfp.h:42-44's x^(p-2), which
+    // differ for a composite p), so a registration with the flag must never change the behaviour of an id someone else holds without it.
     for (size_t i = 0; i < r.mods.size(); ++i)
-      if (!memcmp(r.mods[i].p, M.p, sizeof M.p)) { r.mods[i].flags |= M.flags; *field_id = FIRST_FIELD_ID + (int)i; return ECSIMD_HIP_OK; }   // the same id; a later "prime" sticks
+      if (!memcmp(r.mods[i].p, M.p, sizeof M.p) && (r.mods[i].flags == M.flags || i < 2)) { *field_id = FIRST_FIELD_ID + (int)i; return ECSIMD_HIP_OK; }   // (i < 2: the built-in group orders ARE prime, whatever the caller says)
     if (r.mods.size() >= (size_t)MAX_FIELDS) return ECSIMD_HIP_ERR_BAD_ARG;
     r.mods.push_back(M);
     *field_id = FIRST_FIELD_ID + (int)r.mods.size() - 1;
@@ -758,7 +760,11 @@ int ecsimd_hip_trplu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py,
 
 int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   REQUIRE_CTX();
-  if (x == nullptr && y == nullptr && n) return ecsimd_hip_scalar_mult_base(ctx, curve, k, ox, oy, oz, n, flags & ~ECSIMD_HIP_BASE_MGRY);   // no base point: the generator
+  // no base point AND the caller says so (BASE_GENERATOR): the generator.  Two null pointers alone are an error, as they were before round 4 -- a caller whose
+  // point buffers failed to allocate must not get k G back (and ALG_WINDOWED means another algorithm on a fixed base than on a variable one).
+  if ((flags & ECSIMD_HIP_BASE_GENERATOR) && x == nullptr && y == nullptr)
+    return ecsimd_hip_scalar_mult_base(ctx, curve, k, ox, oy, oz, n, flags & ~(ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_BASE_GENERATOR));
+  if (flags & ECSIMD_HIP_BASE_GENERATOR) return bad(ctx, "BASE_GENERATOR takes x = y = NULL");
   REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy);
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED)) {
@@ -789,6 +795,7 @@ int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[
   return run_ladder(ctx, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, oz, n, flags); }
 int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy);
+  flags &= ~ECSIMD_HIP_BASE_GENERATOR;                            // (implied here)
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG)) {
     const bool big = (flags & ECSIMD_HIP_ALG_WINDOWED_BIG) != 0;         // signed 20-bit windows, table in device memory
@@ -978,7 +985,14 @@ int ecsimd_hip_ecdsa_sign(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, con
   launch::to_affine_batched(st, curve, jx, jy, jz, rx, nullptr, n, true);
   launch::ecdsa_sign_scalars(st, N, e, d, k, rx, r, s_, ok, n);
   hipError_t err = hipGetLastError();
+  // The workspace held the Jacobian k G (X, Y, Z) and its affine x: with the public r, the Z of an unnormalised k G gives bits of the nonce away
+  // (the projective-coordinate leak), and the block outlives the call (grow-only, hipFree does not wipe).  Zero it on the same stream, behind the kernels.
+  if (err == hipSuccess) err = hipMemsetAsync(ctx->workspace, 0, 4 * n * 32, st);
   return err == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, err, "ecdsa_sign launch"); }
+
+int ecsimd_hip_workspace_info(ecsimd_hip_ctx* ctx, const void** dptr, size_t* bytes) {
+  REQUIRE_CTX(); if (!dptr || !bytes) return bad(ctx, "workspace_info: null output");
+  *dptr = ctx->workspace; *bytes = ctx->workspace_bytes; return ECSIMD_HIP_OK; }
 
 int ecsimd_hip_scalar_mult_p256(ecsimd_hip_ctx* ctx, const uint64_t* k, const uint64_t* xm, const uint64_t* ym, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) {
   return ecsimd_hip_scalar_mult(ctx, ECSIMD_HIP_P256, k, xm, ym, ox, oy, oz, n, ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN); }

@@ -231,6 +231,13 @@ ECS_DEV bool g_is_zero(const fe& a) {
   for (int i = 0; i < 8; ++i) d |= a.w[i];
   return d == 0;
 }
+// all ones where a == 0, as data (no compare, no branch)
+ECS_DEV uint32_t g_zero_mask(const fe& a) {
+  uint32_t d = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d |= a.w[i];
+  return (uint32_t)((int32_t)((d | (0u - d)) ^ 0x80000000u) >> 31);
+}
 // a < b as 256-bit integers
 ECS_DEV bool g_less(const fe& a, const fe& b) { fe d; return sub8_3(d, a, b) != 0; }
 

@@ -49,7 +49,8 @@ struct rccl_api {
   bool load() {
     // ECSIMD_HIP_RCCL_LIB=<path>: the RCCL build to use instead of the search below (a deployment's pinned copy; the test double
     // tests/fake_rccl/libfake_rccl.so).  Nothing else is tried when it is set: a typo must not fall back silently.
-    if (const char* forced = getenv("ECSIMD_HIP_RCCL_LIB")) {
+    // secure_getenv: ignored in a set-user-ID / set-group-ID / capability-raised process (this library handles private keys: ecdsa_sign).
+    if (const char* forced = secure_getenv("ECSIMD_HIP_RCCL_LIB")) {
       if (forced[0]) { lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL); if (!lib) return false; }
     }
     // the copy this process already has (torch ships its own librccl.so, soname librccl.so.1): a second RCCL in one process
@@ -191,9 +192,12 @@ int ecsimd_hip_group_init(const int* devices, int n_devices, ecsimd_hip_group** 
   // communicator ("Duplicate GPU detected") and group_init then fails; the test double accepts it, which is how a one-GPU box
   // executes the grouped ncclSend / ncclRecv bookkeeping below (tests/test_gpu_parity.py::test_device_group_rccl_branch_on_a_double).
   std::set<int> distinct(devices, devices + n_devices);
-  const char* force = getenv("ECSIMD_HIP_GROUP_FORCE_RCCL");
-  if (n_devices > 1 && ((int)distinct.size() == n_devices || (force && force[0] == '1'))) {
+  // The hook is honoured only when the library that got loaded IS the test double (ncclGetVersion 99999; no RCCL release answers that).
+  const char* force = secure_getenv("ECSIMD_HIP_GROUP_FORCE_RCCL");
+  const bool forced = n_devices > 1 && (int)distinct.size() != n_devices && force && force[0] == '1';
+  if (n_devices > 1 && ((int)distinct.size() == n_devices || forced)) {
     if (!g->rccl.load()) { (void)ecsimd_hip_group_destroy(g); return ECSIMD_HIP_ERR_HIP; }
+    if (forced) { int v = 0; if (g->rccl.GetVersion(&v) != ncclSuccess || v != 99999) { (void)ecsimd_hip_group_destroy(g); return ECSIMD_HIP_ERR_BAD_ARG; } }
     g->comm.assign((size_t)n_devices, nullptr);
     ncclResult_t r = g->rccl.CommInitAll(g->comm.data(), n_devices, devices);
     if (r != ncclSuccess) { g->comm.clear(); (void)ecsimd_hip_group_destroy(g); return ECSIMD_HIP_ERR_HIP; }

@@ -55,6 +55,10 @@ template <bool REF> __global__ void __launch_bounds__(BLOCK) k_g_sqrt(gmod M, co
 
 // GFp::inverse over a batch for a PRIME modulus (gfp.h:42-44), Montgomery's simultaneous inversion as k_affine.inc's k_inverse_batched:
 // a lane owns m elements `lanes` apart, out[] holds the prefix products on the way up (so out must not alias a).  0 -> 0.
+// The operands are whatever the caller hands over -- the reference never rejects a >= p (tests/ops.cpp:232) -- so "zero" is decided on the
+// canonical PRODUCT, not on the operand's words: for a prime p and acc != 0, acc * v / R = 0 (mod p) exactly when v = 0 (mod p), whatever multiple
+// of a small p the 256-bit v is.  Such an element is left out of the running product (else it would zero the inverses of up to 127 neighbours)
+// and gets 0, the value 0^(p-2) has.  Selects only: the operand may be a secret.
 __global__ void __launch_bounds__(256) k_g_inverse_batched(gmod M, const uint64_t* __restrict__ a, uint64_t* __restrict__ out, size_t n, size_t lanes, int m) {
   const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= lanes) return;
@@ -63,9 +67,8 @@ __global__ void __launch_bounds__(256) k_g_inverse_batched(gmod M, const uint64_
   for (int j = 0; j < m; ++j) {
     const size_t e = (size_t)j * lanes + g;
     if (e >= n) break;
-    fe v = fe_load(a, e);
-    if (g_is_zero(v)) v = one;
-    acc = g_mul(acc, v, M);
+    const fe t = g_mul(acc, fe_load(a, e), M);
+    acc = fe_select(g_zero_mask(t), acc, t);
     fe_store(out, e, acc);
   }
   fe inv = g_inverse_mgry(acc, M);
@@ -73,16 +76,13 @@ __global__ void __launch_bounds__(256) k_g_inverse_batched(gmod M, const uint64_
   while (last >= 0 && (size_t)last * lanes + g >= n) --last;
   for (int j = last; j >= 0; --j) {
     const size_t e = (size_t)j * lanes + g;
-    fe v = fe_load(a, e);
-    const bool zero = g_is_zero(v);
-    if (zero) v = one;
+    const fe v = fe_load(a, e);
     const fe prev = (j > 0) ? fe_load(out, (size_t)(j - 1) * lanes + g) : one;
+    const uint32_t zero = g_zero_mask(g_mul(prev, v, M));        // the same test as on the way up
     fe iv = g_mul(inv, prev, M);
-    inv = g_mul(inv, v, M);
-    if (zero) {
+    inv = fe_select(zero, inv, g_mul(inv, v, M));
 #pragma unroll
-      for (int k = 0; k < 8; ++k) iv.w[k] = 0;
-    }
+    for (int k = 0; k < 8; ++k) iv.w[k] &= ~zero;
     fe_store(out, e, iv);
   }
 }

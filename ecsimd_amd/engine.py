@@ -359,6 +359,16 @@ class Engine:
         self._call("ecdsa_sign", C.c_int(curve), self._ptr(e), self._ptr(d), self._ptr(k), self._ptr(r), self._ptr(s), self._ptr(ok, 0), C.c_size_t(n))
         return r, s, ok
 
+    def workspace_bytes(self):
+        """ecsimd_hip_workspace_info as a uint8 numpy copy of the context's scratch block (diagnostic: what the last call left behind)."""
+        ptr, size = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.ecsimd_hip_workspace_info(self.ctx, C.byref(ptr), C.byref(size)), "workspace_info")
+        self.torch.cuda.synchronize(self.tdev)
+        host = np.empty(size.value, dtype=np.uint8)
+        if size.value:
+            self._check(self.lib.ecsimd_hip_memcpy_d2h(self.ctx, host.ctypes.data_as(C.c_void_p), ptr, C.c_size_t(size.value)), "memcpy_d2h")
+        return host
+
     def scalar_mult_p256(self, k, xm, ym, out=None):
         n = k.shape[0]
         r = out if out is not None else [self.empty(n) for _ in range(3)]

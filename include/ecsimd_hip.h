@@ -68,6 +68,8 @@ enum ecsimd_hip_status {
 enum {
   ECSIMD_HIP_BASE_CLASSICAL = 0,   /* base point (x, y) classical: from_affine is applied first */
   ECSIMD_HIP_BASE_MGRY = 1,        /* base point already Montgomery form (what scalar_mult_p256 receives) */
+  ECSIMD_HIP_BASE_GENERATOR = 512, /* ecsimd_hip_scalar_mult only, with x = y = NULL: the base point is the curve generator (= ecsimd_hip_scalar_mult_base).
+                                      Two null pointers WITHOUT this flag are ECSIMD_HIP_ERR_BAD_ARG, like any other null pointer */
   ECSIMD_HIP_OUT_JACOBIAN = 0,     /* out = (X, Y, Z) Montgomery form, as curve_group::scalar_mult returns */
   ECSIMD_HIP_OUT_AFFINE = 2,       /* out = to_affine(): (x, y) classical; oz may be NULL; oy may be NULL too: the x coordinate only
                                       (ECDH's shared secret, ECDSA's r): the conversion then skips y's two field multiplications, and on P-256 the
@@ -161,8 +163,8 @@ int ecsimd_hip_memcpy_d2d(ecsimd_hip_ctx* ctx, void* dst, const void* src, size_
 int ecsimd_hip_get_constant(int curve, int which, uint64_t out[4]);
 /* A field id for the odd modulus p >= 3 (host pointer, 4 x u64 little-endian limbs): the host derives R mod p, R^2 mod p, -R mod p and m' = -p^-1 mod 2^32
  * (mgry_csts.h:15-35, mgry_mul.h:33-38) once; the element-wise field entry points then accept the id as `curve` (for a field id get_constant
- * reads zero in the curve slots 1-4, 8, 9).  The same p gives the same id (the two curve primes give 0 / 1); ids live as long as the
- * process; thread-safe.  flags: 0 or ECSIMD_HIP_MODULUS_PRIME.  gfp_sqrt needs p = 3 mod 4, as the reference's GFp does (gfp.h:84). */
+ * reads zero in the curve slots 1-4, 8, 9).  The same (p, flags) gives the same id (the two curve primes give 0 / 1 whatever the flags); the same p with and
+ * without MODULUS_PRIME are two ids, so that nobody's gfp_inverse changes under them; ids live as long as the process; thread-safe.  flags: 0 or ECSIMD_HIP_MODULUS_PRIME.  gfp_sqrt needs p = 3 mod 4, as the reference's GFp does (gfp.h:84). */
 int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id);
 
 /* ---- L2: bignum ops (curve independent) ----------------------------------------------- */
@@ -281,7 +283,7 @@ int ecsimd_hip_scalar_mult(ecsimd_hip_ctx*, int curve, const uint64_t* k, const 
 /* curve_group.h:221-251 scalar_mult_1s: ONE scalar (host pointer) for all points; flags as for scalar_mult. */
 int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx*, int curve, const uint64_t k1[4], const uint64_t* x, const uint64_t* y,
                               uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
-/* curve_group.h:35-41 WJG + scalar_mult: k[i] * G (base = the curve generator); ecsimd_hip_scalar_mult with x = y = NULL is the same call.
+/* curve_group.h:35-41 WJG + scalar_mult: k[i] * G (base = the curve generator); ecsimd_hip_scalar_mult with x = y = NULL and ECSIMD_HIP_BASE_GENERATOR is the same call.
  * Small batches (r4): with OUT_AFFINE, no ALG_* / REF_SQUARE_COMPAT / LADDER_RADIX32 flag and n <= 2^16 the product comes from the constant-time
  * 5-bit comb (ALG_WINDOWED | ALG_CONSTANT_TIME's kernel: as safe for secret scalars as the ladder) instead of a 254-iteration ladder launch whose
  * cost does not depend on n -- 0.2 ms instead of 1.3 ms -- with the SAME affine bits: at the ladder's three degenerate scalars (n - 1,
@@ -323,9 +325,14 @@ int ecsimd_hip_ecdsa_verify(ecsimd_hip_ctx*, int curve, const uint64_t* e, const
  * of ALG_WINDOWED | ALG_CONSTANT_TIME), r = x(R) mod n, s = k^-1 (e + r d) mod n on the device (generic Montgomery products on the order's field id, one
  * constant-time division-step inversion shared by up to 128 signatures).  ok[i] = 1 and (r, s) a valid signature, or ok[i] = 0 and r = s = 0 where d or k is
  * out of range or r or s came out 0 (probability ~2^-255: sign again with another nonce).  d and k are treated as SECRETS: no branch or address depends on
- * them (the comb's window loop is checked on the ISA, the scalar-field kernel is selects and branch-free field functions; not pinned on the ISA).
- * r, s must not alias an input.  Workspace: 128 B per element. */
+ * them, checked on the shipped ISA: the comb's window loop by tools/ct_check.py check(), and the comb as a whole, the x-only simultaneous inversion of k G and
+ * the scalar-field kernel (its division-step inversion included) by check_secret_flow, a taint analysis from the loads of d, k and k G to every branch
+ * condition, lane mask in force at a memory access, and address (tests/test_constant_time_isa.py).  The Jacobian k G and its x are zeroed in the context
+ * workspace on the stream before the call returns.  r, s must not alias an input.  Workspace: 128 B per element. */
 int ecsimd_hip_ecdsa_sign(ecsimd_hip_ctx*, int curve, const uint64_t* e, const uint64_t* d, const uint64_t* k, uint64_t* r, uint64_t* s, uint8_t* ok, size_t n);
+/* Diagnostic: the context's grow-only scratch block (device pointer and size; NULL / 0 before the first call that needed one).  What a test reads
+ * back to see that ecdsa_sign left no nonce-derived data behind (tests/test_gpu_fields.py); valid until the next call that grows the block. */
+int ecsimd_hip_workspace_info(ecsimd_hip_ctx* ctx, const void** dptr, size_t* bytes);
 /* lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P) -- P-256, base in Montgomery form with
  * Z = mgry(1), Jacobian Montgomery output. */
 int ecsimd_hip_scalar_mult_p256(ecsimd_hip_ctx*, const uint64_t* k, const uint64_t* xm, const uint64_t* ym,

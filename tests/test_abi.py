@@ -62,7 +62,12 @@ def test_modulus_registry_without_a_gpu(lib, oracle):
     moduli = list(REF_MODULI.values()) + [3, 5, 2**64 + 13, 2**256 - 189] + [int.from_bytes(rng.bytes(32), "big") | 1 for _ in range(8)]
     for p in moduli:
         fid = register_modulus(p)
-        assert fid >= 2 and register_modulus(p, prime=True) == fid
+        assert fid >= 2 and register_modulus(p) == fid
+        # (p, PRIME) is another entry (the flag changes what gfp_inverse computes, so it must not change under a holder of the unflagged id) --
+        # except for the built-in group orders, which ARE prime whatever the caller says
+        builtin = fid in (P256_ORDER, SECP256K1_ORDER)
+        fidp = register_modulus(p, prime=True)
+        assert (fidp == fid) == builtin and register_modulus(p, prime=True) == fidp and register_modulus(p) == fid
         c = oracle.constants(oracle.register_modulus(p))
         for which, key in ((0, "p"), (5, "r_p"), (6, "rsq_p"), (7, "pm1_r_p"), (10, "p_m2"), (11, "p_sqrt")):
             out = (C.c_uint64 * 4)()

@@ -163,3 +163,81 @@ def test_constant_time_glv_loop_of_secp256k1(tmp_path_factory):
     assert ct_check.check_after_secret_load(asm, "k_varwin_mult_glv_ctILi0E") > 8000
     with pytest.raises(ct_check.Violation):
         ct_check.check(asm, "17k_varwin_mult_glvILi4E", allow_global_loads=32)
+
+
+# ---- secret-flow (taint) analysis: the signing path
+# ct_check.check_secret_flow follows every value loaded through a pointer argument named secret to the places where it could change what the
+# machine DOES: branch conditions, addresses, and the lane mask in force at a memory access.  ecdsa_sign = the constant-time comb (k secret),
+# k_to_affine_batched on the Jacobian k G (X, Y, Z as secret as the nonce), k_ecdsa_sign_scalars (d, k, the prefix products in s[]).
+@pytest.fixture(scope="module")
+def gfield_asm(tmp_path_factory):
+    return assembly(tmp_path_factory, "k_gfield")
+
+
+def test_signing_scalar_field_kernel_keeps_d_and_k_out_of_control_flow_and_addresses(gfield_asm):
+    # arguments: (gmod, e, d, k, x, r, s, ok, n, lanes, m) -- d, k and s[] (which carries the nonces' prefix products on the way up) are secret
+    rep = ct_check.check_secret_flow(gfield_asm, "k_ecdsa_sign_scalars", secret_args=[2, 3, 6])
+    assert rep["secret_loads"] >= 6 and rep["instructions"] > 4000 and not rep["secret_scratch"] and not rep["secret_lds"]
+    assert rep["public_branches"] > 0          # it HAS lane-dependent control flow (the batch's ragged tail): on public indices only
+
+
+def test_generic_division_step_inversion_with_a_secret_operand(gfield_asm):
+    rep = ct_check.check_secret_flow(gfield_asm, "k_g_inverse_divsteps", secret_args=[1])
+    assert rep["secret_loads"] == 2 and rep["instructions"] > 1500
+    rep = ct_check.check_secret_flow(gfield_asm, "k_g_inverse_batched", secret_args=[1, 2])       # out[] holds the prefix products
+    assert rep["secret_loads"] >= 4
+
+
+def test_signing_point_kernels_under_the_same_analysis(affine_asm):
+    """The comb with a secret k (the loop is also held to the shape check above) and the simultaneous inversion of k G: zero handling by selects."""
+    rep = ct_check.check_secret_flow(affine_asm, "k_base_windowed_sILi5ELb1ELi256E", secret_args=[0, 2, 3, 4])
+    assert rep["secret_loads"] == 2 and not rep["secret_lds"]          # the table in LDS is public; the scalar never reaches an LDS address
+    rep = ct_check.check_secret_flow(affine_asm, "k_to_affine_batchedILb1E", secret_args=[0, 1, 2, 3, 4])
+    assert rep["secret_loads"] >= 6
+    rep = ct_check.check_secret_flow(affine_asm, "17k_inverse_batched", secret_args=[0, 1])
+    assert rep["secret_loads"] >= 4
+    # the public-scalar comb addresses LDS by digits of k: the analysis has to say so
+    with pytest.raises(ct_check.Violation, match="LDS address"):
+        ct_check.check_secret_flow(affine_asm, "k_base_windowed_sILi7ELb0E", secret_args=[0])
+
+
+def test_the_secret_flow_analysis_refuses_planted_leaks(gfield_asm):
+    """Mutations of the real assembly of k_ecdsa_sign_scalars, each placed right after the first load through the secret pointer k: a branch on a
+    compare of the loaded word, the word moved to the scalar unit and branched on, a load addressed by it, a load under a lane mask made of it --
+    and the controls: the same mutations fed from a PUBLIC register pass."""
+    lines = gfield_asm.splitlines()
+    fn = next(i for i, ln in enumerate(lines) if re.match(r"^_ZN\w*20k_ecdsa_sign_scalars\w*:", ln))
+    end = next(i for i in range(fn, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    blocks = ct_check.parse_function(gfield_asm, "k_ecdsa_sign_scalars")
+    label = next(b[0] for b in blocks if b[0].startswith(".LBB"))
+    # the first global load whose data the analysis calls secret: find it by running the analysis with a tracer on a copy
+    secret_reg = None
+    for i in range(fn, end):
+        m = re.match(r"\s*global_load_dwordx4 v\[(\d+):\d+\], v\[\d+:\d+\], off", lines[i])
+        if m:
+            probe = "\n".join(lines[:i + 1] + ["\ts_waitcnt vmcnt(0)", f"\tv_readfirstlane_b32 s90, v{m.group(1)}", "\ts_cmp_lg_u32 s90, 0", f"\ts_cbranch_scc1 {label}"] + lines[i + 1:])
+            try:
+                ct_check.check_secret_flow(probe, "k_ecdsa_sign_scalars", secret_args=[2, 3, 6])
+            except ct_check.Violation:
+                secret_reg, at = int(m.group(1)), i + 1
+                break
+    assert secret_reg is not None, "no load the analysis treats as secret"
+    v = f"v{secret_reg}"
+    plants = {
+        "lane-mask branch": [f"\tv_cmp_ne_u32_e32 vcc, 0, {v}", f"\ts_cbranch_vccnz {label}"],
+        "scalar branch": [f"\tv_readfirstlane_b32 s90, {v}", "\ts_cmp_lg_u32 s90, 0", f"\ts_cbranch_scc1 {label}"],
+        "address": [f"\tv_mov_b32_e32 v250, {v}", "\tv_mov_b32_e32 v251, 0", "\tglobal_load_dword v252, v[250:251], off"],
+        "masked load": [f"\tv_cmp_ne_u32_e32 vcc, 0, {v}", "\ts_and_saveexec_b64 s[90:91], vcc", "\tglobal_load_dword v252, v[0:1], off", "\ts_mov_b64 exec, s[90:91]"],
+        "exec branch": [f"\tv_cmp_ne_u32_e32 vcc, 0, {v}", "\ts_and_saveexec_b64 s[90:91], vcc", f"\ts_cbranch_execz {label}", "\ts_mov_b64 exec, s[90:91]"],
+    }
+    for name, planted in plants.items():
+        mutated = "\n".join(lines[:at] + planted + lines[at:])
+        with pytest.raises(ct_check.Violation):
+            ct_check.check_secret_flow(mutated, "k_ecdsa_sign_scalars", secret_args=[2, 3, 6])
+        # the control: fed from a public register (the lane's element index, v0 on entry is the work-item id) nothing is reported ...
+        public = [p.replace(v + "\n", "v0\n").replace(f", {v}", ", v0") for p in planted]
+        # ... as long as the plant does not alter control flow for real (the branches jump to an existing label: harmless to the analysis)
+        ct_check.check_secret_flow("\n".join(lines[:fn + 1] + public + lines[fn + 1:]), "k_ecdsa_sign_scalars", secret_args=[2, 3, 6])
+    # a conditional MOVE under a secret lane mask is what field.cuh does on purpose: allowed
+    ok = [f"\tv_cmp_ne_u32_e32 vcc, 0, {v}", "\ts_and_saveexec_b64 s[90:91], vcc", "\tv_mov_b32_e32 v252, 0", "\ts_mov_b64 exec, s[90:91]"]
+    ct_check.check_secret_flow("\n".join(lines[:at] + ok + lines[at:]), "k_ecdsa_sign_scalars", secret_args=[2, 3, 6])

@@ -224,6 +224,27 @@ def test_ecdsa_scalars_at_the_shared_inversion_sizes(engine, openssl, cv):
 
 
 @pytest.mark.parametrize("cv", CURVES)
+def test_ecdsa_sign_leaves_no_nonce_derived_data_in_the_workspace(engine, cv):
+    """VERDICT r4 next 5 / ADVICE r4: the Jacobian k G (X, Y, Z) and its affine x live in the context workspace during ecdsa_sign; the Z of an
+    unnormalised k G together with the public r gives bits of the nonce away, and the block outlives the call.  After the call -- stream order, no
+    extra synchronisation by the caller -- those 4 n elements read back as zeros; the control (the same comb through scalar_mult_base, which
+    promises nothing of the kind) shows that the readback does see what a call leaves behind."""
+    from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, ALG_CONSTANT_TIME
+    order = CURVE_PARAMS[cv]["n"]
+    n = 5000
+    rng = np.random.default_rng(77 + cv)
+    rnd = lambda: engine.to_device(ints_to_arr([to_int(x) % (order - 1) + 1 for x in rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)]))
+    e, d, k = rnd(), rnd(), rnd()
+    engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME)
+    left = engine.workspace_bytes()
+    assert left.size >= 3 * n * 32 and np.count_nonzero(left[:3 * n * 32]) > 2 * n * 32        # the control: a Jacobian k G is lying there
+    r, s, ok = engine.ecdsa_sign(cv, e, d, k)
+    after = engine.workspace_bytes()
+    assert after.size >= 4 * n * 32 and not after[:4 * n * 32].any()
+    assert bool(ok.all()) and bool((engine.to_numpy(r) != 0).any())
+
+
+@pytest.mark.parametrize("cv", CURVES)
 def test_ecdsa_sign_vs_big_ints_and_libcrypto(engine, openssl, cv):
     """ecsimd_hip_ecdsa_sign (k G on the constant-time comb, r and s on the order's field id): (r, s) equal the textbook formulas on Python
     integers with libcrypto's k G, libcrypto's ECDSA_do_verify and this library's own ecdsa_verify accept every one of them, out-of-range
@@ -280,3 +301,36 @@ def test_scalar_field_arithmetic_against_big_ints(gpu, cv):
     u2 = gpu.mgry_mul(fid, ints_to_arr(rv), wm)
     assert arr_to_ints(u1) == [e * pow(s, -1, order) % order for e, s in zip(ev, sv)]
     assert arr_to_ints(u2) == [r * pow(s, -1, order) % order for r, s in zip(rv, sv)]
+
+
+@pytest.mark.parametrize("p", [3, 5, 2**31 - 1, 2**61 - 1, 2**127 - 1, "n_p256", "n_secp256k1"])
+def test_prime_flagged_moduli_through_the_shared_inversion(engine, oracle, p):
+    """ecsimd_hip_register_modulus(p, PRIME) routes gfp_inverse to the shared division-step inversion (one per up to 128 elements).
+    Small primes with canonical operands -- a third of them 0 for p = 3: a zero must come out as 0 WITHOUT zeroing the neighbours that share its
+    inversion -- and, for the two group orders, ANY 256-bit operand (the reference never rejects a >= p, tests/ops.cpp:232; a = n and 2n - ... are 0
+    as field elements): equal to the oracle's x^(p-2) (gfp.h:42-44) on every lane.  The same p registered WITHOUT the flag is another id and keeps
+    the reference's power ladder (a later PRIME registration must not change it under its holder)."""
+    from ecsimd_amd.engine import register_modulus
+    big = isinstance(p, str)
+    if big:
+        p = CURVE_PARAMS[P256 if p == "n_p256" else SECP256K1]["n"]
+    fid = register_modulus(p, prime=True)
+    plain = register_modulus(p, prime=False)
+    assert register_modulus(p, prime=True) == fid and register_modulus(p, prime=False) == plain
+    assert big or fid != plain                                    # (the built-in order ids 2 / 3 are PRIME entries; an unflagged twin is a new id too)
+    oid = oracle.register_modulus(p)
+    n = (1 << 18) + 77
+    rng = np.random.default_rng(p % 1000)
+    a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    if big:
+        a[:6] = ints_to_arr([0, p, 1, p - 1, p + 1, 2**256 - 1])
+        a[1000:1064] = from_int(p)                                # a run of zeros-as-field-elements inside shared inversions
+    else:
+        a = ints_to_arr([to_int(x) % p for x in a[:4096]])
+        a = np.tile(a, ((n + 4095) // 4096, 1))[:n].copy()
+        a[:4] = ints_to_arr([0, 1, p - 1, p // 2])
+    exp = oracle.gfp_inverse(oid, a)
+    for f in (fid, plain):
+        got = engine.to_numpy(engine.gfp_inverse(f, engine.to_device(a)))
+        bad = np.flatnonzero((got != exp).any(axis=1))
+        assert bad.size == 0, (hex(p), f, bad[:8])

@@ -803,9 +803,9 @@ def test_small_base_batches_take_the_comb_and_keep_the_ladders_bits(engine, cv):
     """scalar_mult_base with OUT_AFFINE and no algorithm flag: up to 2^16 lanes go through the constant-time comb (0.2 ms instead of a 1.3 ms
     ladder launch) and must return the LADDER's affine bits -- at its three degenerate scalars too, where the ladder's point is not k*G
     (the lanes take the ladder's coordinates from the context's record).  Checked against the ladder itself run on G as a variable base,
-    on every edge scalar, at the sizes around the route's limit, x-only included, and through ecsimd_hip_scalar_mult with x = y = NULL."""
+    on every edge scalar, at the sizes around the route's limit, x-only included, and through ecsimd_hip_scalar_mult with x = y = NULL | BASE_GENERATOR."""
     import torch
-    from ecsimd_amd import OUT_AFFINE, LADDER_RADIX32
+    from ecsimd_amd import OUT_AFFINE, LADDER_RADIX32, BASE_GENERATOR
     c = CURVE_PARAMS[cv]; order = c["n"]
     edge = [0, 1, 2, 3, order - 2, order - 1, order, order + 1, 2**256 - order - 2, 2**256 - order - 1, 2**256 - order, 2**256 - order + 1,
             2**256 - 1, 2**255, 2**255 - 1, (order - 1) // 2, (order + 1) // 2, 2 * order - 2**256, 31, 32, 2**5 - 1, 2**250]
@@ -825,9 +825,13 @@ def test_small_base_batches_take_the_comb_and_keep_the_ladders_bits(engine, cv):
         if n <= 4096:                                                                 # no base point = the generator, through the variable-base entry point
             ox, oy = engine.empty(n), engine.empty(n)
             engine._bind_stream()
-            rc = engine.lib.ecsimd_hip_scalar_mult(engine.ctx, C.c_int(cv), C.c_void_p(k.data_ptr()), None, None, C.c_void_p(ox.data_ptr()), C.c_void_p(oy.data_ptr()), None,
-                                                   C.c_size_t(n), C.c_int(OUT_AFFINE))
+            args = (engine.ctx, C.c_int(cv), C.c_void_p(k.data_ptr()), None, None, C.c_void_p(ox.data_ptr()), C.c_void_p(oy.data_ptr()), None, C.c_size_t(n))
+            rc = engine.lib.ecsimd_hip_scalar_mult(*args, C.c_int(OUT_AFFINE | BASE_GENERATOR))
             assert rc == 0 and torch.equal(ox, lx) and torch.equal(oy, ly)
+            # two null pointers WITHOUT the flag are an error like any other null pointer (a failed allocation must not yield k G)
+            assert engine.lib.ecsimd_hip_scalar_mult(*args, C.c_int(OUT_AFFINE)) == -1
+            assert engine.lib.ecsimd_hip_scalar_mult(engine.ctx, C.c_int(cv), C.c_void_p(k.data_ptr()), C.c_void_p(gx.data_ptr()), C.c_void_p(gy.data_ptr()),
+                                                     C.c_void_p(ox.data_ptr()), C.c_void_p(oy.data_ptr()), None, C.c_size_t(n), C.c_int(OUT_AFFINE | BASE_GENERATOR)) == -1
     # the Jacobian form is the ladder's at every size (a comb has another representative): level J against the oracle elsewhere; here: unchanged by the route
     k = engine.fill_random(64, SEED, 72)
     gx = engine.to_device(np.tile(from_int(c["gx"]), (64, 1))); gy = engine.to_device(np.tile(from_int(c["gy"]), (64, 1)))

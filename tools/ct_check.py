@@ -42,8 +42,10 @@ def regs_of(tok):
     return out
 
 
-def parse_function(text, want):
-    """[(block_label, in_loop_header_or_None, [instructions])] of the first function whose name contains `want`."""
+def parse_function(text, want, keep_implicit_defs=False):
+    """[(block_label, in_loop_header_or_None, [instructions])] of the first function whose name contains `want`.  keep_implicit_defs: the compiler's
+    `; implicit-def: $sgpr2_sgpr3` notes (the register's value is UNDEFINED from here on as far as the program is concerned: whatever it still
+    holds cannot influence the result) are kept as pseudo-instructions `.implicit_def s2, s3`."""
     lines = text.splitlines()
     start = None
     for i, ln in enumerate(lines):
@@ -76,6 +78,19 @@ def parse_function(text, want):
                 blocks[-1][1] = mh.group(1)
             elif "Loop Header" in t and blocks[-1][0].startswith(".LBB"):
                 blocks[-1][1] = blocks[-1][0][2:]
+        if keep_implicit_defs and t.startswith("; implicit-def: $"):
+            regs = []
+            for m in re.finditer(r"([sv])gpr(\d+)", t):
+                regs.append(f"{m.group(1)}{m.group(2)}")
+            mr = re.search(r"\$([sv])gpr(\d+)_\1gpr(\d+)(?:_\1gpr(\d+))*", t)
+            if mr:                                            # a tuple names its first and last (or every) register: fill the range
+                nums = [int(x) for x in re.findall(r"gpr(\d+)", t)]
+                regs = [f"{mr.group(1)}{i}" for i in range(min(nums), max(nums) + 1)]
+            if "$vcc" in t:
+                regs.append("vcc")
+            if regs:
+                blocks[-1][2].append(".implicit_def " + ", ".join(regs))
+            continue
         if not t or t.startswith(";") or t.startswith("."):
             continue
         blocks[-1][2].append(t.split(";")[0].strip())
@@ -301,6 +316,280 @@ def check_after_secret_load(text, want):
         if re.match(r"^(s_cbranch_vcc|s_cbranch_exec|v_readfirstlane|v_readlane|v_writelane|v_permlane|ds_write|ds_bpermute|ds_permute|ds_swizzle|global_atomic|s_swappc|s_call)", op):
             raise Violation(f"`{inst}` after the scalar has been loaded")
     return len(flat) - first
+
+
+# ---------------------------------------------------------------------------------------------------------------- secret-flow (taint) analysis
+# check() and check_after_secret_load() are SHAPE checks: they know which loop is the bit loop and refuse every lane-mask branch.  A kernel like
+# k_ecdsa_sign_scalars has public lane-dependent control flow (`if (e >= n) break` on the element index) beside its secrets, so the question
+# there is not "is there an exec branch" but "can a SECRET reach one".  check_secret_flow answers that on the ISA: a forward data-flow analysis
+# over the function's control-flow graph to a fixed point.
+#   sources    every global load whose address derives from a kernel argument named secret (by position; pointer provenance is tracked from the
+#              s_load of the kernarg segment through the address arithmetic), scratch reloads once a secret was spilled, LDS reads once a secret
+#              was written to LDS;
+#   propagates through every instruction: the destinations take the union of the sources' tags (SCC, VCC and EXEC are registers like any other;
+#              s_cselect / s_cmov / s_addc / s_subb read SCC);
+#   sinks      the condition of a branch (SCC, VCC, EXEC), the address of a global / scratch / LDS access, and -- while the lane mask EXEC itself is
+#              made of a secret (field.cuh's conditional corrections are moves under EXEC: same issue slots whatever the mask) -- every memory
+#              access, lane read and EXEC branch, whose cost or address set WOULD depend on the mask.  A secret there is a Violation.
+# What it does not model: memory (a secret stored through a pointer NOT named secret and loaded back is lost -- name scratch buffers secret), and
+# instruction timing itself (gfx9 has no data-dependent-latency integer instruction; divides and transcendental ops are refused outright).
+def kernel_args(text, want):
+    """[(offset, size, value_kind)] of the first kernel whose name contains `want`, from the .amdgpu_metadata YAML of the unit."""
+    meta = text[text.index(".amdgpu_metadata"):]
+    for blk in re.split(r"\n  - \.agpr_count:", meta)[1:]:
+        m = re.search(r"\.name:\s+(\S+)", blk)
+        if m and want in m.group(1):
+            return [(int(o), int(z), k) for o, z, k in re.findall(r"\.offset:\s+(\d+)\s+\.size:\s+(\d+)\s+\.value_kind:\s+(\w+)", blk)]
+    raise Violation(f"no kernel metadata for {want!r}")
+
+
+def kernarg_pointer(text, want):
+    """The SGPR pair that holds the kernarg segment pointer on entry, from the kernel descriptor's user-SGPR directives."""
+    m = re.search(r"\.amdhsa_kernel\s+(\S*" + re.escape(want) + r"\S*)(.*?)\.end_amdhsa_kernel", text, re.S)
+    if not m:
+        raise Violation(f"no kernel descriptor for {want!r}")
+    d = dict(re.findall(r"\.amdhsa_user_sgpr_(\w+)\s+(\d+)", m.group(2)))
+    first = 0
+    for name, width in (("private_segment_buffer", 4), ("dispatch_ptr", 2), ("queue_ptr", 2)):
+        if int(d.get(name, "0")):
+            first += width
+    if not int(d.get("kernarg_segment_ptr", "0")):
+        raise Violation("the kernel takes no kernarg segment pointer")
+    return first
+
+
+_IMPLICIT_SCC_READ = re.compile(r"^s_(cselect|cmov|addc|subb|cbranch_scc)")
+_NO_DATA = re.compile(r"^(s_waitcnt|s_nop|s_endpgm|s_barrier|s_setprio|s_sethalt|s_dcache|s_icache|s_code_end|s_ttracedata|s_inst_prefetch|s_clause|s_setreg|s_getreg|s_memtime|s_memrealtime|s_trap|s_branch)")
+_REFUSED = re.compile(r"^(v_rcp|v_rsq|v_sqrt|v_div|v_exp|v_log|v_sin|v_cos|s_sleep|s_swappc|s_call|s_cbranch_cd|s_cbranch_g_fork|s_cbranch_i_fork|s_cbranch_join|global_atomic|flat_|buffer_|ds_bpermute|ds_permute|ds_swizzle|image_)")
+
+
+def _operand_regs(tok):
+    """Registers an operand token names, modifiers (neg(), |x|, sext(), op_sel, offsets) stripped; vcc_lo / vcc_hi / exec_lo / exec_hi fold into vcc / exec."""
+    tok = re.sub(r"\b(offset|offset0|offset1|op_sel|op_sel_hi|neg_lo|neg_hi|clamp|omod|dst_sel|src0_sel|src1_sel|row_\w+|quad_perm|bank_mask|row_mask|bound_ctrl|sc\d|nt|glc|slc)\b[:\[\]\w,]*", " ", tok)
+    out = []
+    for m in re.finditer(r"\b([sv])\[(\d+):(\d+)\]|\b([sv])(\d+)\b|\b(vcc|exec|scc|m0)(?:_lo|_hi)?\b", tok):
+        if m.group(1):
+            out += [(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)]
+        elif m.group(4):
+            out.append((m.group(4), int(m.group(5))))
+        else:
+            out.append(m.group(6))
+    return out
+
+
+def check_secret_flow(text, want, secret_args, public_loads_from=()):
+    """Taint analysis of the first function whose name contains `want`; `secret_args` = positions (0-based) of the pointer arguments whose contents
+    are secret.  Returns a report dict; raises Violation where a secret reaches a sink."""
+    blocks = parse_function(text, want, keep_implicit_defs=True)
+    args = kernel_args(text, want)
+    kptr = kernarg_pointer(text, want)
+    secret_ranges = []
+    for a in secret_args:
+        off, size, kind = args[a]
+        if kind != "global_buffer":
+            raise Violation(f"argument {a} is not a pointer ({kind})")
+        secret_ranges.append((off, off + size, a))
+    labels = {lab: n for n, (lab, _, _) in enumerate(blocks)}
+    succs = {n: set() for n in range(len(blocks))}
+    for n, (lab, _, insts) in enumerate(blocks):
+        falls = True
+        for k, inst in enumerate(insts):
+            op, ops = split_ops(inst)
+            if op.startswith("s_cbranch") and ops and ops[-1] in labels:
+                succs[n].add(labels[ops[-1]])
+            if op == "s_branch":
+                if ops and ops[0] in labels:
+                    succs[n].add(labels[ops[0]])
+                falls = False
+            if op == "s_setpc_b64":
+                tgt = [m.group(1) for j in range(max(0, k - 3), k) for m in [re.search(r"\((\.LBB\w+)-", insts[j])] if m]
+                if not tgt or tgt[0] not in labels:
+                    raise Violation(f"{lab}: `{inst}` is not a relaxed branch to a label of this function")
+                succs[n].add(labels[tgt[0]])
+                falls = False
+            if op == "s_endpgm":
+                falls = False
+        if falls and n + 1 < len(blocks):
+            succs[n].add(n + 1)
+    preds = {n: [m for m in succs if n in succs[m]] for n in range(len(blocks))}
+    S = "S"
+    report = {"kernel": want, "instructions": sum(1 for b in blocks for i in b[2] if not i.startswith(".implicit_def")), "secret_loads": 0, "public_branches": 0, "lane_mask_updates": 0,
+              "secret_scratch": False, "secret_lds": False, "kernarg_sgpr": kptr}
+    kp = {("s", kptr), ("s", kptr + 1)}
+
+    def transfer(n, state, final):
+        """state: {reg: frozenset(tags)} plus the pseudo-registers 'scratch' / 'lds'.  Runs block n; with `final` set it raises on a violation."""
+        st = dict(state)
+        tags = lambda r: st.get(r, frozenset())
+        lab = blocks[n][0]
+        for inst in blocks[n][2]:
+            op, ops = split_ops(inst)
+            if _NO_DATA.match(op):
+                continue
+            if op == ".implicit_def":                            # undefined from here on: stale contents cannot matter
+                for r in [r for o in ops for r in _operand_regs(o)]:
+                    st[r] = frozenset()
+                continue
+            if _REFUSED.match(op):
+                raise Violation(f"{lab}: `{inst}` is not allowed in a kernel that handles secrets")
+            nd = dest_count(op)
+            dst = [r for o in ops[:nd] for r in _operand_regs(o)]
+            src = [r for o in ops[nd:] for r in _operand_regs(o)]
+            if _IMPLICIT_SCC_READ.match(op):
+                src.append("scc")
+            t = frozenset().union(*[tags(r) for r in src]) if src else frozenset()
+            bad = lambda what: (_ for _ in ()).throw(Violation(f"{lab}: a secret reaches {what} of `{inst}`")) if final else None
+            masked = S in tags("exec")                           # the set of active lanes depends on a secret: moves under EXEC are fine (same issue
+            if masked and op.startswith(("global_", "scratch_", "ds_", "s_load", "v_readfirstlane", "v_readlane", "v_writelane", "s_cbranch_exec")):
+                bad("the lane mask (EXEC) in force at")          # slot whatever the mask), anything whose cost or address set depends on it is not
+            if masked and op.startswith("v_"):
+                t = t | tags("exec") | frozenset().union(*[tags(r) for r in dst if isinstance(r, tuple)])    # inactive lanes keep the old value
+            if op.startswith("s_load_dword"):
+                base = set(_operand_regs(ops[1]))
+                if base == kp and re.fullmatch(r"(0x[0-9a-f]+|\d+)", ops[2].split()[0]):
+                    first = int(ops[2].split()[0], 0)
+                    for j, r in enumerate(dst):
+                        b = first + 4 * j
+                        hit = [a for lo, hi, a in secret_ranges if lo <= b < hi]
+                        st[r] = frozenset({f"P{hit[0]}"}) if hit else frozenset()
+                else:                                            # a scalar load through some other pointer: secret if the pointer is
+                    if S in t:
+                        bad("the address")
+                    sec = any(x.startswith("P") for x in t)
+                    for r in dst:
+                        st[r] = frozenset({S}) if sec else frozenset()
+                    report["secret_loads"] += int(sec and final)
+                continue
+            if op.startswith("global_load"):
+                if S in t:
+                    bad("the address")
+                sec = any(x.startswith("P") for x in t)
+                for r in dst:
+                    st[r] = frozenset({S}) if sec else frozenset()
+                report["secret_loads"] += int(sec and final)
+                continue
+            if op.startswith("global_store"):
+                addr = frozenset().union(*[tags(r) for o in (ops[0], ops[2]) for r in _operand_regs(o)])
+                if S in addr:
+                    bad("the address")
+                continue
+            if op.startswith("scratch_load"):
+                if S in frozenset().union(*[tags(r) for o in ops[1:] for r in _operand_regs(o)]):
+                    bad("the address")
+                for r in dst:
+                    st[r] = tags("scratch")
+                continue
+            if op.startswith("scratch_store"):
+                if S in frozenset().union(*[tags(r) for o in [ops[0]] + ops[2:] for r in _operand_regs(o)]):
+                    bad("the address")
+                st["scratch"] = tags("scratch") | frozenset().union(*[tags(r) for r in _operand_regs(ops[1])])
+                continue
+            if op.startswith("ds_read") or op.startswith("ds_load"):
+                if S in frozenset().union(*[tags(r) for r in _operand_regs(ops[1])]):
+                    bad("the LDS address")
+                for r in dst:
+                    st[r] = tags("lds")
+                continue
+            if op.startswith("ds_write") or op.startswith("ds_store"):
+                if S in frozenset().union(*[tags(r) for r in _operand_regs(ops[0])]):
+                    bad("the LDS address")
+                st["lds"] = tags("lds") | frozenset().union(*[tags(r) for o in ops[1:] for r in _operand_regs(o)])
+                continue
+            if op.startswith("s_cbranch_scc"):
+                if S in tags("scc"):
+                    bad("the condition (SCC)")
+                report["public_branches"] += int(final)
+                continue
+            if op.startswith("s_cbranch_vcc"):
+                if S in tags("vcc"):
+                    bad("the condition (VCC)")
+                report["public_branches"] += int(final)
+                continue
+            if op.startswith("s_cbranch_exec"):
+                if S in tags("exec"):
+                    bad("the condition (EXEC)")
+                report["public_branches"] += int(final)
+                continue
+            if op == "s_setpc_b64":
+                continue                                         # (checked above: a relaxed branch to a label)
+            if op.startswith("s_getpc"):
+                for r in dst:
+                    st[r] = frozenset()
+                continue
+            if "saveexec" in op:                                 # sdst = EXEC; EXEC = EXEC op src: a lane mask made of a secret is allowed (see `masked`)
+                for r in dst:
+                    st[r] = tags("exec")
+                st["exec"] = tags("exec") | t
+                st["scc"] = st["exec"]
+                report["lane_mask_updates"] += int(final)
+                continue
+            if op.startswith("v_cmpx"):
+                st["exec"] = tags("exec") | t
+                for r in dst:
+                    st[r] = t
+                report["lane_mask_updates"] += int(final)
+                continue
+            if "exec" in dst:
+                # `s_or_b64 exec, exec, saved` closes a structured region: EXEC is a subset of the saved mask, the result IS the saved mask
+                if op == "s_or_b64" and _operand_regs(ops[1]) == ["exec"]:
+                    t = frozenset().union(*[tags(r) for r in _operand_regs(ops[2])])
+                st["exec"] = t
+                if op.startswith("s_") and SCC_WRITERS.match(op):
+                    st["scc"] = t
+                report["lane_mask_updates"] += int(final)
+                continue
+            if op.startswith(("v_mad_u64_u32", "v_mad_i64_i32", "v_lshl_add_u64", "v_lshlrev_b64", "s_lshl_b64")) and len(dst) >= 2:
+                # dword-precise: the LOW half of a 64-bit multiply-add / shift-left / add does not depend on the high half of its 64-bit operand (the
+                # compiler forms 64-bit element offsets this way and leaves a stale -- possibly secret -- register in the unused high half)
+                pair = lambda o: (lambda rs: (rs[:1], rs[1:]) if len(rs) == 2 else (rs, rs))(_operand_regs(o))
+                un = lambda rs: frozenset().union(*[tags(r) for r in rs]) if rs else frozenset()
+                if op.startswith("v_mad"):
+                    lo = un(_operand_regs(ops[2])) | un(_operand_regs(ops[3])) | un(pair(ops[4])[0])
+                elif op.startswith("v_lshl_add_u64"):
+                    lo = un(pair(ops[1])[0]) | un(_operand_regs(ops[2])) | un(pair(ops[3])[0])
+                else:
+                    sh, val = (ops[1], ops[2]) if op.startswith("v_lshlrev") else (ops[2], ops[1])
+                    lo = un(_operand_regs(sh)) | un(pair(val)[0])
+                st[dst[0]] = lo
+                for r in dst[1:]:
+                    st[r] = t
+                if op.startswith("s_"):
+                    st["scc"] = t
+                continue
+            for r in dst:
+                st[r] = t
+            if op.startswith("s_") and SCC_WRITERS.match(op):
+                st["scc"] = t
+        return st
+
+    def join(states):
+        out = {}
+        for s_ in states:
+            for r, t in s_.items():
+                out[r] = out.get(r, frozenset()) | t
+        return out
+
+    outs = [None] * len(blocks)
+    changed = True
+    rounds = 0
+    while changed:
+        changed = False
+        rounds += 1
+        for n in range(len(blocks)):
+            ins = join([outs[m] for m in preds[n] if outs[m] is not None])
+            o = transfer(n, ins, False)
+            if o != outs[n]:
+                outs[n] = o
+                changed = True
+        if rounds > 200:
+            raise Violation("the analysis did not converge")
+    for n in range(len(blocks)):
+        o = transfer(n, join([outs[m] for m in preds[n] if outs[m] is not None]), True)
+        report["secret_scratch"] |= S in o.get("scratch", frozenset())
+        report["secret_lds"] |= S in o.get("lds", frozenset())
+    if report["secret_loads"] == 0:
+        raise Violation("no load through a secret pointer was found: the analysis did not see the secrets")
+    return report
 
 
 if __name__ == "__main__":
