@@ -81,6 +81,12 @@ import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value
     bash tools/profile.sh "$tag" "$@" > "$out/profile_$tag.txt" 2>&1; rc=$?; tail -8 "$out/profile_$tag.txt"; exit $rc ;;
   secondary)        # tools/bench_kernels.py -> profiles/rNN/secondary_kernels.{json,txt}
     timeout -k 10 900 python tools/bench_kernels.py > "$out/secondary_kernels.json" 2> "$out/secondary_kernels.txt"; rc=$?; tail -70 "$out/secondary_kernels.txt"; exit $rc ;;
+  r5_first)         # round 5: the adapter beside the reference, the scrubbed signing workspace, the shared inversion on small primes, BASE_GENERATOR; then the default bench
+    timeout -k 10 900 python -m pytest tests/test_integration_adapter.py tests/test_gpu_fields.py tests/test_gpu_parity.py -x -q -m gpu \
+      -k "adapter or ecdsa or prime_flagged or small_base or to_affine or inversion or runtime_modulus or random_odd" > "$out/pytest.txt" 2>&1; rc=$?
+    tail -8 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
+    ./oracle/_ref/adapter_driver 512 65536 > "$out/adapter_driver.txt" 2>&1; cat "$out/adapter_driver.txt"
+    timeout -k 10 600 python bench.py > "$out/bench.json" 2> "$out/bench.err"; rc=$?; tail -3 "$out/bench.err"; head -c 1500 "$out/bench.json"; exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
     timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -15 "$out/pytest.txt"; exit $rc ;;
   *) echo "unknown step $name"; exit 2 ;;

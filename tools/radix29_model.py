@@ -27,19 +27,31 @@ I64 = (-(1 << 63), (1 << 63) - 1)
 
 
 class Curve:
-    """Sparse signed form of p in radix 2^29: p = sum c * 2^(29 off) over `terms`, with the term at offset 0 equal to -m0inv^-1."""
-    def __init__(self, name, p, terms, qmul):
-        self.name, self.p, self.terms, self.qmul = name, p, terms, qmul
+    """Sparse signed form of p in radix 2^29: p = sum c * 2^(29 off) over `terms`, with the term at offset 0 equal to -m0inv^-1.
+    tight_sq: zdau29 carry-passes dy - u and dx + u before squaring them (fe29.cuh TIGHT_SQ: every reduction but secp256k1's sparse one needs it)."""
+    def __init__(self, name, p, terms, qmul, tight_sq=True):
+        self.name, self.p, self.terms, self.qmul, self.tight_sq = name, p, terms, qmul, tight_sq
         assert sum(c << (W * o) for o, c in terms) == p, name
         # q = (column * qmul) mod 2^29 makes column + q * (term at offset 0) vanish mod 2^29
         c0 = dict(terms)[0]
         assert (1 + qmul * c0) % (1 << W) == 0, name
+        self.term_ranges = [(o, (c, c)) for o, c in terms]     # what the interval execution multiplies the quotient digits by
+
+    @classmethod
+    def dense(cls, name, p):
+        """ANY odd p < 2^256 (round 5, fe29.cuh r29_ctx<CURVE_GENERIC>: a curve registered at run time): its nine tight limbs as they are,
+        q_k = column * (-p^-1 mod 2^29)."""
+        assert p & 1 and 2 < p < 1 << 256, name
+        return cls(name, p, [(i, l) for i, l in enumerate(to_limbs(p))], (-pow(p, -1, 1 << W)) % (1 << W))
 
 
-# p256 = 2^256 - 2^224 + 2^192 + 2^96 - 1: bit 96 = 3*29 + 9, 192 = 6*29 + 18, 224 = 7*29 + 21, 256 = 8*29 + 24
-CURVE_P256 = Curve("p256", P256, [(0, -1), (3, 1 << 9), (6, 1 << 18), (7, -(1 << 21)), (8, 1 << 24)], 1)
-# secp256k1 = 2^256 - 2^32 - 977: bit 32 = 29 + 3
-CURVE_SECP = Curve("secp256k1", SECP, [(0, -977), (1, -8), (8, 1 << 24)], pow(977, -1, 1 << W))
+class AnyPrime(Curve):
+    """Every odd p < 2^256 at once, for the INTERVAL execution only: each limb of p is the interval [0, 2^29) (the top one [0, 2^24)), the
+    value bound uses p_max = 2^256.  An invariant proven for this object holds for every registered curve: limb and column intervals only grow
+    with the limbs of p, and a value bound c p with the products' (c1 p)(c2 p) / 2^261 + p = (c1 c2 p / 2^261 + 1) p grows with p too."""
+    def __init__(self):
+        self.name, self.p, self.terms, self.qmul, self.tight_sq = "any odd p < 2^256", 1 << 256, None, None, True
+        self.term_ranges = [(i, (0, M29 if i < NL - 1 else (1 << 24) - 1)) for i in range(NL)]
 
 
 def to_limbs(v):
@@ -47,6 +59,17 @@ def to_limbs(v):
     out = [(v >> (W * i)) & M29 for i in range(NL - 1)]
     out.append(v >> (W * (NL - 1)))
     return out
+
+
+# p256 = 2^256 - 2^224 + 2^192 + 2^96 - 1: bit 96 = 3*29 + 9, 192 = 6*29 + 18, 224 = 7*29 + 21, 256 = 8*29 + 24
+CURVE_P256 = Curve("p256", P256, [(0, -1), (3, 1 << 9), (6, 1 << 18), (7, -(1 << 21)), (8, 1 << 24)], 1)
+# secp256k1 = 2^256 - 2^32 - 977: bit 32 = 29 + 3
+CURVE_SECP = Curve("secp256k1", SECP, [(0, -977), (1, -8), (8, 1 << 24)], pow(977, -1, 1 << W), tight_sq=False)
+CURVE_ANY = AnyPrime()
+# registered curves the tests run the exact model on (SEC 2 / RFC 5639 / GB/T 32918 / ANSSI public parameters; all p = 3 mod 4, as the reference's GFp needs)
+BRAINPOOL_P256 = 0xA9FB57DBA1EEA9BC3E660A909D838D726E3BF623D52620282013481D1F6E5377
+SM2_P = 0xFFFFFFFEFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF00000000FFFFFFFFFFFFFFFF
+FRP256_P = 0xF1FD178C0B3AD58F10126DE8CE42435B3961ADBCABC8CA6DE8FCF353D86E9C03
 
 
 def from_limbs(l):
@@ -196,17 +219,17 @@ class Bounds:
 
     def _columns(self, prod, tval):
         cv = self.cv
-        c0 = dict(cv.terms)[0]
+        c0 = dict(cv.term_ranges)[0]
         acc = (0, 0)
         for k in range(2 * NL - 1):
             for x, y in prod(k):
                 acc = self._col(_iadd(acc, _imul(x, y)))
-            for off, c in cv.terms:
+            for off, c in cv.term_ranges:
                 j = k - off
                 if off != 0 and 0 <= j < NL and j < k + 1:
-                    acc = self._col(_iadd(acc, _imul((0, M29), (c, c))))
+                    acc = self._col(_iadd(acc, _imul((0, M29), c)))
             if k < NL:
-                acc = self._col(_iadd(acc, _imul((0, M29), (c0, c0))))
+                acc = self._col(_iadd(acc, _imul((0, M29), c0)))
             acc = (acc[0] >> W, acc[1] >> W)
         # value: (T + Q p) / R' with 0 <= Q < R'
         R = 1 << RBITS
@@ -263,7 +286,7 @@ def zdau29(E, st, swap):
     u = E.norm(E.sub(X3, W1p))
     Cc = E.sqr(u)
     s = E.sub(dy, u)
-    if E.cv is CURVE_P256:                                    # (secp256k1's sparser reduction leaves room: both squares take their operand as it is)
+    if E.cv.tight_sq:                                         # (secp256k1's sparser reduction leaves room: both squares take their operand as it is)
         s = E.norm(s)
     yp = E.norm(E.sub(E.sub(E.sqr(s), Dp), Cc))               # Y3' + 2 A1'
     A2 = E.dbl(A1p)
@@ -274,7 +297,7 @@ def zdau29(E, st, swap):
     W2 = E.mul(W1p, C4)
     A1 = E.mul(Y3p, E.sub(W1, W2))
     w = E.add(dx, u)
-    if E.cv is CURVE_P256:
+    if E.cv.tight_sq:
         w = E.norm(w)
     zz = E.sub(E.sub(E.sqr(w), Cp), Cc)
     z = E.mul(z, zz)
@@ -311,7 +334,7 @@ def prove_invariant(curve=CURVE_P256):
     out = zdau29(E, {k: Iv(v.l, v.v) for k, v in inv.items()}, True)
     for k in inv:
         assert out[k].within(inv[k]), (k, out[k], inv[k])
-    return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length(), "out": out}
+    return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length(), "worst_column": E.worst_col, "out": out}
 
 
 # ---------------------------------------------------------------------------------------------------------------- the combs' mixed addition
@@ -623,6 +646,8 @@ def zdau_field(p, x1, y1, x2, y2, z):
 
 
 if __name__ == "__main__":
+    r = prove_invariant(CURVE_ANY)
+    print(CURVE_ANY.name, "ladder invariant holds; worst column 2^%d (%.6f of 2^63), worst limb 2^%d" % (r["worst_column_bits"], r["worst_column"] / 2**63, r["worst_limb_bits"]))
     for cv in (CURVE_P256, CURVE_SECP):
         r = prove_invariant(cv)
         print(cv.name, "invariant holds; worst column 2^%d, worst limb 2^%d" % (r["worst_column_bits"], r["worst_limb_bits"]))
