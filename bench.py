@@ -61,6 +61,7 @@ ALGO_BYTES_PER_SCALAR_MULT = 192        # 32 B scalar + 64 B point in, 96 B Jaco
 A_PRIORI_PEAK_TMAD32 = 256 * 4 * 16 * 2.4e9 / 1e12
 SEED = 0x5EEDEC51D0000001
 EXIT_PARITY = 3                         # a checker contradicts the GPU result
+LADDER_WORKLOADS = ("ladder", "ladder-ref-compat", "ladder-radix32")
 
 
 class CheckerUnavailable(Exception):
@@ -77,10 +78,13 @@ def parse_args(argv=None):
                          "weak: --log2-batch units per step on every rank")
     ap.add_argument("--global-log2-batch", type=int, default=24, help="strong scaling: scalar mults per step over ALL GPUs = 2^this")
     ap.add_argument("--log2-batch", type=int, default=22, help="weak scaling: scalar mults per GPU per step = 2^this")
-    ap.add_argument("--curve", default="p256", choices=["p256", "secp256k1"])
-    ap.add_argument("--workload", default="ladder", choices=["ladder", "ladder-ref-compat", "ladder-x", "windowed", "windowed-ct", "fixed-base", "fixed-base-ct", "fixed-base-signed", "fixed-base-big"],
+    ap.add_argument("--curve", default="p256", choices=["p256", "secp256k1", "brainpoolP256r1", "sm2", "frp256v1"],
+                    help="p256 / secp256k1: the curves with special-form kernels; the others (ecsimd_amd/curves.py) are registered at run time -- the reference's "
+                         "curve_group<Curve> for any Curve -- and run the ladder workloads on the generic kernels (dense 9-limb prime in SGPRs)")
+    ap.add_argument("--workload", default="ladder", choices=["ladder", "ladder-ref-compat", "ladder-radix32", "ladder-x", "windowed", "windowed-ct", "fixed-base", "fixed-base-ct", "fixed-base-signed", "fixed-base-big"],
                     help="ladder: scalar_mult_p256 variable base, the reference's co-Z ladder, Jacobian out (headline, BASELINE configs[3]); "
                          "ladder-ref-compat: the same with ECSIMD_HIP_REF_SQUARE_COMPAT (the reference's square() as written, dropped carry included); "
+                         "ladder-radix32: the same with ECSIMD_HIP_LADDER_RADIX32 (the 254 iterations on 8 x 32-bit canonical words instead of nine 29-bit limbs); "
                          "ladder-x: x(k*P) only, the constant-time ladder without its Z coordinate (P-256; ECDH's shared secret; affine-level parity); "
                          "windowed: variable base with per-element tables of 8 multiples of P and signed 4-bit windows, affine out (ALG_WINDOWED; affine-level parity); "
                          "windowed-ct: the same with ALG_CONSTANT_TIME (every entry of the lane's table read in every window; secp256k1 keeps the GLV split, on the complete addition law): secret scalars; "
@@ -163,7 +167,8 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from ecsimd_amd import Engine, CURVES, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG, ALG_CONSTANT_TIME, REF_SQUARE_COMPAT
+    from ecsimd_amd import Engine, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG, ALG_CONSTANT_TIME, REF_SQUARE_COMPAT, LADDER_RADIX32
+    from ecsimd_amd.curves import curve_id
     from ecsimd_amd.shard import ShardedRunner, plan
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,13 +197,15 @@ def main():
             # wait on the HOST: an RCCL barrier would keep a spinning kernel on every GPU the child is measuring
             host_group = dist.new_group(backend="gloo")
 
-    curve = CURVES[args.curve]
     import ecsimd_amd
     if not os.path.exists(ecsimd_amd.lib_path()) and local_rank == 0:
         import __graft_entry__
         __graft_entry__.build()         # built artefacts normally travel with the snapshot
     if world > 1:
         dist.barrier()
+    if args.curve not in ("p256", "secp256k1") and args.workload not in LADDER_WORKLOADS:
+        raise SystemExit("a curve registered at run time has the reference's ladder (workloads %s); the table-driven algorithms exist for p256 / secp256k1" % ", ".join(LADDER_WORKLOADS))
+    curve = curve_id(args.curve)        # 0 / 1, or a run-time registration (host arithmetic only)
     eng = Engine(dev_index)             # raises if the HIP library / a gfx950 device is missing: no fallback
     units = (1 << args.global_log2_batch) if args.scaling == "strong" else (1 << args.log2_batch)
     first, n, total_units, rows = plan(args.scaling, units, rank, world)       # this rank's slice of the global synthetic streams
@@ -217,8 +224,8 @@ def main():
     runner = ShardedRunner((3, rows, 4), torch.int64, eng.tdev, world, rank, always_gather=force_dist, via_host=rehearse)
     view = (lambda o: [o[0][:n], o[1][:n], o[2][:n]]) if rows != n else (lambda o: [o[0], o[1], o[2]])
 
-    if args.workload in ("ladder", "ladder-ref-compat"):
-        flags = BASE_MGRY | OUT_JACOBIAN | (REF_SQUARE_COMPAT if args.workload == "ladder-ref-compat" else 0)
+    if args.workload in LADDER_WORKLOADS:
+        flags = BASE_MGRY | OUT_JACOBIAN | (REF_SQUARE_COMPAT if args.workload == "ladder-ref-compat" else LADDER_RADIX32 if args.workload == "ladder-radix32" else 0)
 
         def compute(o):
             eng.scalar_mult(curve, k, xm, ym, flags=flags, out=view(o))
@@ -307,7 +314,7 @@ def main():
                     result["cpu_baseline"].pop("_sample", None)
         if (force_dist or rehearse) and not torch.equal(runner.gathered[0].to(eng.tdev), runner.last_result()):
             failures.append("the gathered shard differs from the computed one")
-        if distributed and args.workload in ("ladder", "ladder-ref-compat"):
+        if distributed and args.workload in LADDER_WORKLOADS:
             # what arrived from the other ranks: rank 0 regenerates the first lanes of every rank's slice of the synthetic streams
             # (seed, global index), runs them through its own ladder and compares with that rank's block of the receive buffer
             m, bad_ranks = 1024, []
@@ -377,8 +384,9 @@ def roofline_object(args, eng, n, avg_ms):
     launch's device time (HIP events on the launch stream); peak = the dependency-free v_mad_u64_u32 stream on the same GPU."""
     mads, ms = eng.peak_mad32(8192, reps=5)
     peak = mads / (ms * 1e-3) / 1e12
-    if args.workload in ("ladder", "ladder-ref-compat"):
-        mad32_unit, bytes_unit, kname = MAD32_PER_SCALAR_MULT, ALGO_BYTES_PER_SCALAR_MULT, "k_scalar_mult"
+    if args.workload in LADDER_WORKLOADS:
+        mad32_unit, bytes_unit = MAD32_PER_SCALAR_MULT, ALGO_BYTES_PER_SCALAR_MULT
+        kname = "k_scalar_mult" if args.curve in ("p256", "secp256k1") else "k_gc_scalar_mult"
     elif args.workload == "ladder-x":
         # P-256: TRPLU (6 + 7), 254 x (8M + 6S), the recovery (12) and the inversion walk (7 + 267 / share); secp256k1: the full ladder + 5 + 267 / share
         share = min(128, max(1, n >> 17))
@@ -436,9 +444,9 @@ def attach_cpu_baseline(args, result, eng, curve, k, bx, by, out, failures):
             result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, base=(bx, by))
         elif args.workload == "ladder-x":
             result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, base=(bx, by), x_only=True)
-        elif args.workload in ("ladder", "ladder-ref-compat"):
-            result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, out, args.cpu_seconds, failures, compat=(args.workload == "ladder-ref-compat"))
-            comp = competitor_openssl(eng, curve, k, bx, by, out, failures)
+        elif args.workload in LADDER_WORKLOADS:
+            result["cpu_baseline"] = cpu_baseline(eng, curve, k, bx, by, out, args.cpu_seconds, failures, compat=(args.workload == "ladder-ref-compat"), name=args.curve)
+            comp = competitor_openssl(eng, curve, k, bx, by, out, failures) if args.curve in ("p256", "secp256k1") else None      # oracle/ossl_check.c knows the two built-in curves
             if comp is not None:
                 result["cpu_baseline"]["competitor_openssl"] = comp
         else:
@@ -471,12 +479,13 @@ def ref_compat_leg(args, result, eng, curve, k, xm, ym, n, peak, failures, steps
     compared = differing = None
     witness = None
     if sample is not None:
-        m, kn, xn, yn, ref, kind, _ = sample
+        m, kn, xn, yn, ref, kind, _, name = sample
         if kind == "reference":
             witness = "the compiled reference (oracle/_ref), the lanes of cpu_baseline"
         else:                                                                 # the exact port is no witness for this mode: the bug-for-bug restatement on a bounded sample
             m = min(m, 4096)
-            ref = loader.Oracle(faithful=True).scalar_mult(curve, kn[:m], xn[:m], yn[:m], threads=usable_cores())
+            fa = loader.Oracle(faithful=True)
+            ref = fa.scalar_mult(checker_curve(fa, name), kn[:m], xn[:m], yn[:m], threads=usable_cores())
             witness = "the bug-for-bug C restatement (oracle/ecsimd_oracle.c, faithful mode)"
         got = [eng.to_numpy(t[:m]) for t in out]
         differing = int(np.count_nonzero((got[0] != ref[0][:m]).any(axis=1) | (got[1] != ref[1][:m]).any(axis=1) | (got[2] != ref[2][:m]).any(axis=1)))
@@ -526,7 +535,7 @@ def main_group(args):
     from ecsimd_amd import Engine, DeviceGroup, CURVES, BASE_MGRY, OUT_JACOBIAN, OUT_AFFINE, GROUP_NO_GATHER, REF_SQUARE_COMPAT
     from ecsimd_amd.shard import plan
     import ecsimd_amd
-    if args.workload not in ("ladder", "ladder-ref-compat", "ladder-x"):
+    if args.workload not in ("ladder", "ladder-ref-compat", "ladder-x") or (args.workload == "ladder-x" and args.curve not in ("p256", "secp256k1")):
         raise SystemExit("--multi group runs the ladder workloads (the group entry point is ecsimd_hip_group_scalar_mult)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     N = args.gpus
@@ -537,7 +546,8 @@ def main_group(args):
     if not os.path.exists(ecsimd_amd.lib_path()):
         import __graft_entry__
         __graft_entry__.build()
-    curve = CURVES[args.curve]
+    from ecsimd_amd.curves import curve_id
+    curve = curve_id(args.curve)
     units = (1 << args.global_log2_batch) if args.scaling == "strong" else (1 << args.log2_batch)
     spans = [plan(args.scaling, units, m, N) for m in range(N)]
     total_units = spans[0][2]
@@ -628,7 +638,7 @@ def committed_traffic(args, n):
         table = json.load(open(tpath))
     except ValueError:
         return None, None
-    key = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult_refsqr", "ladder-x": "k_scalar_mult_x", "windowed": "varwin", "windowed-ct": "varwin_ct",
+    key = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult_refsqr", "ladder-radix32": "k_scalar_mult_radix32", "ladder-x": "k_scalar_mult_x", "windowed": "varwin", "windowed-ct": "varwin_ct",
            "fixed-base": "fixed_base", "fixed-base-ct": "fixed_base_ct", "fixed-base-signed": "fixed_base_signed", "fixed-base-big": "fixed_base_big"}[args.workload]
     for log2 in (24, 22):                                 # a pass at this run's own launch size first
         per = table.get(f"{key}_{args.curve}_2^{log2}")
@@ -814,13 +824,27 @@ def config1_ops8(kind):
     return out
 
 
-def cpu_baseline(eng, curve, k, bx, by, gpu_out, target_s, failures, compat=False):
+def checker_curve(lib, name):
+    """The id of curve `name` in a CHECKER library: 0 / 1 for the built-in curves; a curve registered at run time is one of the instances the compiled
+    reference has (oracle/ref_driver.cpp ops<Curve>, ids 10..12) or a run-time registration of the C restatement."""
+    if name in (None, "p256", "secp256k1"):
+        return {None: 0, "p256": 0, "secp256k1": 1}[name]
+    from ecsimd_amd.curves import NAMED
+    c = NAMED[name]
+    return lib.register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"])
+
+
+def cpu_baseline(eng, curve, k, bx, by, gpu_out, target_s, failures, compat=False, name=None):
     """ecsimd's own CPU path (or the C port) on the host cores, bounded sample, rank 0 only; the
-    sample's CPU result is also compared bit-for-bit with what the GPU produced for those elements."""
+    sample's CPU result is also compared bit-for-bit with what the GPU produced for those elements.  `curve` is the ENGINE's id, `name` the curve's."""
     import numpy as np
     from oracle import loader
     cores = usable_cores()
     impl, kind = load_checkers()
+    if name is None:
+        name = {0: "p256", 1: "secp256k1"}[curve]
+    builtin = name in ("p256", "secp256k1")
+    gpu_curve, curve = curve, checker_curve(impl, name)          # below, `curve` is the checker's id
     to_np = eng.to_numpy
     # calibrate on a small sample, then size the real one for ~target_s seconds
     m0 = 256 * cores
@@ -831,6 +855,7 @@ def cpu_baseline(eng, curve, k, bx, by, gpu_out, target_s, failures, compat=Fals
     kn, xn, yn = (to_np(t[:m]) for t in (k, bx, by))
     if kind == "port" and compat:
         impl = loader.Oracle(faithful=True)              # the bug-for-bug restatement stands in for the reference
+        curve = checker_curve(impl, name)
     t = time.perf_counter(); ref = impl.scalar_mult(curve, kn, xn, yn, threads=cores); dt = time.perf_counter() - t
     got = [to_np(gpu_out[j][:m]) for j in range(3)]
     bad = np.nonzero((got[0] != ref[0]).any(axis=1) | (got[1] != ref[1]).any(axis=1) | (got[2] != ref[2]).any(axis=1))[0]
@@ -848,14 +873,14 @@ def cpu_baseline(eng, curve, k, bx, by, gpu_out, target_s, failures, compat=Fals
             loader.build()
         ex, fa = loader.Oracle(faithful=False), loader.Oracle(faithful=True)
         sub = lambda arrs: [a[bad] for a in arrs]
-        e_ = ex.scalar_mult(curve, kn[bad], xn[bad], yn[bad], threads=min(cores, len(bad)))
-        f_ = fa.scalar_mult(curve, kn[bad], xn[bad], yn[bad], threads=min(cores, len(bad)))
+        e_ = ex.scalar_mult(checker_curve(ex, name), kn[bad], xn[bad], yn[bad], threads=min(cores, len(bad)))
+        f_ = fa.scalar_mult(checker_curve(fa, name), kn[bad], xn[bad], yn[bad], threads=min(cores, len(bad)))
         explained = all(np.array_equal(u, v) for u, v in zip(e_, sub(got))) and all(np.array_equal(u, v) for u, v in zip(f_, sub(ref)))
         if not explained:
             failures.append("cpu_baseline: a lane differs from the reference and the two oracles do not attribute it to the square() defect")
-        ossl = openssl_checker()
+        ossl = openssl_checker() if builtin else None      # libcrypto adjudicates on the two curves oracle/ossl_check.c knows
         if ossl is not None:
-            ax, ay = eng.to_affine(curve, [eng.select_rows(t, bad) for t in gpu_out])
+            ax, ay = eng.to_affine(gpu_curve, [eng.select_rows(t, bad) for t in gpu_out])
             vx, vy, inf = ossl.scalar_mult(curve, kn[bad], xn[bad], yn[bad], threads=1)
             by_ossl = int(np.count_nonzero(~((to_np(ax) != vx).any(axis=1) | (to_np(ay) != vy).any(axis=1) | (inf != 0))))
             if by_ossl != len(bad):
@@ -868,7 +893,7 @@ def cpu_baseline(eng, curve, k, bx, by, gpu_out, target_s, failures, compat=Fals
             failures.append("config 1: the compiled reference and the restatement disagree on benchs/ops.cpp's operations")
     except (OSError, AttributeError) as exc:                # a prebuilt checker without bench_ops: a side figure, not a failure
         c1 = {"error": repr(exc)[:200]}
-    return {"_sample": (m, kn, xn, yn, ref, kind, bool(compat)),          # for ref_compat_leg; removed before the line is printed
+    return {"_sample": (m, kn, xn, yn, ref, kind, bool(compat), name),    # for ref_compat_leg; removed before the line is printed
             "value": m / dt, "unit": "scalar_mults/s", "cores": cores, "kind": kind,
             "per_core": (m / dt) / cores, "one_thread": one, "cpu_model": cpu_model(), "flags": build_flags(kind), "config1_ops8": c1,
             "sample": f"first {m} (scalar, point) pairs of the GPU batch, {dt:.1f} s wall, {cores} threads, "

@@ -17,6 +17,7 @@
 #include "kernels.h"
 #include "point.cuh"   // curve constants for ecsimd_hip_get_constant (host-side constexpr use only)
 #include "gfield.cuh"  // gmod: a run-time modulus as the generic field kernels take it
+#include "gcurve.cuh"  // gcurve: a run-time curve as the generic point kernels and the ladder take it
 
 using namespace ecsimd_hip;
 using launch::BLOCK;
@@ -104,6 +105,8 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 #define REQUIRE_OUT_Y(p) do { if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(p); else if ((p) && !aligned16(p)) return bad(ctx, #p " is not 16-byte aligned"); } while (0)
 #define REQUIRE_CURVE() do { if (curve != ECSIMD_HIP_P256 && curve != ECSIMD_HIP_SECP256K1) return bad(ctx, "unknown curve"); } while (0)
 
+// A curve registered at run time (id >= ECSIMD_HIP_FIRST_REGISTERED_CURVE): the generic kernels of k_gcurve.hip / k_gladder.hip take its record GC.
+#define GENERIC_CURVE(call) do { if (curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE) { gcurve GC; if (!lookup_curve(curve, &GC)) return bad(ctx, "unknown curve id"); RUN(call); } } while (0)
 // Enqueue one launcher call on the context's stream; report launch errors.
 #define RUN(call) do { \
     if (n == 0) return ECSIMD_HIP_OK; \
@@ -331,6 +334,34 @@ int run_ladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, 
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult launch");
 }
 
+bool lookup_curve(int id, gcurve* out);          // the curve registry, below
+// The same for a curve registered at run time: flags BASE_* | OUT_* | LADDER_RADIX32 | REF_SQUARE_COMPAT; the table-driven ALG_* algorithms exist for the
+// two built-in curves only.  x == nullptr: the curve's generator.
+int run_gladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y,
+                uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
+  gcurve GC; if (!lookup_curve(curve, &GC)) return bad(ctx, "unknown curve id");
+  if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM | ECSIMD_HIP_ALG_CONSTANT_TIME))
+    return bad(ctx, "a registered curve has the reference's ladder only (the ALG_* tables exist for P-256 and secp256k1)");
+  if (n == 0) return ECSIMD_HIP_OK;
+  if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e != hipSuccess) return fail(ctx, e, "hipSetDevice");
+  const bool ref = ctx->ref_square || (flags & ECSIMD_HIP_REF_SQUARE_COMPAT);
+  const int lf = (flags & (ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_LADDER_RADIX32)) | (ref ? ECSIMD_HIP_REF_SQUARE_COMPAT : 0);
+  if (flags & ECSIMD_HIP_OUT_AFFINE) {
+    int rc = ensure_workspace(ctx, 3 * n * 32);
+    if (rc != ECSIMD_HIP_OK) return rc;
+    uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
+    launch::gc_scalar_mult(ctx->stream, GC, k, k_stride, x, y, jx, jy, jz, n, lf);
+    if (ref) launch::gc_to_affine(ctx->stream, GC, jx, jy, jz, ox, oy, n, true);       // the reference's own power ladder per element (gfp.h:42-44)
+    else launch::gc_to_affine_batched(ctx->stream, GC, jx, jy, jz, ox, oy, n);
+  } else {
+    launch::gc_scalar_mult(ctx->stream, GC, k, k_stride, x, y, ox, oy, oz, n, lf);
+  }
+  e = hipGetLastError();
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult (registered curve) launch");
+}
+
 // Variable-base windowed multiplication in chunks of VARWIN_CHUNK lanes (1 408 B of scratch per lane: the
 // per-lane tables live in HBM).  `reserve` bytes at the start of the workspace stay untouched (double_scalar_mult).
 constexpr size_t VARWIN_CHUNK = (size_t)1 << 22;
@@ -450,11 +481,59 @@ struct modulus_registry {
 modulus_registry& registry() { static modulus_registry r; return r; }
 constexpr int FIRST_FIELD_ID = 2, MAX_FIELDS = 4096;
 // the record of field id `id` (>= 2); false if there is none
+bool lookup_curve(int id, gcurve* out);
 bool lookup_modulus(int id, gmod* out) {
+  if (id >= ECSIMD_HIP_FIRST_REGISTERED_CURVE) { gcurve G; if (!lookup_curve(id, &G)) return false; *out = G.F; return true; }     // a registered curve's id names its prime's field
   modulus_registry& r = registry();
   std::lock_guard<std::mutex> g(r.mu);
   if (id < FIRST_FIELD_ID || (size_t)(id - FIRST_FIELD_ID) >= r.mods.size()) return false;
   *out = r.mods[id - FIRST_FIELD_ID];
+  return true;
+}
+// ================================================================== run-time curves (round 5)
+// The reference's group layer is a template over ANY curve type -- curve_group<Curve> for every Curve with bn_type, P, A, B, Gx, Gy (curve.h:12-15,
+// curve_group.h:20-33) over a field GFp<WBN, P> that needs p = 3 mod 4 (gfp.h:84).  Here a curve is a run-time record with an id >= FIRST_CURVE_ID:
+// the host derives what the templates derive (the field's constants as for a modulus, Am = a R, Bm = b R: curve_group.h:31-32) plus the 29-bit-limb
+// constants of the ladder's loop, and the generic kernels (k_gcurve.hip, k_gladder.hip) take the 512-byte record as a kernel argument.
+constexpr int FIRST_CURVE_ID = ECSIMD_HIP_FIRST_REGISTERED_CURVE, MAX_CURVES = 4096;
+bool u_is_zero(const u256& a) { return !(a.l[0] | a.l[1] | a.l[2] | a.l[3]); }
+bool u_eq(const u256& a, const u256& b) { return !memcmp(a.l, b.l, 32); }
+u256 u_from(const uint64_t v[4]) { u256 r; memcpy(r.l, v, 32); return r; }
+u256 u_add_mod(const u256& a, const u256& b, const u256& p) {          // a, b < p
+  u256 s; unsigned __int128 c = 0;
+  for (int i = 0; i < 4; ++i) { c += (unsigned __int128)a.l[i] + b.l[i]; s.l[i] = (uint64_t)c; c >>= 64; }
+  if ((uint64_t)c || u_geq(s, p)) { u256 t; (void)u_sub(t, s, p); s = t; }
+  return s;
+}
+u256 u_mul_mod(const u256& a, const u256& b, const u256& p) {          // a, b < p: double-and-add (registration is rare)
+  u256 r = {{0, 0, 0, 0}};
+  for (int i = 255; i >= 0; --i) { u_dbl_mod(r, p); if ((b.l[i >> 6] >> (i & 63)) & 1u) r = u_add_mod(r, a, p); }
+  return r;
+}
+u256 u_shl_mod(u256 a, int bits, const u256& p) { for (int i = 0; i < bits; ++i) u_dbl_mod(a, p); return a; }
+void u_limbs29(int32_t (&out)[9], const u256& v) {                      // tight 29-bit limbs (tools/radix29_model.py to_limbs)
+  for (int i = 0; i < 9; ++i) {
+    const int bit = 29 * i, limb = bit / 64, off = bit % 64;
+    uint64_t w = v.l[limb] >> off;
+    if (off > 64 - 29 && limb + 1 < 4) w |= v.l[limb + 1] << (64 - off);
+    out[i] = (int32_t)(w & (i < 8 ? 0x1fffffffu : 0xffffffu));
+  }
+}
+struct curve_record { gcurve G; u256 a, b, n; bool has_order; };
+struct curve_registry { std::mutex mu; std::vector<curve_record> curves; };
+curve_registry& curves() { static curve_registry r; return r; }
+bool lookup_curve(int id, gcurve* out) {
+  curve_registry& r = curves();
+  std::lock_guard<std::mutex> g(r.mu);
+  if (id < FIRST_CURVE_ID || (size_t)(id - FIRST_CURVE_ID) >= r.curves.size()) return false;
+  *out = r.curves[id - FIRST_CURVE_ID].G;
+  return true;
+}
+bool lookup_curve_record(int id, curve_record* out) {
+  curve_registry& r = curves();
+  std::lock_guard<std::mutex> g(r.mu);
+  if (id < FIRST_CURVE_ID || (size_t)(id - FIRST_CURVE_ID) >= r.curves.size()) return false;
+  *out = r.curves[id - FIRST_CURVE_ID];
   return true;
 }
 }  // namespace
@@ -574,6 +653,57 @@ int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id) {
   } catch (...) { return ECSIMD_HIP_ERR_BAD_ARG; }             // nothing throws across the C ABI
 }
 
+// curve_group<Curve> for any Curve (curve.h:12-15): what the templates derive at compile time, derived here once per curve.
+int ecsimd_hip_register_curve(const uint64_t p[4], const uint64_t a[4], const uint64_t b[4], const uint64_t gx[4], const uint64_t gy[4], const uint64_t n[4], int flags, int* curve_id) {
+  if (!p || !a || !b || !gx || !gy || !curve_id) return ECSIMD_HIP_ERR_BAD_ARG;
+  if (flags & ~ECSIMD_HIP_CURVE_GENERIC_KERNELS) return ECSIMD_HIP_ERR_BAD_ARG;
+  const u256 P = u_from(p), A = u_from(a), B = u_from(b), GX = u_from(gx), GY = u_from(gy);
+  if ((p[0] & 3u) != 3u || (p[0] < 7 && !(p[1] | p[2] | p[3]))) return ECSIMD_HIP_ERR_BAD_ARG;     // p = 3 mod 4 like the reference's GFp (gfp.h:84), p >= 7
+  if (u_geq(A, P) || u_geq(B, P) || u_geq(GX, P) || u_geq(GY, P)) return ECSIMD_HIP_ERR_BAD_ARG;
+  // the generator is on the curve (a typo in any of the five values is caught here): y^2 = x^3 + a x + b
+  { const u256 lhs = u_mul_mod(GY, GY, P), x3 = u_mul_mod(u_mul_mod(GX, GX, P), GX, P);
+    if (!u_eq(lhs, u_add_mod(u_add_mod(x3, u_mul_mod(A, GX, P), P), B, P))) return ECSIMD_HIP_ERR_BAD_ARG; }
+  // non-singular: 4 a^3 + 27 b^2 != 0
+  { const u256 a3 = u_mul_mod(u_mul_mod(A, A, P), A, P), b2 = u_mul_mod(B, B, P);
+    u256 four = {{4, 0, 0, 0}}, c27 = {{27, 0, 0, 0}};
+    if (u_geq(four, P)) (void)u_sub(four, four, P);
+    while (u_geq(c27, P)) (void)u_sub(c27, c27, P);
+    if (u_is_zero(u_add_mod(u_mul_mod(four, a3, P), u_mul_mod(c27, b2, P), P))) return ECSIMD_HIP_ERR_BAD_ARG; }
+  u256 N = {{0, 0, 0, 0}};
+  if (n) { N = u_from(n); if (!(n[0] & 1u) || u_is_zero(N)) return ECSIMD_HIP_ERR_BAD_ARG; }
+  if (!(flags & ECSIMD_HIP_CURVE_GENERIC_KERNELS)) {               // the two built-in curves keep their special-form kernels
+    for (int cv = 0; cv < 2; ++cv) {
+      uint64_t c[5][4];
+      for (int w = 0; w < 5; ++w) (void)ecsimd_hip_get_constant(cv, w, c[w]);
+      if (!memcmp(c[0], p, 32) && !memcmp(c[1], a, 32) && !memcmp(c[2], b, 32) && !memcmp(c[3], gx, 32) && !memcmp(c[4], gy, 32)) { *curve_id = cv; return ECSIMD_HIP_OK; }
+    }
+  }
+  try {
+    curve_record rec; memset(&rec, 0, sizeof rec);
+    rec.a = A; rec.b = B; rec.n = N; rec.has_order = n != nullptr;
+    gcurve& G = rec.G;
+    G.F = make_gmod(p, GMOD_PRIME);                                 // registering a CURVE vouches that p is prime
+    u_words(G.am, u_shl_mod(A, 256, P));                            // to_mgry(A), to_mgry(B): curve_group.h:31-32
+    u_words(G.bm, u_shl_mod(B, 256, P));
+    u_words(G.gx, GX); u_words(G.gy, GY);
+    u_limbs29(G.r29.p, P);
+    G.r29.qinv = G.F.mprime & 0x1fffffffu;                          // -p^-1 mod 2^29 (mprime = -p^-1 mod 2^32)
+    const u256 one = {{1, 0, 0, 0}};
+    u_limbs29(G.r29.in, u_shl_mod(one, 266, P));                    // 2^266 mod p: x 2^256 -> x 2^261 through one product / 2^261
+    u_limbs29(G.r29.out, u_shl_mod(one, 256, P));                   // 2^256 mod p: back
+    curve_registry& r = curves();
+    std::lock_guard<std::mutex> g(r.mu);
+    for (size_t i = 0; i < r.curves.size(); ++i) {
+      const curve_record& o = r.curves[i];
+      if (!memcmp(o.G.F.p, G.F.p, 32) && u_eq(o.a, A) && u_eq(o.b, B) && !memcmp(o.G.gx, G.gx, 32) && !memcmp(o.G.gy, G.gy, 32)) { *curve_id = FIRST_CURVE_ID + (int)i; return ECSIMD_HIP_OK; }
+    }
+    if (r.curves.size() >= (size_t)MAX_CURVES) return ECSIMD_HIP_ERR_BAD_ARG;
+    r.curves.push_back(rec);
+    *curve_id = FIRST_CURVE_ID + (int)r.curves.size() - 1;
+    return ECSIMD_HIP_OK;
+  } catch (...) { return ECSIMD_HIP_ERR_BAD_ARG; }
+}
+
 int ecsimd_hip_get_constant(int curve, int which, uint64_t out[4]) {
   if (!out || which < 0 || which > 11) return ECSIMD_HIP_ERR_BAD_ARG;
 #define PICK(C) do { using K = curve_consts<C>; using E = curve_exps<C>; \
@@ -596,6 +726,19 @@ int ecsimd_hip_get_constant(int curve, int which, uint64_t out[4]) {
   if (curve == ECSIMD_HIP_P256) PICK(CURVE_P256);
   else if (curve == ECSIMD_HIP_SECP256K1) PICK(CURVE_SECP256K1);
   else {
+    // a registered curve: every slot
+    curve_record rec;
+    if (lookup_curve_record(curve, &rec)) {
+      switch (which) {
+        case 1: memcpy(out, rec.a.l, 32); return ECSIMD_HIP_OK;
+        case 2: memcpy(out, rec.b.l, 32); return ECSIMD_HIP_OK;
+        case 3: words_to_limbs(rec.G.gx, out); return ECSIMD_HIP_OK;
+        case 4: words_to_limbs(rec.G.gy, out); return ECSIMD_HIP_OK;
+        case 8: words_to_limbs(rec.G.am, out); return ECSIMD_HIP_OK;
+        case 9: words_to_limbs(rec.G.bm, out); return ECSIMD_HIP_OK;
+        default: break;                                    // the field's slots below
+      }
+    }
     // a field id: p, R mod p, R^2 mod p, -R mod p, p - 2, (p + 1) / 4; the curve slots (a, b, Gx, Gy, a R, b R) read zero
     gmod M;
     if (!lookup_modulus(curve, &M)) return ECSIMD_HIP_ERR_BAD_ARG;
@@ -723,40 +866,53 @@ int ecsimd_hip_gfp_sqrt(ecsimd_hip_ctx* ctx, int curve, const uint64_t* a, uint6
 
 // ---- L4/L5
 int ecsimd_hip_from_affine(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); RUN(launch::from_affine(s, instance(ctx, curve), x, y, jx, jy, jz, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); GENERIC_CURVE(launch::gc_from_affine(s, GC, x, y, jx, jy, jz, n));
+  REQUIRE_CURVE(); RUN(launch::from_affine(s, instance(ctx, curve), x, y, jx, jy, jz, n)); }
 int ecsimd_hip_to_affine(ecsimd_hip_ctx* ctx, int curve, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); REQUIRE_PTR(x);
+  REQUIRE_CTX(); REQUIRE_PTR(jx); REQUIRE_PTR(jy); REQUIRE_PTR(jz); REQUIRE_PTR(x);
   if (y && !aligned16(y)) return bad(ctx, "y is not 16-byte aligned");       // y == NULL: the x coordinate only
   // Simultaneous inversion uses x[] as scratch: only when the outputs do not alias the inputs.
   const bool alias = overlaps(x, jx) || overlaps(x, jy) || overlaps(x, jz) || (y && (overlaps(y, jx) || overlaps(y, jy) || overlaps(y, jz) || overlaps(x, y)));
+  if (alias || ctx->ref_square) GENERIC_CURVE(launch::gc_to_affine(s, GC, jx, jy, jz, x, y, n, ctx->ref_square != 0));
+  GENERIC_CURVE(launch::gc_to_affine_batched(s, GC, jx, jy, jz, x, y, n));
+  REQUIRE_CURVE();
   if (alias || ctx->ref_square) RUN(launch::to_affine(s, instance(ctx, curve), jx, jy, jz, x, y, n));
   RUN(launch::to_affine_batched(s, curve, jx, jy, jz, x, y, n, false)); }
 int ecsimd_hip_compute_y(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, uint64_t* y, uint8_t* ok, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); RUN(launch::compute_y(s, instance(ctx, curve), x, y, ok, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(x); REQUIRE_PTR(y); GENERIC_CURVE(launch::gc_compute_y(s, GC, x, y, ok, n, ctx->ref_square != 0));
+  REQUIRE_CURVE(); RUN(launch::compute_y(s, instance(ctx, curve), x, y, ok, n)); }
 int ecsimd_hip_dblu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz); RUN(launch::dblu(s, instance(ctx, curve), px, py, pz, rx, ry, rz, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz); GENERIC_CURVE(launch::gc_dblu(s, GC, px, py, pz, rx, ry, rz, n, ctx->ref_square != 0));
+  REQUIRE_CURVE(); RUN(launch::dblu(s, instance(ctx, curve), px, py, pz, rx, ry, rz, n)); }
 int ecsimd_hip_zaddu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, const uint64_t* ox, const uint64_t* oy, const uint64_t* oz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(ox); REQUIRE_PTR(oy); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
+  REQUIRE_CTX(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(ox); REQUIRE_PTR(oy); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
   (void)oz;   // co-Z: O.z == P.z by precondition (curve_group.h:92)
-  RUN(launch::zaddu(s, instance(ctx, curve), px, py, pz, ox, oy, rx, ry, rz, n)); }
+  GENERIC_CURVE(launch::gc_zaddu(s, GC, px, py, pz, ox, oy, rx, ry, rz, n, ctx->ref_square != 0));
+  REQUIRE_CURVE(); RUN(launch::zaddu(s, instance(ctx, curve), px, py, pz, ox, oy, rx, ry, rz, n)); }
 int ecsimd_hip_zdau(ecsimd_hip_ctx* ctx, int curve, const uint64_t* px, const uint64_t* py, const uint64_t* pz, uint64_t* qx, uint64_t* qy, uint64_t* qz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(qz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
-  RUN(launch::zdau(s, instance(ctx, curve), px, py, pz, qx, qy, qz, rx, ry, rz, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(qz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
+  GENERIC_CURVE(launch::gc_zdau(s, GC, px, py, pz, qx, qy, qz, rx, ry, rz, n, ctx->ref_square != 0));
+  REQUIRE_CURVE(); RUN(launch::zdau(s, instance(ctx, curve), px, py, pz, qx, qy, qz, rx, ry, rz, n)); }
 int ecsimd_hip_zdau_repeat(ecsimd_hip_ctx* ctx, int curve, const uint64_t* px, const uint64_t* py, const uint64_t* pz, const uint64_t* qx, const uint64_t* qy,
                            uint64_t* rx, uint64_t* ry, uint64_t* sx, uint64_t* sy, uint64_t* oz, size_t n, int iters, uint64_t swap_bits, int radix) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(sx); REQUIRE_PTR(sy); REQUIRE_PTR(oz);
+  REQUIRE_CTX(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(sx); REQUIRE_PTR(sy); REQUIRE_PTR(oz);
   if (iters < 0) return bad(ctx, "iters is negative");
   if (radix != 29 && radix != 32) return bad(ctx, "radix is 29 or 32");
+  if (curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE && ctx->ref_square) return bad(ctx, "zdau_repeat on a registered curve has no reference-square form");
+  GENERIC_CURVE(launch::gc_zdau_repeat(s, GC, px, py, pz, qx, qy, rx, ry, sx, sy, oz, n, iters, swap_bits, radix));
+  REQUIRE_CURVE();
   if (radix == 29 && instance(ctx, curve) != curve) return bad(ctx, "the reduced-radix loop has no reference-square form (the dropped carry depends on the 32-bit Montgomery digits)");
   RUN(launch::zdau_repeat(s, instance(ctx, curve), px, py, pz, qx, qy, rx, ry, sx, sy, oz, n, iters, swap_bits, radix)); }
 int ecsimd_hip_add_z2_1(ecsimd_hip_ctx* ctx, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(ax); REQUIRE_PTR(ay); REQUIRE_PTR(az); REQUIRE_PTR(bx); REQUIRE_PTR(by); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
-  RUN(launch::add_z2_1(s, instance(ctx, curve), ax, ay, az, bx, by, rx, ry, rz, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(ax); REQUIRE_PTR(ay); REQUIRE_PTR(az); REQUIRE_PTR(bx); REQUIRE_PTR(by); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
+  GENERIC_CURVE(launch::gc_add_z2_1(s, GC, ax, ay, az, bx, by, rx, ry, rz, n, ctx->ref_square != 0));
+  REQUIRE_CURVE(); RUN(launch::add_z2_1(s, instance(ctx, curve), ax, ay, az, bx, by, rx, ry, rz, n)); }
 int ecsimd_hip_add_mixed_complete(ecsimd_hip_ctx* ctx, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
   REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(ax); REQUIRE_PTR(ay); REQUIRE_PTR(az); REQUIRE_PTR(bx); REQUIRE_PTR(by); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz);
   RUN(launch::add_mixed_complete(s, curve, ax, ay, az, bx, by, rx, ry, rz, n)); }
 int ecsimd_hip_trplu(ecsimd_hip_ctx* ctx, int curve, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz); RUN(launch::trplu(s, instance(ctx, curve), px, py, pz, rx, ry, rz, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(px); REQUIRE_PTR(py); REQUIRE_PTR(pz); REQUIRE_PTR(rx); REQUIRE_PTR(ry); REQUIRE_PTR(rz); GENERIC_CURVE(launch::gc_trplu(s, GC, px, py, pz, rx, ry, rz, n, ctx->ref_square != 0));
+  REQUIRE_CURVE(); RUN(launch::trplu(s, instance(ctx, curve), px, py, pz, rx, ry, rz, n)); }
 
 int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   REQUIRE_CTX();
@@ -765,8 +921,10 @@ int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, co
   if ((flags & ECSIMD_HIP_BASE_GENERATOR) && x == nullptr && y == nullptr)
     return ecsimd_hip_scalar_mult_base(ctx, curve, k, ox, oy, oz, n, flags & ~(ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_BASE_GENERATOR));
   if (flags & ECSIMD_HIP_BASE_GENERATOR) return bad(ctx, "BASE_GENERATOR takes x = y = NULL");
-  REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy);
+  REQUIRE_PTR(k); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy);
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
+  if (curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE) return run_gladder(ctx, curve, k, 4, x, y, ox, oy, oz, n, flags);
+  REQUIRE_CURVE();
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED)) {
     // per-lane window tables (8 multiples of P) in HBM + signed 4-bit windows (k_varwin.inc): a different algorithm from
     // the reference ladder, so affine output only (SURVEY.md 8(a) level A)
@@ -778,13 +936,15 @@ int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, co
   if (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED (the ladder is constant-time as it is)");
   return run_ladder(ctx, curve, k, 4, x, y, ox, oy, oz, n, flags); }
 int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[4], const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy); if (!k1) return bad(ctx, "k1 is null");
+  REQUIRE_CTX(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy); if (!k1) return bad(ctx, "k1 is null");
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
+  if (curve < ECSIMD_HIP_FIRST_REGISTERED_CURVE) REQUIRE_CURVE();
   launch::words8 w; for (int i = 0; i < 4; ++i) { w.w[2 * i] = (uint32_t)k1[i]; w.w[2 * i + 1] = (uint32_t)(k1[i] >> 32); }
   uint32_t* kdev = ctx->sink + 1024 - 8;    // 32-byte aligned slot at the end of the scratch page
   if (n == 0) return ECSIMD_HIP_OK;
   (void)hipSetDevice(ctx->device);
   store_words(ctx->stream, w, kdev);
+  if (curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE) return run_gladder(ctx, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, oz, n, flags);
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED)) {
     if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
     if ((flags & ECSIMD_HIP_ALG_CONSTANT_TIME) && (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED)) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED only, not ALG_WINDOWED_SIGNED");
@@ -794,9 +954,11 @@ int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[
   if (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED (the ladder is constant-time as it is)");
   return run_ladder(ctx, curve, reinterpret_cast<const uint64_t*>(kdev), 0, x, y, ox, oy, oz, n, flags); }
 int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(k); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy);
+  REQUIRE_CTX(); REQUIRE_PTR(k); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy);
   flags &= ~ECSIMD_HIP_BASE_GENERATOR;                            // (implied here)
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
+  if (curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE) return run_gladder(ctx, curve, k, 4, nullptr, nullptr, ox, oy, oz, n, flags & ~ECSIMD_HIP_BASE_MGRY);
+  REQUIRE_CURVE();
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG)) {
     const bool big = (flags & ECSIMD_HIP_ALG_WINDOWED_BIG) != 0;         // signed 20-bit windows, table in device memory
     const bool six = (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED) != 0;      // signed 7-bit windows, table in LDS
@@ -891,8 +1053,9 @@ int double_scalar_mult_impl(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, 
 }  // namespace
 
 int ecsimd_hip_on_curve(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, uint8_t* ok, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); if (!ok && n) return bad(ctx, "ok is null");
-  RUN(launch::on_curve(s, curve, x, y, ok, n)); }
+  REQUIRE_CTX(); REQUIRE_PTR(x); REQUIRE_PTR(y); if (!ok && n) return bad(ctx, "ok is null");
+  GENERIC_CURVE(launch::gc_on_curve(s, GC, x, y, ok, n));
+  REQUIRE_CURVE(); RUN(launch::on_curve(s, curve, x, y, ok, n)); }
 
 int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                                   uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) {
@@ -989,6 +1152,19 @@ int ecsimd_hip_ecdsa_sign(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, con
   // (the projective-coordinate leak), and the block outlives the call (grow-only, hipFree does not wipe).  Zero it on the same stream, behind the kernels.
   if (err == hipSuccess) err = hipMemsetAsync(ctx->workspace, 0, 4 * n * 32, st);
   return err == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, err, "ecdsa_sign launch"); }
+
+int ecsimd_hip_fe29_raw(ecsimd_hip_ctx* ctx, int curve, int op, const int32_t* in, int32_t* out, size_t n, int swap) {
+  REQUIRE_CTX(); if ((!in || !out) && n) return bad(ctx, "fe29_raw: null pointer");
+  if (op < 0 || op > launch::RAW_SQR) return bad(ctx, "fe29_raw: unknown function");
+  gcurve GC; const bool registered = curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE;
+  if (registered) { if (!lookup_curve(curve, &GC)) return bad(ctx, "unknown curve id"); }
+  else REQUIRE_CURVE();
+  if (n == 0) return ECSIMD_HIP_OK;
+  if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
+  hipError_t e = hipSetDevice(ctx->device); if (e != hipSuccess) return fail(ctx, e, "hipSetDevice");
+  if (!launch::fe29_raw(ctx->stream, registered ? 2 : curve, registered ? &GC : nullptr, op, in, out, n, swap ? 0xffffffffu : 0u)) return bad(ctx, "fe29_raw: this function does not exist for this curve");
+  e = hipGetLastError();
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "fe29_raw launch"); }
 
 int ecsimd_hip_workspace_info(ecsimd_hip_ctx* ctx, const void** dptr, size_t* bytes) {
   REQUIRE_CTX(); if (!dptr || !bytes) return bad(ctx, "workspace_info: null output");

@@ -37,8 +37,20 @@ ECS_DEV int32_t r29_opaque(int32_t c) { int32_t r; asm("s_mov_b32 %0, %1" : "=s"
 ECS_DEV int32_t r29_dbl32(int32_t x) { int32_t r; asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x)); return r; }
 
 template <int C> struct r29_prime;                 // the prime's sparse signed form in radix 2^29 (tools/radix29_model.py Curve.terms)
-template <> struct r29_prime<CURVE_P256> { static constexpr bool p256 = true; };
-template <> struct r29_prime<CURVE_SECP256K1_CLASSICAL> { static constexpr bool p256 = false; static constexpr uint32_t QMUL = 0x12253531u; };   // 977^-1 mod 2^29
+// p256: P-256's reduction and a = -3 formulas; dense: any odd p < 2^256 as nine tight limbs in SGPRs (round 5: curves registered at run time);
+// tight_sq: zdau29 carry-passes dy - u and dx + u before squaring them (the interval proof needs it for every reduction but secp256k1's sparse one)
+template <> struct r29_prime<CURVE_P256> { static constexpr bool p256 = true, dense = false, tight_sq = true; };
+template <> struct r29_prime<CURVE_SECP256K1_CLASSICAL> { static constexpr bool p256 = false, dense = false, tight_sq = false; static constexpr uint32_t QMUL = 0x12253531u; };   // 977^-1 mod 2^29
+template <> struct r29_prime<CURVE_GENERIC> { static constexpr bool p256 = false, dense = true, tight_sq = true; };
+// What the column walk needs beside its operands: nothing for the built-in primes (an empty object, a defaulted last argument of every function below),
+// the prime itself for a registered curve -- wave-uniform values that arrive as a kernel argument and live in SGPRs (tools/radix29_model.py Curve.dense).
+template <int C> struct r29_ctx {};
+template <> struct r29_ctx<CURVE_GENERIC> {
+  int32_t p[9];        // p in tight limbs: limbs 0..7 in [0, 2^29), the top one < 2^24
+  uint32_t qinv;       // -p^-1 mod 2^29: q_k = column * qinv makes column + q_k p vanish mod 2^29
+  int32_t in[9];       // 2^266 mod p, tight: API Montgomery form x 2^256 -> x 2^261
+  int32_t out[9];      // 2^256 mod p, tight: back
+};
 
 ECS_DEV fe29 add29(const fe29& a, const fe29& b) { fe29 r;
 #pragma unroll
@@ -76,7 +88,7 @@ ECS_DEV void cswap29(uint32_t m, fe29& a, fe29& b) {
 // of the carry; the compiler only extracts the digit (v_and_b32) and shifts the column down (v_ashrrev_i64) between two statements.
 struct r29_consts_sgpr { int32_t k9, k18, km21, k24, km8, km977; };
 template <int C, bool SQR, int K> ECS_DEV void fips29_column(int64_t& acc, const fe29& a, const int32_t (&a2)[R29_LIMBS], const fe29& b,
-                                                             int32_t (&q)[R29_LIMBS], fe29& r, const r29_consts_sgpr& k) {
+                                                             int32_t (&q)[R29_LIMBS], fe29& r, const r29_consts_sgpr& k, const r29_ctx<C>& cx) {
   using PR = r29_prime<C>;
   constexpr int lo = K > R29_LIMBS - 1 ? K - (R29_LIMBS - 1) : 0, hi = K < R29_LIMBS - 1 ? K : R29_LIMBS - 1;
   constexpr int NCROSS = SQR ? ((K - 1) / 2 >= lo && K > 0 ? (K - 1) / 2 - lo + 1 : 0) : hi - lo + 1;
@@ -98,6 +110,16 @@ template <int C, bool SQR, int K> ECS_DEV void fips29_column(int64_t& acc, const
     if constexpr (K == 0) r29_col_first<NP>::run(acc, x, y); else r29_col<NP, NR>::run(acc, x, y, qq, cc);
     if constexpr (K < R29_LIMBS) q[K] = (int32_t)acc & R29_MASK;          // acc - q[K] is a multiple of 2^29: the shift below drops it
     else r.l[K - R29_LIMBS] = (int32_t)acc & R29_MASK;
+  } else if constexpr (PR::dense) {
+    // any odd p: + q_j p_(K-j) for every quotient digit already known (j < K), then q_K = column * (-p^-1) mod 2^29 and + q_K p_0 clears the low 29 bits
+    constexpr int jlo = K > R29_LIMBS - 1 ? K - (R29_LIMBS - 1) : 0, jhi = K - 1 < R29_LIMBS - 1 ? K - 1 : R29_LIMBS - 1;
+    constexpr int NR = jhi >= jlo ? jhi - jlo + 1 : 0;
+    int32_t qq[NR > 0 ? NR : 1], cc[NR > 0 ? NR : 1];
+#pragma unroll
+    for (int t = 0; t < NR; ++t) { qq[t] = q[jlo + t]; cc[t] = cx.p[K - jlo - t]; }
+    if constexpr (K == 0) r29_col_first<NP>::run(acc, x, y); else r29_col<NP, NR>::run(acc, x, y, qq, cc);
+    if constexpr (K < R29_LIMBS) { q[K] = (int32_t)((uint32_t)acc * cx.qinv) & R29_MASK; acc += (int64_t)q[K] * cx.p[0]; }
+    else r.l[K - R29_LIMBS] = (int32_t)acc & R29_MASK;
   } else {
     // secp256k1: - 8 q one limb up, + q 2^24 eight up; - 977 q at its own column, after q = column * 977^-1 mod 2^29
     constexpr int NR = (in(K - 1) ? 1 : 0) + (in(K - 8) ? 1 : 0);
@@ -112,10 +134,10 @@ template <int C, bool SQR, int K> ECS_DEV void fips29_column(int64_t& acc, const
   acc >>= R29_BITS;
 }
 template <int C, bool SQR, int... K> ECS_DEV void fips29_columns(int64_t& acc, const fe29& a, const int32_t (&a2)[R29_LIMBS], const fe29& b,
-                                                                int32_t (&q)[R29_LIMBS], fe29& r, const r29_consts_sgpr& k, std::integer_sequence<int, K...>) {
-  (fips29_column<C, SQR, K>(acc, a, a2, b, q, r, k), ...);
+                                                                int32_t (&q)[R29_LIMBS], fe29& r, const r29_consts_sgpr& k, const r29_ctx<C>& cx, std::integer_sequence<int, K...>) {
+  (fips29_column<C, SQR, K>(acc, a, a2, b, q, r, k, cx), ...);
 }
-template <int C, bool SQR> ECS_DEV fe29 fips29(const fe29& a, const fe29& b) {
+template <int C, bool SQR> ECS_DEV fe29 fips29(const fe29& a, const fe29& b, const r29_ctx<C>& cx) {
   int32_t q[R29_LIMBS];
   int32_t a2[R29_LIMBS];
   fe29 r;
@@ -125,12 +147,12 @@ template <int C, bool SQR> ECS_DEV fe29 fips29(const fe29& a, const fe29& b) {
   }
   const r29_consts_sgpr k{r29_opaque(1 << 9), r29_opaque(1 << 18), r29_opaque(-(1 << 21)), r29_opaque(1 << 24), r29_opaque(-8), r29_opaque(-977)};
   int64_t acc;
-  fips29_columns<C, SQR>(acc, a, a2, b, q, r, k, std::make_integer_sequence<int, 2 * R29_LIMBS - 1>{});
+  fips29_columns<C, SQR>(acc, a, a2, b, q, r, k, cx, std::make_integer_sequence<int, 2 * R29_LIMBS - 1>{});
   r.l[R29_LIMBS - 1] = (int32_t)acc;
   return r;
 }
-template <int C> ECS_DEV fe29 mul29(const fe29& a, const fe29& b) { return fips29<C, false>(a, b); }
-template <int C> ECS_DEV fe29 sqr29(const fe29& a) { return fips29<C, true>(a, a); }
+template <int C> ECS_DEV fe29 mul29(const fe29& a, const fe29& b, const r29_ctx<C>& cx = r29_ctx<C>{}) { return fips29<C, false>(a, b, cx); }
+template <int C> ECS_DEV fe29 sqr29(const fe29& a, const r29_ctx<C>& cx = r29_ctx<C>{}) { return fips29<C, true>(a, a, cx); }
 
 // ---------------------------------------------------------------- conversions at the loop's boundary
 // canonical 8 x 32-bit words (a value < 2^256) -> nine tight limbs of the same integer
@@ -177,22 +199,29 @@ template <const int32_t (&ARR)[9]> ECS_DEV fe29 fe29_const() { fe29 r;
 #pragma unroll
   for (int i = 0; i < R29_LIMBS; ++i) r.l[i] = ARR[i];
   return r; }
+ECS_DEV fe29 fe29_from(const int32_t (&arr)[9]) { fe29 r;
+#pragma unroll
+  for (int i = 0; i < R29_LIMBS; ++i) r.l[i] = arr[i];
+  return r; }
+// the constants of the loop's boundary: compile-time tables for the built-in primes, the context's for a registered curve
+template <int C> ECS_DEV fe29 r29_in(const r29_ctx<C>& cx) { if constexpr (r29_prime<C>::dense) return fe29_from(cx.in); else return fe29_const<r29_consts<C>::IN>(); }
+template <int C> ECS_DEV fe29 r29_out(const r29_ctx<C>& cx) { if constexpr (r29_prime<C>::dense) return fe29_from(cx.out); else return fe29_const<r29_consts<C>::OUT>(); }
+template <int C> ECS_DEV int32_t r29_p(const r29_ctx<C>& cx, int i) { if constexpr (r29_prime<C>::dense) return cx.p[i]; else return r29_consts<C>::P[i]; }
 // a field element of the loop's surroundings (canonical, field.cuh's fast domain) -> x * 2^261 in tight limbs
-template <int C> ECS_DEV fe29 enter29(const fe& v) { return mul29<C>(to29(v), fe29_const<r29_consts<C>::IN>()); }
+template <int C> ECS_DEV fe29 enter29(const fe& v, const r29_ctx<C>& cx = r29_ctx<C>{}) { return mul29<C>(to29(v), r29_in<C>(cx), cx); }
 // ... and back: the canonical residue of field.cuh's domain.  `v` is anything the loop holds (|value| < 8 p): the product with a
 // tight constant < p lies in (-p/4, 9p/8), + p makes it positive, a sequential carry pass makes the limbs tight, and two
 // conditional subtractions of p (sign of the top limb after a borrow pass) land in [0, p).
-template <int C> ECS_DEV fe canon29(fe29 t) {                        // a value in (-p, 2p) (leave29 needs (-p, 9p/8)): + p, carry pass, two conditional subtractions
-  using K = r29_consts<C>;
+template <int C> ECS_DEV fe canon29(fe29 t, const r29_ctx<C>& cx = r29_ctx<C>{}) {       // a value in (-p, 2p) (leave29 needs (-p, 9p/8)): + p, carry pass, two conditional subtractions
 #pragma unroll
-  for (int i = 0; i < R29_LIMBS; ++i) t.l[i] += K::P[i];
+  for (int i = 0; i < R29_LIMBS; ++i) t.l[i] += r29_p<C>(cx, i);
 #pragma unroll
   for (int i = 0; i < R29_LIMBS - 1; ++i) { t.l[i + 1] += t.l[i] >> R29_BITS; t.l[i] &= R29_MASK; }
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     fe29 d;
 #pragma unroll
-    for (int i = 0; i < R29_LIMBS; ++i) d.l[i] = t.l[i] - K::P[i];
+    for (int i = 0; i < R29_LIMBS; ++i) d.l[i] = t.l[i] - r29_p<C>(cx, i);
 #pragma unroll
     for (int i = 0; i < R29_LIMBS - 1; ++i) { d.l[i + 1] += d.l[i] >> R29_BITS; d.l[i] &= R29_MASK; }
     const int32_t keep = d.l[R29_LIMBS - 1] >> 31;                     // all ones where t < p
@@ -201,7 +230,7 @@ template <int C> ECS_DEV fe canon29(fe29 t) {                        // a value 
   }
   return from29(t);
 }
-template <int C> ECS_DEV fe leave29(const fe29& v) { return canon29<C>(mul29<C>(v, fe29_const<r29_consts<C>::OUT>())); }
+template <int C> ECS_DEV fe leave29(const fe29& v, const r29_ctx<C>& cx = r29_ctx<C>{}) { return canon29<C>(mul29<C>(v, r29_out<C>(cx), cx), cx); }
 
 // ---------------------------------------------------------------- the ladder iteration
 // Loop state: the co-Z pair (x1, y1), (x2, y2) with y2 kept as dy = y1 - y2 and dx = x1 - x2 carried beside x1, x2 -- differences of
@@ -213,40 +242,40 @@ struct coz29 { fe29 x1, x2, dx, y1, dy, z; };
 // Differences from the 8-word form: the factor 4 of W1 = 4 X3' C, W2 = 4 W1' C rides in on a normalised 4C (one pass makes both
 // products tight and true-valued); A1 is an ordinary product (a shared 18-column product is dearer than the reduction it saves here).
 // NOZ: the x-only ladder's iteration (point.cuh scalar_mult_ladder_x) -- the same without the Z update, 8M + 6S.
-template <int C, bool NOZ = false> ECS_DEV void zdau29(coz29& s, uint32_t oswap) {
-  const fe29 Cp = sqr29<C>(s.dx);
-  const fe29 W1p = mul29<C>(s.x1, Cp);
-  const fe29 W2p = mul29<C>(s.x2, Cp);
-  const fe29 Dp = sqr29<C>(s.dy);
-  const fe29 A1p = mul29<C>(s.y1, sub29(W1p, W2p));
+template <int C, bool NOZ = false> ECS_DEV void zdau29(coz29& s, uint32_t oswap, const r29_ctx<C>& cx = r29_ctx<C>{}) {
+  const fe29 Cp = sqr29<C>(s.dx, cx);
+  const fe29 W1p = mul29<C>(s.x1, Cp, cx);
+  const fe29 W2p = mul29<C>(s.x2, Cp, cx);
+  const fe29 Dp = sqr29<C>(s.dy, cx);
+  const fe29 A1p = mul29<C>(s.y1, sub29(W1p, W2p), cx);
   const fe29 X3 = sub29(sub29(Dp, W1p), W2p);
   const fe29 u = norm29(sub29(X3, W1p));
-  const fe29 Cc = sqr29<C>(u);
-  // (two of the carry passes are P-256's alone: with secp256k1's sparser reduction the interval proof holds with dy - u and dx + u squared as they are)
-  constexpr bool TIGHT_SQ = r29_prime<C>::p256;
+  const fe29 Cc = sqr29<C>(u, cx);
+  // (two of the carry passes are not secp256k1's: with its sparse reduction the interval proof holds with dy - u and dx + u squared as they are)
+  constexpr bool TIGHT_SQ = r29_prime<C>::tight_sq;
   const fe29 dyu = sub29(s.dy, u);
-  fe29 yp = norm29(sub29(sub29(sqr29<C>(TIGHT_SQ ? norm29(dyu) : dyu), Dp), Cc));      // Y3' + 2 A1'
+  fe29 yp = norm29(sub29(sub29(sqr29<C>(TIGHT_SQ ? norm29(dyu) : dyu, cx), Dp), Cc));      // Y3' + 2 A1'
   const fe29 A2 = dbl29(A1p);
   const fe29 Y3p = sub29(yp, A2);
   fe29 ym = norm29(sub29(Y3p, A2));
   const fe29 C4 = norm29<2>(Cc);
-  const fe29 W1 = mul29<C>(X3, C4);
-  const fe29 W2 = mul29<C>(W1p, C4);
-  const fe29 A1 = mul29<C>(Y3p, sub29(W1, W2));
+  const fe29 W1 = mul29<C>(X3, C4, cx);
+  const fe29 W2 = mul29<C>(W1p, C4, cx);
+  const fe29 A1 = mul29<C>(Y3p, sub29(W1, W2), cx);
   if constexpr (!NOZ) {
     const fe29 dxu = add29(s.dx, u);
-    const fe29 zz = sub29(sub29(sqr29<C>(TIGHT_SQ ? norm29(dxu) : dxu), Cp), Cc);
-    s.z = mul29<C>(s.z, zz);
+    const fe29 zz = sub29(sub29(sqr29<C>(TIGHT_SQ ? norm29(dxu) : dxu, cx), Cp), Cc);
+    s.z = mul29<C>(s.z, zz, cx);
   }
   cswap29(oswap, ym, yp);
-  const fe29 D = sqr29<C>(ym);
-  const fe29 Dc = sqr29<C>(yp);
+  const fe29 D = sqr29<C>(ym, cx);
+  const fe29 Dc = sqr29<C>(yp, cx);
   const fe29 W12 = add29(W1, W2);
   s.x1 = sub29(D, W12);
   s.x2 = sub29(Dc, W12);
   s.dx = sub29(D, Dc);
-  const fe29 P1 = mul29<C>(ym, sub29(W1, s.x1));
-  const fe29 P2 = mul29<C>(yp, sub29(W1, s.x2));
+  const fe29 P1 = mul29<C>(ym, sub29(W1, s.x1), cx);
+  const fe29 P2 = mul29<C>(yp, sub29(W1, s.x2), cx);
   s.y1 = sub29(P1, A1);
   s.dy = sub29(P1, P2);
 }

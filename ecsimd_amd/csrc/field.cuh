@@ -28,7 +28,9 @@ namespace ecsimd_hip {
 // mul.h:160-212 -- including the carry it drops at mul.h:186-190 (its own "TODO: carry?", mul.h:207).  Opt-in, for
 // callers that need the reference's bits on the ~3e-6 of scalar multiplications where square(a) != mul(a, a).
 // The dropped carry depends on the Montgomery-form digits, so these instances stay in the Montgomery domain.
-enum : int { CURVE_P256 = 0, CURVE_SECP256K1 = 1, CURVE_SECP256K1_CLASSICAL = 2, CURVE_P256_REFSQR = 3, CURVE_SECP256K1_REFSQR = 4 };
+// CURVE_GENERIC (round 5): a curve registered at RUN time -- the reference's curve_group<Curve> takes any Curve type (curve.h:12-15); its constants travel as a
+// kernel argument (gcurve.cuh), the field layer is gfield.cuh's, the ladder's loop fe29.cuh's with the dense 9-limb prime in SGPRs (r29_ctx<CURVE_GENERIC>).
+enum : int { CURVE_P256 = 0, CURVE_SECP256K1 = 1, CURVE_SECP256K1_CLASSICAL = 2, CURVE_P256_REFSQR = 3, CURVE_SECP256K1_REFSQR = 4, CURVE_GENERIC = 5 };
 
 struct fe { uint32_t w[8]; };                  // little-endian 32-bit words
 struct fe2 { uint32_t w[16]; };                // 512-bit product

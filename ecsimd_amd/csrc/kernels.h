@@ -7,6 +7,7 @@
 
 namespace ecsimd_hip {
 struct gmod;                 // gfield.cuh: a run-time modulus and what the field layer derives from it
+struct gcurve;               // gcurve.cuh: a run-time curve (its field, a R, b R, the generator, the ladder loop's 29-bit constants)
 namespace launch {
 
 constexpr int BLOCK = 256;   // one wave per SIMD of a CU; several workgroups resident per CU
@@ -63,6 +64,28 @@ void gfield_inverse_batched(hipStream_t, const gmod&, const uint64_t* a, uint64_
 void ecdsa_scalars(hipStream_t, const gmod& order, const uint64_t* e, const uint64_t* r, const uint64_t* s, uint64_t* u1, uint64_t* u2, uint8_t* valid, size_t n);
 // ECDSA signing's arithmetic modulo the group order: r = x mod n, s = (e + r d) / k; ok = the inputs are in range and r, s != 0 (secret d, k: selects only)
 void ecdsa_sign_scalars(hipStream_t, const gmod& order, const uint64_t* e, const uint64_t* d, const uint64_t* k, const uint64_t* x, uint64_t* r, uint64_t* s, uint8_t* ok, size_t n);
+
+// k_gcurve.hip / k_gladder.hip: the point layer and the ladder for a curve registered at RUN time (curve_group<Curve> for any Curve: curve.h:12-15).
+// ref = the reference's square() as written; gc_scalar_mult flags: ECSIMD_HIP_BASE_MGRY | LADDER_RADIX32 | REF_SQUARE_COMPAT (Jacobian Montgomery out).
+void gc_from_affine(hipStream_t, const gcurve&, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n);
+void gc_to_affine(hipStream_t, const gcurve&, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n, bool ref);
+void gc_to_affine_batched(hipStream_t, const gcurve&, const uint64_t* jx, const uint64_t* jy, const uint64_t* jz, uint64_t* x, uint64_t* y, size_t n);   // x / y must not alias the inputs
+void gc_compute_y(hipStream_t, const gcurve&, const uint64_t* x, uint64_t* y, uint8_t* ok, size_t n, bool ref);
+void gc_on_curve(hipStream_t, const gcurve&, const uint64_t* x, const uint64_t* y, uint8_t* ok, size_t n);
+void gc_dblu(hipStream_t, const gcurve&, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n, bool ref);
+void gc_zaddu(hipStream_t, const gcurve&, uint64_t* px, uint64_t* py, uint64_t* pz, const uint64_t* qx, const uint64_t* qy, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n, bool ref);
+void gc_zdau(hipStream_t, const gcurve&, const uint64_t* px, const uint64_t* py, const uint64_t* pz, uint64_t* qx, uint64_t* qy, uint64_t* qz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n, bool ref);
+void gc_add_z2_1(hipStream_t, const gcurve&, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n, bool ref);
+void gc_trplu(hipStream_t, const gcurve&, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n, bool ref);
+void gc_scalar_mult(hipStream_t, const gcurve&, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
+void gc_zdau_repeat(hipStream_t, const gcurve&, const uint64_t* px, const uint64_t* py, const uint64_t* pz, const uint64_t* qx, const uint64_t* qy,
+                    uint64_t* rx, uint64_t* ry, uint64_t* sx, uint64_t* sy, uint64_t* oz, size_t n, int iters, uint64_t swap_bits, int radix);
+
+// k_fe29_raw.hip: one function of fe29.cuh on raw 9-limb operands (the diagnostic entry ecsimd_hip_fe29_raw)
+enum fe29_raw_op { RAW_ZDAU = 0, RAW_MADD = 1, RAW_JDBL = 2, RAW_DBL_ADD = 3, RAW_MADDV = 4, RAW_PDBL = 5, RAW_PADD = 6, RAW_MUL = 7, RAW_SQR = 8 };
+constexpr int fe29_raw_inputs(int op) { return op == RAW_ZDAU ? 6 : op == RAW_MUL ? 2 : op == RAW_SQR ? 1 : (op == RAW_JDBL || op == RAW_PDBL) ? 3 : 5; }
+constexpr int fe29_raw_outputs(int op) { return op == RAW_ZDAU ? 6 : (op == RAW_MUL || op == RAW_SQR) ? 1 : 3; }
+bool fe29_raw(hipStream_t, int curve, const gcurve* G, int op, const int32_t* in, int32_t* out, size_t n, uint32_t swap);
 
 // k_point_<curve>.hip
 void from_affine(hipStream_t, int curve, const uint64_t* x, const uint64_t* y, uint64_t* jx, uint64_t* jy, uint64_t* jz, size_t n);

@@ -359,6 +359,17 @@ class Engine:
         self._call("ecdsa_sign", C.c_int(curve), self._ptr(e), self._ptr(d), self._ptr(k), self._ptr(r), self._ptr(s), self._ptr(ok, 0), C.c_size_t(n))
         return r, s, ok
 
+    def fe29_raw(self, curve, op, inputs, swap=0):
+        """ecsimd_hip_fe29_raw: one function of the reduced-radix layer on raw int32 limbs; `inputs` is an int32 tensor (n, NIN, 9); returns (n, NOUT, 9)."""
+        torch = self.torch
+        nout = 6 if op == 0 else 1 if op in (7, 8) else 3
+        assert inputs.dtype == torch.int32 and inputs.dim() == 3 and inputs.shape[2] == 9 and inputs.is_contiguous() and inputs.device.index == self.device
+        n = inputs.shape[0]
+        out = torch.empty((n, nout, 9), dtype=torch.int32, device=self.tdev)
+        self._bind_stream()
+        self._check(self.lib.ecsimd_hip_fe29_raw(self.ctx, C.c_int(curve), C.c_int(op), C.c_void_p(inputs.data_ptr()), C.c_void_p(out.data_ptr()), C.c_size_t(n), C.c_int(swap)), "fe29_raw")
+        return out
+
     def workspace_bytes(self):
         """ecsimd_hip_workspace_info as a uint8 numpy copy of the context's scratch block (diagnostic: what the last call left behind)."""
         ptr, size = C.c_void_p(), C.c_size_t()
@@ -401,6 +412,23 @@ def register_modulus(p: int, prime: bool = False) -> int:
     if rc != 0:
         raise EcsimdHipError(f"ecsimd_hip_register_modulus({p:#x}) failed with {rc} (the modulus must be odd and >= 3)")
     return fid.value
+
+
+CURVE_GENERIC_KERNELS = 1
+FIRST_REGISTERED_CURVE = 0x10000
+
+
+def register_curve(p: int, a: int, b: int, gx: int, gy: int, n: int | None = None, generic_kernels: bool = False) -> int:
+    """ecsimd_hip_register_curve: the curve id of y^2 = x^3 + a x + b over GF(p) with generator (gx, gy) -- the reference's curve_group<Curve> for any
+    Curve, as a run-time registration (process-wide; no GPU needed).  generic_kernels: register P-256 / secp256k1 parameters like any other curve."""
+    lib = load_library()
+    lim = lambda v: (C.c_uint64 * 4)(*[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)])
+    cid = C.c_int(-1)
+    rc = lib.ecsimd_hip_register_curve(lim(p), lim(a % p), lim(b % p), lim(gx), lim(gy), lim(n) if n is not None else None,
+                                       C.c_int(CURVE_GENERIC_KERNELS if generic_kernels else 0), C.byref(cid))
+    if rc != 0:
+        raise EcsimdHipError(f"ecsimd_hip_register_curve(p = {p:#x}) failed with {rc}: p must be a prime = 3 mod 4, the generator on the curve, the curve non-singular")
+    return cid.value
 
 
 def shard_range_c(n_total: int, member: int, members: int):

@@ -1,5 +1,6 @@
-// ecsimd/curve.h -- curve description (reference curve.h:12-30), the map from a curve's prime to the engine's curve id (the two
-// curves with hand-written kernels) and from ANY odd modulus type to a field id (the field layer is as generic in P as the reference's).
+// ecsimd/curve.h -- curve description (reference curve.h:12-30), the map from ANY curve type to the engine's curve id (the two curves with
+// hand-written kernels keep their ids; every other Curve is registered with the engine on first use, as the reference's curve_group<Curve>
+// instantiates for any Curve) and from ANY odd modulus type to a field id (the field layer is as generic in P as the reference's).
 #ifndef ECSIMD_CURVE_H
 #define ECSIMD_CURVE_H
 #include <ecsimd/bignum.h>
@@ -17,11 +18,23 @@ namespace detail {
 using p256_prime = bn256_constant<0xffffffff00000001ull, 0x0000000000000000ull, 0x00000000ffffffffull, 0xffffffffffffffffull>;
 using secp256k1_prime = bn256_constant<0xffffffffffffffffull, 0xffffffffffffffffull, 0xffffffffffffffffull, 0xfffffffefffffc2full>;
 }
-// engine curve id of a prime type P (P::value is the modulus, as in the reference's bignum_cst)
+// engine curve id of one of the two built-in primes (the SEC1 codecs, ECDSA and the table-driven algorithms exist for those curves only)
 template <class P> constexpr int hip_curve_id() {
   if (P::value == detail::p256_prime::value) return ECSIMD_HIP_P256;
   if (P::value == detail::secp256k1_prime::value) return ECSIMD_HIP_SECP256K1;
-  throw "ecsimd: no HIP point kernels for this prime (P-256 and secp256k1 only)";
+  throw "ecsimd: this entry point exists for P-256 and secp256k1 only";
+}
+// Engine curve id of ANY curve type with bn_type, P, A, B, Gx, Gy (the reference's concept, curve.h:12-15; p = 3 mod 4 as its GFp needs, gfp.h:84):
+// curve_nist_p256 / curve_secp256k1 get their special-form kernels (ids 0 / 1), every other Curve is registered on first use
+// (ecsimd_hip_register_curve: host arithmetic only, once per type) and runs on the generic kernels -- points, co-Z formulas, the ladder.
+template <class Curve> inline int hip_curve_id_of() {
+  static const int id = [] {
+    int cid = -1;
+    hip::check(ecsimd_hip_register_curve(Curve::P::value.limbs.data(), Curve::A::value.limbs.data(), Curve::B::value.limbs.data(), Curve::Gx::value.limbs.data(),
+                                         Curve::Gy::value.limbs.data(), nullptr, 0, &cid), "ecsimd_hip_register_curve");
+    return cid;
+  }();
+  return id;
 }
 // Field id of a modulus type P for the element-wise field layer (mod_add ... mgry_pow, GFp<WBN, P>): any odd 256-bit P::value, as in the
 // reference (mgry_mul.h:84-121 details::mgry_reduce<P>, mgry_csts.h:15-35, gfp.h:17-115).  The two curve primes map to their special-form

@@ -16,10 +16,11 @@ struct curve_group {
   using gfp = GFp<WBN, typename Curve::P>;
   using WCP = wide_curve_point<Curve>;
   using WJCP = wide_jacobian_curve_point<Curve>;
-  static constexpr int curve_id = WJCP::curve_id;
+  static int curve_id() { return WJCP::curve_id(); }
 
-  static BN Am() { return mgry_constants<typename Curve::P>::get(8); }      // curve_group.h:32
-  static BN Bm() { return mgry_constants<typename Curve::P>::get(9); }      // curve_group.h:31
+  static BN Am() { return curve_constant(8); }      // curve_group.h:32
+  static BN Bm() { return curve_constant(9); }      // curve_group.h:31
+  static BN curve_constant(int which) { BN r; hip::check(ecsimd_hip_get_constant(curve_id(), which, r.limbs.data()), "ecsimd_hip_get_constant"); return r; }
   static WCP WG(size_t lanes = default_lanes) { return WCP{WBN(lanes, Curve::Gx::value), WBN(lanes, Curve::Gy::value)}; }   // :35-37
   static WJCP WJG(size_t lanes = default_lanes) { return WJCP::from_affine(WG(lanes)); }                                     // :39-41
 
@@ -28,42 +29,42 @@ struct curve_group {
   }
   static WBN compute_y_lanes(WBN const& x, hip::mask& ok) {                  // per-lane validity; y^2 = x^3 + a x + b for either curve
     auto y = WBN::uninitialized(x.size()); ok = hip::mask(x.size());
-    hip::check(ecsimd_hip_compute_y(hip::context(), curve_id, x.data(), y.data(), ok.data(), x.size()), "ecsimd_hip_compute_y"); return y;
+    hip::check(ecsimd_hip_compute_y(hip::context(), curve_id(), x.data(), y.data(), ok.data(), x.size()), "ecsimd_hip_compute_y"); return y;
   }
 
   static WJCP DBLU(WJCP& P) {                                                // :64-87
     P.unshare(); WJCP r = fresh_xy(P.size());                               // co-Z: r and the rewritten P share ONE Z array, written once
-    hip::check(ecsimd_hip_dblu(hip::context(), curve_id, px(P), py(P), pz(P), px(r), py(r), pz(P), P.size()), "ecsimd_hip_dblu"); r.z() = P.z(); return r;
+    hip::check(ecsimd_hip_dblu(hip::context(), curve_id(), px(P), py(P), pz(P), px(r), py(r), pz(P), P.size()), "ecsimd_hip_dblu"); r.z() = P.z(); return r;
   }
   static WJCP ZADDU(WJCP& P, WJCP const& O) {                                // :91-116
     same_length(P.size(), O.size(), "ZADDU");
     P.unshare(); WJCP r = fresh_xy(P.size());
-    hip::check(ecsimd_hip_zaddu(hip::context(), curve_id, px(P), py(P), pz(P), px(O), py(O), pz(O), px(r), py(r), pz(P), P.size()), "ecsimd_hip_zaddu"); r.z() = P.z(); return r;
+    hip::check(ecsimd_hip_zaddu(hip::context(), curve_id(), px(P), py(P), pz(P), px(O), py(O), pz(O), px(r), py(r), pz(P), P.size()), "ecsimd_hip_zaddu"); r.z() = P.z(); return r;
   }
   static WJCP ZDAU(WJCP const& P, WJCP& Q) {                                 // :120-153
     same_length(P.size(), Q.size(), "ZDAU");
     Q.unshare(); WJCP r = fresh_xy(P.size());
-    hip::check(ecsimd_hip_zdau(hip::context(), curve_id, px(P), py(P), pz(P), px(Q), py(Q), pz(Q), px(r), py(r), pz(Q), P.size()), "ecsimd_hip_zdau"); r.z() = Q.z(); return r;
+    hip::check(ecsimd_hip_zdau(hip::context(), curve_id(), px(P), py(P), pz(P), px(Q), py(Q), pz(Q), px(r), py(r), pz(Q), P.size()), "ecsimd_hip_zdau"); r.z() = Q.z(); return r;
   }
   static WJCP ADD_Z2_1(WJCP const& A, WJCP const& B) {                       // :155-179 (B.z must be mgry(1))
     same_length(A.size(), B.size(), "ADD_Z2_1");
     WJCP r = fresh(A.size());
-    hip::check(ecsimd_hip_add_z2_1(hip::context(), curve_id, px(A), py(A), pz(A), px(B), py(B), px(r), py(r), pz(r), A.size()), "ecsimd_hip_add_z2_1"); return r;
+    hip::check(ecsimd_hip_add_z2_1(hip::context(), curve_id(), px(A), py(A), pz(A), px(B), py(B), px(r), py(r), pz(r), A.size()), "ecsimd_hip_add_z2_1"); return r;
   }
   static WJCP TRPLU(WJCP& P) {                                               // :183-186
     P.unshare(); WJCP r = fresh_xy(P.size());
-    hip::check(ecsimd_hip_trplu(hip::context(), curve_id, px(P), py(P), pz(P), px(r), py(r), pz(P), P.size()), "ecsimd_hip_trplu"); r.z() = P.z(); return r;
+    hip::check(ecsimd_hip_trplu(hip::context(), curve_id(), px(P), py(P), pz(P), px(r), py(r), pz(P), P.size()), "ecsimd_hip_trplu"); r.z() = P.z(); return r;
   }
   // k[i] * P[i], P.z must be mgry(1) (:189-218).  One kernel: the whole ladder stays in registers.
   static WJCP scalar_mult(WBN const& x, WJCP P) {
     same_length(x.size(), P.size(), "scalar_mult");
     WJCP r = fresh(P.size());
-    hip::check(ecsimd_hip_scalar_mult(hip::context(), curve_id, x.data(), px(P), py(P), px(r), py(r), pz(r), P.size(), ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN), "ecsimd_hip_scalar_mult"); return r;
+    hip::check(ecsimd_hip_scalar_mult(hip::context(), curve_id(), x.data(), px(P), py(P), px(r), py(r), pz(r), P.size(), ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN), "ecsimd_hip_scalar_mult"); return r;
   }
   // one scalar for every lane (:221-251)
   static WJCP scalar_mult_1s(BN const& x, WJCP P) {
     WJCP r = fresh(P.size());
-    hip::check(ecsimd_hip_scalar_mult_1s(hip::context(), curve_id, x.limbs.data(), px(P), py(P), px(r), py(r), pz(r), P.size(), ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN), "ecsimd_hip_scalar_mult_1s"); return r;
+    hip::check(ecsimd_hip_scalar_mult_1s(hip::context(), curve_id(), x.limbs.data(), px(P), py(P), px(r), py(r), pz(r), P.size(), ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_OUT_JACOBIAN), "ecsimd_hip_scalar_mult_1s"); return r;
   }
 
   // ---- extensions (not in the reference): affine-level entry points over the faster algorithms of the C ABI.
@@ -73,7 +74,7 @@ struct curve_group {
   static WCP scalar_mult_affine(WBN const& x, WCP const& P, bool windowed = true) {
     same_length(x.size(), P.size(), "scalar_mult_affine");
     WCP r{WBN::uninitialized(P.size()), WBN::uninitialized(P.size())};
-    hip::check(ecsimd_hip_scalar_mult(hip::context(), curve_id, x.data(), P.x().data(), P.y().data(), r.x().data(), r.y().data(), nullptr, P.size(),
+    hip::check(ecsimd_hip_scalar_mult(hip::context(), curve_id(), x.data(), P.x().data(), P.y().data(), r.x().data(), r.y().data(), nullptr, P.size(),
                                       ECSIMD_HIP_BASE_CLASSICAL | ECSIMD_HIP_OUT_AFFINE | (windowed ? ECSIMD_HIP_ALG_WINDOWED : 0)), "ecsimd_hip_scalar_mult");
     return r;
   }
@@ -81,12 +82,12 @@ struct curve_group {
   static WJCP add_mixed_complete(WJCP const& A, WJCP const& B) {
     same_length(A.size(), B.size(), "add_mixed_complete");
     WJCP r = fresh(A.size());
-    hip::check(ecsimd_hip_add_mixed_complete(hip::context(), curve_id, px(A), py(A), pz(A), px(B), py(B), px(r), py(r), pz(r), A.size()), "ecsimd_hip_add_mixed_complete"); return r;
+    hip::check(ecsimd_hip_add_mixed_complete(hip::context(), curve_id(), px(A), py(A), pz(A), px(B), py(B), px(r), py(r), pz(r), A.size()), "ecsimd_hip_add_mixed_complete"); return r;
   }
   // k[i] * G through the 20-bit window table of odd multiples in device memory (12 mixed additions), affine classical.
   static WCP scalar_mult_base_affine(WBN const& x) {
     WCP r{WBN::uninitialized(x.size()), WBN::uninitialized(x.size())};
-    hip::check(ecsimd_hip_scalar_mult_base(hip::context(), curve_id, x.data(), r.x().data(), r.y().data(), nullptr, x.size(),
+    hip::check(ecsimd_hip_scalar_mult_base(hip::context(), curve_id(), x.data(), r.x().data(), r.y().data(), nullptr, x.size(),
                                            ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_ALG_WINDOWED_BIG), "ecsimd_hip_scalar_mult_base");
     return r;
   }
@@ -95,7 +96,7 @@ struct curve_group {
   static WCP scalar_mult_affine_secret(WBN const& x, WCP const& P) {
     same_length(x.size(), P.size(), "scalar_mult_affine_secret");
     WCP r{WBN::uninitialized(P.size()), WBN::uninitialized(P.size())};
-    hip::check(ecsimd_hip_scalar_mult(hip::context(), curve_id, x.data(), P.x().data(), P.y().data(), r.x().data(), r.y().data(), nullptr, P.size(),
+    hip::check(ecsimd_hip_scalar_mult(hip::context(), curve_id(), x.data(), P.x().data(), P.y().data(), r.x().data(), r.y().data(), nullptr, P.size(),
                                       ECSIMD_HIP_BASE_CLASSICAL | ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_CONSTANT_TIME), "ecsimd_hip_scalar_mult");
     return r;
   }
@@ -103,7 +104,7 @@ struct curve_group {
   // window read, the wanted one kept under lane masks, no address or branch formed from the scalar; 6.7 x the ladder on G.  Affine classical.
   static WCP scalar_mult_base_affine_secret(WBN const& x) {
     WCP r{WBN::uninitialized(x.size()), WBN::uninitialized(x.size())};
-    hip::check(ecsimd_hip_scalar_mult_base(hip::context(), curve_id, x.data(), r.x().data(), r.y().data(), nullptr, x.size(),
+    hip::check(ecsimd_hip_scalar_mult_base(hip::context(), curve_id(), x.data(), r.x().data(), r.y().data(), nullptr, x.size(),
                                            ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_CONSTANT_TIME), "ecsimd_hip_scalar_mult_base");
     return r;
   }
@@ -113,7 +114,7 @@ struct curve_group {
     same_length(u1.size(), Q.size(), "double_scalar_mult"); same_length(u2.size(), Q.size(), "double_scalar_mult");
     WCP r{WBN::uninitialized(Q.size()), WBN::uninitialized(Q.size())};
     finite = hip::mask(Q.size());
-    hip::check(ecsimd_hip_double_scalar_mult(hip::context(), curve_id, u1.data(), u2.data(), Q.x().data(), Q.y().data(), r.x().data(), r.y().data(),
+    hip::check(ecsimd_hip_double_scalar_mult(hip::context(), curve_id(), u1.data(), u2.data(), Q.x().data(), Q.y().data(), r.x().data(), r.y().data(),
                                              finite.data(), Q.size()), "ecsimd_hip_double_scalar_mult");
     return r;
   }
@@ -121,7 +122,7 @@ struct curve_group {
   static hip::mask ecdsa_verify_rx(WBN const& u1, WBN const& u2, WCP const& Q, WBN const& r) {
     same_length(u1.size(), Q.size(), "ecdsa_verify_rx"); same_length(u2.size(), Q.size(), "ecdsa_verify_rx"); same_length(r.size(), Q.size(), "ecdsa_verify_rx");
     hip::mask ok(Q.size());
-    hip::check(ecsimd_hip_ecdsa_verify_rx(hip::context(), curve_id, u1.data(), u2.data(), Q.x().data(), Q.y().data(), r.data(), ok.data(), Q.size()), "ecsimd_hip_ecdsa_verify_rx");
+    hip::check(ecsimd_hip_ecdsa_verify_rx(hip::context(), curve_id(), u1.data(), u2.data(), Q.x().data(), Q.y().data(), r.data(), ok.data(), Q.size()), "ecsimd_hip_ecdsa_verify_rx");
     return ok;
   }
   // The whole ECDSA verification (SEC 1 v2 4.1.4): e = the digest as an integer (any 256-bit value), (r, s) the signature, Q the public key.
@@ -130,7 +131,7 @@ struct curve_group {
   static hip::mask ecdsa_verify(WBN const& e, WBN const& r, WBN const& s, WCP const& Q) {
     same_length(e.size(), Q.size(), "ecdsa_verify"); same_length(r.size(), Q.size(), "ecdsa_verify"); same_length(s.size(), Q.size(), "ecdsa_verify");
     hip::mask ok(Q.size());
-    hip::check(ecsimd_hip_ecdsa_verify(hip::context(), curve_id, e.data(), r.data(), s.data(), Q.x().data(), Q.y().data(), ok.data(), Q.size()), "ecsimd_hip_ecdsa_verify");
+    hip::check(ecsimd_hip_ecdsa_verify(hip::context(), curve_id(), e.data(), r.data(), s.data(), Q.x().data(), Q.y().data(), ok.data(), Q.size()), "ecsimd_hip_ecdsa_verify");
     return ok;
   }
   // ECDSA signing (SEC 1 v2 4.1.3): digests e, private keys d, the CALLER's nonces k (RFC 6979 or a DRBG).  Returns (r, s); ok[i] is false -- and
@@ -139,7 +140,7 @@ struct curve_group {
     same_length(e.size(), d.size(), "ecdsa_sign"); same_length(k.size(), d.size(), "ecdsa_sign");
     auto r = WBN::uninitialized(d.size()), s = WBN::uninitialized(d.size());
     ok = hip::mask(d.size());
-    hip::check(ecsimd_hip_ecdsa_sign(hip::context(), curve_id, e.data(), d.data(), k.data(), r.data(), s.data(), ok.data(), d.size()), "ecsimd_hip_ecdsa_sign");
+    hip::check(ecsimd_hip_ecdsa_sign(hip::context(), curve_id(), e.data(), d.data(), k.data(), r.data(), s.data(), ok.data(), d.size()), "ecsimd_hip_ecdsa_sign");
     return {r, s};
   }
   // ---- several GPUs: k[i] * P[i] for HOST arrays, sharded over a device group.  P affine classical (x, y);
@@ -154,7 +155,7 @@ struct curve_group {
     host_points r; r.x.resize(n); r.y.resize(n); if (!affine_out) r.z.resize(n);
     auto w = [](std::vector<BN> const& v) { return reinterpret_cast<const uint64_t*>(v.data()); };
     auto m = [](std::vector<BN>& v) { return v.empty() ? nullptr : reinterpret_cast<uint64_t*>(v.data()); };
-    g.check(ecsimd_hip_group_scalar_mult_host(g.handle(), curve_id, w(k), w(px), w(py), m(r.x), m(r.y), m(r.z), n,
+    g.check(ecsimd_hip_group_scalar_mult_host(g.handle(), curve_id(), w(k), w(px), w(py), m(r.x), m(r.y), m(r.z), n,
                                               ECSIMD_HIP_BASE_CLASSICAL | (affine_out ? ECSIMD_HIP_OUT_AFFINE : ECSIMD_HIP_OUT_JACOBIAN)), "ecsimd_hip_group_scalar_mult_host");
     return r;
   }

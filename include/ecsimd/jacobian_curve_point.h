@@ -13,19 +13,19 @@ struct wide_jacobian_curve_point {
   using WBN = curve_wide_bn_t<Curve>;
   using wide_curve_point_t = wide_curve_point<Curve>;
   using gfp = GFp<WBN, typename Curve::P>;
-  static constexpr int curve_id = hip_curve_id<typename Curve::P>();
+  static int curve_id() { return hip_curve_id_of<Curve>(); }       // any Curve: the built-in ids, or a run-time registration
 
   wide_jacobian_curve_point() = default;
   static wide_jacobian_curve_point from_affine(wide_curve_point_t const& pt) {            // :25-31, Z := R mod p
     wide_jacobian_curve_point r; const size_t n = pt.size();
     auto X = WBN::uninitialized(n), Y = WBN::uninitialized(n), Z = WBN::uninitialized(n);
-    hip::check(ecsimd_hip_from_affine(hip::context(), curve_id, pt.x().data(), pt.y().data(), X.data(), Y.data(), Z.data(), n), "ecsimd_hip_from_affine");
+    hip::check(ecsimd_hip_from_affine(hip::context(), curve_id(), pt.x().data(), pt.y().data(), X.data(), Y.data(), Z.data(), n), "ecsimd_hip_from_affine");
     r.x_ = gfp{typename gfp::WMBN{X}}; r.y_ = gfp{typename gfp::WMBN{Y}}; r.z_ = gfp{typename gfp::WMBN{Z}};
     return r;
   }
   wide_curve_point_t to_affine() const {                                                    // :33-42, one inversion per lane
     const size_t n = size(); auto x = WBN::uninitialized(n), y = WBN::uninitialized(n);
-    hip::check(ecsimd_hip_to_affine(hip::context(), curve_id, x_.wbn().data(), y_.wbn().data(), z_.wbn().data(), x.data(), y.data(), n), "ecsimd_hip_to_affine");
+    hip::check(ecsimd_hip_to_affine(hip::context(), curve_id(), x_.wbn().data(), y_.wbn().data(), z_.wbn().data(), x.data(), y.data(), n), "ecsimd_hip_to_affine");
     return {x, y};
   }
   hip::mask operator==(wide_jacobian_curve_point const& o) const { return (x().wbn() == o.x().wbn()) && (y().wbn() == o.y().wbn()) && (z().wbn() == o.z().wbn()); }

@@ -39,13 +39,14 @@ typedef struct ecsimd_hip_ctx ecsimd_hip_ctx;
 
 enum ecsimd_hip_curve {
   ECSIMD_HIP_P256 = 0,      /* curve_nist_p256.h:14-32 */
-  ECSIMD_HIP_SECP256K1 = 1  /* prime of tests/mgry.cpp:25-27 with a=0, b=7 (SEC 2) */
+  ECSIMD_HIP_SECP256K1 = 1, /* prime of tests/mgry.cpp:25-27 with a=0, b=7 (SEC 2) */
+  ECSIMD_HIP_FIRST_REGISTERED_CURVE = 0x10000  /* ids of ecsimd_hip_register_curve start here (r5): curve_group<Curve> for ANY Curve type, curve.h:12-15 */
 };
 
 /* FIELD ids: what the element-wise field entry points (mod_*, mgry_*, gfp_*, get_constant) take as `curve`.  The reference's field layer is
  * generic in the modulus type P (mgry_mul.h:84-121 details::mgry_reduce<P>, mgry_csts.h:15-35 mgry_constants<WBN, P>, gfp.h:17-115 GFp<WBN, P>);
  * here a modulus is a run-time value with an id.  0, 1: the curve primes above (hand-laid special-form kernels); 2, 3: the two group orders n
- * (what ECDSA computes modulo); 4...: moduli registered with ecsimd_hip_register_modulus.  Points, ladders and tables exist for the two curves only. */
+ * (what ECDSA computes modulo); 4...: moduli registered with ecsimd_hip_register_modulus; a curve id of ecsimd_hip_register_curve names its prime's field. */
 enum ecsimd_hip_field {
   ECSIMD_HIP_FIELD_P256_ORDER = 2,      /* n of P-256 (SP 800-186 3.2.1.3) */
   ECSIMD_HIP_FIELD_SECP256K1_ORDER = 3  /* n of secp256k1 (SEC 2 v2 2.4.1) */
@@ -166,6 +167,24 @@ int ecsimd_hip_get_constant(int curve, int which, uint64_t out[4]);
  * reads zero in the curve slots 1-4, 8, 9).  The same (p, flags) gives the same id (the two curve primes give 0 / 1 whatever the flags); the same p with and
  * without MODULUS_PRIME are two ids, so that nobody's gfp_inverse changes under them; ids live as long as the process; thread-safe.  flags: 0 or ECSIMD_HIP_MODULUS_PRIME.  gfp_sqrt needs p = 3 mod 4, as the reference's GFp does (gfp.h:84). */
 int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id);
+
+/* A curve id for y^2 = x^3 + a x + b over GF(p) with generator (gx, gy) -- the reference's curve_group<Curve> instantiated with any Curve type that has
+ * bn_type, P, A, B, Gx, Gy (curve.h:12-15; curve_group.h:25-33 derives Am, Bm from the type, :64-87 DBLU takes a from it, :91-218 the co-Z formulas and the
+ * ladder are curve-independent) -- as a run-time registration: host pointers, 4 x u64 little-endian limbs, classical values < p.  p must be a prime with
+ * p = 3 mod 4 (what the reference's GFp<WBN, P> needs: gfp.h:84) and the caller vouches for its primality; the generator must lie on the curve and the
+ * curve must be non-singular (checked: ECSIMD_HIP_ERR_BAD_ARG).  n = the group order, or NULL (the reference has no order either: its ladder takes any
+ * 256-bit k; stored for callers that need it).  The id (>= ECSIMD_HIP_FIRST_REGISTERED_CURVE; the same parameters give the same id; P-256's or secp256k1's
+ * parameters give 0 / 1 unless flags = ECSIMD_HIP_CURVE_GENERIC_KERNELS, which registers them like any other curve -- how tests hold the generic kernels
+ * to the special-form ones bit for bit) is accepted by
+ *     from_affine, to_affine, compute_y, on_curve, dblu, zaddu, zdau, add_z2_1, trplu, zdau_repeat, scalar_mult, scalar_mult_1s, scalar_mult_base
+ * (flags BASE_* | OUT_* | LADDER_RADIX32 | REF_SQUARE_COMPAT: the reference's ladder; the table-driven ALG_* algorithms, the SEC1 codecs and ECDSA exist
+ * for the two built-in curves only) and, as a FIELD id, by every element-wise field entry point.  Same level-J parity as the built-in curves: X, Y, Z are
+ * the bits the reference instantiated with this Curve returns.  The ladder's 254 iterations run on nine signed 29-bit limbs with the dense p in SGPRs
+ * (81 multiply-adds per reduction where P-256's sparse form has 36); LADDER_RADIX32 / REF_SQUARE_COMPAT run them on 8 x 32-bit canonical words.
+ * Process-wide, thread-safe, ids live as long as the process. */
+enum { ECSIMD_HIP_CURVE_GENERIC_KERNELS = 1 };
+int ecsimd_hip_register_curve(const uint64_t p[4], const uint64_t a[4], const uint64_t b[4], const uint64_t gx[4], const uint64_t gy[4],
+                              const uint64_t n[4], int flags, int* curve_id);
 
 /* ---- L2: bignum ops (curve independent) ----------------------------------------------- */
 /* add.h:11-34  add: out = a + b mod 2^256, carry[i] = carry-out (carry may be NULL) */
@@ -330,6 +349,16 @@ int ecsimd_hip_ecdsa_verify(ecsimd_hip_ctx*, int curve, const uint64_t* e, const
  * condition, lane mask in force at a memory access, and address (tests/test_constant_time_isa.py).  The Jacobian k G and its x are zeroed in the context
  * workspace on the stream before the call returns.  r, s must not alias an input.  Workspace: 128 B per element. */
 int ecsimd_hip_ecdsa_sign(ecsimd_hip_ctx*, int curve, const uint64_t* e, const uint64_t* d, const uint64_t* k, uint64_t* r, uint64_t* s, uint8_t* ok, size_t n);
+/* Diagnostic (r5): ONE function of the reduced-radix layer the multiplication-bound loops run on (fe29.cuh: nine signed 29-bit limbs in 32-bit words,
+ * Montgomery radix 2^261, lazy carries) on RAW operands -- int32 limbs exactly as a loop holds them between two operations: element e's coordinate c, limb l at
+ * in[(e * NIN + c) * 9 + l] (device memory).  What tests use to hand the device the states and operand pairs at which the interval proofs of
+ * tools/radix29_model.py reach their largest 64-bit columns (tests/golden/fe29_witnesses.json) and compare the result limb for limb with the exact model; no
+ * other entry point can produce such inputs (their operands enter the loops as tight limbs).  op (NIN -> NOUT coordinates):
+ *   0 zdau29 (x1, x2, dx, y1, dy, z -> the same six; swap != 0 exchanges the two output points)      1 madd29 (X, Y, Z, x2, y2 -> X, Y, Z)      2 jdbl29 (X, Y, Z ->)
+ *   3 dbl_add29 (X, Y, Z, x2, y2 ->)    4 madd29_hr + madd29v_finish    5 pdbl29, 6 padd29 (secp256k1: the complete law)    7 mul29 (a, b -> r)    8 sqr29 (a -> r)
+ * curve: 0 / 1 (for secp256k1 the loops' own domain: values x * 2^261 of the CLASSICAL x), or a registered curve id (ops 0, 7, 8: the dense reduction).
+ * Operands outside the proven bounds give whatever 32- / 64-bit wrap-around gives. */
+int ecsimd_hip_fe29_raw(ecsimd_hip_ctx* ctx, int curve, int op, const int32_t* in, int32_t* out, size_t n, int swap);
 /* Diagnostic: the context's grow-only scratch block (device pointer and size; NULL / 0 before the first call that needed one).  What a test reads
  * back to see that ecdsa_sign left no nonce-derived data behind (tests/test_gpu_fields.py); valid until the next call that grows the block. */
 int ecsimd_hip_workspace_info(ecsimd_hip_ctx* ctx, const void** dptr, size_t* bytes);

@@ -543,6 +543,30 @@ EXPORT int oracle_register_modulus(const uint64_t *p) {
   return id;
 }
 
+/* A CURVE id for y^2 = x^3 + a x + b over GF(p) with generator (gx, gy) (each 4 x u64 LE limbs, classical): the reference's curve_group<Curve> takes ANY
+ * curve type with bn_type, P, A, B, Gx, Gy (curve.h:12-15; curve_group.h:31-32 derives Am, Bm; :64-87 DBLU takes Am; the rest is curve-independent).
+ * The id is accepted by every function of this file.  The same parameters give the same id; -1 if p is even or the table is full. */
+EXPORT int oracle_register_curve(const uint64_t *p, const uint64_t *a, const uint64_t *b, const uint64_t *gx, const uint64_t *gy) {
+  oracle_init_once();
+  if (!(p[0] & 1)) return -1;
+  pthread_mutex_lock(&g_fields_lock);
+  int id = -1;
+  for (int i = 0; i < g_nfields; ++i) {
+    const oracle_curve *c = &g_curves[i];
+    if (!memcmp(c->p.l, p, 32) && !memcmp(c->a.l, a, 32) && !memcmp(c->b.l, b, 32) && !memcmp(c->gx.l, gx, 32) && !memcmp(c->gy.l, gy, 32)) { id = i; break; }
+  }
+  if (id < 0 && g_nfields < ORACLE_MAXFIELDS) {
+    oracle_curve *c = &g_curves[g_nfields];
+    memset(c, 0, sizeof *c);
+    memcpy(c->p.l, p, 32); memcpy(c->a.l, a, 32); memcpy(c->b.l, b, 32); memcpy(c->gx.l, gx, 32); memcpy(c->gy.l, gy, 32);
+    field_init(c);
+    id = g_nfields;
+    __atomic_store_n(&g_nfields, g_nfields + 1, __ATOMIC_RELEASE);
+  }
+  pthread_mutex_unlock(&g_fields_lock);
+  return id;
+}
+
 EXPORT int oracle_get_constants(int curve, uint64_t *out /* 12 x 4 u64 */, uint32_t *mprime) {
   const oracle_curve *c = curve_of(curve); if (!c) return -1;
   const bn256 *src[12] = {&c->p, &c->a, &c->b, &c->gx, &c->gy, &c->r_p, &c->rsq_p, &c->pm1_r_p, &c->am, &c->bm, &c->p_m2, &c->p_sqrt};

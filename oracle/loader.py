@@ -267,6 +267,13 @@ class Oracle(_Lib):
         assert fid >= 2, (fid, hex(p))
         return fid
 
+    def register_curve(self, p: int, a: int, b: int, gx: int, gy: int) -> int:
+        """Curve id of y^2 = x^3 + a x + b over GF(p) with generator (gx, gy), for every method (the point methods included)."""
+        lim = lambda v: np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+        cid = int(self.lib.oracle_register_curve(_p(lim(p)), _p(lim(a)), _p(lim(b)), _p(lim(gx)), _p(lim(gy))))
+        assert cid >= 2, (cid, hex(p))
+        return cid
+
     def dropped_carries(self) -> int:
         return int(self.lib.oracle_dropped_carries())
 
@@ -286,9 +293,34 @@ REF_MODULI = {
 }
 
 
+# The curves oracle/ref_driver.cpp instantiates curve_group<Curve> for beside P-256 and secp256k1 (its curve ids 10, 11, 12): public parameters
+# (RFC 5639 3.4; GB/T 32918.5 / RFC 8998; ANSSI FRP256v1), every p = 3 mod 4 as the reference's GFp needs.  n = the group order (the reference has none).
+REF_CURVES = {
+    "brainpoolP256r1": dict(ref_id=10,
+        p=0xa9fb57dba1eea9bc3e660a909d838d726e3bf623d52620282013481d1f6e5377, a=0x7d5a0975fc2c3057eef67530417affe7fb8055c126dc5c6ce94a4b44f330b5d9,
+        b=0x26dc5c6ce94a4b44f330b5d9bbd77cbf958416295cf7e1ce6bccdc18ff8c07b6, gx=0x8bd2aeb9cb7e57cb2c4b482ffc81b7afb9de27e1e3bd23c23a4453bd9ace3262,
+        gy=0x547ef835c3dac4fd97f8461a14611dc9c27745132ded8e545c1d54c72f046997, n=0xa9fb57dba1eea9bc3e660a909d838d718c397aa3b561a6f7901e0e82974856a7),
+    "sm2": dict(ref_id=11,
+        p=0xfffffffeffffffffffffffffffffffffffffffff00000000ffffffffffffffff, a=0xfffffffeffffffffffffffffffffffffffffffff00000000fffffffffffffffc,
+        b=0x28e9fa9e9d9f5e344d5a9e4bcf6509a7f39789f515ab8f92ddbcbd414d940e93, gx=0x32c4ae2c1f1981195f9904466a39c9948fe30bbff2660be1715a4589334c74c7,
+        gy=0xbc3736a2f4f6779c59bdcee36b692153d0a9877cc62a474002df32e52139f0a0, n=0xfffffffeffffffffffffffffffffffff7203df6b21c6052b53bbf40939d54123),
+    "frp256v1": dict(ref_id=12,
+        p=0xf1fd178c0b3ad58f10126de8ce42435b3961adbcabc8ca6de8fcf353d86e9c03, a=0xf1fd178c0b3ad58f10126de8ce42435b3961adbcabc8ca6de8fcf353d86e9c00,
+        b=0xee353fca5428a9300d4aba754a44c00fdfec0c9ae4b1a1803075ed967b7bb73f, gx=0xb6b3d4c356c139eb31183d4749d423958c27d2dcaf98b70164c97a2dd98f5cff,
+        gy=0x6142e0f7c8b204911f9271f0f3ecef8c2701c307e8e4c9e183115a1554062cfb, n=0xf1fd178c0b3ad58f10126de8ce42435b53dc67e140d2bf941ffdd459c6d655e1),
+}
+
+
 class Reference(_Lib):
     prefix = "ref_"
     path = os.path.join(HERE, "_ref", "libecsimd_ref.so")
+
+    def register_curve(self, p, a, b, gx, gy) -> int:
+        """The reference is generic at COMPILE time: only the curves of REF_CURVES (and the two built-in ones) have an instance."""
+        for c in REF_CURVES.values():
+            if (c["p"], c["a"], c["b"], c["gx"], c["gy"]) == (p, a, b, gx, gy):
+                return c["ref_id"]
+        raise KeyError(hex(p))
 
     def register_modulus(self, p: int) -> int:
         """The reference is generic at COMPILE time: only the moduli of REF_MODULI have an instance (ids 2..6)."""

@@ -57,6 +57,24 @@ struct curve_secp256k1 {
   struct Gy { static constexpr auto value = bn_from_bytes_BE<bn_type>("483ada7726a3c4655da4fbfc0e1108a8fd17b448a68554199c47d08ffb10d4b8"_hex); };
 };
 
+// Three more curves described with the same concept -- what a caller of the reference does to use curve_group<Curve> on a curve of its own (public
+// parameters: RFC 5639 3.4, GB/T 32918.5 / RFC 8998, ANSSI FRP256v1; every p = 3 mod 4 as GFp needs, gfp.h:84).  brainpoolP256r1: a dense prime and
+// a "random" a; SM2: a sparse prime other than P-256's, a = -3; FRP256v1: a dense prime, a = -3.  Curve ids 10, 11, 12 of this driver.
+#define CURVE_STRUCT(NAME, PH, AH, BH, GXH, GYH) struct NAME { using bn_type = bignum_256; \
+  struct P  { static constexpr auto value = bn_from_bytes_BE<bn_type>(PH##_hex); }; struct A  { static constexpr auto value = bn_from_bytes_BE<bn_type>(AH##_hex); }; \
+  struct B  { static constexpr auto value = bn_from_bytes_BE<bn_type>(BH##_hex); }; struct Gx { static constexpr auto value = bn_from_bytes_BE<bn_type>(GXH##_hex); }; \
+  struct Gy { static constexpr auto value = bn_from_bytes_BE<bn_type>(GYH##_hex); }; }
+CURVE_STRUCT(curve_brainpoolp256r1,
+  "a9fb57dba1eea9bc3e660a909d838d726e3bf623d52620282013481d1f6e5377", "7d5a0975fc2c3057eef67530417affe7fb8055c126dc5c6ce94a4b44f330b5d9", "26dc5c6ce94a4b44f330b5d9bbd77cbf958416295cf7e1ce6bccdc18ff8c07b6",
+  "8bd2aeb9cb7e57cb2c4b482ffc81b7afb9de27e1e3bd23c23a4453bd9ace3262", "547ef835c3dac4fd97f8461a14611dc9c27745132ded8e545c1d54c72f046997");
+CURVE_STRUCT(curve_sm2,
+  "fffffffeffffffffffffffffffffffffffffffff00000000ffffffffffffffff", "fffffffeffffffffffffffffffffffffffffffff00000000fffffffffffffffc", "28e9fa9e9d9f5e344d5a9e4bcf6509a7f39789f515ab8f92ddbcbd414d940e93",
+  "32c4ae2c1f1981195f9904466a39c9948fe30bbff2660be1715a4589334c74c7", "bc3736a2f4f6779c59bdcee36b692153d0a9877cc62a474002df32e52139f0a0");
+CURVE_STRUCT(curve_frp256v1,
+  "f1fd178c0b3ad58f10126de8ce42435b3961adbcabc8ca6de8fcf353d86e9c03", "f1fd178c0b3ad58f10126de8ce42435b3961adbcabc8ca6de8fcf353d86e9c00", "ee353fca5428a9300d4aba754a44c00fdfec0c9ae4b1a1803075ed967b7bb73f",
+  "b6b3d4c356c139eb31183d4749d423958c27d2dcaf98b70164c97a2dd98f5cff", "6142e0f7c8b204911f9271f0f3ecef8c2701c307e8e4c9e183115a1554062cfb");
+#undef CURVE_STRUCT
+
 using BN  = bignum_256;
 using WBN = wide_bignum<BN>;
 using BN512  = bignum_512;
@@ -232,6 +250,9 @@ template <class Curve> struct ops : fops<typename Curve::P> {
 
 using P256 = ops<curve_nist_p256>;
 using K256 = ops<curve_secp256k1>;
+using BP256 = ops<curve_brainpoolp256r1>;
+using SM2 = ops<curve_sm2>;
+using FRP256 = ops<curve_frp256v1>;
 
 // Moduli without a curve (field ids 2..6): the two group orders (SP 800-186 / SEC 2 public data), a prime below 2^255, the
 // largest odd 256-bit value (composite: Montgomery arithmetic needs p odd, not prime) and a 192-bit prime (p << R).
@@ -294,17 +315,19 @@ template <class Curve> double bench_ops(int op, const uint64_t* a, const uint64_
 
 } // namespace
 
-#define DISPATCH(fn, ...) (curve == 0 ? P256::fn(__VA_ARGS__) : curve == 1 ? K256::fn(__VA_ARGS__) : -1)
+#define DISPATCH(fn, ...) (curve == 0 ? P256::fn(__VA_ARGS__) : curve == 1 ? K256::fn(__VA_ARGS__) : curve == 10 ? BP256::fn(__VA_ARGS__) : curve == 11 ? SM2::fn(__VA_ARGS__) : \
+                           curve == 12 ? FRP256::fn(__VA_ARGS__) : -1)
 // the field layer also takes the curve-less moduli
 #define FDISPATCH(fn, ...) (curve == 0 ? P256::fn(__VA_ARGS__) : curve == 1 ? K256::fn(__VA_ARGS__) : curve == 2 ? F2::fn(__VA_ARGS__) : curve == 3 ? F3::fn(__VA_ARGS__) : \
-                            curve == 4 ? F4::fn(__VA_ARGS__) : curve == 5 ? F5::fn(__VA_ARGS__) : curve == 6 ? F6::fn(__VA_ARGS__) : -1)
+                            curve == 4 ? F4::fn(__VA_ARGS__) : curve == 5 ? F5::fn(__VA_ARGS__) : curve == 6 ? F6::fn(__VA_ARGS__) : curve == 10 ? BP256::fn(__VA_ARGS__) : \
+                            curve == 11 ? SM2::fn(__VA_ARGS__) : curve == 12 ? FRP256::fn(__VA_ARGS__) : -1)
 
 extern "C" {
 #define EXPORT __attribute__((visibility("default")))
 typedef const uint64_t* cu64p;
 
 EXPORT int ref_get_constants(int curve, uint64_t* out, uint32_t* mprime) {
-  return curve < 2 ? DISPATCH(constants, out, mprime) : FDISPATCH(field_constants, out, mprime); }
+  return (curve < 2 || curve >= 10) ? DISPATCH(constants, out, mprime) : FDISPATCH(field_constants, out, mprime); }
 
 // curve-independent bignum ops (add.h, sub.h, shift.h, mul.h)
 EXPORT int ref_add(cu64p a, cu64p b, uint64_t* out, uint8_t* carry, size_t n) {

@@ -82,3 +82,10 @@ def golden_moduli():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "ref_moduli_vectors.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_curves():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "ref_curves_vectors.json")) as f:
+        return json.load(f)

@@ -375,6 +375,49 @@ TEST(Batch, RuntimeLengthAndSecp256k1) {
   EXPECT_TRUE(all(five.y() == W256(n, bn_from_bytes_BE<bignum_256>("d8ac222636e5e3d6d4dba9dda6c9c426f788271bab0d6840dca87d3aa6ac62d6"_hex))));
 }
 
+// Round 5: curve_group<Curve> for a curve that is NOT one of the engine's two (the reference's template takes any type with bn_type, P, A, B, Gx, Gy:
+// curve.h:12-15).  brainpoolP256r1 (RFC 5639 3.4) described with the same members; the expected points are the reference's own answers for this curve
+// (tests/golden/ref_curves_vectors.json, minted from the reference instantiated with these parameters).  First use registers the curve with the engine.
+struct curve_brainpoolp256r1 {
+  using bn_type = bignum_256;
+  using P  = bn256_constant<0xa9fb57dba1eea9bcull, 0x3e660a909d838d72ull, 0x6e3bf623d5262028ull, 0x2013481d1f6e5377ull>;
+  using A  = bn256_constant<0x7d5a0975fc2c3057ull, 0xeef67530417affe7ull, 0xfb8055c126dc5c6cull, 0xe94a4b44f330b5d9ull>;
+  using B  = bn256_constant<0x26dc5c6ce94a4b44ull, 0xf330b5d9bbd77cbfull, 0x958416295cf7e1ceull, 0x6bccdc18ff8c07b6ull>;
+  using Gx = bn256_constant<0x8bd2aeb9cb7e57cbull, 0x2c4b482ffc81b7afull, 0xb9de27e1e3bd23c2ull, 0x3a4453bd9ace3262ull>;
+  using Gy = bn256_constant<0x547ef835c3dac4fdull, 0x97f8461a14611dc9ull, 0xc27745132ded8e54ull, 0x5c1d54c72f046997ull>;
+};
+TEST(Curves, AnyCurveThroughCurveGroup) {
+  using K = curve_brainpoolp256r1; using KG = curve_group<K>; using KJ = wide_jacobian_curve_point<K>;
+  EXPECT_TRUE(KG::curve_id() >= ECSIMD_HIP_FIRST_REGISTERED_CURVE);
+  EXPECT_TRUE(curve_group<curve_nist_p256>::curve_id() == ECSIMD_HIP_P256 && curve_group<curve_secp256k1>::curve_id() == ECSIMD_HIP_SECP256K1);
+  EXPECT_TRUE(KG::Am() == bn_from_bytes_BE<bignum_256>("1e4676abd666bc1795ec1e5e6398556ea68123f1c1d20c64d5d18edf69696261"_hex));     // to_mgry(A), curve_group.h:32
+  EXPECT_TRUE(KG::Bm() == bn_from_bytes_BE<bignum_256>("1634f57646a3c93e64ca989357f2e9d90ac34a49cc51bf5905d24d72c0c0f36f"_hex));
+  const auto G = KG::WJG();
+  struct { std::array<uint8_t, 32> k, x, y; } cases[] = {
+    {"0000000000000000000000000000000000000000000000000000000000000005"_hex, "855433a3a4c8e334a5f863e8b69fc1477cf41589c0d8c3fb32f95f7c85fe101d"_hex, "a50c95efc2ad06c4d7e172e40350d911097082129591c88bef9e224a5fd8814c"_hex},
+    {"0bc1b1f28709decb543d9677d2cc9942348f6b984deff409430740942ff38827"_hex, "9531554560f0e4bb5bac426b8e8001bf95592d3b79d265bda2b1de28a474579a"_hex, "35b9ac2a8a75dfdce0eb7aa0127d8b244cf315c89f0c2c04409d2caf717f9798"_hex},
+    {"0a891cecc2bf13b0aca744434a9c9f4bd7bf5c8ed86e2f76e7df72bad813bd80"_hex, "9bcd00f871cc765404f41bcce735aa940d55eb38974f2227e6244a3552d17020"_hex, "291c97f4d254ca5b2c19803a4d5ea365ee5aa6698436278eb1a6db2be8f81ac0"_hex}};
+  for (auto const& c : cases) {
+    const auto xs = bn_from_bytes_BE<bignum_256>(c.k);
+    const auto A1 = KG::scalar_mult(W256{xs}, G).to_affine(), A2 = KG::scalar_mult_1s(xs, G).to_affine();
+    EXPECT_TRUE(all(A1.x() == W256{bn_from_bytes_BE<bignum_256>(c.x)}) && all(A1.y() == W256{bn_from_bytes_BE<bignum_256>(c.y)}));
+    EXPECT_TRUE(all(A2.x() == A1.x()) && all(A2.y() == A1.y()));
+  }
+  // the co-Z formulas compose as on any curve: 2G (DBLU) + G (ZADDU) = 3G = TRPLU; 2 * 3G + G (ZDAU) + G (ADD_Z2_1) = 8G = scalar_mult(8)
+  auto P = G; const auto D = KG::DBLU(P); const auto T = KG::ZADDU(P, D);
+  auto P2 = G; const auto T2 = KG::TRPLU(P2);
+  EXPECT_TRUE(all(T == T2) && all(P == P2));
+  auto Q = P2; const auto S = KG::ZDAU(T2, Q);                                                   // 2 * 3G + G = 7G
+  const auto E = KG::ADD_Z2_1(S, G).to_affine(), E8 = KG::scalar_mult(W256{bignum_256::from(8)}, G).to_affine();
+  EXPECT_TRUE(all(E.x() == E8.x()) && all(E.y() == E8.y()));
+  const auto y = KG::compute_y(E8.x());                                                          // y^2 = x^3 + a x + b with THIS curve's a
+  EXPECT_TRUE(y.has_value() && (all(*y == E8.y()) || all(*y == (KJ::from_affine(E8).opposite().to_affine().y()))));
+  const size_t n = 333;                                                                          // a runtime-length batch on the registered curve
+  W256 k(n, [](size_t i, size_t) { bignum_256 b; b.limbs = {0x9e3779b97f4a7c15ull * (i + 1), i, ~i, 0x0123456789abcdefull ^ (i << 20)}; return b; });
+  const auto J = KG::scalar_mult(k, KG::WJG(n)), J1 = KG::scalar_mult(W256(n, k.get(17)), KG::WJG(n));
+  EXPECT_TRUE(J.x().wbn().get(17) == J1.x().wbn().get(0) && J.z().wbn().get(17) == J1.z().wbn().get(n - 1));
+}
+
 // The curve structs' constants equal the engine's own table (ecsimd_hip_get_constant: 0 p, 1 a, 2 b, 3 Gx, 4 Gy) and
 // the hexadecimal literals of the standards documents.
 template <class K> static void constants_match_engine() {

@@ -131,3 +131,45 @@ def test_group_shard_arithmetic_without_a_gpu():
     import torch
     if not torch.cuda.is_available():
         assert lib.ecsimd_hip_group_init((C.c_int * 1)(0), C.c_int(1), C.byref(g)) == -2 and not g               # no device: no fallback
+
+
+def test_curve_registry_without_a_gpu(lib, oracle):
+    """ecsimd_hip_register_curve is host-only (round 5: curve_group<Curve> for any Curve, curve.h:12-15): what it derives -- the field's constants, Am, Bm
+    (curve_group.h:31-32) -- equals the oracle's for the same curve; the same parameters give the same id, the built-in curves their own ids unless the
+    generic kernels are asked for; and what the reference could not instantiate or what is not a curve is refused: p != 3 mod 4 (gfp.h:84), a generator off
+    the curve, a singular curve, a coordinate >= p, an even or zero order."""
+    from ecsimd_amd.engine import register_curve, EcsimdHipError, FIRST_REGISTERED_CURVE
+    from oracle.loader import REF_CURVES, to_int
+    from helpers import CURVE_PARAMS, P256, SECP256K1
+    seen = set()
+    for name, c in REF_CURVES.items():
+        cid = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"])
+        assert cid >= FIRST_REGISTERED_CURVE and cid not in seen and register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"]) == cid
+        seen.add(cid)
+        want = oracle.constants(oracle.register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"]))
+        for which, key in enumerate(["p", "a", "b", "gx", "gy", "r_p", "rsq_p", "pm1_r_p", "am", "bm", "p_m2", "p_sqrt"]):
+            out = (C.c_uint64 * 4)()
+            assert lib.ecsimd_hip_get_constant(C.c_int(cid), C.c_int(which), out) == 0
+            assert list(out) == [int(v) for v in want[key]], (name, key)
+    for cv in (P256, SECP256K1):
+        c = CURVE_PARAMS[cv]
+        assert register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"]) == cv
+        g = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"], generic_kernels=True)
+        assert g >= FIRST_REGISTERED_CURVE and g not in seen and register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], generic_kernels=True) == g
+    c = REF_CURVES["brainpoolP256r1"]
+    bad = [
+        dict(c, gy=c["gy"] ^ 1),                                             # the generator is not on the curve
+        dict(c, b=(c["b"] + 1) % c["p"]),                                    # ... nor on this one
+        dict(c, gx=c["gx"] + c["p"]) if c["gx"] + c["p"] < 2**256 else dict(c, a=c["p"]),   # a coordinate >= p
+        dict(p=2**255 - 19, a=486662, b=1, gx=9, gy=1),                      # p = 1 mod 4: the reference's GFp does not instantiate (gfp.h:84)
+        dict(c, p=c["p"] + 1),                                               # even
+        dict(p=c["p"], a=0, b=0, gx=0, gy=0),                                # singular (and G = (0, 0) is on it)
+        dict(p=c["p"], a=c["p"] - 3, b=2, gx=1, gy=0),                       # y^2 = x^3 - 3x + 2 = (x - 1)^2 (x + 2): singular, G = (1, 0) on it
+        dict(c, n=c["n"] + 1), dict(c, n=0),                                 # an even / zero order
+    ]
+    for b in bad:
+        with pytest.raises(EcsimdHipError):
+            register_curve(b["p"], b["a"], b["b"], b["gx"], b["gy"], b.get("n"))
+    cid = C.c_int()
+    assert lib.ecsimd_hip_register_curve(None, None, None, None, None, None, C.c_int(0), C.byref(cid)) == -1
+    assert lib.ecsimd_hip_get_constant(C.c_int(FIRST_REGISTERED_CURVE + 4000), C.c_int(0), (C.c_uint64 * 4)()) == -1

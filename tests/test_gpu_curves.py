@@ -1,0 +1,227 @@
+"""GPU parity: curves registered at RUN time (round 5) -- the reference's curve_group<Curve> for any Curve (curve.h:12-15; curve_group.h:25-33, 64-87,
+189-218), here ecsimd_hip_register_curve + the generic kernels (k_gcurve.hip, k_gladder.hip; the ladder's loop on fe29.cuh's 29-bit limbs with the
+dense prime in SGPRs).  Level J like the built-in curves: X, Y, Z bit for bit against
+  * fixtures minted from the REAL reference instantiated for brainpoolP256r1 / SM2 / FRP256v1 (tests/golden/ref_curves_vectors.json),
+  * the oracle with the same curve registered (random, edge-scalar, digit-pattern inputs; ragged sizes),
+  * the compiled reference itself (oracle/_ref: its curve ids 10, 11, 12) at 2^15 lanes, ECSIMD_HIP_REF_SQUARE_COMPAT included,
+and -- the built-in curves' parameters registered with ECSIMD_HIP_CURVE_GENERIC_KERNELS -- against the special-form kernels, entry point by entry point.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from helpers import CURVE_PARAMS, P256, SECP256K1, SEED, from_int, to_int, ints_to_arr
+from oracle.loader import REF_CURVES
+from test_oracle import run_against_curve_fixture, curve_params_of, digit_pattern_operands
+
+pytestmark = pytest.mark.gpu
+THREADS = min(16, os.cpu_count() or 1)
+LADDER_RADIX32, REF_SQUARE_COMPAT, OUT_AFFINE, BASE_MGRY = 256, 64, 2, 1
+
+
+@pytest.fixture(scope="module")
+def gpu(engine):
+    from gpu_adapter import EngineNP
+    return EngineNP(engine)
+
+
+def register(c, generic=False):
+    from ecsimd_amd.engine import register_curve
+    return register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c.get("n"), generic_kernels=generic)
+
+
+def ids(oracle, c, generic=False):
+    return register(c, generic), oracle.register_curve(c["p"], c["a"] % c["p"], c["b"], c["gx"], c["gy"])
+
+
+def same(a, b):
+    return all(np.array_equal(u, v) for u, v in zip(a, b))
+
+
+def test_registered_curves_vs_the_reference_fixtures(gpu, engine, golden_curves):
+    """Every block of ref_curves_vectors.json through the C ABI on a registered curve id: field ops under the curve id as a field id, from_affine /
+    to_affine / compute_y, DBLU ZADDU TRPLU ZDAU ADD_Z2_1, the ladder on 32 edge and random scalars (Jacobian AND affine), scalar_mult_1s."""
+    for name, g in golden_curves["curves"].items():
+        c = curve_params_of(g)
+        cid = register(c)
+        assert cid >= 0x10000 and register(c) == cid
+        run_against_curve_fixture(gpu, g, cid)
+        # the same ladder inputs on canonical words (LADDER_RADIX32) and with the reference's squaring (the fixtures are clear of its defect)
+        sv = g["scalar_mult_var"]
+        k, bx, by = (engine.to_device(ints_to_arr([int(h, 16) for h in sv[key]])) for key in ("k", "bx", "by"))
+        want = [ints_to_arr([int(h, 16) for h in sv[key]]) for key in ("X", "Y", "Z")]
+        for fl in (LADDER_RADIX32, REF_SQUARE_COMPAT):
+            assert same([engine.to_numpy(t) for t in engine.scalar_mult(cid, k, bx, by, flags=fl)], want), (name, fl)
+        ax, ay = engine.scalar_mult(cid, k, bx, by, flags=OUT_AFFINE)
+        assert [format(to_int(v), "064x") for v in engine.to_numpy(ax)] == sv["ax"] and [format(to_int(v), "064x") for v in engine.to_numpy(ay)] == sv["ay"]
+        xo, none = engine.scalar_mult(cid, k, bx, by, flags=OUT_AFFINE, x_only=True)
+        assert none is None and np.array_equal(engine.to_numpy(xo), engine.to_numpy(ax))
+        s1 = g["scalar_mult_1s"]
+        J = engine.scalar_mult_1s(cid, from_int(int(s1["k1"], 16)), engine.to_device(ints_to_arr([int(h, 16) for h in s1["bx"]])), engine.to_device(ints_to_arr([int(h, 16) for h in s1["by"]])))
+        assert [[format(to_int(v), "064x") for v in engine.to_numpy(t)] for t in J] == [s1["X"], s1["Y"], s1["Z"]]
+        sm = g["scalar_mult_G"]
+        J = engine.scalar_mult_base(cid, engine.to_device(ints_to_arr([int(h, 16) for h in sm["k"]])))
+        assert [[format(to_int(v), "064x") for v in engine.to_numpy(t)] for t in J] == [sm["X"], sm["Y"], sm["Z"]]
+
+
+@pytest.mark.parametrize("name", list(REF_CURVES))
+def test_registered_curve_ladder_vs_oracle_on_edge_and_random_scalars(gpu, engine, oracle, name):
+    """The ladder on a registered curve, all three loops (29-bit limbs, canonical words, reference squaring), against the oracle with the same curve
+    registered: every edge scalar of the built-in curves' test (0, 1, n - 1, n, n + 1, 2^256 - n +- 1, 2^256 - 1, 2^255 ...: level J, degenerate
+    outputs included), random 256-bit scalars, lane-distinct base points, ragged batch sizes (1, 3, 257), Montgomery-form and classical base points."""
+    c = REF_CURVES[name]
+    cid, oid = ids(oracle, c)
+    order = c["n"]
+    edge = [0, 1, 2, 3, order - 2, order - 1, order, order + 1, 2**256 - order - 2, 2**256 - order - 1, 2**256 - order, 2**256 - order + 1, 2**256 - 1, 2**255, 2**255 - 1,
+            (order - 1) // 2, (order + 1) // 2, 4, 6, 2**200]
+    n = 1024 + 257
+    rng = np.random.default_rng(sum(name.encode()))
+    k = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    k[:len(edge)] = ints_to_arr(edge)
+    s = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    gx, gy = np.tile(from_int(c["gx"]), (n, 1)), np.tile(from_int(c["gy"]), (n, 1))
+    bx, by = oracle.to_affine(oid, oracle.scalar_mult(oid, s, gx, gy, threads=THREADS))            # lane-distinct points
+    gbx, gby = gpu.scalar_mult(cid, s, gx, gy, affine=True)
+    assert np.array_equal(gbx, bx) and np.array_equal(gby, by)
+    exp = oracle.scalar_mult(oid, k, bx, by, threads=THREADS)
+    for fl in (0, LADDER_RADIX32, REF_SQUARE_COMPAT):
+        got = [engine.to_numpy(t) for t in engine.scalar_mult(cid, engine.to_device(k), engine.to_device(bx), engine.to_device(by), flags=fl)]
+        bad = np.flatnonzero((got[0] != exp[0]).any(axis=1) | (got[1] != exp[1]).any(axis=1) | (got[2] != exp[2]).any(axis=1))
+        assert bad.size == 0, (name, fl, bad[:8])
+    P = oracle.from_affine(oid, bx, by)
+    assert same(gpu.scalar_mult(cid, k, P[0], P[1], mgry_in=True), exp)
+    for m in (1, 3, 257):
+        assert same(gpu.scalar_mult(cid, k[:m], bx[:m], by[:m]), [v[:m] for v in exp])
+    assert same(gpu.scalar_mult_base(cid, k[:300]), oracle.scalar_mult(oid, k[:300], gx[:300], gy[:300], threads=THREADS))
+    # affine output through the shared inversion = the oracle's per-lane to_affine where Z != 0; (0, 0) where Z = 0
+    ax, ay = oracle.to_affine(oid, exp)
+    gax, gay = gpu.scalar_mult(cid, k, bx, by, affine=True)
+    assert np.array_equal(gax, ax) and np.array_equal(gay, ay)
+    empty = engine.scalar_mult(cid, engine.empty(0), engine.empty(0), engine.empty(0))
+    assert all(t.shape[0] == 0 for t in empty)
+
+
+@pytest.mark.parametrize("name", list(REF_CURVES))
+def test_registered_curve_formulas_on_digit_pattern_coordinates(gpu, oracle, name):
+    """DBLU / ZADDU / ZDAU / ADD_Z2_1 / TRPLU as expression DAGs over GF(p) on the carry-heavy digit-pattern family (level J does not need curve points),
+    compute_y (generalised to a != -3 exactly as the oracle is), on_curve, and ecsimd_hip_zdau_repeat in both radices against the oracle's ZDAU iterated."""
+    c = REF_CURVES[name]
+    cid, oid = ids(oracle, c)
+    a = digit_pattern_operands()[::97]
+    pp = np.tile(from_int(c["p"]), (len(a), 1))
+    red = lambda v: oracle.sub_if_above(oracle.sub_if_above(v, pp), pp)
+    x, y = red(a), red(np.roll(a, 1234, axis=0))
+    P = oracle.from_affine(oid, x, y)
+    assert same(gpu.from_affine(cid, x, y), P)
+    (R, Pu), (Rg, Pug) = oracle.dblu(oid, P), gpu.dblu(cid, P)
+    assert same(Rg + Pug, R + Pu), "DBLU"
+    (R3, Pu2), (R3g, Pu2g) = oracle.zaddu(oid, Pu, R), gpu.zaddu(cid, Pu, R)
+    assert same(R3g + Pu2g, R3 + Pu2), "ZADDU"
+    (Rt, Put), (Rtg, Putg) = oracle.trplu(oid, P), gpu.trplu(cid, P)
+    assert same(Rtg + Putg, Rt + Put), "TRPLU"
+    (Rz, Qu), (Rzg, Qug) = oracle.zdau(oid, R3, Pu2), gpu.zdau(cid, R3, Pu2)
+    assert same(Rzg + Qug, Rz + Qu), "ZDAU"
+    assert same(gpu.add_z2_1(cid, Rz, (P[0], P[1])), oracle.add_z2_1(oid, Rz, (P[0], P[1]))), "ADD_Z2_1"
+    assert same(gpu.to_affine(cid, Rz), oracle.to_affine(oid, Rz))
+    yo, oko = oracle.compute_y(oid, x)
+    yg, okg = gpu.compute_y(cid, x)
+    assert np.array_equal(okg, oko) and np.array_equal(yg[oko == 1], yo[oko == 1]) and 0 < int(oko.sum()) < len(x)
+    on = gpu.e.to_numpy(gpu.e.on_curve(cid, gpu._up(x[oko == 1]), gpu._up(yo[oko == 1])))
+    assert on.all() and not gpu.e.to_numpy(gpu.e.on_curve(cid, gpu._up(x[oko == 1]), gpu._up(x[oko == 1]))).all()
+    m = 512
+    P0, Q0 = tuple(v[:m] for v in Rt), tuple(v[:m] for v in Put)
+    for iters, swap in ((1, 0), (1, 1), (2, 0b10), (7, 0b1011001), (67, 0xdeadbeefcafef00d)):
+        Pc, Qc = P0, Q0
+        for t in range(iters):
+            Rr, Qn = oracle.zdau(oid, Pc, Qc)
+            Pc, Qc = (Qn, Rr) if (swap >> (t & 63)) & 1 else (Rr, Qn)
+        exp = (Pc[0], Pc[1], Qc[0], Qc[1], Pc[2])
+        for radix in (29, 32):
+            assert same(gpu.zdau_repeat(cid, P0, (Q0[0], Q0[1]), iters, swap, radix), exp), (radix, iters, hex(swap))
+
+
+@pytest.mark.parametrize("name", list(REF_CURVES))
+def test_registered_curve_vs_the_live_reference(engine, reference, name):
+    """2^15 lanes against the compiled reference instantiated for this curve (oracle/_ref, its ids 10 / 11 / 12): with ECSIMD_HIP_REF_SQUARE_COMPAT not one
+    lane may differ; the default loop (exact squaring) may differ only where the reference's square() dropped a carry (~3e-6 of lanes)."""
+    c = REF_CURVES[name]
+    cid, rid = register(c), c["ref_id"]
+    n = 1 << 15
+    k = engine.fill_random(n, SEED, 40 + rid); s = engine.fill_random(n, SEED, 41 + rid)
+    bx, by = engine.scalar_mult_base(cid, s, flags=OUT_AFFINE)
+    kn, xn, yn = (engine.to_numpy(t) for t in (k, bx, by))
+    ref = reference.scalar_mult(rid, kn, xn, yn, threads=THREADS)
+    got = [engine.to_numpy(t) for t in engine.scalar_mult(cid, k, bx, by, flags=REF_SQUARE_COMPAT)]
+    assert same(got, ref), name
+    got = [engine.to_numpy(t) for t in engine.scalar_mult(cid, k, bx, by)]
+    differing = int(np.count_nonzero((got[0] != ref[0]).any(axis=1) | (got[1] != ref[1]).any(axis=1) | (got[2] != ref[2]).any(axis=1)))
+    assert differing <= 3, (name, differing)
+    engine.lib.ecsimd_hip_set_ref_square_compat(engine.ctx, C.c_int(1))               # the context option: every entry point of the DAG
+    try:
+        P = engine.from_affine(cid, bx, by)
+        R = engine.trplu(cid, P)
+        want = reference.trplu(rid, reference.from_affine(rid, xn, yn))
+        assert same([engine.to_numpy(t) for t in R], want[0]) and same([engine.to_numpy(t) for t in P], want[1])
+        ax, ay = engine.scalar_mult(cid, k[:4096].contiguous(), bx[:4096].contiguous(), by[:4096].contiguous(), flags=OUT_AFFINE)
+        rx, ry = reference.to_affine(rid, [v[:4096] for v in ref])
+        assert np.array_equal(engine.to_numpy(ax), rx) and np.array_equal(engine.to_numpy(ay), ry)
+    finally:
+        engine.lib.ecsimd_hip_set_ref_square_compat(engine.ctx, C.c_int(0))
+
+
+@pytest.mark.parametrize("cv", [P256, SECP256K1])
+def test_builtin_curves_through_the_generic_kernels_equal_the_special_form_kernels(gpu, engine, cv):
+    """P-256 and secp256k1 registered like any other curve (ECSIMD_HIP_CURVE_GENERIC_KERNELS) must return, entry point by entry point and
+    bit for bit, what their special-form kernels return: 2^16 lane-distinct points and scalars, every formula, both ladders' loops, both output forms."""
+    c = dict(CURVE_PARAMS[cv]); c["a"] %= c["p"]
+    gid = register(c, generic=True)
+    assert gid >= 0x10000 and register(c) == cv                          # without the flag the built-in id
+    n = 1 << 16
+    k = engine.fill_random(n, SEED, 60 + cv); s = engine.fill_random(n, SEED, 61 + cv)
+    bx, by = engine.scalar_mult_base(cv, s, flags=OUT_AFFINE)
+    gbx, gby = engine.scalar_mult_base(gid, s, flags=OUT_AFFINE)
+    assert np.array_equal(engine.to_numpy(gbx), engine.to_numpy(bx)) and np.array_equal(engine.to_numpy(gby), engine.to_numpy(by))
+    for fl in (0, LADDER_RADIX32, OUT_AFFINE):
+        assert same([engine.to_numpy(t) for t in engine.scalar_mult(gid, k, bx, by, flags=fl)], [engine.to_numpy(t) for t in engine.scalar_mult(cv, k, bx, by, flags=fl)]), fl
+    assert same([engine.to_numpy(t) for t in engine.scalar_mult(gid, k, bx, by, flags=REF_SQUARE_COMPAT)], [engine.to_numpy(t) for t in engine.scalar_mult(cv, k, bx, by, flags=REF_SQUARE_COMPAT)])
+    k1 = engine.to_numpy(k)[7]
+    assert same([engine.to_numpy(t) for t in engine.scalar_mult_1s(gid, k1, bx, by)], [engine.to_numpy(t) for t in engine.scalar_mult_1s(cv, k1, bx, by)])
+    xn, yn = engine.to_numpy(bx), engine.to_numpy(by)
+    P = gpu.from_affine(cv, xn, yn)
+    assert same(gpu.from_affine(gid, xn, yn), P)
+    (R, Pu), (Rg, Pug) = gpu.dblu(cv, P), gpu.dblu(gid, P)
+    assert same(Rg + Pug, R + Pu)
+    (R3, Pu2), (R3g, Pu2g) = gpu.zaddu(cv, Pu, R), gpu.zaddu(gid, Pu, R)
+    assert same(R3g + Pu2g, R3 + Pu2)
+    (Rz, Qu), (Rzg, Qug) = gpu.zdau(cv, R3, Pu2), gpu.zdau(gid, R3, Pu2)
+    assert same(Rzg + Qug, Rz + Qu)
+    assert same(gpu.add_z2_1(gid, Rz, (P[0], P[1])), gpu.add_z2_1(cv, Rz, (P[0], P[1])))
+    assert same(gpu.trplu(gid, P)[0], gpu.trplu(cv, P)[0])
+    assert same(gpu.to_affine(gid, Rz), gpu.to_affine(cv, Rz))
+    yc, okc = gpu.compute_y(cv, xn); yg, okg = gpu.compute_y(gid, xn)
+    assert okc.all() and np.array_equal(okg, okc) and np.array_equal(yg, yc)
+    for radix in (29, 32):
+        assert same(gpu.zdau_repeat(gid, R3, (Pu2[0], Pu2[1]), 9, 0b101100111, radix), gpu.zdau_repeat(cv, R3, (Pu2[0], Pu2[1]), 9, 0b101100111, radix))
+
+
+def test_registered_curve_entry_points_that_do_not_exist_say_so(engine, oracle):
+    """The table-driven algorithms, the SEC1 codecs and ECDSA exist for the two built-in curves: a registered curve id is refused there (BAD_ARG with a
+    message), never silently served by some other curve's kernels."""
+    c = REF_CURVES["brainpoolP256r1"]
+    cid = register(c)
+    from ecsimd_amd import ALG_WINDOWED, ALG_CONSTANT_TIME, EcsimdHipError
+    k = engine.fill_random(8, SEED, 1)
+    bx, by = engine.scalar_mult_base(cid, k, flags=OUT_AFFINE)
+    for fl in (OUT_AFFINE | ALG_WINDOWED, OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME):
+        with pytest.raises(EcsimdHipError, match="ladder only"):
+            engine.scalar_mult(cid, k, bx, by, flags=fl)
+        with pytest.raises(EcsimdHipError, match="ladder only"):
+            engine.scalar_mult_base(cid, k, flags=fl)
+    with pytest.raises(EcsimdHipError):
+        engine.double_scalar_mult(cid, k, k, bx, by)
+    with pytest.raises(EcsimdHipError):
+        engine.ecdsa_verify(cid, k, k, k, bx, by)
+    with pytest.raises(EcsimdHipError):
+        engine.scalar_mult_base(0x10000 + 4000, k)                       # no such curve

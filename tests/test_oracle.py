@@ -182,6 +182,86 @@ def run_against_golden(impl, golden, cvs=CURVES):
             assert ok.tolist() == g["compute_y"]["ok"] and arr_to_hexes(y) == g["compute_y"]["y"]
 
 
+def run_against_curve_fixture(impl, g, cv):
+    """One curve block of tests/golden/ref_curves_vectors.json (the reference's curve_group<Curve> instantiated for a curve that is not its own) against
+    `impl` under ITS id `cv` of that curve.  Shared by the oracle test below and the GPU test (tests/test_gpu_curves.py)."""
+    f = g["field"]; a, bb = hexes_to_arr(f["a"]), hexes_to_arr(f["b"])
+    for name in ("mod_add", "mod_sub", "mgry_mul"):
+        assert arr_to_hexes(getattr(impl, name)(cv, a, bb)) == f[name], name
+    for name, key in (("mgry_sqr", "mgry_sqr"), ("mgry_from_classical", "from_classical"), ("mgry_to_classical", "to_classical"), ("gfp_inverse", "inverse"), ("gfp_opposite", "opposite")):
+        assert arr_to_hexes(getattr(impl, name)(cv, a)) == f[key], name
+    sm = g["scalar_mult_G"]; k = hexes_to_arr(sm["k"]); n = len(k)
+    cst = g["constants"]; gx = np.tile(from_hex(cst["gx"]), (n, 1)); gy = np.tile(from_hex(cst["gy"]), (n, 1))
+    J = impl.scalar_mult(cv, k, gx, gy)
+    assert [arr_to_hexes(v) for v in J] == [sm["X"], sm["Y"], sm["Z"]]
+    ax, ay = impl.to_affine(cv, J)
+    assert arr_to_hexes(ax) == sm["ax"] and arr_to_hexes(ay) == sm["ay"]
+    sv = g["scalar_mult_var"]; bx, by = hexes_to_arr(sv["bx"]), hexes_to_arr(sv["by"])
+    J = impl.scalar_mult(cv, hexes_to_arr(sv["k"]), bx, by)
+    assert [arr_to_hexes(v) for v in J] == [sv["X"], sv["Y"], sv["Z"]]
+    ax, ay = impl.to_affine(cv, J)
+    assert arr_to_hexes(ax) == sv["ax"] and arr_to_hexes(ay) == sv["ay"]
+    P = impl.from_affine(cv, bx, by); fa = g["from_affine"]
+    assert [arr_to_hexes(v) for v in P] == [fa["X"], fa["Y"], fa["Z"]]
+    Rr, Pu = impl.dblu(cv, P)
+    assert [arr_to_hexes(v) for v in Rr] == g["dblu"]["r"] and [arr_to_hexes(v) for v in Pu] == g["dblu"]["p_updated"]
+    R3, Pu2 = impl.zaddu(cv, Pu, Rr)
+    assert [arr_to_hexes(v) for v in R3] == g["zaddu"]["r"] and [arr_to_hexes(v) for v in Pu2] == g["zaddu"]["p_updated"]
+    Rt, Put = impl.trplu(cv, P)
+    assert [arr_to_hexes(v) for v in Rt] == g["trplu"]["r"] and [arr_to_hexes(v) for v in Put] == g["trplu"]["p_updated"]
+    Rz, Qu = impl.zdau(cv, Rt, Put)
+    assert [arr_to_hexes(v) for v in Rz] == g["zdau"]["r"] and [arr_to_hexes(v) for v in Qu] == g["zdau"]["q_updated"]
+    Ra = impl.add_z2_1(cv, Rz, (P[0], P[1]))
+    assert [arr_to_hexes(v) for v in Ra] == g["add_z2_1"]["r"]
+    tx, ty = impl.to_affine(cv, Ra)
+    assert arr_to_hexes(tx) == g["to_affine"]["x"] and arr_to_hexes(ty) == g["to_affine"]["y"]
+    if "compute_y" in g:
+        y, ok = impl.compute_y(cv, hexes_to_arr(g["compute_y"]["x"]))
+        assert ok.tolist() == g["compute_y"]["ok"] and arr_to_hexes(y) == g["compute_y"]["y"]
+
+
+def curve_params_of(g):
+    return {k: int(g["params"][k], 16) for k in ("p", "a", "b", "gx", "gy", "n")}
+
+
+def test_oracle_on_registered_curves_matches_the_reference_fixtures(oracle, oracle_faithful, golden_curves):
+    """Round 5: the oracle with a curve registered at run time (oracle_register_curve) against fixtures minted from the reference's curve_group<Curve>
+    instantiated for that curve -- brainpoolP256r1 (dense p, a != -3), SM2 (a sparse p that is not P-256's), FRP256v1 (dense p, a = -3)."""
+    for name, g in golden_curves["curves"].items():
+        c = curve_params_of(g)
+        for impl in (oracle, oracle_faithful):
+            cv = impl.register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"])
+            assert cv >= 2 and impl.register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"]) == cv
+            cst = impl.constants(cv)
+            for key, want in g["constants"].items():
+                got = format(cst[key], "08x") if key == "mprime" else format(to_int(cst[key]), "064x")
+                assert got == want, (name, key)
+            run_against_curve_fixture(impl, g, cv)
+
+
+def test_oracle_on_registered_curves_vs_live_reference(oracle_faithful, reference, golden_curves):
+    """... and bug for bug against the compiled reference itself on random lane-distinct inputs (the square() defect included)."""
+    from oracle.loader import REF_CURVES
+    for name, c in REF_CURVES.items():
+        cv, rv = oracle_faithful.register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"]), c["ref_id"]
+        assert reference.register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"]) == rv
+        rng = np.random.default_rng(500 + rv); n = 64
+        rnd = lambda: rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+        gx, gy = np.tile(from_int(c["gx"]), (n, 1)), np.tile(from_int(c["gy"]), (n, 1))
+        k = rnd()
+        Jo, Jr = oracle_faithful.scalar_mult(cv, k, gx, gy, threads=4), reference.scalar_mult(rv, k, gx, gy, threads=4)
+        for u, v in zip(Jo, Jr): assert np.array_equal(u, v), name
+        bx, by = oracle_faithful.to_affine(cv, Jo)
+        for u, v in zip((bx, by), reference.to_affine(rv, Jr)): assert np.array_equal(u, v)
+        k2 = rnd()
+        for u, v in zip(oracle_faithful.scalar_mult(cv, k2, bx, by, threads=4), reference.scalar_mult(rv, k2, bx, by, threads=4)): assert np.array_equal(u, v)
+        P = oracle_faithful.from_affine(cv, bx, by)
+        (Ro, Po), (Rr, Pr) = oracle_faithful.trplu(cv, P), reference.trplu(rv, P)
+        for u, v in zip(Ro + Po, Rr + Pr): assert np.array_equal(u, v)
+        (Zo, Qo), (Zr, Qr) = oracle_faithful.zdau(cv, Ro, Po), reference.zdau(rv, Rr, Pr)
+        for u, v in zip(Zo + Qo, Zr + Qr): assert np.array_equal(u, v)
+
+
 def test_oracle_matches_reference_fixtures(oracle, oracle_faithful, golden):
     run_against_golden(oracle, golden)            # the regular fixtures are defect-free (make_golden.py asserts it):
     run_against_golden(oracle_faithful, golden)   # both modes must reproduce them

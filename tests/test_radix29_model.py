@@ -409,3 +409,111 @@ def test_exact_square_root_chains_on_29_bit_limbs(cv):
             x220 = E.mul(sqr_n(x176, 44), x44); x223 = E.mul(sqr_n(x220, 3), x3)
             t = E.mul(sqr_n(x223, 23), x22); t = E.mul(sqr_n(t, 6), x2); t = sqr_n(t, 2)
         assert val(t) == pow(xv, (p + 1) // 4, p), hex(xv)
+
+
+# ---------------------------------------------------------------- round 5: the proofs are about THE DEVICE CODE
+import re  # noqa: E402
+
+import fe29_structure as fs  # noqa: E402
+
+
+@pytest.mark.parametrize("fn,kind", fs.COVERED, ids=[f"{f.__name__}-{k}" for f, k in fs.COVERED])
+def test_the_device_functions_are_the_model_functions_node_for_node(fn, kind):
+    """fe29.cuh parsed into the expression DAG of each function's outputs == the DAG the model function builds on symbols: the same products and squares on
+    the same operands, the same carry passes (norm29, with their shifts) and value reductions (vred29) in the same places, the same per-curve variants."""
+    dev, mod = fn(kind)
+    assert set(dev) == set(mod)
+    for k in dev:
+        assert dev[k] == mod[k], (fn.__name__, kind, k)
+
+
+def test_the_any_prime_ladder_invariant_and_dense_exact_model():
+    """Round 5 (curves registered at run time): the ladder's invariant holds for EVERY odd p < 2^256 at once (every limb of p an interval), and the exact
+    model with a dense reduction -- q_k = column * (-p^-1), then q_k p over all nine limbs -- tracks the big-int ZDAU on three real primes."""
+    r = m.prove_invariant(m.CURVE_ANY)
+    assert r["worst_column_bits"] <= 63 and r["worst_limb_bits"] <= 31
+    rng = random.Random(5)
+    for name, p in (("brainpoolP256r1", m.BRAINPOOL_P256), ("sm2", m.SM2_P), ("frp256v1", m.FRP256_P), ("p256 as a dense prime", m.P256), ("a 192-bit prime", 2**192 - 2**64 - 1), ("7", 7)):
+        cv = m.Curve.dense(name, p)
+        E = m.Exact(cv)
+        R = 1 << m.RBITS; Rinv = pow(R, -1, p)
+        val = lambda l: m.from_limbs(l) * Rinv % p
+        for it in range(40):
+            x1, y1, x2, y2, z = (rng.randrange(p) for _ in range(5))
+            st = _state(cv, rng, x1, y1, x2, y2, z, lazy=bool(it & 1))
+            for _ in range(3):
+                out = m.zdau29(E, st, False)
+                exp = m.zdau_field(p, x1, y1, x2, y2, z)
+                got = (val(out["x1"]), val(out["y1"]), val(out["x2"]), (val(out["y1"]) - val(out["dy"])) % p, val(out["z"]))
+                assert got == exp, name
+                assert val(out["dx"]) == (exp[0] - exp[2]) % p
+                st = out; x1, y1, x2, y2, z = exp
+
+
+COVERED_FUNCTIONS = ["zdau29", "madd29_hr", "madd29_finish", "madd29v_finish", "jdbl29", "dbl_add29", "zaddu29", "mul21_29", "pdbl29", "padd29"]
+
+
+def _call_sites(text):
+    """(start, end, inner) of every norm29 / norm29<S> / vred29<C> call inside the covered functions of fe29.cuh."""
+    sites = []
+    for name in COVERED_FUNCTIONS:
+        mo = re.search(r"ECS_DEV\s+[\w:<>]+\s+" + name + r"\s*\(", text)
+        k = text.index("{", text.index(")", mo.end()))
+        depth, e = 1, k + 1
+        while depth:
+            depth += {"{": 1, "}": -1}.get(text[e], 0); e += 1
+        for c in re.finditer(r"\b(norm29(?:<\d>)?|vred29<C>)\(", text[k:e]):
+            s0 = k + c.start(); i = k + c.end(); d = 1
+            while d:
+                d += {"(": 1, ")": -1}.get(text[i], 0); i += 1
+            sites.append((s0, i, text[k + c.end():i - 1], name, c.group(1)))
+    return sites
+
+
+def test_dropping_any_single_carry_pass_or_value_reduction_from_the_device_is_detected():
+    """The mutation the structural check exists for: delete ONE norm29 / vred29 call from fe29.cuh (keep its operand) -- for every one of them some
+    covered (function, curve) pair must stop matching the model.  (Round 4 pruned eleven carry passes by search; a twelfth dropped from the device alone
+    would have passed every other test in the tree.)"""
+    text = fs._strip_comments(open(fs.FE29).read())
+    sites = _call_sites(text)
+    assert len(sites) >= 40, len(sites)
+    # a shifting pass is not removable syntactically (norm29<2>(x) = 4x): turn it into the plain pass instead -- the model must notice the shift too
+    for s0, e, inner, name, what in sites:
+        mutated = text[:s0] + ("norm29(" + inner + ")" if what.startswith("norm29<") else inner) + text[e:]
+        caught = False
+        for fn, kind in fs.COVERED:
+            try:
+                dev, mod = fn(kind, mutated)
+            except (KeyError, ValueError):
+                caught = True; break
+            if dev != mod:
+                caught = True; break
+        assert caught, (name, what, inner)
+
+
+def test_the_witness_fixture_is_the_exact_models_and_reaches_the_proven_bounds():
+    """tests/golden/fe29_witnesses.json (run on the device by tests/test_gpu_witness.py): every entry re-executed on the exact model gives
+    the recorded outputs and the recorded worst column, no machine limit is crossed, and the product-level entries sit where they claim: for every proof on the
+    two built-in primes some operand pair reaches >= 15/16 of the column bound the proof derives for that call -- the largest of all exactly 2^63 - 2^34."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fe29_witnesses.json")
+    data = json.load(open(path))
+    curves = {"p256": m.CURVE_P256, "secp256k1": m.CURVE_SECP}
+    curves.update({k: m.Curve.dense(k, int(v, 16)) for k, v in data["curves"].items()})
+    best = {}
+    for e in data["entries"]:
+        E = m.Exact(curves[e["curve"]])
+        if e["kind"] == "product":
+            out = [E.mul(e["in"][0], e["in"][1]) if e["op"] == "mul" else E.sqr(e["in"][0])]
+            key = (e["proof"], e["curve"])
+            best[key] = max(best.get(key, 0), e["worst_column"] / e["proven_column"])
+            assert e["worst_column"] <= e["proven_column"] < 2**63
+        else:
+            out = m.OPS[e["op"]][3](E, [list(x) for x in e["in"]], bool(e["swap"]))
+        assert out == e["out"] and E.worst_col == e["worst_column"], (e["curve"], e["op"])
+    for (proof, curve), ratio in best.items():
+        if curve in ("p256", "secp256k1"):
+            assert ratio >= 15 / 16, (proof, curve, ratio)
+    assert max(e["worst_column"] for e in data["entries"]) >= 2**63 - 2**35
+    import subprocess
+    assert subprocess.run([sys.executable, os.path.join(os.path.dirname(path), "..", "..", "tools", "make_witnesses.py"), "--check"], capture_output=True).returncode == 0

@@ -87,6 +87,10 @@ import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value
     tail -8 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
     ./oracle/_ref/adapter_driver 512 65536 > "$out/adapter_driver.txt" 2>&1; cat "$out/adapter_driver.txt"
     timeout -k 10 600 python bench.py > "$out/bench.json" 2> "$out/bench.err"; rc=$?; tail -3 "$out/bench.err"; head -c 1500 "$out/bench.json"; exit $rc ;;
+  r5_curves)        # round 5: curves registered at run time -- the parity tests, then the three loops' rates on brainpoolP256r1 beside P-256's
+    timeout -k 10 900 python -m pytest tests/test_gpu_curves.py -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?
+    tail -12 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
+    timeout -k 10 600 python tools/curve_perf.py ${1:-22} > "$out/curve_perf.txt" 2>&1; rc=$?; cat "$out/curve_perf.txt"; exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
     timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -15 "$out/pytest.txt"; exit $rc ;;
   *) echo "unknown step $name"; exit 2 ;;

@@ -78,18 +78,22 @@ def from_limbs(l):
 
 # ---------------------------------------------------------------------------------------------------------------- exact execution
 class Exact:
-    """Concrete execution with the machine's limits asserted."""
+    """Concrete execution with the machine's limits asserted; worst_col / worst_limb remember the largest magnitudes met (the witness search's objective)."""
     def __init__(self, curve=CURVE_P256):
         self.cv = curve
+        self.worst_col = 0
+        self.worst_limb = 0
 
-    @staticmethod
-    def _i32(v):
+    def _i32(self, v):
         assert I32[0] <= v <= I32[1], f"limb overflow: {v}"
+        if abs(v) > self.worst_limb:
+            self.worst_limb = abs(v)
         return v
 
-    @staticmethod
-    def _i64(v):
+    def _i64(self, v):
         assert I64[0] <= v <= I64[1], f"column overflow: {v}"
+        if abs(v) > self.worst_col:
+            self.worst_col = abs(v)
         return v
 
     def add(self, a, b): return [self._i32(x + y) for x, y in zip(a, b)]
@@ -186,6 +190,7 @@ class Bounds:
         self.cv = curve
         self.worst_col = 0
         self.worst_limb = 0
+        self.calls = []           # (kind, operand limb boxes, the largest column magnitude of THIS product): what the product-level witnesses aim at
 
     def _limb(self, iv, what="limb"):
         self.worst_limb = max(self.worst_limb, abs(iv[0]), abs(iv[1]))
@@ -237,10 +242,21 @@ class Bounds:
         out = Iv([(0, M29)] * (NL - 1) + [self._limb(acc, "top limb")], val)
         return self._tighten_top(out)
 
+    def _logged(self, kind, boxes, run):
+        before, self.worst_col = self.worst_col, 0
+        out = run()
+        self.calls.append((kind, boxes, self.worst_col))
+        self.worst_col = max(self.worst_col, before)
+        return out
+
     def mul(self, a, b):
-        return self._columns(lambda k: [(a.l[i], b.l[k - i]) for i in range(max(0, k - NL + 1), min(k, NL - 1) + 1)], _imul(a.v, b.v))
+        return self._logged("mul", (list(a.l), list(b.l)), lambda: self._columns(
+            lambda k: [(a.l[i], b.l[k - i]) for i in range(max(0, k - NL + 1), min(k, NL - 1) + 1)], _imul(a.v, b.v)))
 
     def sqr(self, a):
+        return self._logged("sqr", (list(a.l),), lambda: self._sqr(a))
+
+    def _sqr(self, a):
         a2 = [self._limb((2 * x[0], 2 * x[1]), "doubled limb") for x in a.l]
         def prod(k):
             t = [(a2[i], a.l[k - i]) for i in range(max(0, k - NL + 1), min(k, NL - 1) + 1) if i < k - i]
@@ -626,6 +642,124 @@ def padd_field(p, X, Y, Z, x2, y2):
     t4 = (y2 * Z + Y) % p; t5 = (x2 * Z + X) % p
     A = (t1 - 21 * Z) % p; B = (t1 + 21 * Z) % p; Cc = 21 * t5 % p
     return (t3 * A - Cc * t4) % p, (3 * t0 * Cc + B * A) % p, (t4 * B + 3 * t0 * t3) % p
+
+
+# ---------------------------------------------------------------------------------------------------------------- witnesses (round 5)
+# The interval proofs bound every column by 2^63 over the whole invariant box; nothing so far fed the DEVICE an input anywhere near those extremes
+# (random and digit-pattern operands enter the loops as tight limbs).  OPS names, for every function a proof covers, its inputs, the invariant
+# they live in and the model function; witness_search climbs over the box's vertices (every limb at an end of its interval, the top limb chosen so
+# that the value stays inside its interval) towards the largest column the EXACT model meets.  tests/golden/fe29_witnesses.json holds the
+# states found (tools/make_witnesses.py), their exact outputs and how close they come to the proven bound; ecsimd_hip_fe29_raw runs them on
+# the device, limb for limb (tests/test_gpu_witness.py).
+def _op_zdau(E, a, sw): o = zdau29(E, dict(zip(("x1", "x2", "dx", "y1", "dy", "z"), a)), sw); return [o[k] for k in ("x1", "x2", "dx", "y1", "dy", "z")]
+def _op3(fn): return lambda E, a, sw: list(fn(E, *a))
+OPS = {   # name: (op code of ecsimd_hip_fe29_raw, input names, invariant, model function, outputs)
+    "zdau": (0, ("x1", "x2", "dx", "y1", "dy", "z"), ladder_invariant, _op_zdau, 6),
+    "madd": (1, ("X", "Y", "Z", "tx", "ty"), comb_invariant, _op3(madd29), 3),
+    "jdbl": (2, ("X", "Y", "Z"), window_invariant, _op3(jdbl29), 3),
+    "dbl_add": (3, ("X", "Y", "Z", "tx", "ty"), window_invariant, _op3(dbl_add29), 3),
+    "maddv": (4, ("X", "Y", "Z", "tx", "ty"), window_invariant, _op3(lambda E, *a: madd29v(E, *a)), 3),
+    "pdbl": (5, ("X", "Y", "Z"), None, _op3(pdbl29), 3),
+    "padd": (6, ("X", "Y", "Z", "tx", "ty"), None, _op3(padd29), 3),
+}
+OPS["pdbl"] = OPS["pdbl"][:2] + (lambda cv: complete_invariant(cv),) + OPS["pdbl"][3:]
+OPS["padd"] = OPS["padd"][:2] + (lambda cv: complete_invariant(cv),) + OPS["padd"][3:]
+
+
+def _vertex(iv, rng, choice=None):
+    """A concrete state inside the abstract element iv: limbs 0..7 at an end of their interval (choice[i] picks which; random where None), the top
+    limb at the end of what the VALUE interval leaves of its own interval (towards choice[8])."""
+    ch = [rng.getrandbits(1) for _ in range(NL)] if choice is None else list(choice)
+    low = [iv.l[i][ch[i]] for i in range(NL - 1)]
+    S = sum(v << (W * i) for i, v in enumerate(low))
+    sh = W * (NL - 1)
+    lo = max(iv.l[NL - 1][0], -((-(iv.v[0] - S)) // (1 << sh)))
+    hi = min(iv.l[NL - 1][1], (iv.v[1] - S) >> sh)
+    if lo > hi:
+        return None, ch
+    return low + [hi if ch[NL - 1] else lo], ch
+
+
+def product_witnesses(curve, prove, top=3, seed=1, steps=400):
+    """The products and squares of one interval proof whose columns come closest to 2^63, each with a concrete operand pair -- limbs at the ends of the
+    boxes the proof hands that very call -- found by climbing over the box's vertices on the exact model.  [(kind, a, b or None, exact result, achieved
+    worst column, proven worst column of that call)]."""
+    import random
+    rng = random.Random(seed)
+    E0 = prove(curve)
+    calls = E0 if isinstance(E0, list) else None
+    assert calls is not None
+    out = []
+    for kind, boxes, proven in sorted(calls, key=lambda c: -c[2])[:top]:
+        def run(ch):
+            ops = [[box[i][ch[j][i]] for i in range(NL)] for j, box in enumerate(boxes)]
+            E = Exact(curve)
+            r = E.mul(ops[0], ops[1]) if kind == "mul" else E.sqr(ops[0])
+            return ops, r, E.worst_col
+        # start where every limb has its largest magnitude (a sum of nine products is largest when the factors are), then climb
+        ch = [[int(abs(b[1]) >= abs(b[0])) for b in box] for box in boxes]
+        best = run(ch)
+        for _ in range(steps):
+            j, i = rng.randrange(len(boxes)), rng.randrange(NL)
+            t = [list(x) for x in ch]
+            t[j][i] ^= 1
+            r = run(t)
+            if r[2] >= best[2]:
+                best, ch = r, t
+        out.append((kind, best[0][0], best[0][1] if kind == "mul" else None, best[1], best[2], proven))
+    return out
+
+
+def proof_calls(prove_fn):
+    """Adapter: run an interval proof and hand back the log of its products (Bounds.calls)."""
+    def run(curve):
+        holder = {}
+        orig = Bounds.__init__
+        def init(self, cv=CURVE_P256):
+            orig(self, cv); holder["E"] = self
+        Bounds.__init__ = init
+        try:
+            prove_fn(curve)
+        finally:
+            Bounds.__init__ = orig
+        return holder["E"].calls
+    return run
+
+
+def witness_search(op, curve, seed, steps=1500, swap=False):
+    """Hill-climb over vertices of the invariant box of `op` for the largest column of the exact model.  Returns (inputs, outputs, worst column)."""
+    import random
+    rng = random.Random(seed)
+    code, names, inv_fn, fn, nout = OPS[op]
+    inv = inv_fn(curve)
+    ivs = [inv[n] for n in names]
+
+    def run(choices):
+        st = []
+        for iv, ch in zip(ivs, choices):
+            v, _ = _vertex(iv, rng, ch)
+            if v is None:
+                return None
+            st.append(v)
+        E = Exact(curve)
+        out = fn(E, [list(x) for x in st], swap)
+        return st, out, E.worst_col
+
+    best = None
+    while best is None:
+        choices = [[rng.getrandbits(1) for _ in range(NL)] for _ in ivs]
+        best = run(choices)
+    for _ in range(steps):
+        c, i = rng.randrange(len(ivs)), rng.randrange(NL)
+        trial = [list(x) for x in choices]
+        trial[c][i] ^= 1
+        if rng.random() < 0.3:                                     # now and then two flips at once: columns couple neighbouring limbs
+            c2, i2 = rng.randrange(len(ivs)), rng.randrange(NL)
+            trial[c2][i2] ^= 1
+        r = run(trial)
+        if r is not None and r[2] >= best[2]:
+            best, choices = r, trial
+    return best
 
 
 # ---------------------------------------------------------------------------------------------------------------- big-int ZDAU (field values)
