@@ -351,6 +351,7 @@ def base_line(args, world, total_units, n, value, elapsed):
     names = {
         "ladder": f"scalar_mult_{args.curve} variable-base co-Z ladder (reference algorithm), batch {sizes}, Jacobian Montgomery out",
         "ladder-ref-compat": f"scalar_mult_{args.curve} variable-base co-Z ladder with ECSIMD_HIP_REF_SQUARE_COMPAT (the reference's square() as written), batch {sizes}, Jacobian Montgomery out",
+        "ladder-radix32": f"scalar_mult_{args.curve} variable-base co-Z ladder with ECSIMD_HIP_LADDER_RADIX32 (the 254 iterations on 8 x 32-bit canonical words), batch {sizes}, Jacobian Montgomery out",
         "ladder-x": f"scalar_mult_{args.curve} variable-base, x coordinate only: " + ("the co-Z ladder without Z (8M + 6S per bit), x from the curve equation + simultaneous inversion"
                     if args.curve == "p256" else "the co-Z ladder + x-only simultaneous inversion") + f", batch {sizes}, affine x out",
         "windowed": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 multiples of P) + signed 4-bit windows + simultaneous "
@@ -364,7 +365,7 @@ def base_line(args, world, total_units, n, value, elapsed):
              "fixed-base-signed": "signed 7-bit window table in LDS (odd digits, 148 KiB)",
              "fixed-base-big": "20-bit window table of odd multiples (436 MB) in device memory"}
     return {
-        "metric": "P-256 scalar mults/sec (batched)" if args.curve == "p256" else "secp256k1 scalar mults/sec (batched)",
+        "metric": "P-256 scalar mults/sec (batched)" if args.curve == "p256" else f"{args.curve} scalar mults/sec (batched)",
         "value": value, "unit": "scalar_mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
@@ -372,7 +373,9 @@ def base_line(args, world, total_units, n, value, elapsed):
                                                              + fixed[args.workload] + " + simultaneous inversion, affine out"),
                    "element": ("256-bit integers, one per lane in VGPRs: canonical 8 x u32 words (= 4 x u64 limbs) at every kernel boundary; the ladder's 254 iterations run on nine "
                                "signed 29-bit digits in 32-bit words (Montgomery radix 2^261, v_mad_i64_i32 into carry-free 64-bit columns, lazy carries: fe29.cuh) -- "
-                               "REF_SQUARE_COMPAT and LADDER_RADIX32 keep the 8 x u32 v_mad_u64_u32 carry chains") if args.workload == "ladder" else
+                               "REF_SQUARE_COMPAT and LADDER_RADIX32 keep the 8 x u32 v_mad_u64_u32 carry chains"
+                               + ("" if args.curve in ("p256", "secp256k1") else "; this curve is registered at RUN time (the reference's curve_group<Curve> for any Curve): generic kernels, "
+                                  "the dense 9-limb prime in SGPRs, 81 multiply-adds per reduction where P-256's sparse form has 36")) if args.workload == "ladder" else
                               "256-bit integers: 8 x u32 words (= 4 x u64 limbs) in VGPRs, v_mad_u64_u32 carry chains",
                    "global_batch": total_units, "per_gpu_batch": n,
                    "parallelism": (f"group{world}" + ("+rccl_gather" if world > 1 else "") if args.multi == "group" else f"shard{world}" + ("+rccl_gather" if world > 1 else ""))},

@@ -938,6 +938,9 @@ template <int CURVE> ECS_DEV fe mgry_reduce_generic(fe2& t) {
   return res;
 }
 
+#ifndef ECS_K1_REDUCE_MAD64
+#define ECS_K1_REDUCE_MAD64 1          // 0: round 1-4's borrow-tracking rounds (the A/B build)
+#endif
 // secp256k1, Montgomery domain: T * 2^-256 mod p with the prime's special form.  The reference's eight 32-bit rounds
 // (mgry_mul.h:110-116) add q_i * p * W^i, W = 2^32; with p = W^8 - c, c = W + 977, that is  + q_i W^(8+i)  - q_i c W^i:
 //     (T + Q p) / W^8  =  T_hi + Q - E,      Q = sum q_i W^i,   E = (Q c - T_lo) / W^8   (exact: Q c = T_lo mod W^8).
@@ -949,7 +952,27 @@ template <int CURVE> ECS_DEV fe mgry_reduce_generic(fe2& t) {
 // form -- same residue, Montgomery reduction being a function of T and p only.
 ECS_DEV fe mgry_reduce_secp256k1(fe2& t) {
   const uint32_t MP = curve_consts<CURVE_SECP256K1>::MPRIME, K = 977u;
-  fe q; uint32_t dl, dh, sw, xh;
+  fe q; uint32_t dl, dh;
+#if ECS_K1_REDUCE_MAD64
+  // Round 5 (the reference-square ladder of secp256k1 ran 8 % behind P-256's, and this reduction -- which those instances cannot trade
+  // for the classical domain's fold, the dropped carry being a function of the MONTGOMERY digits -- is where: 64 instructions against P-256's 46, sixteen
+  // times per iteration).  The same recurrence with the 64-bit D kept whole:  A = D_i + 977 q_i  is ONE v_mad_u64_u32; its low word IS t_i (that is what
+  // q_i = (t_i - lo(D_i)) * m' means), so (A - t_i) / W = hi(A) with no borrow to track, and  D_(i+1) = hi(A) + q_i.  Five instructions per round, one of
+  // them a full-rate v_sub_u32, where the borrow-tracking form has six half-rate ones.  Same q_i, same D_8: the same residue.
+  uint64_t D = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t sw = t.w[i] - (uint32_t)D;
+    q.w[i] = sw * MP;
+    uint64_t A;                                             // (asm: left to itself the compiler adds hi(A) + q_i as two zero-extended 64-bit values, three moves a round)
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(A) : "v"(q.w[i]), "s"(K), "v"(D) : "vcc");
+    uint32_t lo, hi;
+    asm("v_add_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc" : "=&v"(lo), "=v"(hi) : "v"((uint32_t)(A >> 32)), "v"(q.w[i]) : "vcc");
+    D = ((uint64_t)hi << 32) | lo;
+  }
+  dl = (uint32_t)D; dh = (uint32_t)(D >> 32);
+#else
+  uint32_t sw, xh;
   // %0..%7 = q_0..q_7, %8 = lo(D), %9 = hi(D), %10 = s, %11 = hi(977 q), %12..%19 = t_0..t_7, %20 = m', %21 = 977
 #define ECS_K1_ROUND(QI, TI) \
       "v_sub_co_u32 %10, vcc, " TI ", %8\n\t"        /* s = t_i - lo(D), borrow in VCC */ \
@@ -966,6 +989,7 @@ ECS_DEV fe mgry_reduce_secp256k1(fe2& t) {
       : "v"(t.w[0]), "v"(t.w[1]), "v"(t.w[2]), "v"(t.w[3]), "v"(t.w[4]), "v"(t.w[5]), "v"(t.w[6]), "v"(t.w[7]), "s"(MP), "s"(K)
       : "vcc");
 #undef ECS_K1_ROUND
+#endif
   // res = T_hi + Q - E; carry of the addition and borrow of the subtraction net out to the 257th bit (the value is in [0, 2p))
   fe res;
   lane_mask top;

@@ -91,6 +91,13 @@ import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value
     timeout -k 10 900 python -m pytest tests/test_gpu_curves.py -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?
     tail -12 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
     timeout -k 10 600 python tools/curve_perf.py ${1:-22} > "$out/curve_perf.txt" 2>&1; rc=$?; cat "$out/curve_perf.txt"; exit $rc ;;
+  r5_suite)         # round 5: the whole GPU suite, then the bench lines of a registered curve (default loop, canonical words, reference squaring)
+    timeout -k 10 1000 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -6 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
+    for w in ladder ladder-radix32 ladder-ref-compat; do
+      timeout -k 10 300 python bench.py --curve brainpoolP256r1 --workload $w --global-log2-batch 22 --steps 5 --warmup 1 > "$out/bench_brainpool_$w.json" 2> "$out/bench_brainpool_$w.err" || { rc=$?; tail -5 "$out/bench_brainpool_$w.err"; exit $rc; }
+      python3 -c "
+import json; d=json.load(open('$out/bench_brainpool_$w.json')); r=d['roofline']; c=d['cpu_baseline']; print('$w: %.2f M/s, frac %.3f; cpu %s %.1f k/s on %d cores, %d lanes compared, %d differing' % (d['value']/1e6, r['frac'], c['kind'], c['value']/1e3, c['cores'], c['lanes_compared'], c['lanes_differing_from_gpu']))"
+    done; exit 0 ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
     timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -15 "$out/pytest.txt"; exit $rc ;;
   *) echo "unknown step $name"; exit 2 ;;
