@@ -427,6 +427,7 @@ def roofline_object(args, eng, n, avg_ms):
     achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
     traffic, traffic_src = committed_traffic(args, n)
     return {
+        **committed_pipe(args, n),
         "bound": "valu", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "Tmad32/s", "frac": achieved / peak,
         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": avg_ms, "algorithmic_mad32_per_unit": mad32_unit,
         "hbm": {"achieved": n / (avg_ms * 1e-3) * bytes_unit / 1e9, "peak": 8000.0, "unit": "GB/s",
@@ -629,6 +630,24 @@ def main_group(args):
     emit(json.dumps(result))
     grp.close()
     return EXIT_PARITY if failures else 0
+
+
+def committed_pipe(args, n):
+    """What the VALU pipe does during the dominant kernel, from the committed counter passes and the shipped ISA (tools/pipe_model.py ->
+    profiles/pmc_pipe.json): `frac` above is an ALGORITHMIC rate over the multiply peak (136 mad32 per field multiplication); these four say
+    how many instructions a scalar multiplication really issues, how many of them multiply, that a SIMD issues one every ~4 cycles all the time, and how much
+    of the elapsed time the instruction mix alone accounts for at the measured per-instruction issue costs.  Not measured in this run (like `traffic`)."""
+    path = os.path.join(ROOT, "profiles", "pmc_pipe.json")
+    key = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult_refsqr", "ladder-radix32": "k_scalar_mult_radix32", "fixed-base": "fixed_base"}.get(args.workload)
+    try:
+        rec = json.load(open(path))["kernels"].get(f"{key}_{args.curve}_2^24") if key else None
+    except (OSError, ValueError):
+        rec = None
+    if not rec or "issue_bound_frac" not in rec:
+        return {}
+    return {"valu_instructions_per_unit": rec["valu_instructions_per_unit"], "multiply_instructions_per_unit": rec["multiply_instructions_per_unit"],
+            "cycles_per_valu_instruction_per_simd": rec["cycles_per_valu_instruction_per_simd"], "issue_bound_frac": rec["issue_bound_frac"],
+            "pipe_source": f"profiles/pmc_pipe.json ({rec['source']} + the ISA of build/csrc/{rec['isa_unit']}: tools/pipe_model.py); at 2^24 lanes per launch, not measured in this run"}
 
 
 def committed_traffic(args, n):

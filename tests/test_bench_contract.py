@@ -270,3 +270,50 @@ def test_the_group_leg_child_is_not_a_rank():
             else:
                 os.environ[k] = v
     assert res["ok"] is False and "device(s) visible" in res["stderr_tail"] and "torch.distributed.run" not in res["stderr_tail"], res
+
+
+# ---------------------------------------------------------------- round 5: the line says what the pipe does, and the committed figures cannot go stale silently
+def test_the_committed_pipe_figures_describe_the_isa_the_build_ships():
+    """VERDICT r4 weak 9 / next 6: roofline.{valu_instructions_per_unit, multiply_instructions_per_unit, cycles_per_valu_instruction_per_simd, issue_bound_frac}
+    are read from profiles/pmc_pipe.json (counters of committed rocprofv3 --pmc passes + the instruction mix of the shipped ISA, tools/pipe_model.py).  The
+    day a kernel changes without a re-profile, the loop mix recorded there differs from the ISA `make` leaves under build/csrc: this test fails."""
+    import subprocess
+    import sys
+    if not os.path.exists(os.path.join(ROOT, "build", "csrc", "k_ladder_p256-hip-amdgcn-amd-amdhsa-gfx950.s")):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pipe_model.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    pipe = json.load(open(os.path.join(ROOT, "profiles", "pmc_pipe.json")))["kernels"]
+    lad = pipe["k_scalar_mult_p256_2^24"]
+    # the static count (loop mix x 254 + the straight-line rest) and the SQ_INSTS_VALU counter agree: the ISA the counters saw IS this one
+    assert abs(lad["static_valu_instructions_per_unit"] - lad["valu_instructions_per_unit"]) / lad["valu_instructions_per_unit"] < 0.002
+    assert 3.8 < lad["cycles_per_valu_instruction_per_simd"] < 4.3 and 0.9 < lad["issue_bound_frac"] <= 1.02
+    assert lad["loop_multiply_instructions"] == 1620 and lad["multiply_instructions_per_unit"] < 555968          # 101 multiply instructions per field multiplication, not 136
+
+
+def test_the_committed_traffic_is_the_newest_profiles():
+    """... and roofline.traffic (profiles/pmc_traffic.json) for the headline equals the HBM bytes of the ladder kernel in the NEWEST profiles/rNN/ladder/pmc_summary.json."""
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "ladder", "pmc_summary.json")))[-1]
+    ks = json.load(open(newest))["kernels"]
+    k = next(v for name, v in ks.items() if name.startswith("k_scalar_mult<29> @ 16777216"))
+    table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert abs(table["k_scalar_mult_p256_2^24"] - k["hbm_bytes_per_launch"]["total"]) / k["hbm_bytes_per_launch"]["total"] < 0.002, newest
+    pipe = json.load(open(os.path.join(ROOT, "profiles", "pmc_pipe.json")))["kernels"]["k_scalar_mult_p256_2^24"]
+    assert pipe["source"] == os.path.relpath(newest, ROOT)
+
+
+def test_ref_compat_is_part_of_the_documented_contract():
+    """`ref_compat` -- how fast the path is that is IDENTICAL to the reference on every lane -- is a first-class object of the default line
+    (README "The bench line"), beside `value` -- how fast the path is that is RIGHT.  Every committed default-workload line since round 4 carries it whole."""
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    for word in ("ref_compat", "lanes_compared", "lanes_differing", "issue_bound_frac", "cycles_per_valu_instruction_per_simd"):
+        assert word in readme, word
+    lines = [p for p in LINES if os.path.basename(p) in ("bench_n1_ladder.json", "bench_n1_ladder_secp256k1.json") and os.sep + "r0" in p and int(p.split(os.sep + "r0")[1][0]) >= 4]
+    assert len(lines) >= 2
+    for p in lines:
+        rc = json.load(open(p))["ref_compat"]
+        for key in ("value", "unit", "kernel_ms", "steps", "frac", "frac_of_a_priori_peak", "lanes_compared", "lanes_differing", "compared_with"):
+            assert key in rc, (p, key)
+        assert rc["lanes_differing"] == 0 and rc["lanes_compared"] > 10 ** 6 and rc["unit"] == "scalar_mults/s"

@@ -32,8 +32,26 @@ def test_group_mode_matches_the_plain_line_at_one_gpu():
     for d in (plain, group):
         assert d["n_gpus"] == 1 and d["steps"] == 8 and d["roofline"]["traffic"] is not None and "parity_failures" not in d
         # algorithmic mad32 (136 per field multiplication) over the live v_mad_u64_u32 probe: 0.75 on 8 x 32-bit words
-        # (rounds 1-3), 0.90-0.91 since the loop runs on nine 29-bit limbs (81 multiplies per product instead of 64 + the reduction's)
-        assert 0.6 < d["roofline"]["frac"] < 1.0
+        # (rounds 1-3), 0.90-0.91 since the loop runs on nine 29-bit limbs (81 multiplies per product instead of 64 + the reduction's).
+        # The floor is round 4's committed line minus 4 % box-to-box variance (0.6 would have let the ladder lose a third).
+        assert FLOORS["ladder"] < d["roofline"]["frac"] < 1.0, d["roofline"]["frac"]
+        # the line also says what the pipe does (tools/pipe_model.py): ~4 cycles per VALU instruction per SIMD = issue-saturated
+        assert 3.7 < d["roofline"]["cycles_per_valu_instruction_per_simd"] < 4.4 and 0.9 < d["roofline"]["issue_bound_frac"] <= 1.02
+        assert d["roofline"]["multiply_instructions_per_unit"] < d["roofline"]["valu_instructions_per_unit"] < d["roofline"]["algorithmic_mad32_per_unit"] * 1.3
+
+
+# roofline.frac floors per workload: profiles/r04/bench_n1_*.json (r05 for the lines that are new this round) minus 4 % (boxes differ by that much in clock)
+FLOORS = {"ladder": 0.86, "ladder-ref-compat": 0.63, "fixed-base": 0.86, "windowed": 0.83, "fixed-base-ct": 0.76, "brainpoolP256r1": 0.63}
+
+
+@pytest.mark.parametrize("workload,curve", [("ladder-ref-compat", "p256"), ("ladder-ref-compat", "secp256k1"), ("fixed-base", "p256"), ("windowed", "p256"), ("fixed-base-ct", "p256"), ("ladder", "brainpoolP256r1")])
+def test_every_workload_stays_at_its_committed_fraction_of_the_roof(workload, curve):
+    """a regression guard per workload, not only for the headline -- the reference-compatible ladder (the mode that is identical to
+    the reference on every lane), BASELINE configs[2]'s LDS comb, the windowed variable-base path, the constant-time comb, and a curve registered at run time."""
+    d = run_bench("--workload", workload, "--curve", curve, "--global-log2-batch", "22")
+    floor = FLOORS["brainpoolP256r1"] if curve == "brainpoolP256r1" else FLOORS[workload]
+    assert floor < d["roofline"]["frac"] < 1.0, (workload, curve, d["roofline"]["frac"])
+    assert "parity_failures" not in d
 
 
 def test_two_ranks_rehearsed_on_one_gpu():

@@ -29,6 +29,13 @@ run bench_n1_fixed_base_constant_time_secp256k1 --steps 20 --warmup 2 --workload
 run bench_n1_fixed_base_signed7 --steps 20 --warmup 2 --workload fixed-base-signed
 run bench_n1_fixed_base_signed7_secp256k1 --steps 20 --warmup 2 --workload fixed-base-signed --curve secp256k1
 run bench_n1_fixed_base_big20 --steps 20 --warmup 2 --workload fixed-base-big
+# curves registered at run time (round 5): the generic kernels, dense 9-limb prime in SGPRs
+run bench_n1_ladder_brainpoolP256r1 --steps 10 --warmup 2 --curve brainpoolP256r1
+run bench_n1_ladder_sm2 --steps 10 --warmup 2 --curve sm2
+run bench_n1_ladder_frp256v1 --steps 10 --warmup 2 --curve frp256v1
+run bench_n1_ladder_radix32_brainpoolP256r1 --steps 4 --warmup 1 --curve brainpoolP256r1 --workload ladder-radix32
+run bench_n1_ladder_ref_compat_brainpoolP256r1 --steps 4 --warmup 1 --curve brainpoolP256r1 --workload ladder-ref-compat
+run bench_n1_ladder_radix32_p256 --steps 10 --warmup 2 --workload ladder-radix32
 run bench_n1_group_mode --steps 10 --warmup 2 --multi group
 # the whole N > 1 code path of the one-process-per-GPU mode on the one GPU a builder's box has: RCCL init, side stream, dist.gather
 f=bench_n1_nccl_single_rank_rehearsal

@@ -98,6 +98,21 @@ import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value
       python3 -c "
 import json; d=json.load(open('$out/bench_brainpool_$w.json')); r=d['roofline']; c=d['cpu_baseline']; print('$w: %.2f M/s, frac %.3f; cpu %s %.1f k/s on %d cores, %d lanes compared, %d differing' % (d['value']/1e6, r['frac'], c['kind'], c['value']/1e3, c['cores'], c['lanes_compared'], c['lanes_differing_from_gpu']))"
     done; exit 0 ;;
+  r5_profile)       # round 5: rocprofv3 kernel stats + --pmc passes for the lines the pipe model speaks about, and the two kernels VERDICT r4 next 7 asks about
+    rc=0
+    prof() { tag=$1; shift; bash tools/profile.sh "r05_$tag" "$@" > "$out/profile_$tag.txt" 2>&1 || { rc=$?; tail -5 "$out/profile_$tag.txt"; }; echo "profiled $tag rc=$rc"; }
+    prof ladder
+    prof ladder_secp256k1 --curve secp256k1
+    prof ladder_ref_compat --workload ladder-ref-compat
+    prof ladder_ref_compat_secp256k1 --workload ladder-ref-compat --curve secp256k1
+    prof ladder_brainpoolP256r1 --curve brainpoolP256r1
+    prof fixed_base_big --workload fixed-base-big
+    prof windowed_ct_secp256k1 --workload windowed-ct --curve secp256k1
+    exit $rc ;;
+  r5_ab_k1)         # round 5: the secp256k1 Montgomery reduction's rounds on one 64-bit MAC against rounds 1-4's borrow-tracking form (build/ab_k1old, -DECS_K1_REDUCE_MAD64=0)
+    timeout -k 10 500 python tools/ab_variants.py "--workload ladder-ref-compat --curve secp256k1 --steps 5 --warmup 1" mad64=base borrow_tracking=build/ab_k1old/libecsimd_hip.so > "$out/ab.txt" 2>&1; rc=$?
+    timeout -k 10 300 python tools/ab_variants.py "--workload ladder-ref-compat --curve p256 --steps 5 --warmup 1" p256_for_scale=base >> "$out/ab.txt" 2>&1
+    cat "$out/ab.txt"; exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
     timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -15 "$out/pytest.txt"; exit $rc ;;
   *) echo "unknown step $name"; exit 2 ;;
