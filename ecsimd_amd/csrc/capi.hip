@@ -519,7 +519,9 @@ void u_limbs29(int32_t (&out)[9], const u256& v) {                      // tight
     out[i] = (int32_t)(w & (i < 8 ? 0x1fffffffu : 0xffffffu));
   }
 }
-struct curve_record { gcurve G; u256 a, b, n; bool has_order; };
+struct curve_record { gcurve G; u256 a, b, n; bool has_order; gmod N; bool ecdsa_ok; };
+// the reference ladder's degenerate scalars for a group of order nn (ladder_degenerate above works on uint64_t[4])
+bool u_ladder_degenerate(const u256& nn, const u256& k) { return ladder_degenerate(nn.l, k.l); }
 struct curve_registry { std::mutex mu; std::vector<curve_record> curves; };
 curve_registry& curves() { static curve_registry r; return r; }
 bool lookup_curve(int id, gcurve* out) {
@@ -681,6 +683,21 @@ int ecsimd_hip_register_curve(const uint64_t p[4], const uint64_t a[4], const ui
   try {
     curve_record rec; memset(&rec, 0, sizeof rec);
     rec.a = A; rec.b = B; rec.n = N; rec.has_order = n != nullptr;
+    rec.ecdsa_ok = false;
+    if (n) {
+      // ECDSA on this curve multiplies through the reference's ladder, which is wrong at n - 1, 2^256 - n - 1 and 2^256 - n: such a scalar u is replaced by n - u
+      // (k_gc_ladder_safe_scalars).  That needs n - u to be a good scalar in turn; and x mod n by ONE conditional subtraction needs p < 2n.
+      rec.N = make_gmod(n, GMOD_PRIME);
+      u256 one = {{1, 0, 0, 0}}, zero = {{0, 0, 0, 0}}, nm1, c, cm1, alt, twice;
+      (void)u_sub(nm1, N, one); (void)u_sub(c, zero, N); (void)u_sub(cm1, c, one);
+      bool safe = true;
+      for (const u256* d : {&nm1, &c, &cm1}) if (!u_geq(*d, N)) { (void)u_sub(alt, N, *d); if (u_is_zero(alt) || u_ladder_degenerate(N, alt)) safe = false; }
+      const uint64_t top = N.l[3] >> 63;
+      for (int i = 3; i > 0; --i) twice.l[i] = (N.l[i] << 1) | (N.l[i - 1] >> 63);
+      twice.l[0] = N.l[0] << 1;
+      const bool p_below_2n = top || !u_geq(P, twice);
+      rec.ecdsa_ok = safe && p_below_2n;
+    }
     gcurve& G = rec.G;
     G.F = make_gmod(p, GMOD_PRIME);                                 // registering a CURVE vouches that p is prime
     u_words(G.am, u_shl_mod(A, 256, P));                            // to_mgry(A), to_mgry(B): curve_group.h:31-32
@@ -694,8 +711,13 @@ int ecsimd_hip_register_curve(const uint64_t p[4], const uint64_t a[4], const ui
     curve_registry& r = curves();
     std::lock_guard<std::mutex> g(r.mu);
     for (size_t i = 0; i < r.curves.size(); ++i) {
-      const curve_record& o = r.curves[i];
-      if (!memcmp(o.G.F.p, G.F.p, 32) && u_eq(o.a, A) && u_eq(o.b, B) && !memcmp(o.G.gx, G.gx, 32) && !memcmp(o.G.gy, G.gy, 32)) { *curve_id = FIRST_CURVE_ID + (int)i; return ECSIMD_HIP_OK; }
+      curve_record& o = r.curves[i];
+      if (!memcmp(o.G.F.p, G.F.p, 32) && u_eq(o.a, A) && u_eq(o.b, B) && !memcmp(o.G.gx, G.gx, 32) && !memcmp(o.G.gy, G.gy, 32)) {
+        // the order is additional knowledge about the same curve: a later registration may supply it, never contradict it
+        if (n && o.has_order && !u_eq(o.n, N)) return ECSIMD_HIP_ERR_BAD_ARG;
+        if (n && !o.has_order) { o.n = N; o.N = rec.N; o.has_order = true; o.ecdsa_ok = rec.ecdsa_ok; }
+        *curve_id = FIRST_CURVE_ID + (int)i; return ECSIMD_HIP_OK;
+      }
     }
     if (r.curves.size() >= (size_t)MAX_CURVES) return ECSIMD_HIP_ERR_BAD_ARG;
     r.curves.push_back(rec);
@@ -810,9 +832,12 @@ int ecsimd_hip_mask_bit(ecsimd_hip_ctx* ctx, const uint64_t* a, int bit, uint8_t
   REQUIRE_CTX(); REQUIRE_PTR(a); if (!flag && n) return bad(ctx, "flag is null"); if (bit < 0 || bit > 255) return bad(ctx, "bit index");
   RUN(launch::mask_bit(s, a, bit, flag, n)); }
 int ecsimd_hip_sec1_encode(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, uint8_t* out, size_t n, int compressed) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(out); RUN(launch::sec1_encode(s, curve, x, y, out, n, compressed != 0)); }
+  REQUIRE_CTX(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(out);
+  if (curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE) { gcurve GC; if (!lookup_curve(curve, &GC)) return bad(ctx, "unknown curve id"); curve = ECSIMD_HIP_P256; }     // the encoding does not look at the curve
+  REQUIRE_CURVE(); RUN(launch::sec1_encode(s, curve, x, y, out, n, compressed != 0)); }
 int ecsimd_hip_sec1_decode(ecsimd_hip_ctx* ctx, int curve, const uint8_t* in, uint64_t* x, uint64_t* y, uint8_t* ok, size_t n, int compressed) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(in); REQUIRE_PTR(x); REQUIRE_PTR(y); RUN(launch::sec1_decode(s, curve, in, x, y, ok, n, compressed != 0)); }
+  REQUIRE_CTX(); REQUIRE_PTR(in); REQUIRE_PTR(x); REQUIRE_PTR(y); GENERIC_CURVE(launch::gc_sec1_decode(s, GC, in, x, y, ok, n, compressed != 0));
+  REQUIRE_CURVE(); RUN(launch::sec1_decode(s, curve, in, x, y, ok, n, compressed != 0)); }
 
 // ---- L3.  `curve` is a FIELD id here: a curve's prime (0, 1: the special-form kernels of field.cuh) or a run-time modulus (>= 2: k_gfield.hip).
 #define FIELD_OR_CURVE(generic_call) do { if (curve != ECSIMD_HIP_P256 && curve != ECSIMD_HIP_SECP256K1) { \
@@ -1011,9 +1036,10 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* 
   return run_ladder(ctx, curve, k, 4, nullptr, nullptr, ox, oy, oz, n, flags); }
 int ecsimd_hip_affine_add(ecsimd_hip_ctx* ctx, int curve, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by,
                           uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(ax); REQUIRE_PTR(ay); REQUIRE_PTR(bx); REQUIRE_PTR(by); REQUIRE_PTR(rx);
+  REQUIRE_CTX(); if (curve < ECSIMD_HIP_FIRST_REGISTERED_CURVE) REQUIRE_CURVE(); REQUIRE_PTR(ax); REQUIRE_PTR(ay); REQUIRE_PTR(bx); REQUIRE_PTR(by); REQUIRE_PTR(rx);
   if (ry && !aligned16(ry)) return bad(ctx, "ry is not 16-byte aligned");
   if (overlaps(rx, ax) || overlaps(rx, ay) || overlaps(rx, bx) || overlaps(rx, by)) return bad(ctx, "rx must not alias an input (it is the inversion scratch)");
+  GENERIC_CURVE(launch::gc_affine_add_batched(s, GC, ax, ay, bx, by, rx, ry, finite, n));
   RUN(launch::affine_add_batched(s, curve, ax, ay, bx, by, rx, ry, finite, n)); }
 
 // u1[i]*G + u2[i]*Q[i]: windowed fixed-base product + windowed variable-base product + one batched affine
@@ -1052,6 +1078,69 @@ int double_scalar_mult_impl(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, 
 }
 }  // namespace
 
+// ---- u1 G + u2 Q, ECDSA verification and signing on a curve registered at run time: the reference's ladder twice (no tables exist for such a curve), the
+// scalars kept clear of its three degenerate values (k_gc_ladder_safe_scalars), one shared inversion per product, a batched affine addition.
+namespace {
+constexpr size_t GC_CHUNK = (size_t)1 << 22;
+struct gc_layout { size_t chunk; uint64_t *adj1, *adj2, *j[3], *gx, *gy, *px, *py; uint8_t *neg1, *neg2; size_t bytes; };
+gc_layout gc_plan(uint64_t* base, size_t n) {
+  gc_layout L; L.chunk = n < GC_CHUNK ? n : GC_CHUNK;
+  uint64_t* p = base; const size_t e = 4 * L.chunk;
+  L.adj1 = p; p += e; L.adj2 = p; p += e; for (int i = 0; i < 3; ++i) { L.j[i] = p; p += e; }
+  L.gx = p; p += e; L.gy = p; p += e; L.px = p; p += e; L.py = p; p += e;
+  L.neg1 = reinterpret_cast<uint8_t*>(p); L.neg2 = L.neg1 + ((L.chunk + 15) / 16) * 16;
+  L.bytes = 9 * L.chunk * 32 + 2 * (((L.chunk + 15) / 16) * 16);
+  return L;
+}
+int gc_require_ecdsa(ecsimd_hip_ctx* ctx, int curve, curve_record* rec) {
+  if (!lookup_curve_record(curve, rec)) return bad(ctx, "unknown curve id");
+  if (!rec->has_order) return bad(ctx, "this curve was registered without its group order n");
+  if (!rec->ecdsa_ok) return bad(ctx, "ECDSA on a registered curve needs p < 2n and n - u a good ladder scalar for the ladder's three degenerate u");
+  if (ctx->ref_square) return bad(ctx, "not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT form");
+  return ECSIMD_HIP_OK;
+}
+// one product k P (P = G when x == nullptr) -> affine classical (ox, oy), correct for EVERY k < n; oy may be null (x only: the negation does not touch x)
+void gc_safe_mult(hipStream_t s, const curve_record& rec, const gc_layout& L, uint64_t* adj, uint8_t* neg, const uint64_t* k, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, size_t m) {
+  launch::gc_ladder_safe_scalars(s, rec.N, k, adj, neg, m);
+  launch::gc_scalar_mult(s, rec.G, adj, 4, x, y, L.j[0], L.j[1], L.j[2], m, 0);
+  launch::gc_to_affine_batched(s, rec.G, L.j[0], L.j[1], L.j[2], ox, oy, m);
+  if (oy) launch::gc_negate_where(s, rec.G, neg, oy, m);
+}
+int gc_double_scalar_mult(ecsimd_hip_ctx* ctx, const curve_record& rec, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
+                          uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n, size_t reserve_behind) {
+  (void)hipSetDevice(ctx->device);
+  gc_layout L = gc_plan(nullptr, n);
+  int rc = ensure_workspace(ctx, L.bytes + reserve_behind);
+  if (rc == ECSIMD_HIP_OK) rc = ensure_valid(ctx, (n + 15) / 16 * 16);
+  if (rc != ECSIMD_HIP_OK) return rc;
+  L = gc_plan(ctx->workspace, n);
+  hipStream_t s = ctx->stream;
+  launch::gc_on_curve(s, rec.G, qx, qy, ctx->valid, n);
+  for (size_t first = 0; first < n; first += L.chunk) {
+    const size_t m = (n - first) < L.chunk ? (n - first) : L.chunk;
+    gc_safe_mult(s, rec, L, L.adj1, L.neg1, u1 + 4 * first, nullptr, nullptr, L.gx, L.gy, m);                              // u1 G
+    gc_safe_mult(s, rec, L, L.adj2, L.neg2, u2 + 4 * first, qx + 4 * first, qy + 4 * first, L.px, L.py, m);              // u2 Q
+    launch::gc_affine_add_batched(s, rec.G, L.gx, L.gy, L.px, L.py, rx + 4 * first, ry ? ry + 4 * first : nullptr, finite ? finite + first : nullptr, m);
+  }
+  launch::clear_invalid(s, ctx->valid, rx, ry, finite, n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "double_scalar_mult (registered curve) launch");
+}
+int gc_ecdsa_verify_rx(ecsimd_hip_ctx* ctx, const curve_record& rec, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy, const uint64_t* r, uint8_t* ok, size_t n, size_t extra) {
+  const gc_layout L0 = gc_plan(nullptr, n);
+  const size_t behind = n * 32 + ((n + 15) / 16) * 16;
+  int rc = ensure_workspace(ctx, L0.bytes + behind + extra);
+  if (rc != ECSIMD_HIP_OK) return rc;
+  uint64_t* rx = ctx->workspace + L0.bytes / 8;
+  uint8_t* fin = reinterpret_cast<uint8_t*>(rx + 4 * n);
+  rc = gc_double_scalar_mult(ctx, rec, u1, u2, qx, qy, rx, nullptr, fin, n, behind + extra);
+  if (rc != ECSIMD_HIP_OK) return rc;
+  launch::gc_x_mod_n_equals(ctx->stream, rec.N, rx, fin, r, ok, n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "ecdsa_verify_rx (registered curve) launch");
+}
+}  // namespace
+
 int ecsimd_hip_on_curve(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, uint8_t* ok, size_t n) {
   REQUIRE_CTX(); REQUIRE_PTR(x); REQUIRE_PTR(y); if (!ok && n) return bad(ctx, "ok is null");
   GENERIC_CURVE(launch::gc_on_curve(s, GC, x, y, ok, n));
@@ -1059,8 +1148,14 @@ int ecsimd_hip_on_curve(ecsimd_hip_ctx* ctx, int curve, const uint64_t* x, const
 
 int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                                   uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(u1); REQUIRE_PTR(u2); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(rx);
+  REQUIRE_CTX(); REQUIRE_PTR(u1); REQUIRE_PTR(u2); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(rx);
   if (ry && !aligned16(ry)) return bad(ctx, "ry is not 16-byte aligned");
+  if (curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE) {
+    curve_record rec; int rc = gc_require_ecdsa(ctx, curve, &rec); if (rc != ECSIMD_HIP_OK) return rc;
+    if (n == 0) return ECSIMD_HIP_OK;
+    return gc_double_scalar_mult(ctx, rec, u1, u2, qx, qy, rx, ry, finite, n, 0);
+  }
+  REQUIRE_CURVE();
   if (ctx->ref_square) return bad(ctx, "double_scalar_mult is not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT form");
   if (n == 0) return ECSIMD_HIP_OK;
   return double_scalar_mult_impl(ctx, curve, u1, u2, qx, qy, rx, ry, finite, n, 0); }
@@ -1094,8 +1189,15 @@ int ecdsa_verify_rx_impl(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, con
 
 int ecsimd_hip_ecdsa_verify_rx(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                                const uint64_t* r, uint8_t* ok, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(u1); REQUIRE_PTR(u2); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(r);
+  REQUIRE_CTX(); REQUIRE_PTR(u1); REQUIRE_PTR(u2); REQUIRE_PTR(qx); REQUIRE_PTR(qy); REQUIRE_PTR(r);
   if (!ok && n) return bad(ctx, "ok is null");
+  if (curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE) {
+    curve_record rec; int rc = gc_require_ecdsa(ctx, curve, &rec); if (rc != ECSIMD_HIP_OK) return rc;
+    if (n == 0) return ECSIMD_HIP_OK;
+    (void)hipSetDevice(ctx->device);
+    return gc_ecdsa_verify_rx(ctx, rec, u1, u2, qx, qy, r, ok, n, 0);
+  }
+  REQUIRE_CURVE();
   if (ctx->ref_square) return bad(ctx, "ecdsa_verify_rx is not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT form");
   if (n == 0) return ECSIMD_HIP_OK;
   return ecdsa_verify_rx_impl(ctx, curve, u1, u2, qx, qy, r, ok, n, 0); }
@@ -1104,8 +1206,28 @@ int ecsimd_hip_ecdsa_verify_rx(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u
 // (k_gfield.hip k_ecdsa_scalars: one shared inversion per up to 128 signatures), then the acceptance test above.
 int ecsimd_hip_ecdsa_verify(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, const uint64_t* r, const uint64_t* s_, const uint64_t* qx, const uint64_t* qy,
                             uint8_t* ok, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(e); REQUIRE_PTR(r); REQUIRE_PTR(s_); REQUIRE_PTR(qx); REQUIRE_PTR(qy);
+  REQUIRE_CTX(); REQUIRE_PTR(e); REQUIRE_PTR(r); REQUIRE_PTR(s_); REQUIRE_PTR(qx); REQUIRE_PTR(qy);
   if (!ok && n) return bad(ctx, "ok is null");
+  if (curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE) {
+    // the same verification on a registered curve: u1, u2 modulo ITS order (the record's field of n), then two ladders, an affine addition, x mod n = r
+    curve_record rec; int rc = gc_require_ecdsa(ctx, curve, &rec); if (rc != ECSIMD_HIP_OK) return rc;
+    if (n == 0) return ECSIMD_HIP_OK;
+    if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
+    (void)hipSetDevice(ctx->device);
+    const gc_layout L0 = gc_plan(nullptr, n);
+    const size_t behind = n * 32 + ((n + 15) / 16) * 16, extra = 2 * n * 32 + ((n + 15) / 16) * 16;
+    rc = ensure_workspace(ctx, L0.bytes + behind + extra);
+    if (rc != ECSIMD_HIP_OK) return rc;
+    uint64_t* u1 = ctx->workspace + (L0.bytes + behind) / 8; uint64_t* u2 = u1 + 4 * n;
+    uint8_t* in_range = reinterpret_cast<uint8_t*>(u2 + 4 * n);
+    launch::ecdsa_scalars(ctx->stream, rec.N, e, r, s_, u1, u2, in_range, n);
+    rc = gc_ecdsa_verify_rx(ctx, rec, u1, u2, qx, qy, r, ok, n, extra);
+    if (rc != ECSIMD_HIP_OK) return rc;
+    launch::mask_op(ctx->stream, ECSIMD_HIP_MASK_AND, ok, in_range, ok, n);
+    hipError_t err = hipGetLastError();
+    return err == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, err, "ecdsa_verify (registered curve) launch");
+  }
+  REQUIRE_CURVE();
   if (ctx->ref_square) return bad(ctx, "ecdsa_verify is not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT form");
   if (n == 0) return ECSIMD_HIP_OK;
   if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
@@ -1128,8 +1250,28 @@ int ecsimd_hip_ecdsa_verify(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, c
 
 // Signing: R = k G on the constant-time comb (the kernel behind ALG_WINDOWED | ALG_CONSTANT_TIME), x only; then the scalar-field half.
 int ecsimd_hip_ecdsa_sign(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, const uint64_t* d, const uint64_t* k, uint64_t* r, uint64_t* s_, uint8_t* ok, size_t n) {
-  REQUIRE_CTX(); REQUIRE_CURVE(); REQUIRE_PTR(e); REQUIRE_PTR(d); REQUIRE_PTR(k); REQUIRE_PTR(r); REQUIRE_PTR(s_);
+  REQUIRE_CTX(); REQUIRE_PTR(e); REQUIRE_PTR(d); REQUIRE_PTR(k); REQUIRE_PTR(r); REQUIRE_PTR(s_);
   if (!ok && n) return bad(ctx, "ok is null");
+  if (curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE) {
+    // signing on a registered curve: k G through the reference's ladder -- constant-time as it is (tests/test_constant_time_isa.py holds k_gc_scalar_mult<29, false>
+    // to the same checks as the built-in ladders) -- x by the select-only shared inversion, then the scalar-field kernel with the record's order
+    curve_record rec; int rc = gc_require_ecdsa(ctx, curve, &rec); if (rc != ECSIMD_HIP_OK) return rc;
+    if (overlaps(r, e) || overlaps(r, d) || overlaps(r, k) || overlaps(s_, e) || overlaps(s_, d) || overlaps(s_, k) || overlaps(r, s_)) return bad(ctx, "r and s must not alias an input or each other");
+    if (n == 0) return ECSIMD_HIP_OK;
+    if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
+    (void)hipSetDevice(ctx->device);
+    gc_layout L = gc_plan(nullptr, n);
+    if (L.chunk != n) return bad(ctx, "ecdsa_sign on a registered curve: at most 2^22 signatures per call");
+    rc = ensure_workspace(ctx, L.bytes);
+    if (rc != ECSIMD_HIP_OK) return rc;
+    L = gc_plan(ctx->workspace, n);
+    gc_safe_mult(ctx->stream, rec, L, L.adj1, L.neg1, k, nullptr, nullptr, L.gx, nullptr, n);        // x(k G): the negation of a degenerate nonce's product does not touch x
+    launch::ecdsa_sign_scalars(ctx->stream, rec.N, e, d, k, L.gx, r, s_, ok, n);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) err = hipMemsetAsync(ctx->workspace, 0, L.bytes, ctx->stream);              // the nonce's adjusted copy, the Jacobian k G and x: gone before the call returns
+    return err == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, err, "ecdsa_sign (registered curve) launch");
+  }
+  REQUIRE_CURVE();
   if (ctx->ref_square) return bad(ctx, "ecdsa_sign is not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT form");
   if (!(ECS_FIXED4_ODD && ECS_SIGNED_ODD)) return bad(ctx, "this build (-DECS_FIXED4_ODD=0 / -DECS_SIGNED_ODD=0) has no constant-time comb");
   if (overlaps(r, e) || overlaps(r, d) || overlaps(r, k) || overlaps(s_, e) || overlaps(s_, d) || overlaps(s_, k) || overlaps(r, s_)) return bad(ctx, "r and s must not alias an input or each other");

@@ -99,6 +99,90 @@ __global__ void __launch_bounds__(256) k_gc_to_affine_batched(gcurve G, const ui
     if (y != nullptr) fe_store(y, e, g_to_classical(gc_mul(fe_load(jy, e), gc_mul(iz2, iz, G), G), G.F));
   }
 }
+// Batched affine addition R = A + B (classical coordinates) for a registered curve: k_affine.inc k_affine_add_batched with the generic field -- one shared
+// inversion per lane's m elements; (0, 0) is the point at infinity; finite[i] = 0 marks an infinite sum.  Public data (signature verification).
+__global__ void __launch_bounds__(256) k_gc_affine_add_batched(gcurve G, const uint64_t* __restrict__ ax, const uint64_t* __restrict__ ay, const uint64_t* __restrict__ bx, const uint64_t* __restrict__ by,
+                                                               uint64_t* __restrict__ rx, uint64_t* __restrict__ ry, uint8_t* __restrict__ finite, size_t n, size_t lanes, int m) {
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= lanes) return;
+  const fe one = g_words(G.F.r);
+  auto ld = [&](const uint64_t* p, size_t e) { return g_from_classical(fe_load(p, e), G.F); };
+  fe acc = one;
+  for (int j = 0; j < m; ++j) {
+    const size_t e = (size_t)j * lanes + g;
+    if (e >= n) break;
+    const fe x1 = ld(ax, e), y1 = ld(ay, e), x2 = ld(bx, e), y2 = ld(by, e);
+    const bool inf1 = g_is_zero(x1) && g_is_zero(y1), inf2 = g_is_zero(x2) && g_is_zero(y2);
+    const bool same_x = fe_eq(x1, x2), same_y = fe_eq(y1, y2);
+    fe den = gc_sub(x2, x1, G);
+    if (same_x) den = gc_dbl(y1, G);
+    if (inf1 || inf2 || (same_x && !same_y) || g_is_zero(den)) den = one;
+    acc = gc_mul(acc, den, G);
+    fe_store(rx, e, acc);
+  }
+  fe inv = g_inverse_mgry(acc, G.F);
+  int last = m - 1;
+  while (last >= 0 && (size_t)last * lanes + g >= n) --last;
+  for (int j = last; j >= 0; --j) {
+    const size_t e = (size_t)j * lanes + g;
+    const fe x1 = ld(ax, e), y1 = ld(ay, e), x2 = ld(bx, e), y2 = ld(by, e);
+    const bool inf1 = g_is_zero(x1) && g_is_zero(y1), inf2 = g_is_zero(x2) && g_is_zero(y2);
+    const bool same_x = fe_eq(x1, x2), same_y = fe_eq(y1, y2);
+    fe den = gc_sub(x2, x1, G), num = gc_sub(y2, y1, G);
+    if (same_x) {                                              // tangent slope (3 x^2 + a) / (2 y)
+      den = gc_dbl(y1, G);
+      const fe xx = gc_sqr<false>(x1, G);
+      num = gc_add(gc_add(gc_dbl(xx, G), xx, G), g_words(G.am), G);
+    }
+    const bool no_slope = inf1 || inf2 || (same_x && !same_y) || g_is_zero(den);
+    if (no_slope) den = one;
+    const fe prev = (j > 0) ? fe_load(rx, (size_t)(j - 1) * lanes + g) : one;
+    const fe iden = gc_mul(inv, prev, G);
+    inv = gc_mul(inv, den, G);
+    const fe lam = gc_mul(num, iden, G);
+    fe x3 = gc_sub(gc_sub(gc_sqr<false>(lam, G), x1, G), x2, G);
+    fe y3 = gc_sub(gc_mul(lam, gc_sub(x1, x3, G), G), y1, G);
+    bool fin = true;
+    if (inf1) { x3 = x2; y3 = y2; fin = !inf2; }
+    else if (inf2) { x3 = x1; y3 = y1; }
+    else if (no_slope) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { x3.w[i] = 0; y3.w[i] = 0; }
+      fin = false;
+    }
+    fe_store(rx, e, g_to_classical(x3, G.F));
+    if (ry) fe_store(ry, e, g_to_classical(y3, G.F));
+    if (finite) finite[e] = (uint8_t)fin;
+  }
+}
+// ECDSA's acceptance test: ok = finite && x mod n == r, for x classical in [0, p) and p < 2n (checked by the caller: one conditional subtraction reduces x)
+__global__ void __launch_bounds__(BLOCK) k_gc_x_mod_n_equals(gmod N, const uint64_t* __restrict__ x, const uint8_t* __restrict__ finite, const uint64_t* __restrict__ r, uint8_t* __restrict__ ok, size_t n) {
+  GID; fe v = LD(x);
+  g_cond_sub(v, 0, N);
+  ok[i] = (uint8_t)(finite[i] != 0 && fe_eq(v, LD(r)));
+}
+// The reference's ladder (curve_group.h:189-218 as written) returns a meaningless point at three scalars: n - 1, 2^256 - n - 1 and 2^256 - n (the Joye ladder
+// keeps R0 + R1 = 2^i P and meets n P = infinity inside a formula).  ECDSA on a registered curve multiplies through that ladder, so a
+// scalar u < n that IS one of them is replaced by n - u here and the product's y negated afterwards (neg[i] = 1): u P = -((n - u) P).  The host has checked
+// at registration that n - u is not degenerate in turn.  Selects only: the scalar may be a nonce.
+__global__ void __launch_bounds__(BLOCK) k_gc_ladder_safe_scalars(gmod N, const uint64_t* __restrict__ u, uint64_t* __restrict__ adj, uint8_t* __restrict__ neg, size_t n) {
+  GID; const fe k = LD(u), order = g_words(N.p);
+  fe zero, one, nm1, c, cm1, alt;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { zero.w[j] = 0; one.w[j] = j == 0 ? 1u : 0u; }
+  (void)sub8_3(nm1, order, one); (void)sub8_3(c, zero, order); (void)sub8_3(cm1, c, one);
+  (void)sub8_3(alt, order, k);
+  const uint32_t bad = 0u - (uint32_t)((int)fe_eq(k, nm1) | (int)fe_eq(k, c) | (int)fe_eq(k, cm1));
+  ST(adj, fe_select(bad, alt, k));
+  neg[i] = (uint8_t)(bad & 1u);
+}
+// y -> p - y where neg[i] (classical coordinates; (0, 0), the point at infinity, stays (0, 0))
+__global__ void __launch_bounds__(BLOCK) k_gc_negate_where(gcurve G, const uint8_t* __restrict__ neg, uint64_t* __restrict__ y, size_t n) {
+  GID; const fe v = LD(y);
+  fe d; (void)sub8_3(d, g_words(G.F.p), v);
+  const uint32_t m = (0u - (uint32_t)(neg[i] != 0)) & ~g_zero_mask(v);
+  ST(y, fe_select(m, d, v));
+}
 #undef LD
 #undef ST
 }  // namespace
@@ -120,6 +204,16 @@ void gc_to_affine_batched(hipStream_t s, const gcurve& G, const uint64_t* jx, co
   const size_t lanes = (n + m - 1) / m;
   hipLaunchKernelGGL(k_gc_to_affine_batched, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, G, jx, jy, jz, x, y, n, lanes, (int)m);
 }
+void gc_affine_add_batched(hipStream_t s, const gcurve& G, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) {
+  size_t m = n >> 17; if (m < 1) m = 1; if (m > 128) m = 128;
+  const size_t lanes = (n + m - 1) / m;
+  hipLaunchKernelGGL(k_gc_affine_add_batched, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, G, ax, ay, bx, by, rx, ry, finite, n, lanes, (int)m);
+}
+void gc_x_mod_n_equals(hipStream_t s, const gmod& N, const uint64_t* x, const uint8_t* finite, const uint64_t* r, uint8_t* ok, size_t n) {
+  hipLaunchKernelGGL(k_gc_x_mod_n_equals, grid_for(n), dim3(BLOCK), 0, s, N, x, finite, r, ok, n); }
+void gc_ladder_safe_scalars(hipStream_t s, const gmod& N, const uint64_t* u, uint64_t* adj, uint8_t* neg, size_t n) {
+  hipLaunchKernelGGL(k_gc_ladder_safe_scalars, grid_for(n), dim3(BLOCK), 0, s, N, u, adj, neg, n); }
+void gc_negate_where(hipStream_t s, const gcurve& G, const uint8_t* neg, uint64_t* y, size_t n) { GO(k_gc_negate_where, neg, y, n); }
 #undef GO
 #undef GO_REF
 }  // namespace launch

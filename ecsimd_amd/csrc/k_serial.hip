@@ -10,6 +10,7 @@
 //    curve) or decompresses (y = sqrt(x^3 + a x + b), parity from the prefix) with a per-lane ok flag.
 #include "kernels.h"
 #include "point.cuh"
+#include "gcurve.cuh"
 
 namespace ecsimd_hip {
 namespace {
@@ -113,6 +114,33 @@ template <int C, int REC> __global__ void __launch_bounds__(BLOCK) k_sec1_decode
   fe_store(x, i, xv); fe_store(y, i, yv);
   if (ok) ok[i] = (uint8_t)good;
 }
+// The same for a curve registered at run time (round 5): the generic field, y^2 = x^3 + a x + b with the curve's own a, p = 3 mod 4 like every registered curve.
+template <int REC> __global__ void __launch_bounds__(BLOCK) k_gc_sec1_decode(gcurve G, const uint8_t* __restrict__ in, uint64_t* __restrict__ x, uint64_t* __restrict__ y, uint8_t* __restrict__ ok, size_t n) {
+  __shared__ uint32_t lds[rec_lds<REC>::DWORDS];
+  const size_t first = (size_t)blockIdx.x * BLOCK, i = first + threadIdx.x;
+  stage_in<REC>(lds, in, first, n);
+  if (i >= n) return;
+  const uint8_t* rec = reinterpret_cast<const uint8_t*>(lds) + threadIdx.x * REC;
+  const uint32_t prefix = rec[0];
+  const fe xv = load_be32(rec + 1), P = g_words(G.F.p);
+  const fe xm = g_from_classical(xv, G.F);
+  const fe rhs = gc_add(gc_add(gc_mul(gc_sqr<false>(xm, G), xm, G), gc_mul(g_words(G.am), xm, G), G), g_words(G.bm), G);
+  bool good = g_less(xv, P);
+  fe yv;
+  if constexpr (REC == 65) {
+    yv = load_be32(rec + 33);
+    good = good && prefix == 0x04 && g_less(yv, P) && fe_eq(gc_sqr<false>(g_from_classical(yv, G.F), G), rhs);
+  } else {
+    const fe s = g_pow<false>(rhs, G.F.psqrt, G.F);
+    good = good && (prefix == 0x02 || prefix == 0x03) && fe_eq(gc_sqr<false>(s, G), rhs);
+    yv = g_to_classical(s, G.F);
+    fe neg; (void)sub8_3(neg, P, yv);
+    const uint32_t flip = (0u - (uint32_t)((yv.w[0] & 1u) != (prefix & 1u))) & ~g_zero_mask(yv);      // p - y (0 stays 0)
+    yv = fe_select(flip, neg, yv);
+  }
+  fe_store(x, i, xv); fe_store(y, i, yv);
+  if (ok) ok[i] = (uint8_t)good;
+}
 // Public-key validation (SEC 1 section 3.2.2.1 without the subgroup step: both curves have cofactor 1): ok[i] = x, y < p and
 // y^2 = x^3 + a x + b.  (0, 0) -- this library's encoding of the point at infinity -- fails the equation (b != 0).
 template <int C> __global__ void __launch_bounds__(BLOCK) k_on_curve(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, uint8_t* __restrict__ ok, size_t n) {
@@ -148,6 +176,9 @@ void mask_bit(hipStream_t s, const uint64_t* a, int bit, uint8_t* flag, size_t n
 void sec1_encode(hipStream_t s, int curve, const uint64_t* x, const uint64_t* y, uint8_t* out, size_t n, bool compressed) {
   if (curve == CURVE_P256) { if (compressed) GO((k_sec1_encode<CURVE_P256, 33>), x, y, out, n); else GO((k_sec1_encode<CURVE_P256, 65>), x, y, out, n); }
   else { if (compressed) GO((k_sec1_encode<CURVE_SECP256K1, 33>), x, y, out, n); else GO((k_sec1_encode<CURVE_SECP256K1, 65>), x, y, out, n); }
+}
+void gc_sec1_decode(hipStream_t s, const gcurve& G, const uint8_t* in, uint64_t* x, uint64_t* y, uint8_t* ok, size_t n, bool compressed) {
+  if (compressed) GO((k_gc_sec1_decode<33>), G, in, x, y, ok, n); else GO((k_gc_sec1_decode<65>), G, in, x, y, ok, n);
 }
 void sec1_decode(hipStream_t s, int curve, const uint8_t* in, uint64_t* x, uint64_t* y, uint8_t* ok, size_t n, bool compressed) {
   if (curve == CURVE_P256) { if (compressed) GO((k_sec1_decode<CURVE_P256, 33>), in, x, y, ok, n); else GO((k_sec1_decode<CURVE_P256, 65>), in, x, y, ok, n); }

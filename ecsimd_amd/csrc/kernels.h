@@ -78,6 +78,12 @@ void gc_zdau(hipStream_t, const gcurve&, const uint64_t* px, const uint64_t* py,
 void gc_add_z2_1(hipStream_t, const gcurve&, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n, bool ref);
 void gc_trplu(hipStream_t, const gcurve&, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n, bool ref);
 void gc_scalar_mult(hipStream_t, const gcurve&, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
+// ... and what ECDSA on a registered curve needs on top (public-data affine addition, the acceptance test, the ladder's three degenerate scalars worked around)
+void gc_affine_add_batched(hipStream_t, const gcurve&, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
+void gc_x_mod_n_equals(hipStream_t, const gmod& order, const uint64_t* x, const uint8_t* finite, const uint64_t* r, uint8_t* ok, size_t n);
+void gc_ladder_safe_scalars(hipStream_t, const gmod& order, const uint64_t* u, uint64_t* adj, uint8_t* neg, size_t n);
+void gc_negate_where(hipStream_t, const gcurve&, const uint8_t* neg, uint64_t* y, size_t n);
+void gc_sec1_decode(hipStream_t, const gcurve&, const uint8_t* in, uint64_t* x, uint64_t* y, uint8_t* ok, size_t n, bool compressed);
 void gc_zdau_repeat(hipStream_t, const gcurve&, const uint64_t* px, const uint64_t* py, const uint64_t* pz, const uint64_t* qx, const uint64_t* qy,
                     uint64_t* rx, uint64_t* ry, uint64_t* sx, uint64_t* sy, uint64_t* oz, size_t n, int iters, uint64_t swap_bits, int radix);
 

@@ -18,7 +18,7 @@ namespace detail {
 using p256_prime = bn256_constant<0xffffffff00000001ull, 0x0000000000000000ull, 0x00000000ffffffffull, 0xffffffffffffffffull>;
 using secp256k1_prime = bn256_constant<0xffffffffffffffffull, 0xffffffffffffffffull, 0xffffffffffffffffull, 0xfffffffefffffc2full>;
 }
-// engine curve id of one of the two built-in primes (the SEC1 codecs, ECDSA and the table-driven algorithms exist for those curves only)
+// engine curve id of one of the two built-in primes (the table-driven algorithms exist for those curves only)
 template <class P> constexpr int hip_curve_id() {
   if (P::value == detail::p256_prime::value) return ECSIMD_HIP_P256;
   if (P::value == detail::secp256k1_prime::value) return ECSIMD_HIP_SECP256K1;
@@ -26,12 +26,15 @@ template <class P> constexpr int hip_curve_id() {
 }
 // Engine curve id of ANY curve type with bn_type, P, A, B, Gx, Gy (the reference's concept, curve.h:12-15; p = 3 mod 4 as its GFp needs, gfp.h:84):
 // curve_nist_p256 / curve_secp256k1 get their special-form kernels (ids 0 / 1), every other Curve is registered on first use
-// (ecsimd_hip_register_curve: host arithmetic only, once per type) and runs on the generic kernels -- points, co-Z formulas, the ladder.
+// (ecsimd_hip_register_curve: host arithmetic only, once per type) and runs on the generic kernels -- points, co-Z formulas, the ladder.  A Curve that
+// also names its group order (`using N = ...`, which the reference's concept does not have) gets double_scalar_mult and ECDSA on top of that ladder.
 template <class Curve> inline int hip_curve_id_of() {
   static const int id = [] {
     int cid = -1;
+    const uint64_t* order = nullptr;
+    if constexpr (requires { Curve::N::value; }) order = Curve::N::value.limbs.data();
     hip::check(ecsimd_hip_register_curve(Curve::P::value.limbs.data(), Curve::A::value.limbs.data(), Curve::B::value.limbs.data(), Curve::Gx::value.limbs.data(),
-                                         Curve::Gy::value.limbs.data(), nullptr, 0, &cid), "ecsimd_hip_register_curve");
+                                         Curve::Gy::value.limbs.data(), order, 0, &cid), "ecsimd_hip_register_curve");
     return cid;
   }();
   return id;

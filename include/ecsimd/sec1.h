@@ -31,7 +31,7 @@ inline std::vector<uint8_t> wide_to_bytes_BE(wide_bignum<bignum_256> const& v) {
 }
 template <class Curve> std::vector<uint8_t> sec1_encode(wide_curve_point<Curve> const& pts, bool compressed) {
   const size_t rec = compressed ? 33 : 65; detail::dev_bytes d(pts.size() * rec); std::vector<uint8_t> out(pts.size() * rec);
-  hip::check(ecsimd_hip_sec1_encode(hip::context(), hip_curve_id<typename Curve::P>(), pts.x().data(), pts.y().data(), d.p, pts.size(), compressed), "ecsimd_hip_sec1_encode");
+  hip::check(ecsimd_hip_sec1_encode(hip::context(), hip_curve_id_of<Curve>(), pts.x().data(), pts.y().data(), d.p, pts.size(), compressed), "ecsimd_hip_sec1_encode");
   hip::check(ecsimd_hip_memcpy_d2h(hip::context(), out.data(), d.p, out.size()), "d2h"); return out;
 }
 template <class Curve> wide_curve_point<Curve> sec1_decode(std::vector<uint8_t> const& bytes, bool compressed, hip::mask& ok) {
@@ -39,7 +39,7 @@ template <class Curve> wide_curve_point<Curve> sec1_decode(std::vector<uint8_t> 
   hip::check(ecsimd_hip_memcpy_h2d(hip::context(), d.p, bytes.data(), bytes.size()), "h2d");
   using WBN = typename wide_curve_point<Curve>::WBN;
   auto x = WBN::uninitialized(n), y = WBN::uninitialized(n); ok = hip::mask(n);
-  hip::check(ecsimd_hip_sec1_decode(hip::context(), hip_curve_id<typename Curve::P>(), d.p, x.data(), y.data(), ok.data(), n, compressed), "ecsimd_hip_sec1_decode");
+  hip::check(ecsimd_hip_sec1_decode(hip::context(), hip_curve_id_of<Curve>(), d.p, x.data(), y.data(), ok.data(), n, compressed), "ecsimd_hip_sec1_decode");
   hip::sync(); return {x, y};
 }
 }  // namespace ecsimd

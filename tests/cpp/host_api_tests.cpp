@@ -418,6 +418,51 @@ TEST(Curves, AnyCurveThroughCurveGroup) {
   EXPECT_TRUE(J.x().wbn().get(17) == J1.x().wbn().get(0) && J.z().wbn().get(17) == J1.z().wbn().get(n - 1));
 }
 
+// The first application on such a curve: a Curve type that also names its order n gets u1 G + u2 Q, ECDSA and the SEC1 codecs on top of the reference's
+// ladder (no window tables exist for a registered curve).  Expected values: textbook affine arithmetic on Python integers (tests/test_gpu_curves.py's model).
+struct curve_brainpoolp256r1_n : curve_brainpoolp256r1 {
+  using N = bn256_constant<0xa9fb57dba1eea9bcull, 0x3e660a909d838d71ull, 0x8c397aa3b561a6f7ull, 0x901e0e82974856a7ull>;
+};
+struct curve_sm2_no_order {
+  using bn_type = bignum_256;
+  using P  = bn256_constant<0xfffffffeffffffffull, 0xffffffffffffffffull, 0xffffffff00000000ull, 0xffffffffffffffffull>;
+  using A  = bn256_constant<0xfffffffeffffffffull, 0xffffffffffffffffull, 0xffffffff00000000ull, 0xfffffffffffffffcull>;
+  using B  = bn256_constant<0x28e9fa9e9d9f5e34ull, 0x4d5a9e4bcf6509a7ull, 0xf39789f515ab8f92ull, 0xddbcbd414d940e93ull>;
+  using Gx = bn256_constant<0x32c4ae2c1f198119ull, 0x5f9904466a39c994ull, 0x8fe30bbff2660be1ull, 0x715a4589334c74c7ull>;
+  using Gy = bn256_constant<0xbc3736a2f4f6779cull, 0x59bdcee36b692153ull, 0xd0a9877cc62a4740ull, 0x02df32e52139f0a0ull>;
+};
+TEST(Curves, EcdsaAndSec1OnARegisteredCurve) {
+  using K = curve_brainpoolp256r1_n; using KG = curve_group<K>; using WCP = wide_curve_point<K>;
+  EXPECT_TRUE(KG::curve_id() == curve_group<curve_brainpoolp256r1>::curve_id());                 // the same curve: the order is additional knowledge about it
+  const auto e = "AF2BDBE1AA9B6EC1E2ADE1D694F41FC71A831D0268E9891562113D8A62ADD1BF"_hex, d = "0bc1b1f28709decb543d9677d2cc9942348f6b984deff409430740942ff38827"_hex;
+  const auto k1 = "0a891cecc2bf13b0aca744434a9c9f4bd7bf5c8ed86e2f76e7df72bad813bd80"_hex, k2 = "a9fb57dba1eea9bc3e660a909d838d718c397aa3b561a6f7901e0e82974856a6"_hex;   // k2 = n - 1: the ladder alone is wrong there
+  const auto zero = "0000000000000000000000000000000000000000000000000000000000000000"_hex;
+  hip::mask signed_ok;
+  const auto sig = KG::ecdsa_sign(splat<W256>(e), splat<W256>(d), lanes<W256>(k1, k2, zero, k1), signed_ok);
+  const auto so = signed_ok.host();
+  EXPECT_TRUE(so[0] == 1 && so[1] == 1 && so[2] == 0 && so[3] == 1);
+  EXPECT_TRUE(sig.first.get(0) == bn_from_bytes_BE<bignum_256>("9bcd00f871cc765404f41bcce735aa940d55eb38974f2227e6244a3552d17020"_hex));
+  EXPECT_TRUE(sig.second.get(0) == bn_from_bytes_BE<bignum_256>("1e00473ff879c5454c3e134bb3efb639303ee530dc5a62d255c95c8a8c1fec63"_hex));
+  EXPECT_TRUE(sig.first.get(1) == bn_from_bytes_BE<bignum_256>("8bd2aeb9cb7e57cb2c4b482ffc81b7afb9de27e1e3bd23c23a4453bd9ace3262"_hex));   // x(-G) = x(G)
+  EXPECT_TRUE(sig.second.get(1) == bn_from_bytes_BE<bignum_256>("620eb7b2e74ab24a7e468eb910295d5d45c8bcfe966b106b265cf33a2c88b80a"_hex));
+  const WCP Q{splat<W256>("9531554560f0e4bb5bac426b8e8001bf95592d3b79d265bda2b1de28a474579a"_hex), splat<W256>("35b9ac2a8a75dfdce0eb7aa0127d8b244cf315c89f0c2c04409d2caf717f9798"_hex)};
+  const auto ok = KG::ecdsa_verify(splat<W256>(e), sig.first, sig.second, Q).host();
+  EXPECT_TRUE(ok[0] == 1 && ok[1] == 1 && ok[2] == 0 && ok[3] == 1);
+  EXPECT_TRUE(KG::ecdsa_verify(splat<W256>(d), sig.first, sig.second, Q).count() == 0);            // another message
+  hip::mask fin;
+  const auto sum = KG::double_scalar_mult(lanes<W256>(k2, zero, k1, k1), lanes<W256>(zero, k2, zero, zero), Q, fin);   // (n - 1) G = -G; (n - 1) Q = -Q
+  const auto fh = fin.host();
+  EXPECT_TRUE(fh[0] == 1 && fh[1] == 1 && sum.x().get(0) == K::Gx::value && sum.x().get(1) == Q.x().get(1) && !(sum.y().get(0) == K::Gy::value));
+  hip::mask dec_ok;
+  const auto back = sec1_decode<K>(sec1_encode<K>(Q, true), true, dec_ok);                        // compressed: the square root with THIS curve's a and b
+  EXPECT_TRUE(dec_ok.count() == 4 && all(back == Q));
+  // the curve WITHOUT its order has the reference's layers only
+  bool refused = false;
+  try { (void)curve_group<curve_sm2_no_order>::ecdsa_verify(splat<W256>(e), sig.first, sig.second, wide_curve_point<curve_sm2_no_order>{splat<W256>(e), splat<W256>(e)}); }
+  catch (std::exception const&) { refused = true; }
+  EXPECT_TRUE(refused);
+}
+
 // The curve structs' constants equal the engine's own table (ecsimd_hip_get_constant: 0 p, 1 a, 2 b, 3 Gx, 4 Gy) and
 // the hexadecimal literals of the standards documents.
 template <class K> static void constants_match_engine() {

@@ -170,6 +170,9 @@ def test_curve_registry_without_a_gpu(lib, oracle):
     for b in bad:
         with pytest.raises(EcsimdHipError):
             register_curve(b["p"], b["a"], b["b"], b["gx"], b["gy"], b.get("n"))
+    # the order is additional knowledge about the same curve: a later registration may supply it (C++: a Curve type with `using N`), never contradict it
+    with pytest.raises(EcsimdHipError):
+        register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"] + 2)
     cid = C.c_int()
     assert lib.ecsimd_hip_register_curve(None, None, None, None, None, None, C.c_int(0), C.byref(cid)) == -1
     assert lib.ecsimd_hip_get_constant(C.c_int(FIRST_REGISTERED_CURVE + 4000), C.c_int(0), (C.c_uint64 * 4)()) == -1

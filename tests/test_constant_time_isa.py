@@ -241,3 +241,24 @@ def test_the_secret_flow_analysis_refuses_planted_leaks(gfield_asm):
     # a conditional MOVE under a secret lane mask is what field.cuh does on purpose: allowed
     ok = [f"\tv_cmp_ne_u32_e32 vcc, 0, {v}", "\ts_and_saveexec_b64 s[90:91], vcc", "\tv_mov_b32_e32 v252, 0", "\ts_mov_b64 exec, s[90:91]"]
     ct_check.check_secret_flow("\n".join(lines[:at] + ok + lines[at:]), "k_ecdsa_sign_scalars", secret_args=[2, 3, 6])
+
+
+# ---- the ladder of a curve registered at run time (round 5): the same two checks as the built-in ladders -- ECDSA signing on such a curve puts a nonce through it
+@pytest.fixture(scope="module")
+def gladder_asm(tmp_path_factory):
+    return assembly(tmp_path_factory, "k_gladder")
+
+
+@pytest.mark.parametrize("kernel", ["16k_gc_scalar_multILi29ELb0E", "16k_gc_scalar_multILi32ELb0E", "16k_gc_scalar_multILi32ELb1E"])
+def test_registered_curve_ladder_is_constant_time(gladder_asm, kernel):
+    rep = ct_check.check(gladder_asm, kernel)
+    assert rep["instructions"] > 3400 and len(rep["branches"]) in (2, 3) and len(rep["global_loads"]) == 1
+    assert all(re.match(r"s_cmpk?_(lg|eq)_[iu]32 s\d+, (0x101|0x100|0) ; s_cbranch_scc[01] ", b) for b in rep["branches"]), rep["branches"]
+    flow = ct_check.check_secret_flow(gladder_asm, kernel, secret_args=[1])            # (gcurve, k, ...): the scalar
+    assert flow["secret_loads"] >= 1 and not flow["secret_lds"]
+
+
+def test_registered_curve_signing_helpers_under_the_secret_flow_analysis(tmp_path_factory):
+    asm = assembly(tmp_path_factory, "k_gcurve")
+    assert ct_check.check_secret_flow(asm, "k_gc_ladder_safe_scalars", secret_args=[1, 2, 3])["secret_loads"] >= 1     # the nonce, its adjusted copy, the negation flag
+    assert ct_check.check_secret_flow(asm, "k_gc_to_affine_batched", secret_args=[1, 2, 3, 4, 5])["secret_loads"] >= 6   # the Jacobian k G

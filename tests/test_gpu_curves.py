@@ -207,8 +207,8 @@ def test_builtin_curves_through_the_generic_kernels_equal_the_special_form_kerne
 
 
 def test_registered_curve_entry_points_that_do_not_exist_say_so(engine, oracle):
-    """The table-driven algorithms, the SEC1 codecs and ECDSA exist for the two built-in curves: a registered curve id is refused there (BAD_ARG with a
-    message), never silently served by some other curve's kernels."""
+    """The table-driven ALG_* algorithms exist for the two built-in curves: a registered curve id is refused there (BAD_ARG with a message), never silently
+    served by some other curve's kernels; ECDSA on a registered curve needs the group order it was registered with."""
     c = REF_CURVES["brainpoolP256r1"]
     cid = register(c)
     from ecsimd_amd import ALG_WINDOWED, ALG_CONSTANT_TIME, EcsimdHipError
@@ -220,8 +220,145 @@ def test_registered_curve_entry_points_that_do_not_exist_say_so(engine, oracle):
         with pytest.raises(EcsimdHipError, match="ladder only"):
             engine.scalar_mult_base(cid, k, flags=fl)
     with pytest.raises(EcsimdHipError):
-        engine.double_scalar_mult(cid, k, k, bx, by)
-    with pytest.raises(EcsimdHipError):
-        engine.ecdsa_verify(cid, k, k, k, bx, by)
-    with pytest.raises(EcsimdHipError):
         engine.scalar_mult_base(0x10000 + 4000, k)                       # no such curve
+    # ECDSA needs the group order: the same curve registered WITHOUT n (a different record is impossible -- the parameters are the key -- so: another curve)
+    from ecsimd_amd.engine import register_curve
+    c2 = REF_CURVES["sm2"]
+    # (registered with n elsewhere in this process or not, a curve id without an order must refuse; a fresh curve: y^2 = x^3 + a x + b' through another point)
+    p_ = c2["p"]; gx2 = 5; rhs = None
+    for gx2 in range(5, 200):
+        rhs = (gx2 ** 3 + c2["a"] * gx2 + c2["b"]) % p_
+        gy2 = pow(rhs, (p_ + 1) // 4, p_)
+        if gy2 * gy2 % p_ == rhs:
+            break
+    noorder = register_curve(p_, c2["a"], c2["b"], gx2, gy2)              # SM2's curve with another base point and no order
+    with pytest.raises(EcsimdHipError, match="group order"):
+        engine.ecdsa_verify(noorder, k, k, k, bx, by)
+    with pytest.raises(EcsimdHipError, match="group order"):
+        engine.ecdsa_sign(noorder, k, k, k)
+
+
+# ---------------------------------------------------------------- the first application on a registered curve: ECDSA, u1 G + u2 Q, SEC1 (round 5)
+def _affine_model(c):
+    """Textbook affine arithmetic on Python integers for the curve c (None = infinity): the third opinion next to the oracle and the reference."""
+    p, a = c["p"], c["a"]
+
+    def add(P, Q):
+        if P is None: return Q
+        if Q is None: return P
+        (x1, y1), (x2, y2) = P, Q
+        if x1 == x2:
+            if (y1 + y2) % p == 0: return None
+            lam = (3 * x1 * x1 + a) * pow(2 * y1, -1, p) % p
+        else:
+            lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (lam * lam - x1 - x2) % p
+        return x3, (lam * (x1 - x3) - y1) % p
+
+    def mul(k, P):
+        R = None
+        for bit in bin(k)[2:] if k else "":
+            R = add(R, R)
+            if bit == "1": R = add(R, P)
+        return R
+    return add, mul
+
+
+@pytest.mark.parametrize("name", list(REF_CURVES))
+def test_ecdsa_and_double_scalar_mult_on_a_registered_curve(engine, name):
+    """ecsimd_hip_ecdsa_sign / _verify / double_scalar_mult / affine_add with a registered curve id: two passes of the reference's ladder (the scalars kept clear of
+    its three degenerate values by k_gc_ladder_safe_scalars), one shared inversion each, a batched affine addition, the arithmetic modulo the curve's own n.
+    Against textbook affine arithmetic on Python integers: signatures from (e, d, k) incl. the nonces at which the ladder alone is wrong (n - 1, 2^256 - n,
+    2^256 - n - 1), u1 G + u2 Q incl. those scalars, Q = +-G (tangent, infinity); a 2^14 sign -> verify round trip; every input tampered in turn."""
+    c = REF_CURVES[name]
+    cid = register(c)
+    p, n_, G = c["p"], c["n"], (c["gx"], c["gy"])
+    add, mul = _affine_model(c)
+    up = engine.to_device
+    rng = np.random.default_rng(sum(name.encode()) + 5)
+    rnd = lambda: int.from_bytes(rng.bytes(32), "big") % (n_ - 1) + 1
+    special = [k for k in (n_ - 1, 2**256 - n_, 2**256 - n_ - 1, 1, 2, n_ - 2) if 0 < k < n_]
+    m = 40
+    d = [rnd() for _ in range(m)]; k = special + [rnd() for _ in range(m - len(special))]; e = [int.from_bytes(rng.bytes(32), "big") for _ in range(m)]
+    r_, s_, ok = (engine.to_numpy(t) for t in engine.ecdsa_sign(cid, up(ints_to_arr(e)), up(ints_to_arr(d)), up(ints_to_arr(k))))
+    Q = [mul(di, G) for di in d]
+    for i in range(m):
+        rr = mul(k[i], G)[0] % n_
+        ss = pow(k[i], -1, n_) * (e[i] + rr * d[i]) % n_
+        assert ok[i] == 1 and (to_int(r_[i]), to_int(s_[i])) == (rr, ss), (name, i, hex(k[i]))
+    qx, qy = up(ints_to_arr([q[0] for q in Q])), up(ints_to_arr([q[1] for q in Q]))
+    assert engine.to_numpy(engine.ecdsa_verify(cid, up(ints_to_arr(e)), up(r_), up(s_), qx, qy)).all()
+    # u1 G + u2 Q on scalars the ladder alone gets wrong, and on sums that are tangents or infinity
+    u1 = special + [5, 7, 0, 9] + [rnd() for _ in range(8)]
+    u2 = [3] * len(special) + [n_ - 5, 7, 4, 0] + special[:2] + [rnd() for _ in range(6)]
+    Qs = [Q[i] for i in range(len(special))] + [G, G, G, G] + [Q[20 + i] for i in range(8)]
+    mm = len(u1)
+    rx, ry, fin = (engine.to_numpy(t) for t in engine.double_scalar_mult(cid, up(ints_to_arr(u1)), up(ints_to_arr(u2[:mm])), up(ints_to_arr([q[0] for q in Qs])), up(ints_to_arr([q[1] for q in Qs]))))
+    for i in range(mm):
+        want = add(mul(u1[i], G), mul(u2[i], Qs[i]))
+        assert (bool(fin[i]), (to_int(rx[i]), to_int(ry[i]))) == ((want is not None), want if want is not None else (0, 0)), (name, i)
+    sx, sy, sf = (engine.to_numpy(t) for t in engine.affine_add(cid, (qx[:8].contiguous(), qy[:8].contiguous()), (qx[:8].contiguous(), qy[:8].contiguous())))
+    assert all((to_int(sx[i]), to_int(sy[i])) == add(Q[i], Q[i]) and sf[i] == 1 for i in range(8))
+    # a larger round trip, then every input tampered in turn
+    N = 1 << 14
+    tile = lambda v: np.tile(ints_to_arr(v), ((N + len(v) - 1) // len(v), 1))[:N].copy()
+    dd = tile(d); kk = engine.to_numpy(engine.fill_random(N, SEED, 90)); kk[:, 3] >>= np.uint64(2); ee = engine.to_numpy(engine.fill_random(N, SEED, 91))
+    R, S, OK = engine.ecdsa_sign(cid, up(ee), up(dd), up(kk))
+    assert bool(OK.all())
+    QX, QY = up(tile([q[0] for q in Q])), up(tile([q[1] for q in Q]))
+    assert bool(engine.ecdsa_verify(cid, up(ee), R, S, QX, QY).all())
+    bad_e = ee.copy(); bad_e[:, 0] ^= np.uint64(1)
+    assert not engine.to_numpy(engine.ecdsa_verify(cid, up(bad_e), R, S, QX, QY)).any()
+    Rn, Sn = engine.to_numpy(R).copy(), engine.to_numpy(S).copy()
+    t = Rn.copy(); t[:, 0] ^= np.uint64(2)
+    assert not engine.to_numpy(engine.ecdsa_verify(cid, up(ee), up(t), S, QX, QY)).any()
+    t = Sn.copy(); t[:, 1] ^= np.uint64(4)
+    assert not engine.to_numpy(engine.ecdsa_verify(cid, up(ee), R, up(t), QX, QY)).any()
+    assert not engine.to_numpy(engine.ecdsa_verify(cid, up(ee), R, S, up(np.roll(engine.to_numpy(QX), 1, axis=0)), up(np.roll(engine.to_numpy(QY), 1, axis=0))))[:len(d)].all()
+    zero = np.zeros_like(Rn); order = np.tile(from_int(n_), (N, 1))
+    for rr, ss in ((zero, Sn), (Rn, zero), (order, Sn), (Rn, order)):
+        assert not engine.to_numpy(engine.ecdsa_verify(cid, up(ee), up(rr), up(ss), QX, QY)).any()
+    offx = engine.to_numpy(QX).copy(); offx[:, 0] ^= np.uint64(1)                                   # off the curve (or another point: either way no valid signature)
+    assert not engine.to_numpy(engine.ecdsa_verify(cid, up(ee), R, S, up(offx), QY)).any()
+    assert not engine.to_numpy(engine.ecdsa_verify(cid, up(ee), R, S, up(zero), up(zero))).any()     # Q = (0, 0): the point at infinity
+    low_s = ints_to_arr([(n_ - to_int(v)) for v in Sn[:64]])                                        # (r, n - s) verifies too: ECDSA's malleability, as on the built-in curves
+    assert engine.to_numpy(engine.ecdsa_verify(cid, up(ee[:64].copy()), up(Rn[:64].copy()), up(low_s), QX[:64].contiguous(), QY[:64].contiguous())).all()
+    engine.ecdsa_sign(cid, up(ee[:4096].copy()), up(dd[:4096].copy()), up(kk[:4096].copy()))          # nothing nonce-derived stays behind a signing call
+    assert not engine.workspace_bytes()[:9 * 4096 * 32 + 2 * 4096].any()                             # capi.hip gc_plan: adjusted nonce, Jacobian k G, affine x, the flags
+
+
+@pytest.mark.parametrize("name", list(REF_CURVES))
+def test_sec1_codecs_on_a_registered_curve(engine, oracle, name):
+    """SEC 1 2.3.3 / 2.3.4 on a registered curve: uncompressed and compressed round trips of 4 099 lane-distinct points, the square-root branch with the
+    curve's own a, per-lane validity (x >= p, x not on the curve, a wrong prefix, y off by one)."""
+    c = REF_CURVES[name]
+    cid, oid = ids(oracle, c)
+    n = 4099
+    s = engine.fill_random(n, SEED, 77)
+    x, y = engine.scalar_mult_base(cid, s, flags=OUT_AFFINE)
+    for compressed in (False, True):
+        rec = engine.sec1_encode(cid, x, y, compressed)
+        dx, dy, ok = engine.sec1_decode(cid, rec, compressed)
+        assert bool(ok.all()) and np.array_equal(engine.to_numpy(dx), engine.to_numpy(x)) and np.array_equal(engine.to_numpy(dy), engine.to_numpy(y)), (name, compressed)
+    rec = engine.sec1_encode(cid, x, y, True).cpu().numpy().copy()
+    yo, oko = oracle.compute_y(oid, engine.to_numpy(x))
+    assert oko.all()
+    rec[0, 0] = 0x05                                                       # a prefix that is none
+    rec[1, 1:] = np.frombuffer((c["p"] + 1).to_bytes(32, "big"), dtype=np.uint8) if c["p"] + 1 < 2**256 else rec[1, 1:]        # x >= p
+    xs = engine.to_numpy(x)
+    bump = 2
+    while True:                                                             # an x with no point on the curve
+        xv = (to_int(xs[2]) + bump) % c["p"]; rhs = (xv ** 3 + c["a"] * xv + c["b"]) % c["p"]
+        if pow(rhs, (c["p"] - 1) // 2, c["p"]) != 1:
+            break
+        bump += 1
+    rec[2, 1:] = np.frombuffer(xv.to_bytes(32, "big"), dtype=np.uint8)
+    import torch
+    _, _, ok = engine.sec1_decode(cid, torch.from_numpy(rec).to(engine.tdev), True)
+    okn = engine.to_numpy(ok)
+    assert not okn[:3].any() and okn[3:].all()
+    full = engine.sec1_encode(cid, x, y, False).cpu().numpy().copy()
+    full[5, 64] ^= 1                                                        # y off by one
+    _, _, ok = engine.sec1_decode(cid, torch.from_numpy(full).to(engine.tdev), False)
+    okn = engine.to_numpy(ok)
+    assert okn[5] == 0 and okn[:5].all() and okn[6:].all()

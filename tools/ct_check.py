@@ -473,16 +473,28 @@ def check_secret_flow(text, want, secret_args, public_loads_from=()):
                 if S in addr:
                     bad("the address")
                 continue
-            if op.startswith("scratch_load"):
-                if S in frozenset().union(*[tags(r) for o in ops[1:] for r in _operand_regs(o)]):
+            if op.startswith("scratch_load") or op.startswith("scratch_store"):
+                # spill slots are constant-addressed (`off ... offset:N`): tracked per dword, so that a spilled POINTER does not inherit the taint of a
+                # spilled field word (k_gc_scalar_mult<32, *> spills both); any other addressing form falls back to one location for all of scratch
+                addr_ops = ops[1:] if op.startswith("scratch_load") else [ops[0]] + ops[2:]
+                if S in frozenset().union(*[tags(r) for o in addr_ops for r in _operand_regs(o)]):
                     bad("the address")
-                for r in dst:
-                    st[r] = tags("scratch")
-                continue
-            if op.startswith("scratch_store"):
-                if S in frozenset().union(*[tags(r) for o in [ops[0]] + ops[2:] for r in _operand_regs(o)]):
-                    bad("the address")
-                st["scratch"] = tags("scratch") | frozenset().union(*[tags(r) for r in _operand_regs(ops[1])])
+                mo = re.search(r"offset:(\d+)", inst)
+                mw = re.search(r"dwordx(\d)", op)
+                width = int(mw.group(1)) if mw else 1
+                constant = all(o.split()[0] == "off" or re.fullmatch(r"s\d+", o.split()[0]) for o in addr_ops)
+                slots = [f"scratch@{(int(mo.group(1)) if mo else 0) + 4 * j}" for j in range(width)] if constant else None
+                if op.startswith("scratch_load"):
+                    for j, r in enumerate(dst):
+                        st[r] = tags("scratch") | (tags(slots[j]) if slots and j < len(slots) else frozenset())
+                else:
+                    data = _operand_regs(ops[1])
+                    if slots:
+                        for j, r in enumerate(data):
+                            if j < len(slots):
+                                st[slots[j]] = tags(r)
+                    else:
+                        st["scratch"] = tags("scratch") | frozenset().union(*[tags(r) for r in data])
                 continue
             if op.startswith("ds_read") or op.startswith("ds_load"):
                 if S in frozenset().union(*[tags(r) for r in _operand_regs(ops[1])]):
@@ -585,7 +597,7 @@ def check_secret_flow(text, want, secret_args, public_loads_from=()):
             raise Violation("the analysis did not converge")
     for n in range(len(blocks)):
         o = transfer(n, join([outs[m] for m in preds[n] if outs[m] is not None]), True)
-        report["secret_scratch"] |= S in o.get("scratch", frozenset())
+        report["secret_scratch"] |= any(S in t_ for k_, t_ in o.items() if isinstance(k_, str) and k_.startswith("scratch"))
         report["secret_lds"] |= S in o.get("lds", frozenset())
     if report["secret_loads"] == 0:
         raise Violation("no load through a secret pointer was found: the analysis did not see the secrets")
