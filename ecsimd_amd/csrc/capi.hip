@@ -84,6 +84,7 @@ struct ecsimd_hip_ctx {
   uint8_t* valid;              // grow-only: per-lane public-key validity of double_scalar_mult / ecdsa_verify_rx
   size_t valid_bytes;
   int ref_square;              // ecsimd_hip_set_ref_square_compat: the reference's square() as written (mul.h:160-212)
+  std::vector<std::pair<int, uint32_t*>> gcomb;   // per registered curve: the 4-bit odd-digit table of multiples of its generator (k_gcomb.hip; built on first use)
   char err[256];
 };
 
@@ -337,11 +338,14 @@ int run_ladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, 
 bool lookup_curve(int id, gcurve* out);          // the curve registry, below
 // The same for a curve registered at run time: flags BASE_* | OUT_* | LADDER_RADIX32 | REF_SQUARE_COMPAT; the table-driven ALG_* algorithms exist for the
 // two built-in curves only.  x == nullptr: the curve's generator.
+int run_gcomb(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, size_t n, int flags);
 int run_gladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y,
                 uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   gcurve GC; if (!lookup_curve(curve, &GC)) return bad(ctx, "unknown curve id");
+  if (x == nullptr && k_stride == 4 && (flags & ECSIMD_HIP_ALG_WINDOWED) && !(flags & (ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM)))
+    return run_gcomb(ctx, curve, k, ox, oy, n, flags);          // k G from the generator's table in LDS (k_gcomb.hip)
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM | ECSIMD_HIP_ALG_CONSTANT_TIME))
-    return bad(ctx, "a registered curve has the reference's ladder only (the ALG_* tables exist for P-256 and secp256k1)");
+    return bad(ctx, "a registered curve has the reference's ladder only (and ALG_WINDOWED [| ALG_CONSTANT_TIME] for its generator): the other ALG_* tables exist for P-256 and secp256k1");
   if (n == 0) return ECSIMD_HIP_OK;
   if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
   hipError_t e = hipSetDevice(ctx->device);
@@ -569,6 +573,7 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->sink);
   (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->windowct_table[0]); (void)hipFree(ctx->windowct_table[1]); (void)hipFree(ctx->window16_table[0]); (void)hipFree(ctx->window16_table[1]); (void)hipFree(ctx->workspace); (void)hipFree(ctx->valid); (void)hipFree(ctx->base_special[0]); (void)hipFree(ctx->base_special[1]);
+  for (auto& t : ctx->gcomb) (void)hipFree(t.second);
   (void)hipEventDestroy(ctx->handoff);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -1092,6 +1097,92 @@ gc_layout gc_plan(uint64_t* base, size_t n) {
   L.bytes = 9 * L.chunk * 32 + 2 * (((L.chunk + 15) / 16) * 16);
   return L;
 }
+// The comb of a registered curve (k_gcomb.hip): 64 windows x 8 odd multiples (2d + 1) 16^w G, then k* G and the record {k*, 0} (k_affine.inc comb_special's
+// layout).  Needs the order (the recoding works modulo n) with n >= 2^255 (k mod n by one subtraction).  Every entry comes from the reference's ladder on this
+// curve -- whose degenerate scalars the entries' multipliers must not be (checked; k* by way of n - k* if it is one) -- through the shared inversion.
+bool gc_comb_possible(const curve_record& rec) { return rec.has_order && (rec.n.l[3] >> 63) != 0; }
+int ensure_gc_comb(ecsimd_hip_ctx* ctx, int curve, const curve_record& rec, const uint32_t** out) {
+  for (auto& t : ctx->gcomb) if (t.first == curve) { *out = t.second; return ECSIMD_HIP_OK; }
+  if (!gc_comb_possible(rec)) return bad(ctx, "the windowed algorithms on a registered curve need its group order n, n >= 2^255");
+  if (capturing(ctx)) return bad(ctx, "a window table would have to be built during stream capture: run this call once before capturing");
+  constexpr int W = launch::GCOMB_WINDOWS, PER = launch::GCOMB_ENTRIES;
+  constexpr size_t table_entries = (size_t)W * PER, entries = table_entries + 1;
+  std::vector<uint64_t> host_k;
+  try { host_k.assign(entries * 4, 0); ctx->gcomb.reserve(ctx->gcomb.size() + 1); } catch (...) { return bad(ctx, "window table: out of host memory"); }
+  for (int w = 0; w < W; ++w)
+    for (int d = 0; d < PER; ++d) {
+      uint64_t* e = &host_k[((size_t)w * PER + d) * 4];
+      const int pos = 4 * w, limb = pos / 64, off = pos % 64;
+      const unsigned __int128 v = (unsigned __int128)(2u * (unsigned)d + 1u) << off;
+      e[limb] = (uint64_t)v;
+      if (limb + 1 < 4) e[limb + 1] = (uint64_t)(v >> 64);
+      u256 m; for (int l = 0; l < 4; ++l) m.l[l] = e[l];
+      if (u_ladder_degenerate(rec.n, m)) return bad(ctx, "window table: a table multiplier is one of the ladder's degenerate scalars on this curve");
+    }
+  // k* = n - 2 (n mod 16), and only if bit 4 of it is clear (k_affine.inc comb_special: the high-to-low order); its point by way of n - k* if the ladder cannot do k*
+  uint64_t kstar[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool negate_special = false;
+  {
+    u256 m2 = {{2 * (rec.n.l[0] & 15u), 0, 0, 0}}, ks;
+    (void)u_sub(ks, rec.n, m2);
+    const bool have = ((ks.l[0] >> 4) & 1u) == 0;
+    if (have) for (int l = 0; l < 4; ++l) kstar[l] = ks.l[l];
+    u256 mult = have ? ks : u256{{1, 0, 0, 0}};                  // without a k*: any scalar, the point is never used
+    if (have && u_ladder_degenerate(rec.n, ks)) {
+      u256 alt; (void)u_sub(alt, rec.n, ks);
+      if (u_is_zero(alt) || u_ladder_degenerate(rec.n, alt)) return bad(ctx, "window table: neither k* nor n - k* is a scalar the ladder multiplies correctly");
+      mult = alt; negate_special = true;
+    }
+    for (int l = 0; l < 4; ++l) host_k[table_entries * 4 + l] = mult.l[l];
+  }
+  (void)hipSetDevice(ctx->device);
+  uint64_t* kd = nullptr;
+  uint32_t* table = nullptr;
+  hipError_t e = hipMalloc(&kd, 6 * entries * 32 + 64);
+  if (e == hipSuccess) e = hipMalloc(&table, (entries + 1) * 64);
+  uint64_t* tx = kd + entries * 4; uint64_t* ty = tx + entries * 4;
+  uint64_t* jx = ty + entries * 4; uint64_t* jy = jx + entries * 4; uint64_t* jz = jy + entries * 4;
+  uint8_t* flag = reinterpret_cast<uint8_t*>(jz + entries * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(kd, host_k.data(), entries * 32, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(flag, 1, 16, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // host_k must outlive the copy
+  if (e == hipSuccess) {
+    launch::gc_scalar_mult(ctx->stream, rec.G, kd, 4, nullptr, nullptr, jx, jy, jz, entries, 0);
+    launch::gc_to_affine_batched(ctx->stream, rec.G, jx, jy, jz, tx, ty, entries);
+    if (negate_special) launch::gc_negate_where(ctx->stream, rec.G, flag, ty + table_entries * 4, 1);
+    launch::gc_pack_table(ctx->stream, rec.G, tx, ty, table, (int)entries);
+    e = hipMemcpyAsync(table + entries * 16, kstar, 64, hipMemcpyHostToDevice, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  (void)hipFree(kd);
+  if (e != hipSuccess) { (void)hipFree(table); return fail(ctx, e, "window table build (registered curve)"); }
+  ctx->gcomb.emplace_back(curve, table);
+  *out = table;
+  return ECSIMD_HIP_OK;
+}
+launch::words8 order_words(const curve_record& rec) { launch::words8 w; for (int i = 0; i < 4; ++i) { w.w[2 * i] = (uint32_t)rec.n.l[i]; w.w[2 * i + 1] = (uint32_t)(rec.n.l[i] >> 32); } return w; }
+}  // namespace
+namespace {
+// scalar_mult_base(registered curve, ALG_WINDOWED [| ALG_CONSTANT_TIME] | OUT_AFFINE): the comb, then the shared inversion -- the true k G for every k
+// (k mod n = 0: (0, 0)), which is the ladder's affine result everywhere but at the ladder's degenerate scalars.
+int run_gcomb(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, size_t n, int flags) {
+  if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
+  if (ctx->ref_square || (flags & (ECSIMD_HIP_REF_SQUARE_COMPAT | ECSIMD_HIP_LADDER_RADIX32))) return bad(ctx, "ALG_WINDOWED is not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT / LADDER_RADIX32 form");
+  curve_record rec; if (!lookup_curve_record(curve, &rec)) return bad(ctx, "unknown curve id");
+  if (n == 0) return gc_comb_possible(rec) ? ECSIMD_HIP_OK : bad(ctx, "the windowed algorithms on a registered curve need its group order n, n >= 2^255");
+  if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
+  (void)hipSetDevice(ctx->device);
+  const uint32_t* table = nullptr;
+  int rc = ensure_gc_comb(ctx, curve, rec, &table);
+  if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 3 * n * 32);
+  if (rc != ECSIMD_HIP_OK) return rc;
+  uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
+  launch::gc_base_windowed(ctx->stream, rec.G, order_words(rec), k, table, jx, jy, jz, n, (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) != 0);
+  launch::gc_to_affine_batched(ctx->stream, rec.G, jx, jy, jz, ox, oy, n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult_base (registered curve, windowed) launch");
+}
 int gc_require_ecdsa(ecsimd_hip_ctx* ctx, int curve, curve_record* rec) {
   if (!lookup_curve_record(curve, rec)) return bad(ctx, "unknown curve id");
   if (!rec->has_order) return bad(ctx, "this curve was registered without its group order n");
@@ -1106,19 +1197,24 @@ void gc_safe_mult(hipStream_t s, const curve_record& rec, const gc_layout& L, ui
   launch::gc_to_affine_batched(s, rec.G, L.j[0], L.j[1], L.j[2], ox, oy, m);
   if (oy) launch::gc_negate_where(s, rec.G, neg, oy, m);
 }
-int gc_double_scalar_mult(ecsimd_hip_ctx* ctx, const curve_record& rec, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
+int gc_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve_of, const curve_record& rec, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                           uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n, size_t reserve_behind) {
   (void)hipSetDevice(ctx->device);
   gc_layout L = gc_plan(nullptr, n);
   int rc = ensure_workspace(ctx, L.bytes + reserve_behind);
   if (rc == ECSIMD_HIP_OK) rc = ensure_valid(ctx, (n + 15) / 16 * 16);
   if (rc != ECSIMD_HIP_OK) return rc;
+  const uint32_t* comb = nullptr;                                   // u1 G from the generator's table where the curve has one (n >= 2^255), else a ladder pass
+  if (gc_comb_possible(rec) && !capturing(ctx)) { rc = ensure_gc_comb(ctx, curve_of, rec, &comb); if (rc != ECSIMD_HIP_OK) return rc; }
   L = gc_plan(ctx->workspace, n);
   hipStream_t s = ctx->stream;
   launch::gc_on_curve(s, rec.G, qx, qy, ctx->valid, n);
   for (size_t first = 0; first < n; first += L.chunk) {
     const size_t m = (n - first) < L.chunk ? (n - first) : L.chunk;
-    gc_safe_mult(s, rec, L, L.adj1, L.neg1, u1 + 4 * first, nullptr, nullptr, L.gx, L.gy, m);                              // u1 G
+    if (comb) {
+      launch::gc_base_windowed(s, rec.G, order_words(rec), u1 + 4 * first, comb, L.j[0], L.j[1], L.j[2], m, false);
+      launch::gc_to_affine_batched(s, rec.G, L.j[0], L.j[1], L.j[2], L.gx, L.gy, m);
+    } else gc_safe_mult(s, rec, L, L.adj1, L.neg1, u1 + 4 * first, nullptr, nullptr, L.gx, L.gy, m);                       // u1 G
     gc_safe_mult(s, rec, L, L.adj2, L.neg2, u2 + 4 * first, qx + 4 * first, qy + 4 * first, L.px, L.py, m);              // u2 Q
     launch::gc_affine_add_batched(s, rec.G, L.gx, L.gy, L.px, L.py, rx + 4 * first, ry ? ry + 4 * first : nullptr, finite ? finite + first : nullptr, m);
   }
@@ -1126,14 +1222,14 @@ int gc_double_scalar_mult(ecsimd_hip_ctx* ctx, const curve_record& rec, const ui
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "double_scalar_mult (registered curve) launch");
 }
-int gc_ecdsa_verify_rx(ecsimd_hip_ctx* ctx, const curve_record& rec, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy, const uint64_t* r, uint8_t* ok, size_t n, size_t extra) {
+int gc_ecdsa_verify_rx(ecsimd_hip_ctx* ctx, int curve_of, const curve_record& rec, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy, const uint64_t* r, uint8_t* ok, size_t n, size_t extra) {
   const gc_layout L0 = gc_plan(nullptr, n);
   const size_t behind = n * 32 + ((n + 15) / 16) * 16;
   int rc = ensure_workspace(ctx, L0.bytes + behind + extra);
   if (rc != ECSIMD_HIP_OK) return rc;
   uint64_t* rx = ctx->workspace + L0.bytes / 8;
   uint8_t* fin = reinterpret_cast<uint8_t*>(rx + 4 * n);
-  rc = gc_double_scalar_mult(ctx, rec, u1, u2, qx, qy, rx, nullptr, fin, n, behind + extra);
+  rc = gc_double_scalar_mult(ctx, curve_of, rec, u1, u2, qx, qy, rx, nullptr, fin, n, behind + extra);
   if (rc != ECSIMD_HIP_OK) return rc;
   launch::gc_x_mod_n_equals(ctx->stream, rec.N, rx, fin, r, ok, n);
   hipError_t e = hipGetLastError();
@@ -1153,7 +1249,7 @@ int ecsimd_hip_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t
   if (curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE) {
     curve_record rec; int rc = gc_require_ecdsa(ctx, curve, &rec); if (rc != ECSIMD_HIP_OK) return rc;
     if (n == 0) return ECSIMD_HIP_OK;
-    return gc_double_scalar_mult(ctx, rec, u1, u2, qx, qy, rx, ry, finite, n, 0);
+    return gc_double_scalar_mult(ctx, curve, rec, u1, u2, qx, qy, rx, ry, finite, n, 0);
   }
   REQUIRE_CURVE();
   if (ctx->ref_square) return bad(ctx, "double_scalar_mult is not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT form");
@@ -1195,7 +1291,7 @@ int ecsimd_hip_ecdsa_verify_rx(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u
     curve_record rec; int rc = gc_require_ecdsa(ctx, curve, &rec); if (rc != ECSIMD_HIP_OK) return rc;
     if (n == 0) return ECSIMD_HIP_OK;
     (void)hipSetDevice(ctx->device);
-    return gc_ecdsa_verify_rx(ctx, rec, u1, u2, qx, qy, r, ok, n, 0);
+    return gc_ecdsa_verify_rx(ctx, curve, rec, u1, u2, qx, qy, r, ok, n, 0);
   }
   REQUIRE_CURVE();
   if (ctx->ref_square) return bad(ctx, "ecdsa_verify_rx is not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT form");
@@ -1221,7 +1317,7 @@ int ecsimd_hip_ecdsa_verify(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, c
     uint64_t* u1 = ctx->workspace + (L0.bytes + behind) / 8; uint64_t* u2 = u1 + 4 * n;
     uint8_t* in_range = reinterpret_cast<uint8_t*>(u2 + 4 * n);
     launch::ecdsa_scalars(ctx->stream, rec.N, e, r, s_, u1, u2, in_range, n);
-    rc = gc_ecdsa_verify_rx(ctx, rec, u1, u2, qx, qy, r, ok, n, extra);
+    rc = gc_ecdsa_verify_rx(ctx, curve, rec, u1, u2, qx, qy, r, ok, n, extra);
     if (rc != ECSIMD_HIP_OK) return rc;
     launch::mask_op(ctx->stream, ECSIMD_HIP_MASK_AND, ok, in_range, ok, n);
     hipError_t err = hipGetLastError();
@@ -1253,8 +1349,8 @@ int ecsimd_hip_ecdsa_sign(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, con
   REQUIRE_CTX(); REQUIRE_PTR(e); REQUIRE_PTR(d); REQUIRE_PTR(k); REQUIRE_PTR(r); REQUIRE_PTR(s_);
   if (!ok && n) return bad(ctx, "ok is null");
   if (curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE) {
-    // signing on a registered curve: k G through the reference's ladder -- constant-time as it is (tests/test_constant_time_isa.py holds k_gc_scalar_mult<29, false>
-    // to the same checks as the built-in ladders) -- x by the select-only shared inversion, then the scalar-field kernel with the record's order
+    // signing on a registered curve: k G from the constant-time comb of its generator (k_gcomb.hip; n < 2^255: through the reference's ladder, constant-time as it
+    // is -- tests/test_constant_time_isa.py holds both to the ISA), x by the select-only shared inversion, then the scalar-field kernel with the record's order
     curve_record rec; int rc = gc_require_ecdsa(ctx, curve, &rec); if (rc != ECSIMD_HIP_OK) return rc;
     if (overlaps(r, e) || overlaps(r, d) || overlaps(r, k) || overlaps(s_, e) || overlaps(s_, d) || overlaps(s_, k) || overlaps(r, s_)) return bad(ctx, "r and s must not alias an input or each other");
     if (n == 0) return ECSIMD_HIP_OK;
@@ -1264,8 +1360,13 @@ int ecsimd_hip_ecdsa_sign(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, con
     if (L.chunk != n) return bad(ctx, "ecdsa_sign on a registered curve: at most 2^22 signatures per call");
     rc = ensure_workspace(ctx, L.bytes);
     if (rc != ECSIMD_HIP_OK) return rc;
+    const uint32_t* comb = nullptr;                             // k G from the generator's table, every entry of a window read (constant time), where the curve has one
+    if (gc_comb_possible(rec) && !capturing(ctx)) { rc = ensure_gc_comb(ctx, curve, rec, &comb); if (rc != ECSIMD_HIP_OK) return rc; }
     L = gc_plan(ctx->workspace, n);
-    gc_safe_mult(ctx->stream, rec, L, L.adj1, L.neg1, k, nullptr, nullptr, L.gx, nullptr, n);        // x(k G): the negation of a degenerate nonce's product does not touch x
+    if (comb) {
+      launch::gc_base_windowed(ctx->stream, rec.G, order_words(rec), k, comb, L.j[0], L.j[1], L.j[2], n, true);
+      launch::gc_to_affine_batched(ctx->stream, rec.G, L.j[0], L.j[1], L.j[2], L.gx, nullptr, n);
+    } else gc_safe_mult(ctx->stream, rec, L, L.adj1, L.neg1, k, nullptr, nullptr, L.gx, nullptr, n);  // x(k G): the negation of a degenerate nonce's product does not touch x
     launch::ecdsa_sign_scalars(ctx->stream, rec.N, e, d, k, L.gx, r, s_, ok, n);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) err = hipMemsetAsync(ctx->workspace, 0, L.bytes, ctx->stream);              // the nonce's adjusted copy, the Jacobian k G and x: gone before the call returns

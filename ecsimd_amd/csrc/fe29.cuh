@@ -288,24 +288,25 @@ template <int C, bool NOZ = false> ECS_DEV void zdau29(coz29& s, uint32_t oswap,
 // Z tight; table coordinates tight, y possibly negated.  Three carry passes: H and r feed squares, V - X3 is 31 bits wide before its product.
 struct jpoint29 { fe29 x, y, z; };
 // (Two halves, so that a caller can look at H and r -- R = +-T is H = 0, then r = 0: is_zero29 below -- before paying for the rest.)
-template <int C> ECS_DEV void madd29_hr(const jpoint29& P, const fe29& x2, const fe29& y2, fe29& H, fe29& r) {
-  const fe29 Z1Z1 = sqr29<C>(P.z);
-  const fe29 U2 = mul29<C>(x2, Z1Z1);
-  const fe29 S2 = mul29<C>(y2, mul29<C>(Z1Z1, P.z));
+template <int C> ECS_DEV void madd29_hr(const jpoint29& P, const fe29& x2, const fe29& y2, fe29& H, fe29& r, const r29_ctx<C>& cx = r29_ctx<C>{}) {
+  const fe29 Z1Z1 = sqr29<C>(P.z, cx);
+  const fe29 U2 = mul29<C>(x2, Z1Z1, cx);
+  const fe29 S2 = mul29<C>(y2, mul29<C>(Z1Z1, P.z, cx), cx);
   H = norm29(sub29(U2, P.x));
   r = norm29(sub29(S2, P.y));
 }
-template <int C> ECS_DEV jpoint29 madd29_finish(const jpoint29& P, const fe29& H, const fe29& r) {
-  const fe29 HH = sqr29<C>(H);
-  const fe29 HHH = mul29<C>(H, HH);
-  const fe29 V = mul29<C>(P.x, HH);
+template <int C> ECS_DEV jpoint29 madd29_finish(const jpoint29& P, const fe29& H, const fe29& r, const r29_ctx<C>& cx = r29_ctx<C>{}) {
+  const fe29 HH = sqr29<C>(H, cx);
+  const fe29 HHH = mul29<C>(H, HH, cx);
+  const fe29 V = mul29<C>(P.x, HH, cx);
   jpoint29 R;
-  R.z = mul29<C>(P.z, H);
-  R.x = sub29(sub29(sqr29<C>(r), HHH), dbl29(V));
-  R.y = sub29(mul29<C>(r, norm29(sub29(V, R.x))), mul29<C>(P.y, HHH));
+  R.z = mul29<C>(P.z, H, cx);
+  R.x = sub29(sub29(sqr29<C>(r, cx), HHH), dbl29(V));
+  R.y = sub29(mul29<C>(r, norm29(sub29(V, R.x)), cx), mul29<C>(P.y, HHH, cx));
   return R;
 }
-template <int C> ECS_DEV jpoint29 madd29(const jpoint29& P, const fe29& x2, const fe29& y2) { fe29 H, r; madd29_hr<C>(P, x2, y2, H, r); return madd29_finish<C>(P, H, r); }
+template <int C> ECS_DEV jpoint29 madd29(const jpoint29& P, const fe29& x2, const fe29& y2, const r29_ctx<C>& cx = r29_ctx<C>{}) {
+  fe29 H, r; madd29_hr<C>(P, x2, y2, H, r, cx); return madd29_finish<C>(P, H, r, cx); }
 // ---------------------------------------------------------------- the variable-base window loop (round 4)
 // Doublings multiply by 3, 4 and 8, and on lazy limbs nothing ever takes a multiple of p away: a Montgomery product only divides by 2^261 ~ 32 p,
 // so values above ~10 p GROW from one doubling to the next.  vred29 is the missing piece: v -> v - k p with k = round(top limb / 2^24) -- the top

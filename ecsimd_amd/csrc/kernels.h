@@ -78,6 +78,10 @@ void gc_zdau(hipStream_t, const gcurve&, const uint64_t* px, const uint64_t* py,
 void gc_add_z2_1(hipStream_t, const gcurve&, const uint64_t* ax, const uint64_t* ay, const uint64_t* az, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n, bool ref);
 void gc_trplu(hipStream_t, const gcurve&, uint64_t* px, uint64_t* py, uint64_t* pz, uint64_t* rx, uint64_t* ry, uint64_t* rz, size_t n, bool ref);
 void gc_scalar_mult(hipStream_t, const gcurve&, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
+// k_gcomb.hip: k G on a registered curve from a 4-bit odd-digit table of multiples of its generator in LDS (64 windows x 8 entries x 64 B + k* G + k*)
+constexpr int GCOMB_WINDOWS = 64, GCOMB_ENTRIES = 8;
+void gc_pack_table(hipStream_t, const gcurve& G, const uint64_t* tx, const uint64_t* ty, uint32_t* table, int entries);
+void gc_base_windowed(hipStream_t, const gcurve& G, const words8& order, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, bool constant_time);
 // ... and what ECDSA on a registered curve needs on top (public-data affine addition, the acceptance test, the ladder's three degenerate scalars worked around)
 void gc_affine_add_batched(hipStream_t, const gcurve&, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
 void gc_x_mod_n_equals(hipStream_t, const gmod& order, const uint64_t* x, const uint8_t* finite, const uint64_t* r, uint8_t* ok, size_t n);

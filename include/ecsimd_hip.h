@@ -177,12 +177,15 @@ int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id);
  * parameters give 0 / 1 unless flags = ECSIMD_HIP_CURVE_GENERIC_KERNELS, which registers them like any other curve -- how tests hold the generic kernels
  * to the special-form ones bit for bit) is accepted by
  *     from_affine, to_affine, compute_y, on_curve, dblu, zaddu, zdau, add_z2_1, trplu, zdau_repeat, scalar_mult, scalar_mult_1s, scalar_mult_base
- * (flags BASE_* | OUT_* | LADDER_RADIX32 | REF_SQUARE_COMPAT: the reference's ladder; the table-driven ALG_* algorithms exist for the two built-in curves
- * only), by affine_add, sec1_encode, sec1_decode and -- when n was given, p < 2n, and n - u is a good ladder scalar for u in {n - 1, 2^256 - n - 1, 2^256 - n}
- * (every prime-order curve of this size) -- by double_scalar_mult, ecdsa_verify_rx, ecdsa_verify, ecdsa_sign: no tables exist for such a curve, so these are
- * two (sign: one) passes of the ladder with the scalars kept clear of its three degenerate values (u -> n - u and the result negated), correct for every
- * scalar in [0, n); ecdsa_sign's ladder pass is the constant-time loop and its scratch is zeroed like the built-in curves'.  And, as a FIELD id, by every
- * element-wise field entry point.  Same level-J parity as the built-in curves: X, Y, Z are
+ * (flags BASE_* | OUT_* | LADDER_RADIX32 | REF_SQUARE_COMPAT: the reference's ladder; of the table-driven algorithms a registered curve has ONE:
+ * scalar_mult_base with ALG_WINDOWED [| ALG_CONSTANT_TIME] | OUT_AFFINE -- a 4-bit odd-digit table of multiples of ITS generator in LDS, built from the
+ * ladder on first use, for a curve registered with its order n >= 2^255: the true k G for every k, (0, 0) for k = 0 mod n; per-lane tables for a variable
+ * base and the other ALG_* shapes exist for the two built-in curves only), by affine_add, sec1_encode, sec1_decode and -- when n was given, p < 2n, and
+ * n - u is a good ladder scalar for u in {n - 1, 2^256 - n - 1, 2^256 - n} (every prime-order curve of this size) -- by double_scalar_mult,
+ * ecdsa_verify_rx, ecdsa_verify, ecdsa_sign: u1 G (sign: k G, every table entry of a window read) comes from the generator's table, u2 Q from a pass of
+ * the ladder with the scalar kept clear of its three degenerate values (u -> n - u and the result negated) -- correct for every scalar in [0, n);
+ * ecdsa_sign's scratch is zeroed like the built-in curves'.  (n < 2^255: ladder passes instead of the table.)  And, as a FIELD id, by every element-wise
+ * field entry point.  Same level-J parity as the built-in curves: X, Y, Z are
  * the bits the reference instantiated with this Curve returns.  The ladder's 254 iterations run on nine signed 29-bit limbs with the dense p in SGPRs
  * (81 multiply-adds per reduction where P-256's sparse form has 36); LADDER_RADIX32 / REF_SQUARE_COMPAT run them on 8 x 32-bit canonical words.
  * Process-wide, thread-safe, ids live as long as the process. */

@@ -453,6 +453,9 @@ TEST(Curves, EcdsaAndSec1OnARegisteredCurve) {
   const auto sum = KG::double_scalar_mult(lanes<W256>(k2, zero, k1, k1), lanes<W256>(zero, k2, zero, zero), Q, fin);   // (n - 1) G = -G; (n - 1) Q = -Q
   const auto fh = fin.host();
   EXPECT_TRUE(fh[0] == 1 && fh[1] == 1 && sum.x().get(0) == K::Gx::value && sum.x().get(1) == Q.x().get(1) && !(sum.y().get(0) == K::Gy::value));
+  const W256 ks(300, [](size_t i, size_t) { bignum_256 b; b.limbs = {0x9e3779b97f4a7c15ull * (i + 1), i * 77, ~i, 0x0123456789abcdefull ^ (i << 20)}; return b; });
+  const auto ladder = KG::scalar_mult(ks, KG::WJG(300)).to_affine();                              // the generator's comb (plain and constant-time) = the ladder's points
+  EXPECT_TRUE(all(KG::scalar_mult_base_affine(ks) == ladder) && all(KG::scalar_mult_base_affine_secret(ks) == ladder));
   hip::mask dec_ok;
   const auto back = sec1_decode<K>(sec1_encode<K>(Q, true), true, dec_ok);                        // compressed: the square root with THIS curve's a and b
   EXPECT_TRUE(dec_ok.count() == 4 && all(back == Q));

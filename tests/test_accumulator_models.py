@@ -168,3 +168,34 @@ def test_the_family_is_the_gpu_tests_family():
     from test_oracle import digit_pattern_operands
     assert len(digit_pattern_operands()[::100]) == 16797
     assert len(family(P256, 10)) > 16797 + 100
+
+
+@pytest.mark.parametrize("name", ["brainpoolP256r1", "sm2", "frp256v1"])
+def test_generator_comb_of_a_registered_curve(name):
+    """k_gcomb.hip runs the top4 shape with the order of a curve registered at run time (n >= 2^255 is what capi.hip ensure_gc_comb asks for): the same walk
+    with that n -- no addition is exceptional except the last one at k* = n - 2 (n mod 16) when bit 4 of it is clear."""
+    from oracle.loader import REF_CURVES
+    from test_oracle import digit_pattern_operands
+    n = REF_CURVES[name]["n"]
+    assert n >> 255 == 1
+    ks = kstar(n, 4, 64, True)
+    fam = arr_to_ints(digit_pattern_operands()[::100])
+    for v in (ks, n - 2 * (n % 16)):
+        fam += [v, v + 1, v - 1, v + 2, v - 2, n - v, n - v + 1, n - v - 1, v + n, n - v + n]
+    fam += [1, 2, 3, n - 1, n - 2, n + 1, n + 2, (n - 1) // 2, (n + 1) // 2, (1 << 256) - n, (1 << 256) - n - 1, (1 << 256) - n + 1, M256, 1 << 255, (1 << 255) - 1]
+    rng = random.Random(sum(name.encode()))
+    fam += [rng.getrandbits(256) for _ in range(50000)]
+    hits = 0
+    for k in fam:
+        if not 0 < k <= M256:
+            continue
+        a = odd_representative(k, n)
+        if a is None:
+            continue
+        ev = walk_comb(a, n, 4, 64, True)
+        if a == ks:
+            assert ev == [(0, "R = T")], (name, hex(k), ev)
+            hits += 1
+        else:
+            assert ev == [], (name, hex(k), ev)
+    assert hits >= 2 if ks else hits == 0

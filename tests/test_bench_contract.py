@@ -206,10 +206,10 @@ def test_native_chatter_cannot_reach_stdout(tmp_path):
 
 
 def test_designs_results_table_is_the_committed_json():
-    """VERDICT r2 "record drift": DESIGN.md section 4's table is generated from profiles/r04/bench_n1_*.json."""
+    """VERDICT r2 "record drift": DESIGN.md section 4's table is generated from profiles/r05/bench_n1_*.json."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "results_table.py"), "r04", "--check"], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "results_table.py"), "r05", "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
 
 
@@ -248,6 +248,31 @@ def test_round4_lines_carry_the_reference_compatible_rate_and_the_new_fractions(
         assert d.get("parity_failures") is None, name
     assert r4["fixed_base"]["value"] > 320e6 and r4["fixed_base_secp256k1"]["value"] > 320e6           # BASELINE configs[2] on the reduced radix (r3: 295)
     assert r4["fixed_base_constant_time"]["value"] > 350e6 and r4["fixed_base_signed7"]["value"] > 530e6
+
+
+def test_round5_lines_carry_what_the_pipe_does_and_the_registered_curves():
+    """every ladder line of round 5 says what the VALU pipe does (instructions per unit, multiplies among them, cycles per instruction
+    per SIMD, how much of the elapsed time the instruction mix alone accounts for); the default line's `ref_compat` object is the documented contract (value,
+    frac, lanes compared, 0 differing); curves registered at run time have lines of their own, compared with the compiled reference instantiated for them."""
+    r5 = {os.path.basename(p)[len("bench_n1_"):-len(".json")]: json.load(open(p)) for p in LINES if os.sep + "r05" + os.sep in p}
+    assert len(r5) >= 25
+    for name in ("ladder", "ladder_secp256k1", "ladder_ref_compat_p256", "ladder_ref_compat_secp256k1", "ladder_brainpoolP256r1"):
+        r = r5[name]["roofline"]
+        assert r["multiply_instructions_per_unit"] < r["valu_instructions_per_unit"], name
+        assert 3.7 < r["cycles_per_valu_instruction_per_simd"] < 4.3 and 0.9 < r["issue_bound_frac"] < 1.15, name
+    rc = r5["ladder"]["ref_compat"]
+    assert rc["lanes_compared"] > 10 ** 6 and rc["lanes_differing"] == 0 and rc["steps"] >= 3 and 0.6 < rc["frac"] < 0.75 and 40e6 < rc["value"] < r5["ladder"]["value"]
+    for name in ("ladder_brainpoolP256r1", "ladder_sm2", "ladder_frp256v1"):
+        d = r5[name]
+        assert name[len("ladder_"):] in d["metric"] and 38e6 < d["value"] < 48e6 and 0.6 < d["roofline"]["frac"] < 0.75, name
+        c = d["cpu_baseline"]
+        assert c["kind"] == "reference" and c["lanes_compared"] > 10 ** 5 and c["lanes_differing_from_gpu"] <= 8, name      # the reference's dropped carry: ~4e-6 of lanes
+    for name, d in r5.items():
+        assert d.get("parity_failures") is None, name
+        assert d["roofline"]["traffic"] is None or d["roofline"]["traffic"] > 0, name
+    for name in ("ladder", "ladder_secp256k1", "group_mode"):
+        assert 54e6 < r5[name]["value"] < 64e6 and 0.86 < r5[name]["roofline"]["frac"] < 1.0, name
+    assert r5["ladder_ref_compat_secp256k1"]["value"] > 41e6                                                        # r4: 40.06 (the Montgomery rounds on one 64-bit MAC)
 
 
 def test_the_group_leg_child_is_not_a_rank():

@@ -262,3 +262,22 @@ def test_registered_curve_signing_helpers_under_the_secret_flow_analysis(tmp_pat
     asm = assembly(tmp_path_factory, "k_gcurve")
     assert ct_check.check_secret_flow(asm, "k_gc_ladder_safe_scalars", secret_args=[1, 2, 3])["secret_loads"] >= 1     # the nonce, its adjusted copy, the negation flag
     assert ct_check.check_secret_flow(asm, "k_gc_to_affine_batched", secret_args=[1, 2, 3, 4, 5])["secret_loads"] >= 6   # the Jacobian k G
+
+
+def test_registered_curve_constant_time_comb(tmp_path_factory):
+    """k_gc_base_windowed<true> (ecdsa_sign and scalar_mult_base(ALG_WINDOWED | ALG_CONSTANT_TIME) on a registered curve): the built-in constant-time comb's
+    three checks -- one branch in the window loop (its counter), 32 LDS reads at loop-invariant addresses, no global access; nothing branches on a lane
+    mask after the scalar is loaded; no secret (the scalar, the Jacobian k G) reaches an address, a branch, EXEC at a memory access or a lane-crossing
+    instruction -- and the same template without the flag is refused by both analyses."""
+    asm = assembly(tmp_path_factory, "k_gcomb")
+    kern = "18k_gc_base_windowedILb1E"
+    rep = ct_check.check(asm, kern, allow_global_loads=0, allow_lds_reads=True)
+    assert rep["instructions"] > 2400 and rep["lds_reads"] == 32 and rep["scratch"] == 0 and rep["global_loads"] == []
+    assert len(rep["branches"]) == 1 and re.match(r"s_cmpk?_(lg|eq)_[iu]32 s\d+, \S+ ; s_cbranch_scc[01] ", rep["branches"][0]), rep["branches"]
+    assert ct_check.check_after_secret_load(asm, kern) > 4000
+    flow = ct_check.check_secret_flow(asm, kern, secret_args=[2, 4, 5, 6])             # (gcurve, order, k, table, ox, oy, oz, n)
+    assert flow["secret_loads"] >= 1 and not flow["secret_lds"] and not flow["secret_scratch"]
+    with pytest.raises(ct_check.Violation, match="LDS address"):
+        ct_check.check(asm, "18k_gc_base_windowedILb0E", allow_global_loads=0, allow_lds_reads=True)
+    with pytest.raises(ct_check.Violation, match="LDS address"):
+        ct_check.check_secret_flow(asm, "18k_gc_base_windowedILb0E", secret_args=[2])

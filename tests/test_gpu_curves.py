@@ -214,11 +214,15 @@ def test_registered_curve_entry_points_that_do_not_exist_say_so(engine, oracle):
     from ecsimd_amd import ALG_WINDOWED, ALG_CONSTANT_TIME, EcsimdHipError
     k = engine.fill_random(8, SEED, 1)
     bx, by = engine.scalar_mult_base(cid, k, flags=OUT_AFFINE)
+    from ecsimd_amd import ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG
     for fl in (OUT_AFFINE | ALG_WINDOWED, OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME):
         with pytest.raises(EcsimdHipError, match="ladder only"):
-            engine.scalar_mult(cid, k, bx, by, flags=fl)
+            engine.scalar_mult(cid, k, bx, by, flags=fl)                  # a variable base: no per-lane tables on a registered curve
+    for fl in (OUT_AFFINE | ALG_WINDOWED_SIGNED, OUT_AFFINE | ALG_WINDOWED_BIG, OUT_AFFINE | ALG_CONSTANT_TIME):
         with pytest.raises(EcsimdHipError, match="ladder only"):
             engine.scalar_mult_base(cid, k, flags=fl)
+    with pytest.raises(EcsimdHipError, match="OUT_AFFINE"):
+        engine.scalar_mult_base(cid, k, flags=ALG_WINDOWED)                # the comb's Jacobian representative is not the reference's
     with pytest.raises(EcsimdHipError):
         engine.scalar_mult_base(0x10000 + 4000, k)                       # no such curve
     # ECDSA needs the group order: the same curve registered WITHOUT n (a different record is impossible -- the parameters are the key -- so: another curve)
@@ -236,6 +240,8 @@ def test_registered_curve_entry_points_that_do_not_exist_say_so(engine, oracle):
         engine.ecdsa_verify(noorder, k, k, k, bx, by)
     with pytest.raises(EcsimdHipError, match="group order"):
         engine.ecdsa_sign(noorder, k, k, k)
+    with pytest.raises(EcsimdHipError, match="group order"):
+        engine.scalar_mult_base(noorder, k, flags=OUT_AFFINE | ALG_WINDOWED)   # the comb recodes modulo n
 
 
 # ---------------------------------------------------------------- the first application on a registered curve: ECDSA, u1 G + u2 Q, SEC1 (round 5)
@@ -362,3 +368,51 @@ def test_sec1_codecs_on_a_registered_curve(engine, oracle, name):
     _, _, ok = engine.sec1_decode(cid, torch.from_numpy(full).to(engine.tdev), False)
     okn = engine.to_numpy(ok)
     assert okn[5] == 0 and okn[:5].all() and okn[6:].all()
+
+
+@pytest.mark.parametrize("name", list(REF_CURVES))
+def test_generator_comb_on_a_registered_curve(engine, name):
+    """scalar_mult_base(ALG_WINDOWED [| ALG_CONSTANT_TIME] | OUT_AFFINE) with a registered curve id (k_gcomb.hip: 4-bit odd-digit table of multiples of the
+    curve's generator in LDS, built from the reference's ladder on first use): the ladder's affine points lane for lane on 2^17 + 77 random 256-bit scalars,
+    the true k G (textbook affine arithmetic on Python integers) on the edge scalars -- the comb's own exceptional scalar k* = n - 2 (n mod 16) and its images,
+    0 and n (infinity: (0, 0)), and the three scalars at which the LADDER is wrong -- and the x-only form."""
+    c = REF_CURVES[name]
+    cid = register(c)
+    n_ = c["n"]
+    add, mul = _affine_model(c)
+    G = (c["gx"], c["gy"])
+    ks = n_ - 2 * (n_ % 16)
+    edge = [0, 1, 2, 3, 15, 16, 17, 31, 32, 33, n_ - 2, n_ - 1, n_, n_ + 1, n_ + 2, ks, ks - 1, ks + 1, n_ - ks, ks + n_ if ks + n_ < 2**256 else ks, 2**256 - n_ - 1, 2**256 - n_,
+            2**256 - n_ + 1, 2**256 - 1, 2**255, 2**255 - 1, (n_ - 1) // 2, (n_ + 1) // 2, 0x1111111111111111111111111111111111111111111111111111111111111111, 2**252, 16**63, 15 * 16**63]
+    N = (1 << 17) + 77
+    rng = np.random.default_rng(sum(name.encode()) + 9)
+    k = rng.integers(0, 2**64, size=(N, 4), dtype=np.uint64)
+    k[:len(edge)] = ints_to_arr(edge)
+    kd = engine.to_device(k)
+    lx, ly = (engine.to_numpy(t) for t in engine.scalar_mult_base(cid, kd, flags=OUT_AFFINE))
+    from ecsimd_amd import ALG_WINDOWED, ALG_CONSTANT_TIME
+    for fl in (ALG_WINDOWED, ALG_WINDOWED | ALG_CONSTANT_TIME):
+        wx, wy = (engine.to_numpy(t) for t in engine.scalar_mult_base(cid, kd, flags=OUT_AFFINE | fl))
+        for i, kv in enumerate(edge):
+            want = mul(kv % n_, G)
+            assert (to_int(wx[i]), to_int(wy[i])) == (want if want is not None else (0, 0)), (name, fl, i, hex(kv))
+        assert np.array_equal(wx[len(edge):], lx[len(edge):]) and np.array_equal(wy[len(edge):], ly[len(edge):]), (name, fl)
+        xo, none = engine.scalar_mult_base(cid, kd, flags=OUT_AFFINE | fl, x_only=True)
+        assert none is None and np.array_equal(engine.to_numpy(xo), wx)
+    for m in (1, 3, 255, 257):                                              # ragged batches: a partial workgroup still loads the whole table
+        wx, wy = (engine.to_numpy(t) for t in engine.scalar_mult_base(cid, engine.to_device(k[40:40 + m].copy()), flags=OUT_AFFINE | ALG_WINDOWED))
+        assert np.array_equal(wx, lx[40:40 + m]) and np.array_equal(wy, ly[40:40 + m])
+    assert all(t.shape[0] == 0 for t in engine.scalar_mult_base(cid, engine.empty(0), flags=OUT_AFFINE | ALG_WINDOWED))
+
+
+@pytest.mark.parametrize("cv", [P256, SECP256K1])
+def test_generator_comb_of_a_builtin_curve_through_the_generic_kernels(engine, cv):
+    """P-256 / secp256k1 registered like any other curve (ECSIMD_HIP_CURVE_GENERIC_KERNELS): the generic comb returns the built-in comb's affine points."""
+    c = CURVE_PARAMS[cv]
+    gid = register(c, generic=True)
+    from ecsimd_amd import ALG_WINDOWED, ALG_CONSTANT_TIME
+    k = engine.fill_random(1 << 16, SEED, 123)
+    kn = engine.to_numpy(k); kn[:4] = ints_to_arr([0, c["n"], c["n"] - 2, 2]); k = engine.to_device(kn)       # P-256's k* = n - 2
+    want = [engine.to_numpy(t) for t in engine.scalar_mult_base(cv, k, flags=OUT_AFFINE | ALG_WINDOWED)]
+    for fl in (ALG_WINDOWED, ALG_WINDOWED | ALG_CONSTANT_TIME):
+        assert same([engine.to_numpy(t) for t in engine.scalar_mult_base(gid, k, flags=OUT_AFFINE | fl)], want), (cv, fl)

@@ -110,4 +110,30 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     wire = e.sec1_encode(cv, b2x, b2y, False)
     row(f"sec1_decode<{nm}> uncompressed (validation)", n2, timeit(lambda: e.sec1_decode(cv, wire, False)), 4 * 136, 65 + 64, "points")
     del k, s2, b2x, b2y, P2, outj, wire
+# (r5) a curve registered at run time: the reference's layers on the generic kernels, and the first application on top of its ladder (no tables for such a curve)
+from ecsimd_amd.curves import curve_id
+for nm in ("brainpoolP256r1",):
+    cv = curve_id(nm)
+    n2 = 1 << 22
+    k = e.fill_random(n2, SEED, 1, clear_top_bits=1); s2 = e.fill_random(n2, SEED, 2)
+    b2x, b2y = e.scalar_mult_base(cv, s2, flags=2); P2 = e.from_affine(cv, b2x, b2y)
+    outj = [e.empty(n2) for _ in range(3)]
+    inv_g = 255 + 12                                                   # x^(p-2)-sized work per shared inversion on the generic words (division steps in fact: ~ 88 products)
+    row(f"scalar_mult<{nm}> ladder, Jacobian out (generic kernels, dense prime)", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=1, out=outj), 5), 555968, 192, "scalar mults")
+    row(f"scalar_mult<{nm}> ladder, affine out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=3, out=outj), 5), 555968 + 19 * 136, 160, "scalar mults")
+    row(f"to_affine<{nm}> (simultaneous inversion)", n2, timeit(lambda: e.to_affine(cv, outj)), int((7 + 88 / 32) * 136), 256, "points")
+    u1 = e.fill_random(n2, SEED, 21, clear_top_bits=1)
+    comb = 63 * 11 * 136                                               # the generator's 4-bit comb: 63 mixed additions (8M + 3S)
+    row(f"scalar_mult_base<{nm}> windowed (the generator's comb in LDS), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 4, out=outj)), comb + int((7 + 88 / 32) * 136), 96, "scalar mults")
+    row(f"scalar_mult_base<{nm}> windowed, constant time (every entry of a window read), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 4 | 128, out=outj)), comb + int((7 + 88 / 32) * 136), 96, "scalar mults")
+    two = comb + 555968 + int((2 * (7 + 88 / 32) + 6 + 88 / 32) * 136)   # the comb, one ladder pass, two conversions, the affine addition with its shared inversion
+    row(f"double_scalar_mult<{nm}> u1*G + u2*Q (the comb + one pass of the ladder)", n2, timeit(lambda: e.double_scalar_mult(cv, u1, k, b2x, b2y), 5), two, 160, "verifications")
+    rr = e.fill_random(n2, SEED, 22, clear_top_bits=1); ss = e.fill_random(n2, SEED, 23, clear_top_bits=1)
+    row(f"ecdsa_verify<{nm}> (e, r, s, Q -> ok)", n2, timeit(lambda: e.ecdsa_verify(cv, u1, rr, ss, b2x, b2y), 5), two + 6 * 136, 161, "verifications")
+    row(f"ecdsa_sign<{nm}> (e, d, k -> r, s: k G on the constant-time comb)", n2, timeit(lambda: e.ecdsa_sign(cv, u1, rr, ss), 5), comb + int((4 + 88 / 32 + 9 + 7) * 136), 160, "signatures")
+    wire = e.sec1_encode(cv, b2x, b2y, True)
+    row(f"sec1_decode<{nm}> compressed (decompression: x^((p+1)/4) on the generic words)", n2, timeit(lambda: e.sec1_decode(cv, wire, True)), (253 + 7 + 4) * 136, 33 + 64, "points")
+    wire = e.sec1_encode(cv, b2x, b2y, False)
+    row(f"sec1_decode<{nm}> uncompressed (validation)", n2, timeit(lambda: e.sec1_decode(cv, wire, False)), 4 * 136, 65 + 64, "points")
+    del k, s2, b2x, b2y, P2, outj, wire, u1, rr, ss
 print(json.dumps(out, indent=1))

@@ -42,7 +42,7 @@ import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value
     [ $rc -eq 0 ] && TRAFFIC_EXTRA_COUNTERS="TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_sum" bash tools/profile_traffic.sh r04 ${@:-windowed windowed-ct} > "$out/traffic.txt" 2>&1; rc=$?; tail -8 "$out/traffic.txt"
     exit $rc ;;
   soak)             # the ladder (default: radix 29; and REF_SQUARE_COMPAT) against the compiled reference: tools/soak.py <log2 lanes> <batches>
-    timeout -k 10 1000 python tools/soak.py ${1:-23} ${2:-4} > "$out/soak.txt" 2>&1; rc=$?; tail -12 "$out/soak.txt"; exit $rc ;;
+    timeout -k 10 1000 python tools/soak.py ${1:-23} ${2:-4} ${3:-p256,secp256k1} > "$out/soak.txt" 2>&1; rc=$?; tail -12 "$out/soak.txt"; exit $rc ;;
   soak_alg)         # every window kernel (fixed base: 4 combs; variable base: plain, constant-time; x only) against the ladder, lane for lane: tools/soak_windowed.py <log2 lanes> <batches>
     timeout -k 10 1000 python tools/soak_windowed.py ${1:-22} ${2:-32} > "$out/soak_alg.txt" 2>&1; rc=$?; tail -6 "$out/soak_alg.txt"; exit $rc ;;
   bench_all)        # every bench line profiles/rNN keeps
