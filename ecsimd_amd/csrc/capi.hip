@@ -833,6 +833,17 @@ int ecsimd_hip_from_bytes_be(ecsimd_hip_ctx* ctx, const uint8_t* bytes, uint64_t
   REQUIRE_CTX(); REQUIRE_PTR(bytes); REQUIRE_PTR(out); RUN(launch::bytes_be(s, bytes, out, n)); }
 int ecsimd_hip_to_bytes_be(ecsimd_hip_ctx* ctx, const uint64_t* in, uint8_t* bytes, size_t n) {
   REQUIRE_CTX(); REQUIRE_PTR(in); REQUIRE_PTR(bytes); RUN(launch::bytes_be(s, in, bytes, n)); }
+// The reference's register layout (four lanes per wide, limb-major: bignum.h:99-100) <-> the ABI's one element per lane, on the device.
+int ecsimd_hip_wide4_to_lanes(ecsimd_hip_ctx* ctx, const void* wides, size_t record_bytes, size_t offset_bytes, uint64_t* out, size_t n_wides) {
+  REQUIRE_CTX(); const size_t n = 4 * n_wides; REQUIRE_PTR(out); if (!wides && n) return bad(ctx, "wides is null");
+  if (record_bytes < 128 || (record_bytes & 7u) || (offset_bytes & 7u) || offset_bytes + 128 > record_bytes || (reinterpret_cast<uintptr_t>(wides) & 7u)) return bad(ctx, "a wide is 128 bytes at an 8-byte aligned offset inside its record");
+  if (n_wides > (size_t)0x7fffffff * (BLOCK / 4)) return bad(ctx, "batch too large");
+  RUN(launch::wide4_to_lanes(s, wides, record_bytes, offset_bytes, out, n)); }
+int ecsimd_hip_lanes_to_wide4(ecsimd_hip_ctx* ctx, const uint64_t* in, void* wides, size_t record_bytes, size_t offset_bytes, size_t n_wides) {
+  REQUIRE_CTX(); const size_t n = 4 * n_wides; REQUIRE_PTR(in); if (!wides && n) return bad(ctx, "wides is null");
+  if (record_bytes < 128 || (record_bytes & 7u) || (offset_bytes & 7u) || offset_bytes + 128 > record_bytes || (reinterpret_cast<uintptr_t>(wides) & 7u)) return bad(ctx, "a wide is 128 bytes at an 8-byte aligned offset inside its record");
+  if (n_wides > (size_t)0x7fffffff * (BLOCK / 4)) return bad(ctx, "batch too large");
+  RUN(launch::lanes_to_wide4(s, in, wides, record_bytes, offset_bytes, n)); }
 int ecsimd_hip_mask_bit(ecsimd_hip_ctx* ctx, const uint64_t* a, int bit, uint8_t* flag, size_t n) {
   REQUIRE_CTX(); REQUIRE_PTR(a); if (!flag && n) return bad(ctx, "flag is null"); if (bit < 0 || bit > 255) return bad(ctx, "bit index");
   RUN(launch::mask_bit(s, a, bit, flag, n)); }

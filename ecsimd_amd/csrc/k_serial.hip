@@ -30,6 +30,27 @@ __global__ void __launch_bounds__(BLOCK) k_mask_bit(const uint64_t* __restrict__
   flag[i] = (uint8_t)((w[bit >> 5] >> (bit & 31)) & 1u);
 }
 
+// ---- the reference's register layout <-> one element per lane (round 5) -----------------------
+// The reference's wide_bignum<bignum_256> is eve::wide<bignum, fixed<4>>: four 256-bit lanes stored limb-major, u64[limb * 4 + lane]
+// (bignum.h:99-100, eve/arch/cpu/as_register.hpp:55-60) -- 128 bytes per wide, and a Jacobian point is three of them.  A caller that keeps
+// reference types copies its array of wides to the device AS IT IS and these two kernels do the 4 x 4 transposition at HBM speed: wide w of a
+// record array (record_bytes apart, the wide at offset_bytes) <-> elements 4w .. 4w + 3 of the ABI's array (u64[4 * e + limb]).
+// One thread per ELEMENT: its 32 bytes of the ABI side are two 16-byte accesses, consecutive threads consecutive; on the wide side the four
+// threads of a wide cover 32 contiguous bytes per limb.
+__global__ void __launch_bounds__(BLOCK) k_wide4_to_lanes(const uint8_t* __restrict__ wides, size_t record_bytes, size_t offset_bytes, uint4* __restrict__ out, size_t n) {
+  GID;
+  const uint2* w = reinterpret_cast<const uint2*>(wides + (i >> 2) * record_bytes + offset_bytes) + (i & 3);
+  const uint2 l0 = w[0], l1 = w[4], l2 = w[8], l3 = w[12];
+  out[2 * i] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+  out[2 * i + 1] = make_uint4(l2.x, l2.y, l3.x, l3.y);
+}
+__global__ void __launch_bounds__(BLOCK) k_lanes_to_wide4(const uint4* __restrict__ in, uint8_t* __restrict__ wides, size_t record_bytes, size_t offset_bytes, size_t n) {
+  GID;
+  const uint4 a = in[2 * i], b = in[2 * i + 1];
+  uint2* w = reinterpret_cast<uint2*>(wides + (i >> 2) * record_bytes + offset_bytes) + (i & 3);
+  w[0] = make_uint2(a.x, a.y); w[4] = make_uint2(a.z, a.w); w[8] = make_uint2(b.x, b.y); w[12] = make_uint2(b.z, b.w);
+}
+
 // ---- SEC1 records through LDS -------------------------------------------------------------
 template <int REC> struct rec_lds {            // 256 records of REC bytes, dword-granular staging
   static constexpr int BYTES = BLOCK * REC;    // 8448 (33) or 16640 (65): both multiples of 4
@@ -173,6 +194,10 @@ void on_curve(hipStream_t s, int curve, const uint64_t* x, const uint64_t* y, ui
 void clear_invalid(hipStream_t s, const uint8_t* valid, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n) { GO(k_clear_invalid, valid, rx, ry, finite, n); }
 void bytes_be(hipStream_t s, const void* in, void* out, size_t n) { GO(k_bytes_be, static_cast<const uint4*>(in), static_cast<uint4*>(out), n); }
 void mask_bit(hipStream_t s, const uint64_t* a, int bit, uint8_t* flag, size_t n) { GO(k_mask_bit, a, bit, flag, n); }
+void wide4_to_lanes(hipStream_t s, const void* wides, size_t record_bytes, size_t offset_bytes, uint64_t* out, size_t n) {
+  GO(k_wide4_to_lanes, static_cast<const uint8_t*>(wides), record_bytes, offset_bytes, reinterpret_cast<uint4*>(out), n); }
+void lanes_to_wide4(hipStream_t s, const uint64_t* in, void* wides, size_t record_bytes, size_t offset_bytes, size_t n) {
+  GO(k_lanes_to_wide4, reinterpret_cast<const uint4*>(in), static_cast<uint8_t*>(wides), record_bytes, offset_bytes, n); }
 void sec1_encode(hipStream_t s, int curve, const uint64_t* x, const uint64_t* y, uint8_t* out, size_t n, bool compressed) {
   if (curve == CURVE_P256) { if (compressed) GO((k_sec1_encode<CURVE_P256, 33>), x, y, out, n); else GO((k_sec1_encode<CURVE_P256, 65>), x, y, out, n); }
   else { if (compressed) GO((k_sec1_encode<CURVE_SECP256K1, 33>), x, y, out, n); else GO((k_sec1_encode<CURVE_SECP256K1, 65>), x, y, out, n); }

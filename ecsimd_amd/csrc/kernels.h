@@ -35,6 +35,8 @@ constexpr int PEAK_MADS_PER_LANE_PER_ITER = 64;
 // k_serial.hip (wire formats; HBM-bound)
 void bytes_be(hipStream_t, const void* in, void* out, size_t n);
 void mask_bit(hipStream_t, const uint64_t* a, int bit, uint8_t* flag, size_t n);
+void wide4_to_lanes(hipStream_t, const void* wides, size_t record_bytes, size_t offset_bytes, uint64_t* out, size_t n);      // n = ELEMENTS (4 per wide)
+void lanes_to_wide4(hipStream_t, const uint64_t* in, void* wides, size_t record_bytes, size_t offset_bytes, size_t n);
 void sec1_encode(hipStream_t, int curve, const uint64_t* x, const uint64_t* y, uint8_t* out, size_t n, bool compressed);
 void sec1_decode(hipStream_t, int curve, const uint8_t* in, uint64_t* x, uint64_t* y, uint8_t* ok, size_t n, bool compressed);
 void on_curve(hipStream_t, int curve, const uint64_t* x, const uint64_t* y, uint8_t* ok, size_t n);                 // classical (x, y): x, y < p and on the curve

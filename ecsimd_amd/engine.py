@@ -214,6 +214,16 @@ class Engine:
         n = a.shape[0]; out = self.torch.empty((n, 32), dtype=self.torch.uint8, device=self.tdev)
         self._call("to_bytes_be", self._ptr(a), self._bytes_ptr(out), C.c_size_t(n)); return out
 
+    def wide4_to_lanes(self, wides, record_bytes=128, offset_bytes=0, n_wides=None):
+        """ecsimd_hip_wide4_to_lanes: a device uint8 tensor holding records with one reference wide (u64[limb * 4 + lane]) each -> (4 * wides, 4) elements."""
+        n_wides = wides.numel() // record_bytes if n_wides is None else n_wides
+        out = self.empty(4 * n_wides)
+        self._call("wide4_to_lanes", self._bytes_ptr(wides), C.c_size_t(record_bytes), C.c_size_t(offset_bytes), self._ptr(out), C.c_size_t(n_wides)); return out
+
+    def lanes_to_wide4(self, a, wides, record_bytes=128, offset_bytes=0):
+        """ecsimd_hip_lanes_to_wide4: elements 4w .. 4w + 3 of `a` -> the wide at offset_bytes of record w of the device uint8 tensor `wides` (in place)."""
+        self._call("lanes_to_wide4", self._ptr(a), self._bytes_ptr(wides), C.c_size_t(record_bytes), C.c_size_t(offset_bytes), C.c_size_t(a.shape[0] // 4)); return wides
+
     def mask_bit(self, a, bit):
         n = a.shape[0]; f = self.flags(n)
         self._call("mask_bit", self._ptr(a), C.c_int(bit), self._ptr(f, 0), C.c_size_t(n)); return f

@@ -226,6 +226,15 @@ int ecsimd_hip_if_else(ecsimd_hip_ctx*, const uint8_t* mask, const uint64_t* a, 
  * element <-> 4 x u64 little-endian limbs.  `bytes` is a device pointer, 16-byte aligned. */
 int ecsimd_hip_from_bytes_be(ecsimd_hip_ctx*, const uint8_t* bytes, uint64_t* out, size_t n);
 int ecsimd_hip_to_bytes_be(ecsimd_hip_ctx*, const uint64_t* in, uint8_t* bytes, size_t n);
+/* The reference's own data format on the device (r5).  Its wide_bignum<bignum_256> is eve::wide<bignum, fixed<4>> -- four 256-bit lanes stored limb-major,
+ * u64[limb * 4 + lane], 128 bytes (bignum.h:99-100; eve/arch/cpu/as_register.hpp:55-60) -- and a wide_jacobian_curve_point is three of them
+ * (jacobian_curve_point.h:14-58).  A caller that keeps reference types copies its array of wides / points to the device as it is; these two do the 4 x 4
+ * transposition there, at HBM speed, instead of a per-lane loop on the host: wide w of a record array (`record_bytes` apart, the wide at `offset_bytes`
+ * inside its record: 128 / 0 for an array of wides; 384 / 0, 128, 256 for x, y, z of an array of Jacobian points) <-> elements 4w .. 4w + 3 of an ABI
+ * array (u64[4 * e + limb]).  `wides` is a device pointer, 8-byte aligned; record_bytes and offset_bytes multiples of 8.
+ * integration/scalar_mult_p256_adapter.cpp is the caller. */
+int ecsimd_hip_wide4_to_lanes(ecsimd_hip_ctx*, const void* wides, size_t record_bytes, size_t offset_bytes, uint64_t* out, size_t n_wides);
+int ecsimd_hip_lanes_to_wide4(ecsimd_hip_ctx*, const uint64_t* in, void* wides, size_t record_bytes, size_t offset_bytes, size_t n_wides);
 /* utility.h:45-51 wide_mask_bit: flag[i] = bit `bit` (0..255, 0 = least significant) of a[i] */
 int ecsimd_hip_mask_bit(ecsimd_hip_ctx*, const uint64_t* a, int bit, uint8_t* flag, size_t n);
 /* SEC 1 v2 2.3.3: affine classical (x, y) -> 04||X||Y (65 B per point) or, compressed, 02/03||X (33 B). */

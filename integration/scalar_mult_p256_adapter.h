@@ -20,5 +20,9 @@ using WJCP  = ecsimd::wide_jacobian_curve_point<Curve>;
 ecsimd_mi355x::WJCP scalar_mult_p256(ecsimd_mi355x::WBN const& x, ecsimd_mi355x::WJCP const& P);
 // The batch form: out[w] = scalar_mult_p256(x[w], P[w]) for every wide, 4 * x.size() lanes in ONE launch (the three spans have one length).
 void scalar_mult_p256(std::span<const ecsimd_mi355x::WBN> x, std::span<const ecsimd_mi355x::WJCP> P, std::span<ecsimd_mi355x::WJCP> out);
-// The context the adapter runs on (created on first use, device 0): for options such as ecsimd_hip_set_ref_square_compat.
+// true when the spans travel as raw bytes and the lane transposition runs on the device (the layout check passed)
+bool scalar_mult_p256_transposes_on_the_device();
+// ECSIMD_HIP_REF_SQUARE_COMPAT for every launch of the adapter (large batches run on two contexts: set the option here, not on one of them)
+void scalar_mult_p256_set_ref_square_compat(bool on);
+// The context the adapter runs on (created on first use, device 0).
 ecsimd_hip_ctx* scalar_mult_p256_context();

@@ -9,7 +9,8 @@
 //      X, Y, Z compared limb for limb with curve_group<curve_nist_p256>::scalar_mult computed by the reference in this process --
 //      with ECSIMD_HIP_REF_SQUARE_COMPAT set through the C ABI, so that not one limb may differ (the reference's square() drops a carry on
 //      ~3e-6 of random scalar multiplications: DESIGN.md section 5), then once more without it (exact squaring; differing lanes are reported);
-//   3. the batch form's rate, staging and PCIe included: `rate_wides` wides in one call.
+//   3. the batch form's rate, staging and PCIe included: `rate_wides` wides in one call (argv[2]; argv[3]: a second size).  ECSIMD_ADAPTER_HOST_TRANSPOSE=1
+//      selects the adapter's per-lane host conversion instead of the device transposition (the A/B).
 #include "../integration/scalar_mult_p256_adapter.h"
 
 #include <ecsimd/literals.h>
@@ -55,7 +56,7 @@ size_t lanes_differing(WJCP const& a, WJCP const& b) {
 
 int main(int argc, char** argv) {
   const size_t wides = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 256;
-  const size_t rate_wides = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : (size_t)1 << 16;
+  const size_t rate_wides0 = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : (size_t)1 << 16;
 
   // ---- 1. tests/curve_group.cpp:117-173 (ScalarMult) through the adapter
   {
@@ -94,22 +95,26 @@ int main(int argc, char** argv) {
         return BN::from(c); }};
     if (wides) ref[0] = CG::scalar_mult(x[0], P[0]);
   }
-  ecsimd_hip_ctx* c = scalar_mult_p256_context();
+  CHECK(scalar_mult_p256_context() != nullptr);
   size_t diff_compat = 0, diff_exact = 0, diff_wide = 0;
-  CHECK(ecsimd_hip_set_ref_square_compat(c, 1) == 0);
+  scalar_mult_p256_set_ref_square_compat(true);
   scalar_mult_p256(std::span<const WBN>(x), std::span<const WJCP>(P), std::span<WJCP>(got));            // the batch form: ONE launch
   for (size_t w = 0; w < wides; ++w) diff_compat += lanes_differing(got[w], ref[w]);
   for (size_t w = 0; w < wides && w < 8; ++w) diff_wide += lanes_differing(scalar_mult_p256(x[w], P[w]), ref[w]);     // the reference's own signature
   CHECK(diff_compat == 0); CHECK(diff_wide == 0);
-  CHECK(ecsimd_hip_set_ref_square_compat(c, 0) == 0);
+  scalar_mult_p256_set_ref_square_compat(false);
   scalar_mult_p256(std::span<const WBN>(x), std::span<const WJCP>(P), std::span<WJCP>(got));
   for (size_t w = 0; w < wides; ++w) diff_exact += lanes_differing(got[w], ref[w]);
   std::printf("lane-distinct: %zu lanes through the batch form; differing from the in-process reference: %zu with REF_SQUARE_COMPAT (must be 0), %zu with exact squaring "
               "(the reference's dropped carry: ~3e-6 per lane); four-lane form on %zu wides: %zu differing\n", 4 * wides, diff_compat, diff_exact, wides < 8 ? wides : (size_t)8, diff_wide);
   CHECK(diff_exact <= 1 + wides / 1000);
 
-  // ---- 3. the batch form's rate (AoSoA <-> AoS conversion, H2D, one launch, D2H: everything a caller pays)
-  if (rate_wides) {
+  // ---- 3. the batch form's rate (AoSoA <-> AoS conversion, H2D, one launch, D2H: everything a caller pays); argv[3]: a second, larger size
+  std::printf("lane transposition: %s\n", scalar_mult_p256_transposes_on_the_device() ? "on the device (the spans travel as raw bytes: the layout check passed)" : "per lane on the host");
+  if (!std::getenv("ECSIMD_ADAPTER_HOST_TRANSPOSE")) CHECK(scalar_mult_p256_transposes_on_the_device());
+  for (int arg = 2; arg < 4; ++arg) {
+    const size_t rate_wides = arg == 2 ? rate_wides0 : (argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 0);
+    if (!rate_wides) continue;
     std::vector<WBN> bx(rate_wides); std::vector<WJCP> bP(rate_wides, P.empty() ? CG::WJG() : P[0]), bout(rate_wides);
     for (size_t w = 0; w < rate_wides; ++w) { bx[w] = random_wide(3, w); if (!P.empty()) bP[w] = P[w % wides]; }
     scalar_mult_p256(std::span<const WBN>(bx), std::span<const WJCP>(bP), std::span<WJCP>(bout));       // warm-up (sizes the staging)
@@ -118,11 +123,21 @@ int main(int argc, char** argv) {
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const auto r0 = std::chrono::steady_clock::now();
     size_t sample = rate_wides < 64 ? rate_wides : 64, bad = 0;
-    for (size_t w = 0; w < sample; ++w) bad += lanes_differing(bout[w], CG::scalar_mult(bx[w], bP[w])) > 1;       // (a sample of the big batch against the reference as well)
+    auto pick = [&](size_t i) { return i + 1 == sample ? rate_wides - 1 : i * (rate_wides / sample) + (i % 3); };      // spread over the batch (every chunk of a large one), the last wide included
+    for (size_t i = 0; i < sample; ++i) { const size_t w = pick(i); bad += lanes_differing(bout[w], CG::scalar_mult(bx[w], bP[w])) > 1; }       // (a sample of the big batch against the reference as well)
     const double rdt = std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
     CHECK(bad == 0);
     std::printf("batch form: %zu wides = %zu lanes in one call: %.3f ms = %.2f M scalar mults/s (conversion + PCIe + launch); the reference on this host thread: %.2f k/s\n",
                 rate_wides, 4 * rate_wides, 1e3 * dt, 4e-6 * rate_wides / dt, 4e-3 * sample / rdt);
+    if (arg == 3) {                                                     // the large batch once more with the reference's squaring: the sampled wides may not differ in one limb
+      scalar_mult_p256_set_ref_square_compat(true);
+      scalar_mult_p256(std::span<const WBN>(bx), std::span<const WJCP>(bP), std::span<WJCP>(bout));
+      scalar_mult_p256_set_ref_square_compat(false);
+      size_t d = 0;
+      for (size_t i = 0; i < sample; ++i) { const size_t w = pick(i); d += lanes_differing(bout[w], CG::scalar_mult(bx[w], bP[w])); }
+      CHECK(d == 0);
+      std::printf("the same batch with REF_SQUARE_COMPAT: %zu sampled wides spread over the batch, %zu lanes differ (must be 0)\n", sample, d);
+    }
   }
   std::printf(failures ? "adapter_driver: %d check(s) FAILED\n" : "adapter_driver ok (%d failed)\n", failures);
   return failures ? 1 : 0;

@@ -954,6 +954,37 @@ def test_scalar_mult_p256_entry_point(engine, oracle):
     assert all(np.array_equal(engine.to_numpy(u), v) for u, v in zip(got, exp))
 
 
+def test_reference_register_layout_on_the_device(engine):
+    """ecsimd_hip_wide4_to_lanes / _lanes_to_wide4 (r5): the reference's wide_bignum -- four lanes, limb-major u64[limb * 4 + lane] (bignum.h:99-100) -- and
+    its Jacobian point of three wides, transposed on the device against numpy: an array of wides (records of 128 bytes), x / y / z of an array of points
+    (records of 384 bytes, offsets 0 / 128 / 256), ragged counts, a record with padding behind the wide; and what the entry points refuse."""
+    import torch
+    from ecsimd_amd import EcsimdHipError
+    rng = np.random.default_rng(5)
+    for wides in (1, 3, 64, 1000 + 77):
+        rec = rng.integers(0, 2**64, size=(wides, 3, 4, 4), dtype=np.uint64)                    # [wide][x, y, z][limb][lane]
+        dev = torch.from_numpy(rec.view(np.uint8).reshape(-1)).to(engine.tdev)
+        for comp in range(3):
+            got = engine.to_numpy(engine.wide4_to_lanes(dev, 384, 128 * comp, wides))
+            want = rec[:, comp].transpose(0, 2, 1).reshape(4 * wides, 4)                        # element 4w + lane, limb
+            assert np.array_equal(got, want), (wides, comp)
+        back = torch.zeros_like(dev)
+        for comp in range(3):
+            engine.lanes_to_wide4(engine.wide4_to_lanes(dev, 384, 128 * comp, wides), back, 384, 128 * comp)
+        assert torch.equal(back, dev)
+        one = torch.from_numpy(np.ascontiguousarray(rec[:, 1]).view(np.uint8).reshape(-1)).to(engine.tdev)      # a plain array of wides
+        assert np.array_equal(engine.to_numpy(engine.wide4_to_lanes(one)), rec[:, 1].transpose(0, 2, 1).reshape(4 * wides, 4))
+        pad = torch.zeros(wides * 136, dtype=torch.uint8, device=engine.tdev)                   # 8 bytes of something else behind each wide: left alone
+        engine.lanes_to_wide4(engine.wide4_to_lanes(one), pad, 136, 0)
+        p = pad.cpu().numpy().reshape(wides, 136)
+        assert np.array_equal(p[:, :128].reshape(-1), one.cpu().numpy()) and not p[:, 128:].any()
+    dev = torch.zeros(1024, dtype=torch.uint8, device=engine.tdev)
+    for rb, off in ((120, 0), (128, 8), (132, 0), (384, 260), (384, 12)):
+        with pytest.raises(EcsimdHipError, match="128 bytes"):
+            engine.wide4_to_lanes(dev, rb, off, 2)
+    assert engine.wide4_to_lanes(dev, 128, 0, 0).shape[0] == 0
+
+
 @pytest.mark.parametrize("cv", CURVES)
 def test_wire_formats(engine, oracle, cv):
     """Device byte codecs: 32 big-endian bytes <-> limbs (serialization.h:12-48 over a batch), wide_mask_bit

@@ -52,7 +52,8 @@ def test_reference_side_adapter_compiles_and_links():
     syms = subprocess.run(["nm", "-DC", "--defined-only", OUT], capture_output=True, text=True, check=True).stdout
     assert "scalar_mult_p256(eve::" in syms and "scalar_mult_p256(std::span<" in syms, "the adapter does not export the reference's entry point and its batch form"
     undefined = subprocess.run(["nm", "-D", "--undefined-only", OUT], capture_output=True, text=True, check=True).stdout
-    for f in ("ecsimd_hip_init", "ecsimd_hip_scalar_mult_p256", "ecsimd_hip_memcpy_h2d", "ecsimd_hip_memcpy_d2h", "ecsimd_hip_malloc", "ecsimd_hip_free"):
+    for f in ("ecsimd_hip_init", "ecsimd_hip_scalar_mult_p256", "ecsimd_hip_memcpy_h2d", "ecsimd_hip_memcpy_d2h", "ecsimd_hip_malloc", "ecsimd_hip_free",
+              "ecsimd_hip_wide4_to_lanes", "ecsimd_hip_lanes_to_wide4"):
         assert f in undefined, f
     assert "libecsimd_hip.so" in subprocess.run(["ldd", OUT], capture_output=True, text=True).stdout
     exe = build_driver()
@@ -65,10 +66,15 @@ def test_the_adapter_executes_beside_the_reference_on_the_gpu():
     exe = build_driver()
     if exe is None:
         pytest.skip("oracle/_ref/adapter_driver did not travel here and cannot be built without the reference's sources")
-    r = subprocess.run([exe, "512", str(1 << 15)], capture_output=True, text=True, timeout=800)
+    r = subprocess.run([exe, "512", str(1 << 15), str((1 << 18) + 1234)], capture_output=True, text=True, timeout=800)     # the third size: three chunks on two contexts, a ragged tail
     print(r.stdout, r.stderr[-2000:])
     assert r.returncode == 0 and "adapter_driver ok (0 failed)" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     assert "scenarios of tests/curve_group.cpp ScalarMult through the adapter: ok" in r.stdout
     m = re.search(r"lane-distinct: (\d+) lanes .*?: (\d+) with REF_SQUARE_COMPAT \(must be 0\), (\d+) with exact squaring .*?: (\d+) differing", r.stdout)
     assert m and int(m.group(1)) == 2048 and int(m.group(2)) == 0 and int(m.group(4)) == 0
     assert re.search(r"batch form: 32768 wides = 131072 lanes in one call", r.stdout)
+    assert re.search(r"batch form: 263378 wides = 1053512 lanes in one call", r.stdout) and re.search(r"the same batch with REF_SQUARE_COMPAT: 64 sampled wides spread over the batch, 0 lanes differ", r.stdout)
+    assert "lane transposition: on the device" in r.stdout                       # the spans travelled as raw bytes (the adapter's layout check passed)
+    # ... and the adapter's other path (the per-lane conversion on the host, taken when a compiler lays the reference's types out differently): the same checks
+    r = subprocess.run([exe, "128", "0"], capture_output=True, text=True, timeout=800, env=dict(os.environ, ECSIMD_ADAPTER_HOST_TRANSPOSE="1"))
+    assert r.returncode == 0 and "adapter_driver ok (0 failed)" in r.stdout and "lane transposition: per lane on the host" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

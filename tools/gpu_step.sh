@@ -113,6 +113,13 @@ import json; d=json.load(open('$out/bench_brainpool_$w.json')); r=d['roofline'];
     timeout -k 10 500 python tools/ab_variants.py "--workload ladder-ref-compat --curve secp256k1 --steps 5 --warmup 1" mad64=base borrow_tracking=build/ab_k1old/libecsimd_hip.so > "$out/ab.txt" 2>&1; rc=$?
     timeout -k 10 300 python tools/ab_variants.py "--workload ladder-ref-compat --curve p256 --steps 5 --warmup 1" p256_for_scale=base >> "$out/ab.txt" 2>&1
     cat "$out/ab.txt"; exit $rc ;;
+  r5_adapter)       # round 5: the reference's register layout transposed on the device -- its test, the adapter beside the reference (device transposition, then the host loop: the A/B), the PCIe-inclusive rate
+    timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_integration_adapter.py -x -q -m gpu -k "register_layout or adapter or wire_formats" > "$out/pytest.txt" 2>&1; rc=$?
+    tail -5 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
+    timeout -k 10 600 ./oracle/_ref/adapter_driver 512 65536 1048576 > "$out/adapter_driver.txt" 2>&1 || rc=$?; cat "$out/adapter_driver.txt"
+    ECSIMD_ADAPTER_HOST_TRANSPOSE=1 timeout -k 10 600 ./oracle/_ref/adapter_driver 512 65536 1048576 > "$out/adapter_driver_host_transpose.txt" 2>&1 || rc=$?; cat "$out/adapter_driver_host_transpose.txt"
+    timeout -k 10 300 python tools/pcie_rate.py > "$out/pcie_rate.txt" 2>&1 || rc=$?; cat "$out/pcie_rate.txt"
+    exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
     timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -15 "$out/pytest.txt"; exit $rc ;;
   *) echo "unknown step $name"; exit 2 ;;

@@ -82,7 +82,8 @@ for nm in names:
                 ref_wrong = (rx != vx).any(axis=1) | (ry != vy).any(axis=1)
                 conf = int(np.count_nonzero(gpu_right & ref_wrong))
         tot += n; diff += len(bad); unexplained += 0 if ok else len(bad); confirmed += conf; compat_diff += cbad
-        print(f"{nm} batch {b}: {n} lanes, {len(bad)} differ from the reference (explained by its square() defect: {ok}; libcrypto sides with the GPU on {conf}); "
+        who = "textbook affine arithmetic on Python integers" if reg else "libcrypto"
+        print(f"{nm} batch {b}: {n} lanes, {len(bad)} differ from the reference (explained by its square() defect: {ok}; {who} sides with the GPU on {conf}); "
               f"with REF_SQUARE_COMPAT {cbad} differ   [{time.time()-t0:.0f}s]", flush=True)
 print(f"TOTAL {tot} scalar multiplications per mode: exact ladder {diff} lanes differ from the reference ({diff/tot:.2e}), unexplained {unexplained}, "
       f"confirmed by OpenSSL (registered curves: by textbook affine arithmetic) {confirmed if ossl is not None else 'n/a'}; REF_SQUARE_COMPAT ladder {compat_diff} lanes differ")
