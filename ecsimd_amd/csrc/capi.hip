@@ -1216,7 +1216,7 @@ int gc_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve_of, const curve_record&
   if (rc == ECSIMD_HIP_OK) rc = ensure_valid(ctx, (n + 15) / 16 * 16);
   if (rc != ECSIMD_HIP_OK) return rc;
   const uint32_t* comb = nullptr;                                   // u1 G from the generator's table where the curve has one (n >= 2^255), else a ladder pass
-  if (gc_comb_possible(rec) && !capturing(ctx)) { rc = ensure_gc_comb(ctx, curve_of, rec, &comb); if (rc != ECSIMD_HIP_OK) return rc; }
+  if (gc_comb_possible(rec)) { rc = ensure_gc_comb(ctx, curve_of, rec, &comb); if (rc != ECSIMD_HIP_OK) { if (!capturing(ctx)) return rc; comb = nullptr; } }   // (no table yet and a capture in progress: the ladder)
   L = gc_plan(ctx->workspace, n);
   hipStream_t s = ctx->stream;
   launch::gc_on_curve(s, rec.G, qx, qy, ctx->valid, n);
@@ -1372,7 +1372,7 @@ int ecsimd_hip_ecdsa_sign(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, con
     rc = ensure_workspace(ctx, L.bytes);
     if (rc != ECSIMD_HIP_OK) return rc;
     const uint32_t* comb = nullptr;                             // k G from the generator's table, every entry of a window read (constant time), where the curve has one
-    if (gc_comb_possible(rec) && !capturing(ctx)) { rc = ensure_gc_comb(ctx, curve, rec, &comb); if (rc != ECSIMD_HIP_OK) return rc; }
+    if (gc_comb_possible(rec)) { rc = ensure_gc_comb(ctx, curve, rec, &comb); if (rc != ECSIMD_HIP_OK) { if (!capturing(ctx)) return rc; comb = nullptr; } }   // (no table yet and a capture in progress: the ladder)
     L = gc_plan(ctx->workspace, n);
     if (comb) {
       launch::gc_base_windowed(ctx->stream, rec.G, order_words(rec), k, comb, L.j[0], L.j[1], L.j[2], n, true);
