@@ -34,7 +34,12 @@ template <int C, int OP> __global__ void __launch_bounds__(BLOCK) k_fe29_raw(r29
     O(0, mul29<C>(I(0), I(1), cx));
   } else if constexpr (OP == launch::RAW_SQR) {
     O(0, sqr29<C>(I(0), cx));
-  } else if constexpr (!r29_prime<C>::dense) {                                // the window kernels' functions exist for the two built-in primes
+  } else if constexpr (r29_prime<C>::dense) {                                 // a registered curve: the generator's comb runs madd29 with the dense reduction (k_gcomb.hip)
+    const jpoint29 P{I(0), I(1), I(2)};
+    jpoint29 R = P;
+    if constexpr (OP == launch::RAW_MADD) R = madd29<C>(P, I(3), I(4), cx);
+    O(0, R.x); O(1, R.y); O(2, R.z);
+  } else {                                                                    // the window kernels' functions exist for the two built-in primes
     const jpoint29 P{I(0), I(1), I(2)};
     jpoint29 R;
     if constexpr (OP == launch::RAW_MADD) R = madd29<C>(P, I(3), I(4));
@@ -56,7 +61,9 @@ template <int C> static bool raw_dispatch(hipStream_t s, const r29_ctx<C>& cx, i
     CASE(RAW_ZDAU); CASE(RAW_MUL); CASE(RAW_SQR);
     default: break;
   }
-  if constexpr (!r29_prime<C>::dense) {
+  if constexpr (r29_prime<C>::dense) {
+    switch (op) { CASE(RAW_MADD); default: break; }
+  } else {
     switch (op) {
       CASE(RAW_MADD); CASE(RAW_JDBL); CASE(RAW_DBL_ADD); CASE(RAW_MADDV);
       default: break;

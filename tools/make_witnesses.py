@@ -28,7 +28,7 @@ CURVES = {"p256": m.CURVE_P256, "secp256k1": m.CURVE_SECP}
 CURVES.update({k: m.Curve.dense(k, p) for k, p in DENSE.items()})
 PROOFS = [("ladder", m.prove_invariant, ("p256", "secp256k1")), ("comb", m.prove_comb_invariant, ("p256", "secp256k1")), ("window", m.prove_window_invariant, ("p256", "secp256k1")),
           ("glv", m.prove_glv_invariant, ("secp256k1",)), ("complete", m.prove_complete_invariant, ("secp256k1",))]
-FUNCTIONS = [("zdau", ("p256", "secp256k1", "brainpoolP256r1", "sm2", "frp256v1")), ("madd", ("p256", "secp256k1")), ("jdbl", ("p256", "secp256k1")), ("dbl_add", ("p256", "secp256k1")),
+FUNCTIONS = [("zdau", ("p256", "secp256k1", "brainpoolP256r1", "sm2", "frp256v1")), ("madd", ("p256", "secp256k1", "brainpoolP256r1", "sm2", "frp256v1")), ("jdbl", ("p256", "secp256k1")), ("dbl_add", ("p256", "secp256k1")),
              ("maddv", ("p256", "secp256k1")), ("pdbl", ("secp256k1",)), ("padd", ("secp256k1",))]
 
 
@@ -44,6 +44,12 @@ def build():
     for kind in DENSE:
         for what, a, b, r, ach, proven in m.product_witnesses(CURVES[kind], lambda cv: any_calls, top=4, seed=9):
             entries.append({"kind": "product", "proof": "ladder, any odd p < 2^256", "curve": kind, "op": "mul" if what == "mul" else "sqr", "swap": 0,
+                            "in": [a] + ([b] if b is not None else []), "out": [r], "worst_column": ach, "proven_column": proven})
+    # ... and the comb's (k_gcomb.hip: madd29 with the dense reduction), proven for any odd p as it stands
+    any_comb = m.proof_calls(m.prove_comb_invariant)(m.CURVE_ANY)
+    for kind in DENSE:
+        for what, a, b, r, ach, proven in m.product_witnesses(CURVES[kind], lambda cv: any_comb, top=3, seed=11):
+            entries.append({"kind": "product", "proof": "comb, any odd p < 2^256", "curve": kind, "op": "mul" if what == "mul" else "sqr", "swap": 0,
                             "in": [a] + ([b] if b is not None else []), "out": [r], "worst_column": ach, "proven_column": proven})
     for op, kinds in FUNCTIONS:
         for kind in kinds:
