@@ -109,6 +109,15 @@ import json; d=json.load(open('$out/bench_brainpool_$w.json')); r=d['roofline'];
     prof fixed_base_big --workload fixed-base-big
     prof windowed_ct_secp256k1 --workload windowed-ct --curve secp256k1
     exit $rc ;;
+  r5_profile2)      # round 5: the same passes for the remaining ladder lines (the two other registered curves, the canonical-word loops), so that no bench line carries traffic: null
+    rc=0
+    prof() { tag=$1; shift; bash tools/profile.sh "r05_$tag" "$@" > "$out/profile_$tag.txt" 2>&1 || { rc=$?; tail -5 "$out/profile_$tag.txt"; }; echo "profiled $tag rc=$rc"; }
+    prof ladder_sm2 --curve sm2
+    prof ladder_frp256v1 --curve frp256v1
+    prof ladder_radix32_p256 --workload ladder-radix32
+    prof ladder_radix32_brainpoolP256r1 --workload ladder-radix32 --curve brainpoolP256r1
+    prof ladder_ref_compat_brainpoolP256r1 --workload ladder-ref-compat --curve brainpoolP256r1
+    exit $rc ;;
   r5_ab_k1)         # round 5: the secp256k1 Montgomery reduction's rounds on one 64-bit MAC against rounds 1-4's borrow-tracking form (build/ab_k1old, -DECS_K1_REDUCE_MAD64=0)
     timeout -k 10 500 python tools/ab_variants.py "--workload ladder-ref-compat --curve secp256k1 --steps 5 --warmup 1" mad64=base borrow_tracking=build/ab_k1old/libecsimd_hip.so > "$out/ab.txt" 2>&1; rc=$?
     timeout -k 10 300 python tools/ab_variants.py "--workload ladder-ref-compat --curve p256 --steps 5 --warmup 1" p256_for_scale=base >> "$out/ab.txt" 2>&1
