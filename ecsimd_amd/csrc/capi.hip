@@ -84,7 +84,9 @@ struct ecsimd_hip_ctx {
   uint8_t* valid;              // grow-only: per-lane public-key validity of double_scalar_mult / ecdsa_verify_rx
   size_t valid_bytes;
   int ref_square;              // ecsimd_hip_set_ref_square_compat: the reference's square() as written (mul.h:160-212)
-  std::vector<std::pair<int, uint32_t*>> gcomb;   // per registered curve: the 4-bit odd-digit table of multiples of its generator (k_gcomb.hip; built on first use)
+  struct gcomb_entry { int curve; uint32_t* table; uint64_t* special; };
+  std::vector<gcomb_entry> gcomb;   // per registered curve: the 4-bit odd-digit table of multiples of its generator (k_gcomb.hip) and, for the small-batch route, the ladder's
+                                    // three degenerate scalars with its affine results for them on G (as base_special); built on first use
   char err[256];
 };
 
@@ -339,6 +341,8 @@ bool lookup_curve(int id, gcurve* out);          // the curve registry, below
 // The same for a curve registered at run time: flags BASE_* | OUT_* | LADDER_RADIX32 | REF_SQUARE_COMPAT; the table-driven ALG_* algorithms exist for the
 // two built-in curves only.  x == nullptr: the curve's generator.
 int run_gcomb(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, size_t n, int flags);
+constexpr int GC_NOT_TAKEN = -1000;
+int gc_small_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, size_t n, int flags);
 int run_gladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y,
                 uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   gcurve GC; if (!lookup_curve(curve, &GC)) return bad(ctx, "unknown curve id");
@@ -573,7 +577,7 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->sink);
   (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->windowct_table[0]); (void)hipFree(ctx->windowct_table[1]); (void)hipFree(ctx->window16_table[0]); (void)hipFree(ctx->window16_table[1]); (void)hipFree(ctx->workspace); (void)hipFree(ctx->valid); (void)hipFree(ctx->base_special[0]); (void)hipFree(ctx->base_special[1]);
-  for (auto& t : ctx->gcomb) (void)hipFree(t.second);
+  for (auto& t : ctx->gcomb) { (void)hipFree(t.table); (void)hipFree(t.special); }
   (void)hipEventDestroy(ctx->handoff);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -998,7 +1002,11 @@ int ecsimd_hip_scalar_mult_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* 
   REQUIRE_CTX(); REQUIRE_PTR(k); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy);
   flags &= ~ECSIMD_HIP_BASE_GENERATOR;                            // (implied here)
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);
-  if (curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE) return run_gladder(ctx, curve, k, 4, nullptr, nullptr, ox, oy, oz, n, flags & ~ECSIMD_HIP_BASE_MGRY);
+  if (curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE) {
+    int rc = gc_small_base(ctx, curve, k, ox, oy, n, flags);       // small batches, affine output, no algorithm asked for: the constant-time comb, the ladder's bits kept
+    if (rc != GC_NOT_TAKEN) return rc;
+    return run_gladder(ctx, curve, k, 4, nullptr, nullptr, ox, oy, oz, n, flags & ~ECSIMD_HIP_BASE_MGRY);
+  }
   REQUIRE_CURVE();
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG)) {
     const bool big = (flags & ECSIMD_HIP_ALG_WINDOWED_BIG) != 0;         // signed 20-bit windows, table in device memory
@@ -1113,7 +1121,7 @@ gc_layout gc_plan(uint64_t* base, size_t n) {
 // curve -- whose degenerate scalars the entries' multipliers must not be (checked; k* by way of n - k* if it is one) -- through the shared inversion.
 bool gc_comb_possible(const curve_record& rec) { return rec.has_order && (rec.n.l[3] >> 63) != 0; }
 int ensure_gc_comb(ecsimd_hip_ctx* ctx, int curve, const curve_record& rec, const uint32_t** out) {
-  for (auto& t : ctx->gcomb) if (t.first == curve) { *out = t.second; return ECSIMD_HIP_OK; }
+  for (auto& t : ctx->gcomb) if (t.curve == curve) { *out = t.table; return ECSIMD_HIP_OK; }
   if (!gc_comb_possible(rec)) return bad(ctx, "the windowed algorithms on a registered curve need its group order n, n >= 2^255");
   if (capturing(ctx)) return bad(ctx, "a window table would have to be built during stream capture: run this call once before capturing");
   constexpr int W = launch::GCOMB_WINDOWS, PER = launch::GCOMB_ENTRIES;
@@ -1168,9 +1176,35 @@ int ensure_gc_comb(ecsimd_hip_ctx* ctx, int curve, const curve_record& rec, cons
   if (e == hipSuccess) e = hipGetLastError();
   (void)hipFree(kd);
   if (e != hipSuccess) { (void)hipFree(table); return fail(ctx, e, "window table build (registered curve)"); }
-  ctx->gcomb.emplace_back(curve, table);
+  ctx->gcomb.push_back({curve, table, nullptr});
   *out = table;
   return ECSIMD_HIP_OK;
+}
+// The small-batch route's record for a registered curve (ensure_base_special for the built-in ones): n - 1, 2^256 - n - 1, 2^256 - n and what the reference's
+// ladder returns for them on G, affine -- computed by the very launches run_gladder(OUT_AFFINE) makes.
+int ensure_gc_base_special(ecsimd_hip_ctx* ctx, int curve, const curve_record& rec, const uint64_t** out) {
+  for (auto& t : ctx->gcomb) if (t.curve == curve && t.special) { *out = t.special; return ECSIMD_HIP_OK; }
+  if (capturing(ctx)) return bad(ctx, "a record would have to be built during stream capture: run this call once before capturing");
+  u256 one = {{1, 0, 0, 0}}, zero = {{0, 0, 0, 0}}, s3[3];
+  (void)u_sub(s3[0], rec.n, one); (void)u_sub(s3[2], zero, rec.n); (void)u_sub(s3[1], s3[2], one);
+  uint64_t host[12];
+  for (int j = 0; j < 3; ++j) { if (!u_ladder_degenerate(rec.n, s3[j])) return bad(ctx, "base_special: not a degenerate scalar"); for (int l = 0; l < 4; ++l) host[4 * j + l] = s3[j].l[l]; }
+  uint64_t* r = nullptr; uint64_t* tmp = nullptr;
+  hipError_t e = hipMalloc(&r, 9 * 32);
+  if (e == hipSuccess) e = hipMalloc(&tmp, 9 * 32);
+  if (e == hipSuccess) e = hipMemcpyAsync(r, host, 3 * 32, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) {
+    launch::gc_scalar_mult(ctx->stream, rec.G, r, 4, nullptr, nullptr, tmp, tmp + 12, tmp + 24, 3, 0);
+    launch::gc_to_affine_batched(ctx->stream, rec.G, tmp, tmp + 12, tmp + 24, r + 12, r + 24, 3);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  (void)hipFree(tmp);
+  if (e != hipSuccess) { (void)hipFree(r); return fail(ctx, e, "base_special build (registered curve)"); }
+  for (auto& t : ctx->gcomb) if (t.curve == curve) { t.special = r; *out = r; return ECSIMD_HIP_OK; }
+  (void)hipFree(r);
+  return bad(ctx, "base_special: the curve's table is missing");
 }
 launch::words8 order_words(const curve_record& rec) { launch::words8 w; for (int i = 0; i < 4; ++i) { w.w[2 * i] = (uint32_t)rec.n.l[i]; w.w[2 * i + 1] = (uint32_t)(rec.n.l[i] >> 32); } return w; }
 }  // namespace
@@ -1193,6 +1227,30 @@ int run_gcomb(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, u
   launch::gc_to_affine_batched(ctx->stream, rec.G, jx, jy, jz, ox, oy, n);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult_base (registered curve, windowed) launch");
+}
+// scalar_mult_base(registered curve, OUT_AFFINE, no ALG_* / ladder flag) on up to 2^16 lanes: as for the built-in curves (ecsimd_hip_scalar_mult_base below) a
+// ladder launch costs its 254 iterations however few lanes it has; the constant-time comb costs 63 additions.  Its affine result is the true k G -- the ladder's
+// everywhere but at the ladder's three degenerate scalars, and there the lanes take the ladder's own coordinates from the record: the same bits out.
+int gc_small_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, size_t n, int flags) {
+  constexpr int other = ECSIMD_HIP_REF_SQUARE_COMPAT | ECSIMD_HIP_LADDER_RADIX32 | ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG |
+                        ECSIMD_HIP_ALG_NO_ENDOMORPHISM | ECSIMD_HIP_ALG_CONSTANT_TIME;
+  if (!(flags & ECSIMD_HIP_OUT_AFFINE) || (flags & other) || ctx->ref_square || n == 0 || n > SMALL_BASE_MAX) return GC_NOT_TAKEN;
+  curve_record rec; if (!lookup_curve_record(curve, &rec) || !gc_comb_possible(rec)) return GC_NOT_TAKEN;
+  (void)hipSetDevice(ctx->device);
+  const uint32_t* table = nullptr; const uint64_t* special = nullptr;
+  int rc = ensure_gc_comb(ctx, curve, rec, &table);
+  if (rc == ECSIMD_HIP_OK) rc = ensure_gc_base_special(ctx, curve, rec, &special);
+  if (rc != ECSIMD_HIP_OK) { ctx->err[0] = 0; return GC_NOT_TAKEN; }                     // (a capture in progress and nothing built yet, a curve whose table cannot be built: the ladder)
+  if (capturing(ctx) && ctx->workspace_bytes < 3 * n * 32) return GC_NOT_TAKEN;
+  rc = ensure_workspace(ctx, 3 * n * 32);
+  if (rc != ECSIMD_HIP_OK) return rc;
+  uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
+  hipStream_t s = ctx->stream;
+  launch::gc_base_windowed(s, rec.G, order_words(rec), k, table, jx, jy, jz, n, true);
+  launch::gc_to_affine_batched(s, rec.G, jx, jy, jz, ox, oy, n);
+  launch::patch_special(s, k, special, ox, oy, n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult_base (registered curve, small batch) launch");
 }
 int gc_require_ecdsa(ecsimd_hip_ctx* ctx, int curve, curve_record* rec) {
   if (!lookup_curve_record(curve, rec)) return bad(ctx, "unknown curve id");

@@ -15,7 +15,13 @@ using launch::BLOCK;
 #define GLADDER_WAVES_PER_SIMD 3
 #endif
 
-template <int RADIX, bool REF> __global__ void __launch_bounds__(BLOCK, GLADDER_WAVES_PER_SIMD)
+// The canonical-word loops want 188 / 178 registers: at 3 waves per SIMD 27 / 11 of them spill (constant-addressed scratch, re-read in every iteration: 6.7 /
+// 4.7 GB per 2^24 launch where 3.2 are algorithmic) -- and are still no slower than spill-free at 2 waves (20.3 against 19.8 M/s with the reference's squaring,
+// 20.66 against 20.63 without: profiles/r05/ab_generic_radix32_ladders_waves_per_simd.txt).  These are the A/B and bit-identical forms; the default loop spills nothing.
+#ifndef GLADDER32_WAVES_PER_SIMD
+#define GLADDER32_WAVES_PER_SIMD 3
+#endif
+template <int RADIX, bool REF> __global__ void __launch_bounds__(BLOCK, RADIX == 29 ? GLADDER_WAVES_PER_SIMD : GLADDER32_WAVES_PER_SIMD)
 k_gc_scalar_mult(gcurve G, const uint64_t* __restrict__ k, int k_stride, const uint64_t* __restrict__ x, const uint64_t* __restrict__ y,
                  uint64_t* __restrict__ ox, uint64_t* __restrict__ oy, uint64_t* __restrict__ oz, size_t n, int flags) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;

@@ -184,8 +184,9 @@ int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id);
  * n - u is a good ladder scalar for u in {n - 1, 2^256 - n - 1, 2^256 - n} (every prime-order curve of this size) -- by double_scalar_mult,
  * ecdsa_verify_rx, ecdsa_verify, ecdsa_sign: u1 G (sign: k G, every table entry of a window read) comes from the generator's table, u2 Q from a pass of
  * the ladder with the scalar kept clear of its three degenerate values (u -> n - u and the result negated) -- correct for every scalar in [0, n);
- * ecdsa_sign's scratch is zeroed like the built-in curves'.  (n < 2^255: ladder passes instead of the table.)  And, as a FIELD id, by every element-wise
- * field entry point.  Same level-J parity as the built-in curves: X, Y, Z are
+ * ecdsa_sign's scratch is zeroed like the built-in curves'.  (n < 2^255: ladder passes instead of the table.)  Like the built-in curves', a call of
+ * scalar_mult_base(OUT_AFFINE) without an algorithm flag on up to 2^16 lanes takes that comb (constant time) and returns the ladder's affine bits, its
+ * three degenerate scalars included.  And, as a FIELD id, by every element-wise field entry point.  Same level-J parity as the built-in curves: X, Y, Z are
  * the bits the reference instantiated with this Curve returns.  The ladder's 254 iterations run on nine signed 29-bit limbs with the dense p in SGPRs
  * (81 multiply-adds per reduction where P-256's sparse form has 36); LADDER_RADIX32 / REF_SQUARE_COMPAT run them on 8 x 32-bit canonical words.
  * Process-wide, thread-safe, ids live as long as the process. */

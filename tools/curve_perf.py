@@ -56,3 +56,28 @@ for cv, nm in ((P256, "P-256"), (SECP256K1, "secp256k1")):
     assert all(np.array_equal(u, v) for u, v in zip(a, b)), "generic != special"
     rate(cv, LADDER_RADIX32, f"{nm}: built-in, 8 x 32-bit canonical words (LADDER_RADIX32)")
 print("outputs of the compared pairs are identical on the first 4096 lanes")
+
+# small batches of k G on a registered curve: the default route (the constant-time comb up to 2^16 lanes) against the ladder launch it replaces
+import time
+c = REF_CURVES["brainpoolP256r1"]
+cid = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"])
+print("brainpoolP256r1, scalar_mult_base(OUT_AFFINE): wall time of ONE synchronous call (best of 7)")
+for lg in (2, 8, 12, 16):
+    m = 1 << lg
+    k = eng.fill_random(m, SEED, 5)
+    out = [eng.empty(m) for _ in range(3)]
+    def best(fl):
+        eng.scalar_mult_base(cid, k, flags=fl, out=out); torch.cuda.synchronize()
+        ts = []
+        for _ in range(7):
+            t = time.perf_counter(); eng.scalar_mult_base(cid, k, flags=fl, out=out); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+        return min(ts)
+    ladder = best(OUT_AFFINE | LADDER_RADIX32)                                          # an explicit ladder flag keeps the ladder (on canonical words)
+    gx = eng.to_device(np.tile(np.array([(c["gx"] >> (64 * j)) & (2**64 - 1) for j in range(4)], dtype=np.uint64), (m, 1)))
+    gy = eng.to_device(np.tile(np.array([(c["gy"] >> (64 * j)) & (2**64 - 1) for j in range(4)], dtype=np.uint64), (m, 1)))
+    t0 = best(OUT_AFFINE)
+    eng.scalar_mult(cid, k, gx, gy, flags=OUT_AFFINE, out=out); torch.cuda.synchronize()
+    ts = []
+    for _ in range(7):
+        t = time.perf_counter(); eng.scalar_mult(cid, k, gx, gy, flags=OUT_AFFINE, out=out); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+    print(f"  2^{lg:<2d} lanes: default route {1e3 * t0:7.3f} ms; the 29-bit ladder on G as a variable base {1e3 * min(ts):7.3f} ms; LADDER_RADIX32 {1e3 * ladder:7.3f} ms")

@@ -118,6 +118,15 @@ import json; d=json.load(open('$out/bench_brainpool_$w.json')); r=d['roofline'];
     prof ladder_radix32_brainpoolP256r1 --workload ladder-radix32 --curve brainpoolP256r1
     prof ladder_ref_compat_brainpoolP256r1 --workload ladder-ref-compat --curve brainpoolP256r1
     exit $rc ;;
+  r5_small)         # round 5: the small-batch route of a registered curve (tests, latencies), then the generic canonical-word ladders at 2 against 3 waves per SIMD (build/ab_g32w3: -DGLADDER32_WAVES_PER_SIMD=3, 27 / 11 registers spilled)
+    timeout -k 10 900 python -m pytest tests/test_gpu_curves.py -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?
+    tail -5 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
+    timeout -k 10 600 python tools/curve_perf.py 22 > "$out/curve_perf.txt" 2>&1 || rc=$?; cat "$out/curve_perf.txt"
+    for w in ladder-ref-compat ladder-radix32; do
+      echo "== brainpoolP256r1 $w" >> "$out/ab.txt"
+      timeout -k 10 400 python tools/ab_variants.py "--curve brainpoolP256r1 --workload $w --global-log2-batch 22 --steps 3 --warmup 1" waves2=base waves3=build/ab_g32w3/libecsimd_hip.so >> "$out/ab.txt" 2>&1 || rc=$?
+    done
+    cat "$out/ab.txt"; exit $rc ;;
   r5_ab_k1)         # round 5: the secp256k1 Montgomery reduction's rounds on one 64-bit MAC against rounds 1-4's borrow-tracking form (build/ab_k1old, -DECS_K1_REDUCE_MAD64=0)
     timeout -k 10 500 python tools/ab_variants.py "--workload ladder-ref-compat --curve secp256k1 --steps 5 --warmup 1" mad64=base borrow_tracking=build/ab_k1old/libecsimd_hip.so > "$out/ab.txt" 2>&1; rc=$?
     timeout -k 10 300 python tools/ab_variants.py "--workload ladder-ref-compat --curve p256 --steps 5 --warmup 1" p256_for_scale=base >> "$out/ab.txt" 2>&1
