@@ -452,3 +452,65 @@ def test_small_base_batches_on_a_registered_curve_take_the_comb_and_keep_the_lad
     k = engine.fill_random(64, SEED, 172)
     gx = engine.to_device(np.tile(from_int(c["gx"]), (64, 1))); gy = engine.to_device(np.tile(from_int(c["gy"]), (64, 1)))
     assert all(torch.equal(a, b) for a, b in zip(engine.scalar_mult_base(cid, k), engine.scalar_mult(cid, k, gx, gy)))      # Jacobian: the ladder's representative
+
+
+def test_device_group_on_a_registered_curve(engine):
+    """ecsimd_hip_group_scalar_mult with a registered curve id (the registry is process-wide, every member's context sees the same id): three members on device 0,
+    uneven shards, Jacobian and affine, gathered into member 0's arrays = one context's ladder on the whole batch; the host-array form too."""
+    import torch
+    from ecsimd_amd import DeviceGroup, shard_range_c
+    c = REF_CURVES["brainpoolP256r1"]
+    cid = register(c)
+    n = 5003; G = 3
+    grp = DeviceGroup([0] * G)
+    try:
+        k = engine.fill_random(n, SEED, 201); s_ = engine.fill_random(n, SEED, 202)
+        bx, by = engine.scalar_mult_base(cid, s_, flags=OUT_AFFINE)
+        exp = engine.scalar_mult(cid, k, bx, by)
+        spans = [shard_range_c(n, m, G) for m in range(G)]
+        cut = lambda t: [t[f:f + cnt].contiguous() for f, cnt in spans]
+        got, _ = grp.scalar_mult(cid, cut(k), cut(bx), cut(by), n)
+        assert all(torch.equal(a, b) for a, b in zip(got, exp))
+        (ax, ay), _ = grp.scalar_mult(cid, cut(k), cut(bx), cut(by), n, flags=OUT_AFFINE)
+        ex, ey = engine.to_affine(cid, exp)
+        assert torch.equal(ax, ex) and torch.equal(ay, ey)
+        H = grp.scalar_mult_host(cid, *(engine.to_numpy(t) for t in (k, bx, by)))
+        assert all(np.array_equal(h, engine.to_numpy(e)) for h, e in zip(H, exp))
+    finally:
+        grp.close()
+
+
+def test_registered_curve_entry_points_replay_from_a_hip_graph(engine):
+    """The ladder, the generator's comb (small-batch route and ALG_WINDOWED), u1 G + u2 Q and ecdsa_verify on a registered curve captured into one hipGraph after a
+    warm-up call (which builds the comb's table and the record of the degenerate scalars and sizes the workspace); new inputs in place, replay = eager calls."""
+    import torch
+    from ecsimd_amd import ALG_WINDOWED
+    c = REF_CURVES["frp256v1"]
+    cid = register(c)
+    n = 1 << 14
+    k = engine.fill_random(n, SEED, 191, clear_top_bits=1); s = engine.fill_random(n, SEED, 192, clear_top_bits=1)
+    bx, by = engine.scalar_mult_base(cid, s, flags=OUT_AFFINE)
+    J = [engine.empty(n) for _ in range(3)]; A = [engine.empty(n) for _ in range(2)]; W = [engine.empty(n) for _ in range(2)]
+
+    def run():
+        engine.scalar_mult(cid, k, bx, by, out=J)
+        engine.scalar_mult_base(cid, k, flags=OUT_AFFINE, out=A + [None])                       # <= 2^16 lanes: the constant-time comb + the patch
+        engine.scalar_mult_base(cid, k, flags=OUT_AFFINE | ALG_WINDOWED, out=W + [None])
+        return engine.double_scalar_mult(cid, s, k, bx, by), engine.ecdsa_verify(cid, s, k, s, bx, by)
+    run(); torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            D, V = run()
+    torch.cuda.synchronize()
+    k.copy_(engine.fill_random(n, SEED, 193, clear_top_bits=1))
+    g.replay(); torch.cuda.synchronize()
+    got = [t.clone() for t in J + A + W + list(D) + [V]]
+    ej = engine.scalar_mult(cid, k, bx, by)
+    ea = engine.scalar_mult_base(cid, k, flags=OUT_AFFINE | LADDER_RADIX32)                      # the ladder itself
+    ed = engine.double_scalar_mult(cid, s, k, bx, by); ev = engine.ecdsa_verify(cid, s, k, s, bx, by)
+    torch.cuda.synchronize()
+    want = list(ej) + list(ea) + list(ea) + list(ed) + [ev]
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
