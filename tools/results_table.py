@@ -61,7 +61,10 @@ def table(rnd):
             if c.get("one_thread"):
                 cpu += f"; 1 thread: {c['one_thread']['value'] / 1e3:.2f} k/s"
             cpu += ")"
-            lanes = f"{c['lanes_compared']:,} / {c['lanes_differing_from_gpu']} / {c.get('lanes_differing_confirmed_by_openssl')}"
+            settled = c.get("lanes_differing_confirmed_by_openssl")
+            if settled is None and c.get("lanes_differing_confirmed_by_textbook_arithmetic") is not None:
+                settled = f"{c['lanes_differing_confirmed_by_textbook_arithmetic']} (textbook arithmetic: libcrypto's harness has no such curve)"
+            lanes = f"{c['lanes_compared']:,} / {c['lanes_differing_from_gpu']} / {'—' if settled is None else settled}"
         else:
             cpu, lanes = "—", "—"
         rows.append(f"| {LABEL[name]} | {d['value'] / 1e6:,.2f} | {r['kernel_ms']:.2f} | {r['achieved']:.2f} / {r['peak']:.2f} = **{r['frac']:.3f}** | {traffic} | {cpu} | {lanes} |")
