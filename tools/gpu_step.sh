@@ -44,7 +44,7 @@ import json; d=json.load(open('$out/bench.json')); r=d['roofline']; print('value
   soak)             # the ladder (default: radix 29; and REF_SQUARE_COMPAT) against the compiled reference: tools/soak.py <log2 lanes> <batches>
     timeout -k 10 1000 python tools/soak.py ${1:-23} ${2:-4} ${3:-p256,secp256k1} > "$out/soak.txt" 2>&1; rc=$?; tail -12 "$out/soak.txt"; exit $rc ;;
   soak_alg)         # every window kernel (fixed base: 4 combs; variable base: plain, constant-time; x only) against the ladder, lane for lane: tools/soak_windowed.py <log2 lanes> <batches>
-    timeout -k 10 1000 python tools/soak_windowed.py ${1:-22} ${2:-32} > "$out/soak_alg.txt" 2>&1; rc=$?; tail -6 "$out/soak_alg.txt"; exit $rc ;;
+    timeout -k 10 1000 python tools/soak_windowed.py ${1:-22} ${2:-32} ${3:-} > "$out/soak_alg.txt" 2>&1; rc=$?; tail -6 "$out/soak_alg.txt"; exit $rc ;;
   bench_all)        # every bench line profiles/rNN keeps
     bash tools/bench_all.sh ${1:-r04} > "$out/bench_all.txt" 2>&1; rc=$?; cat "$out/bench_all.txt" | head -30; exit $rc ;;
   comb29)           # round 4: the combs' additions on 29-bit limbs -- every test that runs a comb, then A/B against the radix-32 build (build/ab_comb32)

@@ -2,7 +2,7 @@
 """Soak run on the GPU alone: the three ways this library computes an affine k*P must agree lane for lane --
 the reference ladder (+ simultaneous inversion), the per-element-table windowed path (ALG_WINDOWED, and its constant-time form) and, for
 P = G, the three window-table kernels and the constant-time form of the 4-bit one; and the x-only products (on P-256 the ladder without Z) must give the same x.  Different algorithms over the same field layer: a disagreement means a bug
-in one of them.  Usage: soak_windowed.py [lanes_per_batch_log2=22] [batches=8]"""
+in one of them.  Usage: soak_windowed.py [lanes_per_batch_log2=22] [batches=8] [registered curves, comma-separated]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
@@ -33,5 +33,24 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
         d_x = int(((xo != l[0]).any(dim=1) | (xg != gl[0]).any(dim=1)).sum())
         tot += 3 * n; bad += d_fixed + d_var + d_x
         print(f"{nm} batch {b}: {n} fixed-base + {n} variable-base + {n} x-only lanes, differing: {d_fixed} / {d_var} / {d_x}   [{time.time()-t0:.0f}s]", flush=True)
+# (r5) curves registered at run time: the generator's comb (plain and constant-time) against the ladder, and u1 G + u2 Q (the comb + a ladder pass + an affine
+# addition) against two ladder passes and the same addition -- argv[3] = comma-separated names, e.g. brainpoolP256r1,sm2,frp256v1
+for nm in (sys.argv[3].split(",") if len(sys.argv) > 3 else []):
+    from ecsimd_amd.curves import curve_id
+    cv = curve_id(nm)
+    for b in range(batches):
+        seed = 0x5EED0000 + 131 * b + (cv & 0xff) + 77
+        k = e.fill_random(n, seed, 1, clear_top_bits=1); s = e.fill_random(n, seed, 2, clear_top_bits=1)
+        gl = e.scalar_mult_base(cv, s, flags=OUT_AFFINE)
+        g4 = e.scalar_mult_base(cv, s, flags=OUT_AFFINE | ALG_WINDOWED)
+        gct = e.scalar_mult_base(cv, s, flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME)
+        d_fixed = int(((g4[0] != gl[0]).any(dim=1) | (g4[1] != gl[1]).any(dim=1) | (gct[0] != gl[0]).any(dim=1) | (gct[1] != gl[1]).any(dim=1)).sum())
+        del g4, gct
+        dx, dy, fin = e.double_scalar_mult(cv, s, k, gl[0], gl[1])                         # s G + k (s G)
+        l = e.scalar_mult(cv, k, gl[0], gl[1], flags=OUT_AFFINE)
+        ax, ay, afin = e.affine_add(cv, gl, l)
+        d_var = int(((dx != ax).any(dim=1) | (dy != ay).any(dim=1) | (fin != afin)).sum())
+        tot += 2 * n; bad += d_fixed + d_var
+        print(f"{nm} batch {b}: {n} fixed-base (comb, constant-time comb vs ladder) + {n} u1 G + u2 Q lanes, differing: {d_fixed} / {d_var}   [{time.time()-t0:.0f}s]", flush=True)
 print(f"TOTAL {tot} scalar multiplications compared across algorithms, {bad} lanes differ")
 sys.exit(1 if bad else 0)
