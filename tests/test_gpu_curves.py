@@ -514,3 +514,96 @@ def test_registered_curve_entry_points_replay_from_a_hip_graph(engine):
     torch.cuda.synchronize()
     want = list(ej) + list(ea) + list(ea) + list(ed) + [ev]
     assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+def _is_prime(n_):
+    if n_ < 2:
+        return False
+    for q in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if n_ % q == 0:
+            return n_ == q
+    d, r = n_ - 1, 0
+    while d % 2 == 0:
+        d //= 2; r += 1
+    for a_ in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):                    # deterministic below 3.3e24, a strong probable-prime test above
+        x = pow(a_, d, n_)
+        if x in (1, n_ - 1):
+            continue
+        for _ in range(r - 1):
+            x = x * x % n_
+            if x == n_ - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def _random_curve(bits, seed, a_kind):
+    """A curve nobody compiled anything for: a random prime p = 3 mod 4 of `bits` bits, random a (or -3, 0), random b with 4a^3 + 27b^2 != 0, a point on it."""
+    import random
+    rng = random.Random(seed)
+    while True:
+        p_ = rng.getrandbits(bits) | (1 << (bits - 1)) | 3
+        if _is_prime(p_):
+            break
+    while True:
+        a_ = {"random": rng.randrange(p_), "-3": p_ - 3, "0": 0}[a_kind]
+        b_ = rng.randrange(1, p_)
+        if (4 * a_ ** 3 + 27 * b_ * b_) % p_ == 0:
+            continue
+        for _ in range(200):
+            x = rng.randrange(p_)
+            rhs = (x ** 3 + a_ * x + b_) % p_
+            y = pow(rhs, (p_ + 1) // 4, p_)
+            if y * y % p_ == rhs and y != 0:
+                return dict(p=p_, a=a_, b=b_, gx=x, gy=y)
+
+
+@pytest.mark.parametrize("bits,a_kind", [(256, "random"), (256, "-3"), (256, "0"), (255, "random"), (254, "random"), (233, "random"), (224, "-3"), (192, "random"), (129, "random"),
+                                         (128, "0"), (64, "random"), (61, "random"), (33, "random"), (32, "random"), (31, "-3"), (17, "random")])
+def test_curves_nobody_compiled_anything_for(gpu, engine, oracle, bits, a_kind):
+    """"Any curve" means any: random primes p = 3 mod 4 from 17 to 256 bits -- the top limbs of the 29-bit representation empty, p one bit short of 2^256, p with
+    its top bit set -- with a random a, a = -3 and a = 0, registered WITHOUT a group order (the reference's concept has none), against the oracle with the same
+    curve registered: the point formulas on points of the curve, the ladder's three loops on random and edge scalars (level J: X, Y, Z), the affine conversion
+    through the shared inversion, on_curve / compute_y, and what needs an order is refused."""
+    c = _random_curve(bits, 1000 * bits + len(a_kind), a_kind)
+    cid = register(c)
+    oid = oracle.register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"])
+    n = 300
+    rng = np.random.default_rng(bits)
+    k = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    k[:12] = ints_to_arr([0, 1, 2, 3, 4, 5, 2**256 - 1, 2**255, c["p"], c["p"] - 1, c["p"] + 1 if c["p"] + 1 < 2**256 else 7, 2**200 + 1])
+    gx, gy = np.tile(from_int(c["gx"]), (n, 1)), np.tile(from_int(c["gy"]), (n, 1))
+    s = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    B = oracle.scalar_mult(oid, s, gx, gy, threads=THREADS)                                      # lane-distinct points s G (Jacobian; a few may be degenerate: Z = 0)
+    bx, by = oracle.to_affine(oid, B)
+    live = ~((bx == 0).all(axis=1) & (by == 0).all(axis=1))                                      # small groups: s G may be infinity
+    bx, by, k, gx, gy, s = (v[live] for v in (bx, by, k, gx, gy, s))
+    assert live.sum() > n // 2
+    assert same(gpu.scalar_mult(cid, s, gx, gy), [v[live] for v in B])
+    exp = oracle.scalar_mult(oid, k, bx, by, threads=THREADS)
+    for fl in (0, LADDER_RADIX32):
+        got = [engine.to_numpy(t) for t in engine.scalar_mult(cid, engine.to_device(k), engine.to_device(bx), engine.to_device(by), flags=fl)]
+        assert same(got, exp), (bits, a_kind, fl, np.flatnonzero((got[0] != exp[0]).any(axis=1))[:6])
+    ax, ay = oracle.to_affine(oid, exp)
+    gax, gay = gpu.scalar_mult(cid, k, bx, by, affine=True)
+    assert np.array_equal(gax, ax) and np.array_equal(gay, ay)
+    P = oracle.from_affine(oid, bx, by)
+    (R, Pu), (Rg, Pug) = oracle.dblu(oid, P), gpu.dblu(cid, P)
+    assert same(Rg + Pug, R + Pu)
+    (R3, Pu2), (R3g, Pu2g) = oracle.zaddu(oid, Pu, R), gpu.zaddu(cid, Pu, R)
+    assert same(R3g + Pu2g, R3 + Pu2)
+    assert same(gpu.add_z2_1(cid, R3, (P[0], P[1])), oracle.add_z2_1(oid, R3, (P[0], P[1])))
+    on = engine.to_numpy(engine.on_curve(cid, engine.to_device(bx), engine.to_device(by)))
+    assert on.all()
+    off = by.copy(); off[:, 0] ^= np.uint64(1)
+    assert not engine.to_numpy(engine.on_curve(cid, engine.to_device(bx), engine.to_device(off))).any()
+    from ecsimd_amd import EcsimdHipError, ALG_WINDOWED
+    kd = engine.to_device(k)
+    with pytest.raises(EcsimdHipError, match="group order"):
+        engine.scalar_mult_base(cid, kd, flags=OUT_AFFINE | ALG_WINDOWED)
+    with pytest.raises(EcsimdHipError, match="group order"):
+        engine.ecdsa_verify(cid, kd, kd, kd, kd, kd)
+    lx, ly = engine.scalar_mult_base(cid, kd, flags=OUT_AFFINE)                                   # no order: the small-batch route does not apply, the ladder runs
+    ex = oracle.to_affine(oid, oracle.scalar_mult(oid, k, gx, gy, threads=THREADS))
+    assert np.array_equal(engine.to_numpy(lx), ex[0]) and np.array_equal(engine.to_numpy(ly), ex[1])
