@@ -151,6 +151,15 @@ def test_curve_registry_without_a_gpu(lib, oracle):
             out = (C.c_uint64 * 4)()
             assert lib.ecsimd_hip_get_constant(C.c_int(cid), C.c_int(which), out) == 0
             assert list(out) == [int(v) for v in want[key]], (name, key)
+    from test_gpu_curves import _random_curve                                  # random primes p = 3 mod 4 of every size: what the host derives for them
+    for bits, kind in ((17, "random"), (31, "-3"), (64, "random"), (129, "0"), (255, "random"), (256, "random")):
+        c = _random_curve(bits, 1000 * bits + len(kind), kind)
+        cid = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"])
+        want = oracle.constants(oracle.register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"]))
+        for which, key in enumerate(["p", "a", "b", "gx", "gy", "r_p", "rsq_p", "pm1_r_p", "am", "bm", "p_m2", "p_sqrt"]):
+            out = (C.c_uint64 * 4)()
+            assert lib.ecsimd_hip_get_constant(C.c_int(cid), C.c_int(which), out) == 0
+            assert list(out) == [int(v) for v in want[key]], (bits, key)
     for cv in (P256, SECP256K1):
         c = CURVE_PARAMS[cv]
         assert register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"]) == cv
