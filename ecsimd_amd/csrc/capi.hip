@@ -719,14 +719,13 @@ int ecsimd_hip_register_curve(const uint64_t p[4], const uint64_t a[4], const ui
     u_limbs29(G.r29.out, u_shl_mod(one, 256, P));                   // 2^256 mod p: back
     curve_registry& r = curves();
     std::lock_guard<std::mutex> g(r.mu);
+    // Entries are keyed on the curve AND the order it was registered with (none is a value of its own): what an id does -- the small-batch route of
+    // scalar_mult_base, the comb, ECDSA -- depends on n, so a later registration with another n (or the first one with any) must never change the
+    // behaviour of an id somebody else holds (the rule the modulus registry follows for its PRIME flag).
     for (size_t i = 0; i < r.curves.size(); ++i) {
-      curve_record& o = r.curves[i];
-      if (!memcmp(o.G.F.p, G.F.p, 32) && u_eq(o.a, A) && u_eq(o.b, B) && !memcmp(o.G.gx, G.gx, 32) && !memcmp(o.G.gy, G.gy, 32)) {
-        // the order is additional knowledge about the same curve: a later registration may supply it, never contradict it
-        if (n && o.has_order && !u_eq(o.n, N)) return ECSIMD_HIP_ERR_BAD_ARG;
-        if (n && !o.has_order) { o.n = N; o.N = rec.N; o.has_order = true; o.ecdsa_ok = rec.ecdsa_ok; }
-        *curve_id = FIRST_CURVE_ID + (int)i; return ECSIMD_HIP_OK;
-      }
+      const curve_record& o = r.curves[i];
+      if (!memcmp(o.G.F.p, G.F.p, 32) && u_eq(o.a, A) && u_eq(o.b, B) && !memcmp(o.G.gx, G.gx, 32) && !memcmp(o.G.gy, G.gy, 32) &&
+          o.has_order == rec.has_order && (!rec.has_order || u_eq(o.n, N))) { *curve_id = FIRST_CURVE_ID + (int)i; return ECSIMD_HIP_OK; }
     }
     if (r.curves.size() >= (size_t)MAX_CURVES) return ECSIMD_HIP_ERR_BAD_ARG;
     r.curves.push_back(rec);
@@ -840,11 +839,13 @@ int ecsimd_hip_to_bytes_be(ecsimd_hip_ctx* ctx, const uint64_t* in, uint8_t* byt
 // The reference's register layout (four lanes per wide, limb-major: bignum.h:99-100) <-> the ABI's one element per lane, on the device.
 int ecsimd_hip_wide4_to_lanes(ecsimd_hip_ctx* ctx, const void* wides, size_t record_bytes, size_t offset_bytes, uint64_t* out, size_t n_wides) {
   REQUIRE_CTX(); const size_t n = 4 * n_wides; REQUIRE_PTR(out); if (!wides && n) return bad(ctx, "wides is null");
+  if (static_cast<const void*>(out) == wides) return bad(ctx, "the transposition is not in place: out must not alias wides");
   if (record_bytes < 128 || (record_bytes & 7u) || (offset_bytes & 7u) || offset_bytes + 128 > record_bytes || (reinterpret_cast<uintptr_t>(wides) & 7u)) return bad(ctx, "a wide is 128 bytes at an 8-byte aligned offset inside its record");
   if (n_wides > (size_t)0x7fffffff * (BLOCK / 4)) return bad(ctx, "batch too large");
   RUN(launch::wide4_to_lanes(s, wides, record_bytes, offset_bytes, out, n)); }
 int ecsimd_hip_lanes_to_wide4(ecsimd_hip_ctx* ctx, const uint64_t* in, void* wides, size_t record_bytes, size_t offset_bytes, size_t n_wides) {
   REQUIRE_CTX(); const size_t n = 4 * n_wides; REQUIRE_PTR(in); if (!wides && n) return bad(ctx, "wides is null");
+  if (static_cast<const void*>(in) == wides) return bad(ctx, "the transposition is not in place: wides must not alias in");
   if (record_bytes < 128 || (record_bytes & 7u) || (offset_bytes & 7u) || offset_bytes + 128 > record_bytes || (reinterpret_cast<uintptr_t>(wides) & 7u)) return bad(ctx, "a wide is 128 bytes at an 8-byte aligned offset inside its record");
   if (n_wides > (size_t)0x7fffffff * (BLOCK / 4)) return bad(ctx, "batch too large");
   RUN(launch::lanes_to_wide4(s, in, wides, record_bytes, offset_bytes, n)); }

@@ -27,7 +27,8 @@ template <class P> constexpr int hip_curve_id() {
 // Engine curve id of ANY curve type with bn_type, P, A, B, Gx, Gy (the reference's concept, curve.h:12-15; p = 3 mod 4 as its GFp needs, gfp.h:84):
 // curve_nist_p256 / curve_secp256k1 get their special-form kernels (ids 0 / 1), every other Curve is registered on first use
 // (ecsimd_hip_register_curve: host arithmetic only, once per type) and runs on the generic kernels -- points, co-Z formulas, the ladder.  A Curve that
-// also names its group order (`using N = ...`, which the reference's concept does not have) gets double_scalar_mult and ECDSA on top of that ladder.
+// also names its group order (`using N = ...`, which the reference's concept does not have) gets the generator's comb, double_scalar_mult and ECDSA on top
+// of that ladder (another registration, another id: an id's behaviour never changes under its holder).
 template <class Curve> inline int hip_curve_id_of() {
   static const int id = [] {
     int cid = -1;

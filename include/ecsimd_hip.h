@@ -173,7 +173,8 @@ int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id);
  * ladder are curve-independent) -- as a run-time registration: host pointers, 4 x u64 little-endian limbs, classical values < p.  p must be a prime with
  * p = 3 mod 4 (what the reference's GFp<WBN, P> needs: gfp.h:84) and the caller vouches for its primality; the generator must lie on the curve and the
  * curve must be non-singular (checked: ECSIMD_HIP_ERR_BAD_ARG).  n = the group order, or NULL (the reference has no order either: its ladder takes any
- * 256-bit k; stored for callers that need it).  The id (>= ECSIMD_HIP_FIRST_REGISTERED_CURVE; the same parameters give the same id; P-256's or secp256k1's
+ * 256-bit k; with it the id gains the entry points listed below).  The id (>= ECSIMD_HIP_FIRST_REGISTERED_CURVE; the same parameters -- the order, or its
+ * absence, included -- give the same id, so nobody's registration changes what an id somebody else holds does; P-256's or secp256k1's
  * parameters give 0 / 1 unless flags = ECSIMD_HIP_CURVE_GENERIC_KERNELS, which registers them like any other curve -- how tests hold the generic kernels
  * to the special-form ones bit for bit) is accepted by
  *     from_affine, to_affine, compute_y, on_curve, dblu, zaddu, zdau, add_z2_1, trplu, zdau_repeat, scalar_mult, scalar_mult_1s, scalar_mult_base
@@ -232,7 +233,7 @@ int ecsimd_hip_to_bytes_be(ecsimd_hip_ctx*, const uint64_t* in, uint8_t* bytes, 
  * (jacobian_curve_point.h:14-58).  A caller that keeps reference types copies its array of wides / points to the device as it is; these two do the 4 x 4
  * transposition there, at HBM speed, instead of a per-lane loop on the host: wide w of a record array (`record_bytes` apart, the wide at `offset_bytes`
  * inside its record: 128 / 0 for an array of wides; 384 / 0, 128, 256 for x, y, z of an array of Jacobian points) <-> elements 4w .. 4w + 3 of an ABI
- * array (u64[4 * e + limb]).  `wides` is a device pointer, 8-byte aligned; record_bytes and offset_bytes multiples of 8.
+ * array (u64[4 * e + limb]).  `wides` is a device pointer, 8-byte aligned; record_bytes and offset_bytes multiples of 8; not in place.
  * integration/scalar_mult_p256_adapter.cpp is the caller. */
 int ecsimd_hip_wide4_to_lanes(ecsimd_hip_ctx*, const void* wides, size_t record_bytes, size_t offset_bytes, uint64_t* out, size_t n_wides);
 int ecsimd_hip_lanes_to_wide4(ecsimd_hip_ctx*, const uint64_t* in, void* wides, size_t record_bytes, size_t offset_bytes, size_t n_wides);

@@ -433,7 +433,7 @@ struct curve_sm2_no_order {
 };
 TEST(Curves, EcdsaAndSec1OnARegisteredCurve) {
   using K = curve_brainpoolp256r1_n; using KG = curve_group<K>; using WCP = wide_curve_point<K>;
-  EXPECT_TRUE(KG::curve_id() == curve_group<curve_brainpoolp256r1>::curve_id());                 // the same curve: the order is additional knowledge about it
+  EXPECT_TRUE(KG::curve_id() != curve_group<curve_brainpoolp256r1>::curve_id());                 // the order is part of the registration's key: the id without it keeps the reference's layers only
   const auto e = "AF2BDBE1AA9B6EC1E2ADE1D694F41FC71A831D0268E9891562113D8A62ADD1BF"_hex, d = "0bc1b1f28709decb543d9677d2cc9942348f6b984deff409430740942ff38827"_hex;
   const auto k1 = "0a891cecc2bf13b0aca744434a9c9f4bd7bf5c8ed86e2f76e7df72bad813bd80"_hex, k2 = "a9fb57dba1eea9bc3e660a909d838d718c397aa3b561a6f7901e0e82974856a6"_hex;   // k2 = n - 1: the ladder alone is wrong there
   const auto zero = "0000000000000000000000000000000000000000000000000000000000000000"_hex;

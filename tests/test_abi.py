@@ -144,7 +144,7 @@ def test_curve_registry_without_a_gpu(lib, oracle):
     seen = set()
     for name, c in REF_CURVES.items():
         cid = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"])
-        assert cid >= FIRST_REGISTERED_CURVE and cid not in seen and register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"]) == cid
+        assert cid >= FIRST_REGISTERED_CURVE and cid not in seen and register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"]) == cid
         seen.add(cid)
         want = oracle.constants(oracle.register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"]))
         for which, key in enumerate(["p", "a", "b", "gx", "gy", "r_p", "rsq_p", "pm1_r_p", "am", "bm", "p_m2", "p_sqrt"]):
@@ -164,7 +164,7 @@ def test_curve_registry_without_a_gpu(lib, oracle):
         c = CURVE_PARAMS[cv]
         assert register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"]) == cv
         g = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"], generic_kernels=True)
-        assert g >= FIRST_REGISTERED_CURVE and g not in seen and register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], generic_kernels=True) == g
+        assert g >= FIRST_REGISTERED_CURVE and g not in seen and register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"], generic_kernels=True) == g
     c = REF_CURVES["brainpoolP256r1"]
     bad = [
         dict(c, gy=c["gy"] ^ 1),                                             # the generator is not on the curve
@@ -179,9 +179,12 @@ def test_curve_registry_without_a_gpu(lib, oracle):
     for b in bad:
         with pytest.raises(EcsimdHipError):
             register_curve(b["p"], b["a"], b["b"], b["gx"], b["gy"], b.get("n"))
-    # the order is additional knowledge about the same curve: a later registration may supply it (C++: a Curve type with `using N`), never contradict it
-    with pytest.raises(EcsimdHipError):
-        register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"] + 2)
+    # the order is part of the key: what an id does depends on it (the comb, ECDSA), so a registration with another order -- or without one -- is another id and
+    # never changes what an id somebody else holds does
+    with_n = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"])
+    without = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"])
+    other = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"] + 2)
+    assert len({with_n, without, other}) == 3 and register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"]) == with_n and register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"]) == without
     cid = C.c_int()
     assert lib.ecsimd_hip_register_curve(None, None, None, None, None, None, C.c_int(0), C.byref(cid)) == -1
     assert lib.ecsimd_hip_get_constant(C.c_int(FIRST_REGISTERED_CURVE + 4000), C.c_int(0), (C.c_uint64 * 4)()) == -1
