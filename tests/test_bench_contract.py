@@ -266,10 +266,12 @@ def test_round5_lines_carry_what_the_pipe_does_and_the_registered_curves():
         d = r5[name]
         assert name[len("ladder_"):] in d["metric"] and 38e6 < d["value"] < 48e6 and 0.6 < d["roofline"]["frac"] < 0.75, name
         c = d["cpu_baseline"]
-        assert c["kind"] == "reference" and c["lanes_compared"] > 10 ** 5 and c["lanes_differing_from_gpu"] <= 8, name      # the reference's dropped carry: ~4e-6 of lanes
+        assert c["kind"] == "reference" and c["lanes_compared"] > 10 ** 5 and c["lanes_differing_from_gpu"] <= 12, name      # the reference's dropped carry: ~4e-6 of lanes
+        # ... every one of them settled for the GPU by textbook affine arithmetic on Python integers (libcrypto's harness has no such curve)
+        assert c["lanes_differing_confirmed_by_textbook_arithmetic"] == c["lanes_differing_from_gpu"], name
     for name, d in r5.items():
         assert d.get("parity_failures") is None, name
-        assert d["roofline"]["traffic"] is None or d["roofline"]["traffic"] > 0, name
+        assert d["roofline"]["traffic"] is not None and d["roofline"]["traffic"] > 0, name           # a committed counter pass for every line
     for name in ("ladder", "ladder_secp256k1", "group_mode"):
         assert 54e6 < r5[name]["value"] < 64e6 and 0.86 < r5[name]["roofline"]["frac"] < 1.0, name
     assert r5["ladder_ref_compat_secp256k1"]["value"] > 41e6                                                        # r4: 40.06 (the Montgomery rounds on one 64-bit MAC)
