@@ -134,6 +134,40 @@ template <bool REF> ECS_DEV void gc_to_affine(const gjpoint& P, fe& ax, fe& ay, 
   ay = g_to_classical(gc_mul(P.y, invZ3, G), G.F);
 }
 
+// a^e for a public, wave-uniform exponent (gfp.h:46-54 sqrt() = a^((p + 1) / 4) is the caller) on 3b's 29-bit limbs: the power of a canonical residue does
+// not depend on how the exponent is walked (point.cuh fe_sqrt_candidate29 does the same with fixed chains for the built-in primes), so this walks it from
+// the top in sliding windows of three bits over {a, a^3, a^5, a^7} -- 254 squarings + ~64 products of 126 / 162 multiply-adds where g_pow's canonical
+// words spend ~450 / ~520 instructions on each of 254 + ~127.  Control flow is made of the exponent's bits alone (SGPRs).  Every factor is the output of
+// a product (tight limbs), as in the ladder's loop.
+ECS_DEV fe gc_pow29(const fe& a, const uint32_t (&e)[8], const gcurve& G) {
+  constexpr int C = CURVE_GENERIC;
+  const r29_ctx<C>& cx = G.r29;
+  int i = -1;
+  for (int t = 255; t >= 0; --t) if ((e[t >> 5] >> (t & 31)) & 1u) { i = t; break; }
+  if (i < 0) return g_words(G.F.r);                                  // a^0
+  const fe29 x1 = enter29<C>(a, cx);
+  const fe29 x2 = sqr29<C>(x1, cx);
+  const fe29 x3 = mul29<C>(x2, x1, cx), x5 = mul29<C>(x3, x2, cx), x7 = mul29<C>(x5, x2, cx);
+  auto bit = [&](int t) -> uint32_t { return t < 0 ? 0u : (e[t >> 5] >> (t & 31)) & 1u; };
+  fe29 r = x1;
+  bool started = false;
+#pragma unroll 1
+  while (i >= 0) {
+    if (!bit(i)) { r = sqr29<C>(r, cx); --i; continue; }
+    int len = 3;                                                     // the longest window of at most three bits that ends in a one
+    while (len > 1 && (i - len + 1 < 0 || !bit(i - len + 1))) --len;
+    uint32_t val = 0;
+    for (int t = 0; t < len; ++t) val = (val << 1) | bit(i - t);
+    const fe29 f = val == 1u ? x1 : val == 3u ? x3 : val == 5u ? x5 : x7;
+    if (started) {
+      for (int t = 0; t < len; ++t) r = sqr29<C>(r, cx);
+      r = mul29<C>(r, f, cx);
+    } else { r = f; started = true; }
+    i -= len;
+  }
+  return leave29<C>(r, cx);
+}
+
 // ---------------------------------------------------------------- the ladder (curve_group.h:189-218)
 // TRPLU, the opening swaps and the even-k correction on canonical words as point.cuh ladder_core29; the 254 iterations on nine signed 29-bit limbs.
 ECS_DEV uint32_t gc_ladder_core29(const uint32_t* __restrict__ kwords, const fe& xm, const fe& ym, fe& px, fe& py, fe& z, const gcurve& G) {

@@ -23,7 +23,9 @@ template <bool REF> __global__ void __launch_bounds__(BLOCK) k_gc_compute_y(gcur
   GID;
   const fe xm = g_from_classical(LD(x), G.F);
   const fe rhs = gc_add(gc_add(gc_mul(gc_sqr<REF>(xm, G), xm, G), gc_mul(g_words(G.am), xm, G), G), g_words(G.bm), G);
-  const fe s = g_pow<REF>(rhs, G.F.psqrt, G.F);
+  fe s;
+  if constexpr (REF) s = g_pow<true>(rhs, G.F.psqrt, G.F);          // the reference's own power ladder, its squarings as written (mgry_ops.h:44-86)
+  else s = gc_pow29(rhs, G.F.psqrt, G);
   if (ok) ok[i] = (uint8_t)fe_eq(gc_sqr<REF>(s, G), rhs);
   ST(y, g_to_classical(s, G.F));
 }

@@ -152,7 +152,7 @@ template <int REC> __global__ void __launch_bounds__(BLOCK) k_gc_sec1_decode(gcu
     yv = load_be32(rec + 33);
     good = good && prefix == 0x04 && g_less(yv, P) && fe_eq(gc_sqr<false>(g_from_classical(yv, G.F), G), rhs);
   } else {
-    const fe s = g_pow<false>(rhs, G.F.psqrt, G.F);
+    const fe s = gc_pow29(rhs, G.F.psqrt, G);
     good = good && (prefix == 0x02 || prefix == 0x03) && fe_eq(gc_sqr<false>(s, G), rhs);
     yv = g_to_classical(s, G.F);
     fe neg; (void)sub8_3(neg, P, yv);

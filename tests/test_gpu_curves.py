@@ -596,6 +596,9 @@ def test_curves_nobody_compiled_anything_for(gpu, engine, oracle, bits, a_kind):
     assert same(gpu.add_z2_1(cid, R3, (P[0], P[1])), oracle.add_z2_1(oid, R3, (P[0], P[1])))
     on = engine.to_numpy(engine.on_curve(cid, engine.to_device(bx), engine.to_device(by)))
     assert on.all()
+    xs = np.concatenate([bx, ints_to_arr([(v * 7 + 3) % c["p"] for v in range(64)])])           # x of points, and x values of which about half have no point
+    (yg, okg), (yo, oko) = gpu.compute_y(cid, xs), oracle.compute_y(oid, xs)                       # the square root: 29-bit sliding windows against the oracle's power ladder
+    assert np.array_equal(okg, oko) and np.array_equal(yg, yo) and okg[:len(bx)].all() and (bits < 20 or not okg.all())
     off = by.copy(); off[:, 0] ^= np.uint64(1)
     assert not engine.to_numpy(engine.on_curve(cid, engine.to_device(bx), engine.to_device(off))).any()
     from ecsimd_amd import EcsimdHipError, ALG_WINDOWED

@@ -517,3 +517,12 @@ def test_the_witness_fixture_is_the_exact_models_and_reaches_the_proven_bounds()
     assert max(e["worst_column"] for e in data["entries"]) >= 2**63 - 2**35
     import subprocess
     assert subprocess.run([sys.executable, os.path.join(os.path.dirname(path), "..", "..", "tools", "make_witnesses.py"), "--check"], capture_output=True).returncode == 0
+
+
+def test_power_chains_need_no_carry_pass():
+    """gcurve.cuh gc_pow29 (the square root on a registered curve: sliding windows over a, a^3, a^5, a^7) and point.cuh fe_sqrt_candidate29 (the built-in primes'
+    fixed chains) multiply and square nothing but outputs of products: that set is closed under sqr29 / mul29 -- for P-256, secp256k1 and EVERY odd p < 2^256 --
+    with the worst column a bit below the ladder's, and its members are in leave29's domain."""
+    for cv in (m.CURVE_P256, m.CURVE_SECP, m.CURVE_ANY):
+        r = m.prove_pow_chain(cv)
+        assert r["worst_column_bits"] <= 62 and r["worst_limb_bits"] <= 30, (cv, r)

@@ -353,6 +353,23 @@ def prove_invariant(curve=CURVE_P256):
     return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length(), "worst_column": E.worst_col, "out": out}
 
 
+def prove_pow_chain(curve=CURVE_P256):
+    """gcurve.cuh gc_pow29 / point.cuh fe_sqrt_candidate29: a^e as a chain of sqr29 / mul29 whose every factor is the output of a product (or of enter29, a
+    product too).  Closure: with T = what a product of canonical-width operands can return, a square or a product of members of T lies in T again, nothing
+    overflows on the way, and a member of T is in leave29's domain.  (The ladder's invariant is wider than T -- differences of products -- which is why this
+    chain needs no carry pass at all.)"""
+    E = Bounds(curve)
+    p = curve.p
+    B = 1 << W
+    canonical = Iv([(0, B - 1)] * (NL - 1) + [(0, (1 << 24) - 1)], (0, p - 1))              # to29 of a canonical residue; the constants 2^266 mod p, 2^256 mod p too
+    T = Iv([(0, B - 1)] * (NL - 1) + [(-1, (1 << 24) + (1 << 20))], (-(p >> 5), p + (p >> 4)))   # what a product returns: tight limbs, a value in (-p/32, 17 p/16)
+    for v in (E.mul(canonical, canonical), E.sqr(T), E.mul(T, T), E.mul(T, canonical)):     # enter29; a square, a product of two members; one by a table power
+        assert v.within(T), (v, T)
+    out = E.mul(T, canonical)                                                                # leave29's product by 2^256 mod p ...
+    assert -p < out.v[0] and out.v[1] < 2 * p, out                                           # ... lands in canon29's domain
+    return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length(), "factor": T}
+
+
 # ---------------------------------------------------------------------------------------------------------------- the combs' mixed addition
 def madd29(E, X1, Y1, Z1, x2, y2):
     """fe29.cuh madd29<C> (= madd29_hr + madd29_finish): Jacobian (X1, Y1, Z1) + affine (x2, y2), Hankerson-Menezes-Vanstone Alg. 3.22 as
