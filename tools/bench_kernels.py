@@ -132,7 +132,8 @@ for nm in ("brainpoolP256r1",):
     row(f"ecdsa_verify<{nm}> (e, r, s, Q -> ok)", n2, timeit(lambda: e.ecdsa_verify(cv, u1, rr, ss, b2x, b2y), 5), two + 6 * 136, 161, "verifications")
     row(f"ecdsa_sign<{nm}> (e, d, k -> r, s: k G on the constant-time comb)", n2, timeit(lambda: e.ecdsa_sign(cv, u1, rr, ss), 5), comb + int((4 + 88 / 32 + 9 + 7) * 136), 160, "signatures")
     wire = e.sec1_encode(cv, b2x, b2y, True)
-    row(f"sec1_decode<{nm}> compressed (decompression: x^((p+1)/4) on the generic words)", n2, timeit(lambda: e.sec1_decode(cv, wire, True)), (253 + 7 + 4) * 136, 33 + 64, "points")
+    row(f"sec1_decode<{nm}> compressed (decompression: x^((p+1)/4) in sliding windows on 29-bit limbs)", n2, timeit(lambda: e.sec1_decode(cv, wire, True)), (253 + 64 + 4) * 136, 33 + 64, "points",
+        executed_mad32=254 * 126 + 68 * 162 + 6 * 200)                   # sqr29 126 / mul29 162 multiply-adds with the dense reduction; right-hand side and check on canonical words
     wire = e.sec1_encode(cv, b2x, b2y, False)
     row(f"sec1_decode<{nm}> uncompressed (validation)", n2, timeit(lambda: e.sec1_decode(cv, wire, False)), 4 * 136, 65 + 64, "points")
     del k, s2, b2x, b2y, P2, outj, wire, u1, rr, ss
