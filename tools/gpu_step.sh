@@ -138,6 +138,14 @@ import json; d=json.load(open('$out/bench_brainpool_$w.json')); r=d['roofline'];
     ECSIMD_ADAPTER_HOST_TRANSPOSE=1 timeout -k 10 600 ./oracle/_ref/adapter_driver 512 65536 1048576 > "$out/adapter_driver_host_transpose.txt" 2>&1 || rc=$?; cat "$out/adapter_driver_host_transpose.txt"
     timeout -k 10 300 python tools/pcie_rate.py > "$out/pcie_rate.txt" 2>&1 || rc=$?; cat "$out/pcie_rate.txt"
     exit $rc ;;
+  r5_final)         # round 5, the final tree on ONE box: the secondary kernels, the registered curves' rates and latencies, the adapter and the PCIe-inclusive rate (bench_all and pytest_gpu are their own steps: time)
+    rc=0
+    timeout -k 10 900 python tools/bench_kernels.py > "$out/secondary_kernels.json" 2> "$out/secondary_kernels.txt" || rc=$?; tail -12 "$out/secondary_kernels.txt"
+    timeout -k 10 600 python tools/curve_perf.py 22 > "$out/curve_perf.txt" 2>&1 || rc=$?; tail -8 "$out/curve_perf.txt"
+    timeout -k 10 600 ./oracle/_ref/adapter_driver 512 65536 1048576 > "$out/adapter_driver.txt" 2>&1 || rc=$?; cat "$out/adapter_driver.txt"
+    ECSIMD_ADAPTER_HOST_TRANSPOSE=1 timeout -k 10 600 ./oracle/_ref/adapter_driver 512 65536 1048576 > "$out/adapter_driver_host_transpose.txt" 2>&1 || rc=$?; tail -4 "$out/adapter_driver_host_transpose.txt"
+    timeout -k 10 300 python tools/pcie_rate.py > "$out/pcie_rate.txt" 2>&1 || rc=$?; cat "$out/pcie_rate.txt"
+    exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
     timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -15 "$out/pytest.txt"; exit $rc ;;
   *) echo "unknown step $name"; exit 2 ;;
