@@ -87,6 +87,8 @@ struct ecsimd_hip_ctx {
   struct gcomb_entry { int curve; uint32_t* table; uint64_t* special; };
   std::vector<gcomb_entry> gcomb;   // per registered curve: the 4-bit odd-digit table of multiples of its generator (k_gcomb.hip) and, for the small-batch route, the ladder's
                                     // three degenerate scalars with its affine results for them on G (as base_special); built on first use
+  ecsimd_hip_ctx* helper;      // ecsimd_hip_scalar_mult_host: the second stream's context (created on first use, destroyed with this one)
+  uint64_t* hstage; size_t hstage_bytes;    // ... and this context's staging block for one chunk (grow-only)
   char err[256];
 };
 
@@ -563,7 +565,7 @@ int ecsimd_hip_init(int device, ecsimd_hip_ctx** out) {
   ecsimd_hip_ctx* ctx = new (std::nothrow) ecsimd_hip_ctx();
   if (!ctx) return ECSIMD_HIP_ERR_HIP;
   ctx->device = device; ctx->cus = prop.multiProcessorCount; ctx->err[0] = 0; ctx->sink = nullptr;
-  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->window6_table[0] = ctx->window6_table[1] = nullptr; ctx->windowct_table[0] = ctx->windowct_table[1] = nullptr; ctx->window16_table[0] = ctx->window16_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0; ctx->ref_square = 0; ctx->valid = nullptr; ctx->valid_bytes = 0; ctx->base_special[0] = ctx->base_special[1] = nullptr;
+  ctx->window_table[0] = ctx->window_table[1] = nullptr; ctx->window6_table[0] = ctx->window6_table[1] = nullptr; ctx->windowct_table[0] = ctx->windowct_table[1] = nullptr; ctx->window16_table[0] = ctx->window16_table[1] = nullptr; ctx->workspace = nullptr; ctx->workspace_bytes = 0; ctx->ref_square = 0; ctx->valid = nullptr; ctx->valid_bytes = 0; ctx->base_special[0] = ctx->base_special[1] = nullptr; ctx->helper = nullptr; ctx->hstage = nullptr; ctx->hstage_bytes = 0;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ECSIMD_HIP_ERR_HIP; }
   ctx->stream = ctx->own_stream;
   if (hipEventCreateWithFlags(&ctx->handoff, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return ECSIMD_HIP_ERR_HIP; }
@@ -578,6 +580,8 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
   (void)hipFree(ctx->sink);
   (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->windowct_table[0]); (void)hipFree(ctx->windowct_table[1]); (void)hipFree(ctx->window16_table[0]); (void)hipFree(ctx->window16_table[1]); (void)hipFree(ctx->workspace); (void)hipFree(ctx->valid); (void)hipFree(ctx->base_special[0]); (void)hipFree(ctx->base_special[1]);
   for (auto& t : ctx->gcomb) { (void)hipFree(t.table); (void)hipFree(t.special); }
+  (void)hipFree(ctx->hstage);
+  if (ctx->helper) (void)ecsimd_hip_destroy(ctx->helper);
   (void)hipEventDestroy(ctx->handoff);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -981,6 +985,70 @@ int ecsimd_hip_scalar_mult(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, co
   }
   if (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) return bad(ctx, "ALG_CONSTANT_TIME modifies ALG_WINDOWED (the ladder is constant-time as it is)");
   return run_ladder(ctx, curve, k, 4, x, y, ox, oy, oz, n, flags); }
+// ---- host arrays in, host arrays out: the PCIe-inclusive form of scalar_mult.  Chunks of 2^19 elements alternate between this context and a helper context (a
+// second HIP stream): while the ladder of one chunk runs, the calling thread copies the next chunk in on the other side and launches it, then waits for the
+// previous chunk and copies it out -- the copies of one chunk overlap the ladder of its neighbour and the GPU always has a launch queued; the caller's arrays
+// may be ordinary pageable memory.  Synchronous: returns with the results in place.
+namespace {
+constexpr size_t HOST_CHUNK = (size_t)1 << 19;
+struct host_side { ecsimd_hip_ctx* c; uint64_t *k, *x, *y, *o[3]; };
+int host_stage(ecsimd_hip_ctx* c, size_t elems, int arrays, host_side* S) {
+  const size_t bytes = (size_t)arrays * elems * 32;
+  if (c->hstage_bytes < bytes) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->hstage); c->hstage = nullptr; c->hstage_bytes = 0;
+    hipError_t e = hipMalloc(&c->hstage, bytes);
+    if (e != hipSuccess) return fail(c, e, "scalar_mult_host staging");
+    c->hstage_bytes = bytes;
+  }
+  uint64_t* p = c->hstage;
+  S->c = c; S->k = p; S->x = p + 4 * elems; S->y = p + 8 * elems;
+  for (int j = 0; j < 3; ++j) S->o[j] = p + (size_t)(3 + j) * 4 * elems;
+  return ECSIMD_HIP_OK;
+}
+}  // namespace
+int ecsimd_hip_scalar_mult_host(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
+  REQUIRE_CTX();
+  const bool generator = (flags & ECSIMD_HIP_BASE_GENERATOR) != 0, affine = (flags & ECSIMD_HIP_OUT_AFFINE) != 0;
+  if (!k || !ox) return n ? bad(ctx, "k / ox is null") : ECSIMD_HIP_OK;
+  if (generator ? (x || y) : (!x || !y)) return bad(ctx, "a base point array is missing (or BASE_GENERATOR came with one)");
+  if (!affine && (!oy || !oz)) return bad(ctx, "a Jacobian result needs ox, oy and oz");
+  if (n == 0) return ECSIMD_HIP_OK;
+  if (capturing(ctx)) return bad(ctx, "scalar_mult_host copies and synchronises: not inside a stream capture");
+  (void)hipSetDevice(ctx->device);
+  const size_t chunk = n < HOST_CHUNK ? n : HOST_CHUNK, chunks = (n + chunk - 1) / chunk;
+  if (chunks > 1 && !ctx->helper) { int rc = ecsimd_hip_init(ctx->device, &ctx->helper); if (rc != ECSIMD_HIP_OK) return bad(ctx, "scalar_mult_host: the helper context could not be created"); }
+  host_side S[2];
+  for (int i = 0; i < (chunks > 1 ? 2 : 1); ++i) {
+    ecsimd_hip_ctx* c = i == 0 ? ctx : ctx->helper;
+    c->ref_square = ctx->ref_square;
+    int rc = host_stage(c, chunk, 6, &S[i]);
+    if (rc != ECSIMD_HIP_OK) { if (c != ctx) snprintf(ctx->err, sizeof ctx->err, "%s", c->err); return rc; }
+  }
+  auto report = [&](ecsimd_hip_ctx* c, int rc) { if (c != ctx) snprintf(ctx->err, sizeof ctx->err, "%s", c->err); return rc; };
+  auto launch = [&](size_t ci) -> int {
+    host_side& s = S[ci & 1];
+    const size_t first = ci * chunk, m = (n - first) < chunk ? (n - first) : chunk;
+    int rc = ecsimd_hip_memcpy_h2d(s.c, s.k, k + 4 * first, m * 32);
+    if (rc == ECSIMD_HIP_OK && !generator) rc = ecsimd_hip_memcpy_h2d(s.c, s.x, x + 4 * first, m * 32);
+    if (rc == ECSIMD_HIP_OK && !generator) rc = ecsimd_hip_memcpy_h2d(s.c, s.y, y + 4 * first, m * 32);
+    if (rc == ECSIMD_HIP_OK) rc = ecsimd_hip_scalar_mult(s.c, curve, s.k, generator ? nullptr : s.x, generator ? nullptr : s.y, s.o[0], oy ? s.o[1] : nullptr, affine ? nullptr : s.o[2], m, flags);
+    return report(s.c, rc);
+  };
+  auto drain = [&](size_t ci) -> int {
+    host_side& s = S[ci & 1];
+    const size_t first = ci * chunk, m = (n - first) < chunk ? (n - first) : chunk;
+    int rc = ecsimd_hip_memcpy_d2h(s.c, ox + 4 * first, s.o[0], m * 32);               // (waits for this side's kernels, then copies)
+    if (rc == ECSIMD_HIP_OK && oy) rc = ecsimd_hip_memcpy_d2h(s.c, oy + 4 * first, s.o[1], m * 32);
+    if (rc == ECSIMD_HIP_OK && !affine) rc = ecsimd_hip_memcpy_d2h(s.c, oz + 4 * first, s.o[2], m * 32);
+    return report(s.c, rc);
+  };
+  for (size_t ci = 0; ci <= chunks; ++ci) {
+    if (ci < chunks) { int rc = launch(ci); if (rc != ECSIMD_HIP_OK) { if (ci > 0) (void)ecsimd_hip_sync(S[(ci - 1) & 1].c); return rc; } }
+    if (ci > 0) { int rc = drain(ci - 1); if (rc != ECSIMD_HIP_OK) return rc; }
+  }
+  return ECSIMD_HIP_OK;
+}
 int ecsimd_hip_scalar_mult_1s(ecsimd_hip_ctx* ctx, int curve, const uint64_t k1[4], const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   REQUIRE_CTX(); REQUIRE_PTR(x); REQUIRE_PTR(y); REQUIRE_PTR(ox); REQUIRE_OUT_Y(oy); if (!k1) return bad(ctx, "k1 is null");
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) REQUIRE_PTR(oz);

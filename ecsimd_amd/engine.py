@@ -336,6 +336,21 @@ class Engine:
         self._call("scalar_mult_1s", C.c_int(curve), e, self._ptr(x), self._ptr(y), *[self._ptr(t) for t in r], C.c_size_t(n), C.c_int(flags))
         return tuple(r[:2]) if flags & 2 else tuple(r)
 
+    def scalar_mult_host(self, curve, k, x=None, y=None, flags=0, x_only=False, out=None):
+        """ecsimd_hip_scalar_mult_host: numpy uint64 (n, 4) arrays in HOST memory in and out (x = y = None: the generator); chunked, copies overlapped with ladders."""
+        k = np.ascontiguousarray(k, dtype=np.uint64); n = k.shape[0]
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
+        if x is None:
+            from .flags import BASE_GENERATOR
+            flags |= BASE_GENERATOR
+        else:
+            x = np.ascontiguousarray(x, dtype=np.uint64); y = np.ascontiguousarray(y, dtype=np.uint64)
+            assert x.shape == y.shape == k.shape
+        outs = (list(out) if out is not None else [np.empty_like(k) for _ in range(1 if (flags & 2 and x_only) else 2 if flags & 2 else 3)]) + [None, None]     # (out: arrays to reuse -- fresh ones are first touched inside the call)
+        self._bind_stream()
+        self._check(self.lib.ecsimd_hip_scalar_mult_host(self.ctx, C.c_int(curve), ptr(k), ptr(x), ptr(y), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), C.c_size_t(n), C.c_int(flags)), "scalar_mult_host")
+        return tuple(o for o in outs if o is not None)
+
     def scalar_mult_base(self, curve, k, flags=0, out=None, x_only=False):
         n = k.shape[0]
         r = out if out is not None else self._fresh_out(n, flags, x_only)

@@ -380,6 +380,13 @@ int ecsimd_hip_fe29_raw(ecsimd_hip_ctx* ctx, int curve, int op, const int32_t* i
 /* Diagnostic: the context's grow-only scratch block (device pointer and size; NULL / 0 before the first call that needed one).  What a test reads
  * back to see that ecdsa_sign left no nonce-derived data behind (tests/test_gpu_fields.py); valid until the next call that grows the block. */
 int ecsimd_hip_workspace_info(ecsimd_hip_ctx* ctx, const void** dptr, size_t* bytes);
+/* scalar_mult with every array in HOST memory (n elements each; pageable is fine): the PCIe-inclusive form of the hot path.  Same curve ids, flags and
+ * meaning as ecsimd_hip_scalar_mult (x = y = NULL with ECSIMD_HIP_BASE_GENERATOR: k G; OUT_AFFINE: oz unused, oy optional).  Chunks of 2^19 elements
+ * alternate between the context and a helper context it creates on first use (a second stream): the copies of one chunk overlap the ladder of its
+ * neighbour.  Synchronous -- returns with the results in place; not capturable.  One MI355X, 2^22 elements of pageable memory: 56 M scalar mults/s against
+ * 58 with the arrays resident in HBM (reuse the output arrays: fresh pages are first touched inside the call).  The reference's own types instead of arrays: integration/scalar_mult_p256_adapter.cpp. */
+int ecsimd_hip_scalar_mult_host(ecsimd_hip_ctx*, int curve, const uint64_t* k, const uint64_t* x, const uint64_t* y,
+                                uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags);
 /* lib/scalar_mult_p256.cpp:10-12: scalar_mult_p256(x, P) -- P-256, base in Montgomery form with
  * Z = mgry(1), Jacobian Montgomery output. */
 int ecsimd_hip_scalar_mult_p256(ecsimd_hip_ctx*, const uint64_t* k, const uint64_t* xm, const uint64_t* ym,

@@ -954,6 +954,54 @@ def test_scalar_mult_p256_entry_point(engine, oracle):
     assert all(np.array_equal(engine.to_numpy(u), v) for u, v in zip(got, exp))
 
 
+def test_host_array_form_overlaps_copies_and_ladders_and_returns_the_same_bits(engine):
+    """ecsimd_hip_scalar_mult_host (r5): every array in pageable host memory, chunks of 2^19 elements alternating between the context and its helper context.
+    The same bits as the device-resident entry point on one element, a ragged small batch, one chunk + 5 and three chunks + 77 (both sides used twice, a ragged
+    tail): Jacobian, affine, x only, the generator form, a windowed algorithm on secp256k1, a registered curve, the context's reference-square option on both
+    sides; and what it refuses."""
+    import torch
+    from ecsimd_amd import OUT_AFFINE, ALG_WINDOWED, BASE_GENERATOR, EcsimdHipError
+    from ecsimd_amd.curves import curve_id
+    big = 3 * (1 << 19) + 77
+    k = engine.fill_random(big, SEED, 301); s = engine.fill_random(big, SEED, 302)
+    for cv in (P256, SECP256K1, curve_id("brainpoolP256r1")):
+        bx, by = engine.scalar_mult_base(cv, s, flags=OUT_AFFINE)
+        kn, xn, yn = (engine.to_numpy(t) for t in (k, bx, by))
+        for n in ((1, 1000, (1 << 19) + 5, big) if cv == P256 else ((1 << 19) + 5,)):
+            dev = [t[:n].contiguous() for t in (k, bx, by)]
+            J = engine.scalar_mult(cv, *dev)
+            H = engine.scalar_mult_host(cv, kn[:n], xn[:n], yn[:n])
+            assert len(H) == 3 and all(np.array_equal(h, engine.to_numpy(j)) for h, j in zip(H, J)), (cv, n)
+            A = engine.scalar_mult(cv, *dev, flags=OUT_AFFINE)
+            H = engine.scalar_mult_host(cv, kn[:n], xn[:n], yn[:n], flags=OUT_AFFINE)
+            assert len(H) == 2 and all(np.array_equal(h, engine.to_numpy(a)) for h, a in zip(H, A)), (cv, n)
+            (hx,) = engine.scalar_mult_host(cv, kn[:n], xn[:n], yn[:n], flags=OUT_AFFINE, x_only=True)
+            assert np.array_equal(hx, engine.to_numpy(A[0]))
+            G = engine.scalar_mult_host(cv, kn[:n], flags=OUT_AFFINE)                        # no base: the generator
+            assert all(np.array_equal(g, engine.to_numpy(b)) for g, b in zip(G, engine.scalar_mult_base(cv, dev[0], flags=OUT_AFFINE)))
+        if cv == SECP256K1:
+            n = (1 << 19) + 5
+            W = engine.scalar_mult_host(cv, kn[:n], xn[:n], yn[:n], flags=OUT_AFFINE | ALG_WINDOWED)      # per-lane tables: each side's context has its own workspace
+            assert all(np.array_equal(w, engine.to_numpy(a)) for w, a in zip(W, engine.scalar_mult(cv, k[:n].contiguous(), bx[:n].contiguous(), by[:n].contiguous(), flags=OUT_AFFINE)))
+    n = 2 * (1 << 19) + 3                                                                     # the context option reaches the helper context too
+    pat = np.array([0, 0xffffffff, 0x80000000, 0x7fffffff, 1, 0xfffffffe], dtype=np.uint64)
+    w = pat[np.random.default_rng(9).integers(0, len(pat), size=(n, 8))]
+    kk = (w[:, 0::2] | (w[:, 1::2] << np.uint64(32))).astype(np.uint64)                        # carry-heavy scalars do not matter; carry-heavy COORDINATES do: take them from the ladder itself
+    bx, by = engine.scalar_mult_base(P256, engine.to_device(kk), flags=OUT_AFFINE)
+    engine.set_ref_square_compat(True)
+    try:
+        want = engine.scalar_mult(P256, k[:n].contiguous(), bx, by)
+        got = engine.scalar_mult_host(P256, engine.to_numpy(k[:n]), engine.to_numpy(bx), engine.to_numpy(by))
+    finally:
+        engine.set_ref_square_compat(False)
+    assert all(np.array_equal(g, engine.to_numpy(w_)) for g, w_ in zip(got, want))
+    kn = engine.to_numpy(k[:8])
+    with pytest.raises(EcsimdHipError, match="base point"):
+        engine.scalar_mult_host(P256, kn, kn, kn, flags=BASE_GENERATOR)
+    assert engine.lib.ecsimd_hip_scalar_mult_host(engine.ctx, C.c_int(P256), kn.ctypes.data_as(C.c_void_p), None, None, kn.ctypes.data_as(C.c_void_p), None, None, C.c_size_t(8), C.c_int(0)) == -1
+    assert all(h.shape[0] == 0 for h in engine.scalar_mult_host(P256, kn[:0], kn[:0], kn[:0]))
+
+
 def test_reference_register_layout_on_the_device(engine):
     """ecsimd_hip_wide4_to_lanes / _lanes_to_wide4 (r5): the reference's wide_bignum -- four lanes, limb-major u64[limb * 4 + lane] (bignum.h:99-100) -- and
     its Jacobian point of three wides, transposed on the device against numpy: an array of wides (records of 128 bytes), x / y / z of an array of points

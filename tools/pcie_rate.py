@@ -36,3 +36,14 @@ run(2)
 t = time.perf_counter(); run(batches); dt = time.perf_counter() - t
 h2d = 3 * n * 32; d2h = 3 * n * 32
 print(f"PCIe-inclusive: {batches * n / dt / 1e6:.2f} M scalar mults/s ({dt / batches * 1e3:.1f} ms per 2^22 batch; {h2d/1e6:.0f} MB up + {d2h/1e6:.0f} MB down per batch)")
+
+# the C ABI's own host-array entry point (ecsimd_hip_scalar_mult_host, r5): PAGEABLE numpy arrays in and out, chunks of 2^19 on two contexts
+import numpy as np
+kn, xn, yn = (np.ascontiguousarray(e.to_numpy(t)) for t in (k, bx, by))
+out = e.scalar_mult_host(P256, kn, xn, yn)                     # warm-up: the helper context, the staging, and the output arrays' pages (a caller reuses its buffers)
+reps = 4
+t = time.perf_counter()
+for _ in range(reps):
+    e.scalar_mult_host(P256, kn, xn, yn, out=out)
+dt = (time.perf_counter() - t) / reps
+print(f"ecsimd_hip_scalar_mult_host, pageable arrays: {n / dt / 1e6:.2f} M scalar mults/s ({dt * 1e3:.1f} ms per 2^22 batch, classical base in, Jacobian out)")
