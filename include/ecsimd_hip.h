@@ -177,7 +177,7 @@ int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id);
  * absence, included -- give the same id, so nobody's registration changes what an id somebody else holds does; P-256's or secp256k1's
  * parameters give 0 / 1 unless flags = ECSIMD_HIP_CURVE_GENERIC_KERNELS, which registers them like any other curve -- how tests hold the generic kernels
  * to the special-form ones bit for bit) is accepted by
- *     from_affine, to_affine, compute_y, on_curve, dblu, zaddu, zdau, add_z2_1, trplu, zdau_repeat, scalar_mult, scalar_mult_1s, scalar_mult_base
+ *     from_affine, to_affine, compute_y, on_curve, dblu, zaddu, zdau, add_z2_1, trplu, zdau_repeat, scalar_mult, scalar_mult_1s, scalar_mult_base, scalar_mult_host
  * (flags BASE_* | OUT_* | LADDER_RADIX32 | REF_SQUARE_COMPAT: the reference's ladder; of the table-driven algorithms a registered curve has ONE:
  * scalar_mult_base with ALG_WINDOWED [| ALG_CONSTANT_TIME] | OUT_AFFINE -- a 4-bit odd-digit table of multiples of ITS generator in LDS, built from the
  * ladder on first use, for a curve registered with its order n >= 2^255: the true k G for every k, (0, 0) for k = 0 mod n; per-lane tables for a variable
