@@ -1,7 +1,8 @@
 /* abi_smoke.c -- the C ABI of include/ecsimd_hip.h driven from plain C99 (no C++, no Python): what a cgo / JNI / ctypes binding
  * would call.  k*G for 1000 scalars through one context, then the same batch through a device group of three members on
  * device 0 (host-array form: shards, gather), and the two results must agree byte for byte.  Also checks the KAT of
- * tests/curve_group.cpp:142,150 (k = 0bc1...8827, P = G: the x coordinate) at the affine level.
+ * tests/curve_group.cpp:142,150 (k = 0bc1...8827, P = G: the x coordinate) at the affine level.  Round 5: the host-array form, a curve registered at run
+ * time (its ladder against its comb) and the reference's four-lane register layout through the device transposition.
  * Build: gcc -std=c99 -pedantic -Wall -Werror -I include tests/c/abi_smoke.c -L ecsimd_amd -lecsimd_hip   (tests/test_c_abi.py) */
 #include <ecsimd_hip.h>
 
@@ -50,6 +51,35 @@ int main(void) {
     for (j = 0; j < 32; ++j) sprintf(hex + 2 * j, "%02x", be[j]);
     if (strcmp(hex, kat_x) != 0) { fprintf(stderr, "KAT tests/curve_group.cpp:150: got %s\n", hex); return 1; }
     CHECK(ecsimd_hip_free(ctx, d)); CHECK(ecsimd_hip_free(ctx, db));
+  }
+  /* round 5 from plain C: the host-array form (pageable arrays in and out) gives the same bytes; a curve registered at run time (brainpoolP256r1, RFC 5639 3.4)
+   * multiplies its generator, the comb and the ladder agree, and the reference's four-lane register layout round-trips through the device transposition */
+  CHECK(ecsimd_hip_scalar_mult_host(ctx, ECSIMD_HIP_P256, &hk[0][0], &hx[0][0], &hy[0][0], &bx[0][0], &by[0][0], NULL, N, ECSIMD_HIP_OUT_AFFINE));
+  if (memcmp(ax, bx, sizeof ax) != 0 || memcmp(ay, by, sizeof ay) != 0) { fprintf(stderr, "scalar_mult_host differs from the device-resident form\n"); return 1; }
+  {
+    const uint64_t bp[4] = {0x2013481d1f6e5377ull, 0x6e3bf623d5262028ull, 0x3e660a909d838d72ull, 0xa9fb57dba1eea9bcull};
+    const uint64_t ba[4] = {0xe94a4b44f330b5d9ull, 0xfb8055c126dc5c6cull, 0xeef67530417affe7ull, 0x7d5a0975fc2c3057ull};
+    const uint64_t bb[4] = {0x6bccdc18ff8c07b6ull, 0x958416295cf7e1ceull, 0xf330b5d9bbd77cbfull, 0x26dc5c6ce94a4b44ull};
+    const uint64_t bgx[4] = {0x3a4453bd9ace3262ull, 0xb9de27e1e3bd23c2ull, 0x2c4b482ffc81b7afull, 0x8bd2aeb9cb7e57cbull};
+    const uint64_t bgy[4] = {0x5c1d54c72f046997ull, 0xc27745132ded8e54ull, 0x97f8461a14611dc9ull, 0x547ef835c3dac4fdull};
+    const uint64_t bn[4] = {0x901e0e82974856a7ull, 0x8c397aa3b561a6f7ull, 0x3e660a909d838d71ull, 0xa9fb57dba1eea9bcull};
+    static uint64_t lx[N][4], ly[N][4], cx[N][4], cy[N][4], wide[N][4];
+    uint64_t* w = NULL;
+    int cid = -1;
+    CHECK(ecsimd_hip_register_curve(bp, ba, bb, bgx, bgy, bn, 0, &cid));
+    if (cid < ECSIMD_HIP_FIRST_REGISTERED_CURVE) { fprintf(stderr, "register_curve: id %d\n", cid); return 1; }
+    CHECK(ecsimd_hip_scalar_mult_host(ctx, cid, &hk[0][0], NULL, NULL, &lx[0][0], &ly[0][0], NULL, N, ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_BASE_GENERATOR | ECSIMD_HIP_LADDER_RADIX32));   /* the ladder */
+    CHECK(ecsimd_hip_scalar_mult_host(ctx, cid, &hk[0][0], NULL, NULL, &cx[0][0], &cy[0][0], NULL, N, ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_BASE_GENERATOR | ECSIMD_HIP_ALG_WINDOWED));   /* the generator's comb */
+    if (memcmp(lx, cx, sizeof lx) != 0 || memcmp(ly, cy, sizeof ly) != 0) { fprintf(stderr, "registered curve: the comb differs from the ladder\n"); return 1; }
+    CHECK(ecsimd_hip_malloc(ctx, (void**)&w, N * 32));
+    CHECK(ecsimd_hip_memcpy_h2d(ctx, x, lx, N * 32));
+    CHECK(ecsimd_hip_lanes_to_wide4(ctx, x, w, 128, 0, N / 4));                       /* N / 4 wides of four lanes, limb-major */
+    CHECK(ecsimd_hip_memcpy_d2h(ctx, wide, w, N * 32));
+    for (i = 0; i < N; ++i) { const uint64_t* rec = &wide[(i / 4) * 4][0]; size_t l; for (l = 0; l < 4; ++l) if (rec[4 * l + (i % 4)] != lx[i][l]) { fprintf(stderr, "lanes_to_wide4: element %zu limb %zu\n", i, l); return 1; } }
+    CHECK(ecsimd_hip_wide4_to_lanes(ctx, w, 128, 0, y, N / 4));
+    CHECK(ecsimd_hip_memcpy_d2h(ctx, cy, y, N * 32));
+    if (memcmp(cy, lx, sizeof lx) != 0) { fprintf(stderr, "wide4 round trip\n"); return 1; }
+    CHECK(ecsimd_hip_free(ctx, w));
   }
   CHECK(ecsimd_hip_group_destroy(grp));
   CHECK(ecsimd_hip_free(ctx, k)); CHECK(ecsimd_hip_free(ctx, x)); CHECK(ecsimd_hip_free(ctx, y));
