@@ -608,6 +608,7 @@ static int switch_stream(ecsimd_hip_ctx* ctx, hipStream_t next) {
 int ecsimd_hip_set_stream(ecsimd_hip_ctx* ctx, void* s) { REQUIRE_CTX(); return switch_stream(ctx, (hipStream_t)s); }
 int ecsimd_hip_use_own_stream(ecsimd_hip_ctx* ctx) { REQUIRE_CTX(); return switch_stream(ctx, ctx->own_stream); }
 int ecsimd_hip_set_ref_square_compat(ecsimd_hip_ctx* ctx, int on) { REQUIRE_CTX(); ctx->ref_square = on ? 1 : 0; return ECSIMD_HIP_OK; }
+int ecsimd_hip_get_ref_square_compat(const ecsimd_hip_ctx* ctx) { return ctx ? ctx->ref_square : ECSIMD_HIP_ERR_BAD_ARG; }
 int ecsimd_hip_sync(ecsimd_hip_ctx* ctx) {
   REQUIRE_CTX();
   hipError_t e = hipStreamSynchronize(ctx->stream);

@@ -149,6 +149,8 @@ int ecsimd_hip_sync(ecsimd_hip_ctx* ctx);
  * walk exponents bit by bit as mgry_ops.h:44-86 does, so a caller gets the compiled reference's bits on every input.
  * Off by default.  The windowed algorithms are not the reference's and refuse to run while it is on. */
 int ecsimd_hip_set_ref_square_compat(ecsimd_hip_ctx* ctx, int on);
+/* The option as it stands: 0 / 1 (a caller that runs one job on two contexts mirrors it: integration/scalar_mult_p256_adapter.cpp); < 0: ctx is NULL. */
+int ecsimd_hip_get_ref_square_compat(const ecsimd_hip_ctx* ctx);
 const char* ecsimd_hip_last_error(const ecsimd_hip_ctx* ctx);
 const char* ecsimd_hip_version(void);
 int ecsimd_hip_malloc(ecsimd_hip_ctx* ctx, void** dptr, size_t bytes);

@@ -97,7 +97,6 @@ side& side_of(int i) {
   if (!s[i].c) { if (i == 0) s[0].c = ctx(); else if (int rc = ecsimd_hip_init(0, &s[1].c)) die("ecsimd_hip_init", rc, nullptr); }
   return s[i];
 }
-int ref_square_option = 0;                                   // scalar_mult_p256_set_ref_square_compat: applied to whichever contexts exist
 struct chunk_plan { uint8_t *dxw, *dpw, *dow; uint64_t *dk, *px, *py, *ox, *oy, *oz; size_t pb; };
 chunk_plan plan(side& S, size_t wides, size_t rec) {
   const size_t n = 4 * wides, xb = wides * 128, pb = wides * rec;
@@ -135,7 +134,8 @@ void batch_raw(std::span<const WBN> x, std::span<const WJCP> P, std::span<WJCP> 
   }
   const size_t chunks = (wides + CHUNK_WIDES - 1) / CHUNK_WIDES;
   chunk_plan B[2];
-  for (int i = 0; i < 2; ++i) { side& S = side_of(i); if (int rc = ecsimd_hip_set_ref_square_compat(S.c, ref_square_option)) die("set_ref_square_compat", rc, S.c); B[i] = plan(S, CHUNK_WIDES, rec); }
+  const int option = ecsimd_hip_get_ref_square_compat(side_of(0).c);          // whatever the caller set on the adapter's context holds for the second one too
+  for (int i = 0; i < 2; ++i) { side& S = side_of(i); if (int rc = ecsimd_hip_set_ref_square_compat(S.c, option)) die("set_ref_square_compat", rc, S.c); B[i] = plan(S, CHUNK_WIDES, rec); }
   for (size_t c = 0; c <= chunks; ++c) {
     if (c < chunks) {
       const size_t first = c * CHUNK_WIDES, m = (wides - first) < CHUNK_WIDES ? (wides - first) : CHUNK_WIDES;
@@ -153,8 +153,7 @@ void batch_raw(std::span<const WBN> x, std::span<const WJCP> P, std::span<WJCP> 
 
 ecsimd_hip_ctx* scalar_mult_p256_context() { return ctx(); }
 void scalar_mult_p256_set_ref_square_compat(bool on) {
-  ref_square_option = on ? 1 : 0;
-  if (int rc = ecsimd_hip_set_ref_square_compat(ctx(), ref_square_option)) die("set_ref_square_compat", rc, ctx());
+  if (int rc = ecsimd_hip_set_ref_square_compat(ctx(), on ? 1 : 0)) die("set_ref_square_compat", rc, ctx());
 }
 bool scalar_mult_p256_transposes_on_the_device() { return layout().ok; }
 

@@ -22,7 +22,8 @@ ecsimd_mi355x::WJCP scalar_mult_p256(ecsimd_mi355x::WBN const& x, ecsimd_mi355x:
 void scalar_mult_p256(std::span<const ecsimd_mi355x::WBN> x, std::span<const ecsimd_mi355x::WJCP> P, std::span<ecsimd_mi355x::WJCP> out);
 // true when the spans travel as raw bytes and the lane transposition runs on the device (the layout check passed)
 bool scalar_mult_p256_transposes_on_the_device();
-// ECSIMD_HIP_REF_SQUARE_COMPAT for every launch of the adapter (large batches run on two contexts: set the option here, not on one of them)
+// ECSIMD_HIP_REF_SQUARE_COMPAT for every launch of the adapter (= ecsimd_hip_set_ref_square_compat on the context below; large batches run on a second context
+// as well, which takes the option over from this one at every call)
 void scalar_mult_p256_set_ref_square_compat(bool on);
-// The context the adapter runs on (created on first use, device 0).
+// The context the adapter runs on (created on first use, device 0): its options are the adapter's.
 ecsimd_hip_ctx* scalar_mult_p256_context();
