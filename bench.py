@@ -203,8 +203,8 @@ def main():
         __graft_entry__.build()         # built artefacts normally travel with the snapshot
     if world > 1:
         dist.barrier()
-    if args.curve not in ("p256", "secp256k1") and args.workload not in LADDER_WORKLOADS:
-        raise SystemExit("a curve registered at run time has the reference's ladder (workloads %s); the table-driven algorithms exist for p256 / secp256k1" % ", ".join(LADDER_WORKLOADS))
+    if args.curve not in ("p256", "secp256k1") and args.workload not in LADDER_WORKLOADS + ("windowed",):
+        raise SystemExit("a curve registered at run time has the reference's ladder (workloads %s) and the public-scalar window loop (windowed); the other table-driven algorithms exist for p256 / secp256k1" % ", ".join(LADDER_WORKLOADS))
     curve = curve_id(args.curve)        # 0 / 1, or a run-time registration (host arithmetic only)
     eng = Engine(dev_index)             # raises if the HIP library / a gfx950 device is missing: no fallback
     units = (1 << args.global_log2_batch) if args.scaling == "strong" else (1 << args.log2_batch)
@@ -355,7 +355,9 @@ def base_line(args, world, total_units, n, value, elapsed):
         "ladder-x": f"scalar_mult_{args.curve} variable-base, x coordinate only: " + ("the co-Z ladder without Z (8M + 6S per bit), x from the curve equation + simultaneous inversion"
                     if args.curve == "p256" else "the co-Z ladder + x-only simultaneous inversion") + f", batch {sizes}, affine x out",
         "windowed": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 multiples of P) + signed 4-bit windows + simultaneous "
-                    f"inversion{' + GLV split k = k1 + k2*lambda, the table over one Z and the loop on the isomorphic curve' if args.curve == 'secp256k1' else ''}, batch {sizes}, affine out",
+                    f"inversion{' + GLV split k = k1 + k2*lambda, the table over one Z and the loop on the isomorphic curve' if args.curve == 'secp256k1' else ''}"
+                    + ("" if args.curve in ("p256", "secp256k1") else "; this curve is registered at RUN time: generic kernels (k_gvarwin.hip), the dense 9-limb prime in SGPRs, the eight odd multiples over one Z "
+                       "and the loop on the isomorphic curve in modified Jacobian coordinates (a general a)") + f", batch {sizes}, affine out",
         "windowed-ct": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 odd multiples of P) + signed 4-bit windows (odd digits), ALG_CONSTANT_TIME: "
                        f"all 8 entries of the lane's table read in every window, kept under lane masks"
                        + (" (secp256k1: GLV split k = k1 + k2*lambda on the complete addition law of a = 0 curves)" if args.curve == "secp256k1" else "") + f"; + simultaneous inversion, batch {sizes}, affine out",
@@ -412,8 +414,14 @@ def roofline_object(args, eng, n, avg_ms):
             # table {1..8}P over ONE Z (k_varwin_table_iso: a doubling, P over its Z, six co-Z additions, the backward walk of 5 products per entry -- no inversion), the
             # loop on the isomorphic curve, one product by the common Z at the end
             fm = (dbl + 4 + 6 * 7 + 7 * 5) + 32 * (4 * dbl + 2 * 11 + 1) + (2 * 11 + 1) + 1 + (7 + inv / share)
+        registered = args.curve not in ("p256", "secp256k1")
+        if registered:
+            # k_gvarwin.hip: the table over one Z (a doubling of 7, P over its Z 4, seven co-Z additions, 2 + 7 x 5 on the walk back, 4 entering products),
+            # a' = a Zg^4 (4), 63 windows x (W = a' Z^4: 3; doublings of 8, 8, 7 in modified Jacobian coordinates; the fused double-add 18), Z' Zg and the three
+            # leaving products (4), then the shared inversion (the field's generic division steps, priced as P-256's 267)
+            fm = (7 + 4 + 7 * 7 + 2 + 7 * 5 + 4) + 4 + 63 * (3 + 8 + 8 + 7 + 18) + 4 + (7 + 267 / share)
         mad32_unit, bytes_unit = int(fm * 136), 160
-        kname = ("k_varwin_mult_glv_ct + k_varwin_multiples_chain" if (args.workload == "windowed-ct" and args.curve == "secp256k1") else
+        kname = "k_gvw_mult + k_gvw_table + k_gc_to_affine_batched" if registered else ("k_varwin_mult_glv_ct + k_varwin_multiples_chain" if (args.workload == "windowed-ct" and args.curve == "secp256k1") else
                  "k_varwin_mult_odd<true> + k_varwin_odd_multiples" if args.workload == "windowed-ct" else "k_varwin_mult_odd<false> + k_varwin_odd_multiples" if args.curve == "p256"
                  else "k_varwin_mult_glv + k_varwin_table_iso") + ("" if (args.workload == "windowed" and args.curve == "secp256k1") else " + k_varwin_invert_last + k_varwin_chain_to_table") + " + k_to_affine_batched"
     else:
@@ -445,7 +453,7 @@ def attach_cpu_baseline(args, result, eng, curve, k, bx, by, out, failures):
     process exits EXIT_PARITY after printing."""
     try:
         if args.workload in ("windowed", "windowed-ct"):
-            result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, base=(bx, by))
+            result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, base=(bx, by), name=args.curve)
         elif args.workload == "ladder-x":
             result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, base=(bx, by), x_only=True)
         elif args.workload in LADDER_WORKLOADS:
@@ -695,7 +703,7 @@ def openssl_checker():
     return loader.OpenSSLCheck()
 
 
-def cpu_baseline_affine(eng, curve, k, gpu_out, target_s, failures, base=None, x_only=False):
+def cpu_baseline_affine(eng, curve, k, gpu_out, target_s, failures, base=None, x_only=False, name=None):
     """Affine-output workloads on the CPU: the reference has ONE way to compute k*P -- scalar_mult(k, P) followed
     by to_affine() (exactly what its benchmark times, benchs/curve_group.cpp:23-35; P = G for config 3, `base` =
     the per-element points for the windowed variable-base workload).  Compared with the GPU's windowed result at
@@ -704,7 +712,11 @@ def cpu_baseline_affine(eng, curve, k, gpu_out, target_s, failures, base=None, x
     from oracle import loader
     cores = usable_cores()
     impl, kind = load_checkers()
-    c = impl.constants(curve)
+    builtin = name in (None, "p256", "secp256k1")
+    if not builtin:                                     # a curve registered at run time (variable base only): below, `curve` is the checker's id
+        assert base is not None
+        curve = checker_curve(impl, name)
+    c = impl.constants(curve) if base is None else None
     m0 = 256 * cores
     kn = eng.to_numpy(k[:m0])
     points = (lambda m_: (np.tile(c["gx"], (m_, 1)), np.tile(c["gy"], (m_, 1)))) if base is None else \
@@ -720,16 +732,21 @@ def cpu_baseline_affine(eng, curve, k, gpu_out, target_s, failures, base=None, x
     explained, by_ossl = True, None
     if len(bad):                                        # reference square() defect: the exact oracle must side with the GPU
         ex = loader.Oracle(faithful=False)
-        ea = ex.to_affine(curve, ex.scalar_mult(curve, kn[bad], gx[bad], gy[bad], threads=min(cores, len(bad))))
+        exc = curve if builtin else checker_curve(ex, name)
+        ea = ex.to_affine(exc, ex.scalar_mult(exc, kn[bad], gx[bad], gy[bad], threads=min(cores, len(bad))))
         explained = bool(np.array_equal(ea[0], gx_[bad]) and (x_only or np.array_equal(ea[1], gy_[bad])))
-        ossl = openssl_checker()
+        ossl = openssl_checker() if builtin else None    # libcrypto's harness knows the two built-in curves; a registered curve's lanes are settled by textbook arithmetic
+        if not builtin:
+            from ecsimd_amd.curves import NAMED
+            ti = lambda v: sum(int(w) << (64 * j) for j, w in enumerate(v))
+            by_ossl = sum(1 for lane in bad if textbook_scalar_mult(NAMED[name], ti(kn[lane]), ti(gx[lane]), ti(gy[lane])) == (ti(gx_[lane]), ti(gy_[lane])))
         if ossl is not None:
             vx, vy, inf = ossl.scalar_mult(curve, kn[bad], gx[bad], gy[bad], threads=1)
             by_ossl = int(np.count_nonzero(~((gx_[bad] != vx).any(axis=1) | ((gy_[bad] != vy).any(axis=1) & (not x_only)) | (inf != 0))))
     if not explained:
         failures.append("cpu_baseline: a lane differs from the reference and the exact oracle does not side with the GPU")
     if by_ossl is not None and by_ossl != len(bad):
-        failures.append("cpu_baseline: libcrypto does not confirm the GPU on a lane where it differs from the reference")
+        failures.append("cpu_baseline: libcrypto (a registered curve: textbook affine arithmetic) does not confirm the GPU on a lane where it differs from the reference")
     return {"value": m / dt, "unit": "scalar_mults/s", "cores": cores, "kind": kind,
             "per_core": (m / dt) / cores, "cpu_model": cpu_model(), "flags": build_flags(kind),
             "one_thread": one_thread_rate(lambda m1: impl.to_affine(curve, impl.scalar_mult(curve, kn[:m1], gx[:m1], gy[:m1], threads=1)), (m / dt) / cores, m),
@@ -737,7 +754,7 @@ def cpu_baseline_affine(eng, curve, k, gpu_out, target_s, failures, base=None, x
                       f"{dt:.1f} s wall, {cores} threads (to_affine single-threaded)",
             "lanes_compared": int(m), "lanes_differing_from_gpu": int(len(bad)),
             "differences_all_explained_by_reference_square_defect": bool(explained),
-            "lanes_differing_confirmed_by_openssl": by_ossl}
+            ("lanes_differing_confirmed_by_openssl" if builtin else "lanes_differing_confirmed_by_textbook_arithmetic"): by_ossl}
 
 
 def competitor_openssl(eng, curve, k, bx, by, gpu_out, failures, seconds=3.0, check_lanes=8192):

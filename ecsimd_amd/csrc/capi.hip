@@ -345,13 +345,16 @@ bool lookup_curve(int id, gcurve* out);          // the curve registry, below
 int run_gcomb(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, size_t n, int flags);
 constexpr int GC_NOT_TAKEN = -1000;
 int gc_small_base(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, uint64_t* oy, size_t n, int flags);
+int run_gvarwin(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, size_t n, int flags, size_t reserve);
 int run_gladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y,
                 uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, int flags) {
   gcurve GC; if (!lookup_curve(curve, &GC)) return bad(ctx, "unknown curve id");
   if (x == nullptr && k_stride == 4 && (flags & ECSIMD_HIP_ALG_WINDOWED) && !(flags & (ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM)))
     return run_gcomb(ctx, curve, k, ox, oy, n, flags);          // k G from the generator's table in LDS (k_gcomb.hip)
+  if (x != nullptr && (flags & ECSIMD_HIP_ALG_WINDOWED) && !(flags & (ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM | ECSIMD_HIP_ALG_CONSTANT_TIME)))
+    return run_gvarwin(ctx, curve, k, k_stride, x, y, ox, oy, n, flags, 0);   // k P from the lane's own table of odd multiples (k_gvarwin.hip)
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM | ECSIMD_HIP_ALG_CONSTANT_TIME))
-    return bad(ctx, "a registered curve has the reference's ladder only (and ALG_WINDOWED [| ALG_CONSTANT_TIME] for its generator): the other ALG_* tables exist for P-256 and secp256k1");
+    return bad(ctx, "a registered curve has the reference's ladder, ALG_WINDOWED [| ALG_CONSTANT_TIME] for its generator and ALG_WINDOWED (public scalars) for a variable base: the other ALG_* tables exist for P-256 and secp256k1");
   if (n == 0) return ECSIMD_HIP_OK;
   if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
   hipError_t e = hipSetDevice(ctx->device);
@@ -1172,18 +1175,22 @@ int double_scalar_mult_impl(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, 
 }
 }  // namespace
 
-// ---- u1 G + u2 Q, ECDSA verification and signing on a curve registered at run time: the reference's ladder twice (no tables exist for such a curve), the
-// scalars kept clear of its three degenerate values (k_gc_ladder_safe_scalars), one shared inversion per product, a batched affine addition.
+// ---- u1 G + u2 Q, ECDSA verification and signing on a curve registered at run time: with the group order (n >= 2^255) u1 G from the generator's comb
+// (k_gcomb.hip) and u2 Q from the lane's own window table (k_gvarwin.hip: verification's scalars are public); without it the reference's ladder twice, the
+// scalars kept clear of its three degenerate values (k_gc_ladder_safe_scalars); one shared inversion per product, a batched affine addition.
 namespace {
 constexpr size_t GC_CHUNK = (size_t)1 << 22;
-struct gc_layout { size_t chunk; uint64_t *adj1, *adj2, *j[3], *gx, *gy, *px, *py; uint8_t *neg1, *neg2; size_t bytes; };
-gc_layout gc_plan(uint64_t* base, size_t n) {
+struct gc_layout { size_t chunk; uint64_t *adj1, *adj2, *j[3], *gx, *gy, *px, *py, *win; uint8_t *neg1, *neg2; size_t bytes; };
+// win: u2 Q goes through the window loop (k_gvarwin.hip), whose per-lane tables follow the nine arrays
+gc_layout gc_plan(uint64_t* base, size_t n, bool win = false) {
   gc_layout L; L.chunk = n < GC_CHUNK ? n : GC_CHUNK;
   uint64_t* p = base; const size_t e = 4 * L.chunk;
   L.adj1 = p; p += e; L.adj2 = p; p += e; for (int i = 0; i < 3; ++i) { L.j[i] = p; p += e; }
   L.gx = p; p += e; L.gy = p; p += e; L.px = p; p += e; L.py = p; p += e;
+  const size_t wbytes = win ? launch::gc_varwin_scratch_bytes(L.chunk) : 0;
+  L.win = win ? p : nullptr; p += wbytes / 8;
   L.neg1 = reinterpret_cast<uint8_t*>(p); L.neg2 = L.neg1 + ((L.chunk + 15) / 16) * 16;
-  L.bytes = 9 * L.chunk * 32 + 2 * (((L.chunk + 15) / 16) * 16);
+  L.bytes = 9 * L.chunk * 32 + wbytes + 2 * (((L.chunk + 15) / 16) * 16);
   return L;
 }
 // The comb of a registered curve (k_gcomb.hip): 64 windows x 8 odd multiples (2d + 1) 16^w G, then k* G and the record {k*, 0} (k_affine.inc comb_special's
@@ -1298,6 +1305,30 @@ int run_gcomb(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, u
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult_base (registered curve, windowed) launch");
 }
+// scalar_mult(registered curve, ALG_WINDOWED | OUT_AFFINE) on a variable base: per-lane tables of the eight odd multiples of P over one Z, the window loop on the
+// isomorphic curve (k_gvarwin.hip), then the shared inversion -- the true k P for every k (k = 0 mod n: (0, 0)), public scalars.  In chunks of 2^22 lanes
+// (640 B of scratch per lane).  `reserve` bytes at the start of the workspace stay untouched (gc_double_scalar_mult).
+int run_gvarwin(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, size_t n, int flags, size_t reserve) {
+  if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
+  if (ctx->ref_square || (flags & ECSIMD_HIP_REF_SQUARE_COMPAT)) return bad(ctx, "ALG_WINDOWED is not the reference's algorithm: no ECSIMD_HIP_REF_SQUARE_COMPAT form");
+  if (flags & ECSIMD_HIP_LADDER_RADIX32) return bad(ctx, "LADDER_RADIX32 selects a ladder loop: not with ALG_WINDOWED");
+  curve_record rec; if (!lookup_curve_record(curve, &rec)) return bad(ctx, "unknown curve id");
+  if (!gc_comb_possible(rec)) return bad(ctx, "the windowed algorithms on a registered curve need its group order n, n >= 2^255");
+  if (n == 0) return ECSIMD_HIP_OK;
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e != hipSuccess) return fail(ctx, e, "hipSetDevice");
+  const size_t chunk = n < VARWIN_CHUNK ? n : VARWIN_CHUNK;
+  int rc = ensure_workspace(ctx, reserve + launch::gc_varwin_scratch_bytes(chunk));
+  if (rc != ECSIMD_HIP_OK) return rc;
+  uint64_t* scratch = ctx->workspace + reserve / 8;
+  for (size_t first = 0; first < n; first += chunk) {
+    const size_t m = (n - first) < chunk ? (n - first) : chunk;
+    launch::gc_varwin_scalar_mult(ctx->stream, rec.G, order_words(rec), k + (size_t)k_stride * first, k_stride, x + 4 * first, y + 4 * first, flags & ECSIMD_HIP_BASE_MGRY,
+                                  scratch, ox + 4 * first, oy ? oy + 4 * first : nullptr, m);
+  }
+  e = hipGetLastError();
+  return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult (registered curve, windowed) launch");
+}
 // scalar_mult_base(registered curve, OUT_AFFINE, no ALG_* / ladder flag) on up to 2^16 lanes: as for the built-in curves (ecsimd_hip_scalar_mult_base below) a
 // ladder launch costs its 254 iterations however few lanes it has; the constant-time comb costs 63 additions.  Its affine result is the true k G -- the ladder's
 // everywhere but at the ladder's three degenerate scalars, and there the lanes take the ladder's own coordinates from the record: the same bits out.
@@ -1339,13 +1370,14 @@ void gc_safe_mult(hipStream_t s, const curve_record& rec, const gc_layout& L, ui
 int gc_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve_of, const curve_record& rec, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                           uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n, size_t reserve_behind) {
   (void)hipSetDevice(ctx->device);
-  gc_layout L = gc_plan(nullptr, n);
+  const bool win = gc_comb_possible(rec);                           // u2 Q from the lane's own window table where the curve has its order (n >= 2^255), else a ladder pass
+  gc_layout L = gc_plan(nullptr, n, win);
   int rc = ensure_workspace(ctx, L.bytes + reserve_behind);
   if (rc == ECSIMD_HIP_OK) rc = ensure_valid(ctx, (n + 15) / 16 * 16);
   if (rc != ECSIMD_HIP_OK) return rc;
   const uint32_t* comb = nullptr;                                   // u1 G from the generator's table where the curve has one (n >= 2^255), else a ladder pass
   if (gc_comb_possible(rec)) { rc = ensure_gc_comb(ctx, curve_of, rec, &comb); if (rc != ECSIMD_HIP_OK) { if (!capturing(ctx)) return rc; comb = nullptr; } }   // (no table yet and a capture in progress: the ladder)
-  L = gc_plan(ctx->workspace, n);
+  L = gc_plan(ctx->workspace, n, win);
   hipStream_t s = ctx->stream;
   launch::gc_on_curve(s, rec.G, qx, qy, ctx->valid, n);
   for (size_t first = 0; first < n; first += L.chunk) {
@@ -1354,7 +1386,8 @@ int gc_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve_of, const curve_record&
       launch::gc_base_windowed(s, rec.G, order_words(rec), u1 + 4 * first, comb, L.j[0], L.j[1], L.j[2], m, false);
       launch::gc_to_affine_batched(s, rec.G, L.j[0], L.j[1], L.j[2], L.gx, L.gy, m);
     } else gc_safe_mult(s, rec, L, L.adj1, L.neg1, u1 + 4 * first, nullptr, nullptr, L.gx, L.gy, m);                       // u1 G
-    gc_safe_mult(s, rec, L, L.adj2, L.neg2, u2 + 4 * first, qx + 4 * first, qy + 4 * first, L.px, L.py, m);              // u2 Q
+    if (win) launch::gc_varwin_scalar_mult(s, rec.G, order_words(rec), u2 + 4 * first, 4, qx + 4 * first, qy + 4 * first, 0, L.win, L.px, L.py, m);   // u2 Q (public scalars)
+    else gc_safe_mult(s, rec, L, L.adj2, L.neg2, u2 + 4 * first, qx + 4 * first, qy + 4 * first, L.px, L.py, m);
     launch::gc_affine_add_batched(s, rec.G, L.gx, L.gy, L.px, L.py, rx + 4 * first, ry ? ry + 4 * first : nullptr, finite ? finite + first : nullptr, m);
   }
   launch::clear_invalid(s, ctx->valid, rx, ry, finite, n);
@@ -1362,7 +1395,7 @@ int gc_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve_of, const curve_record&
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "double_scalar_mult (registered curve) launch");
 }
 int gc_ecdsa_verify_rx(ecsimd_hip_ctx* ctx, int curve_of, const curve_record& rec, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy, const uint64_t* r, uint8_t* ok, size_t n, size_t extra) {
-  const gc_layout L0 = gc_plan(nullptr, n);
+  const gc_layout L0 = gc_plan(nullptr, n, gc_comb_possible(rec));
   const size_t behind = n * 32 + ((n + 15) / 16) * 16;
   int rc = ensure_workspace(ctx, L0.bytes + behind + extra);
   if (rc != ECSIMD_HIP_OK) return rc;
@@ -1449,7 +1482,7 @@ int ecsimd_hip_ecdsa_verify(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, c
     if (n == 0) return ECSIMD_HIP_OK;
     if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
     (void)hipSetDevice(ctx->device);
-    const gc_layout L0 = gc_plan(nullptr, n);
+    const gc_layout L0 = gc_plan(nullptr, n, gc_comb_possible(rec));
     const size_t behind = n * 32 + ((n + 15) / 16) * 16, extra = 2 * n * 32 + ((n + 15) / 16) * 16;
     rc = ensure_workspace(ctx, L0.bytes + behind + extra);
     if (rc != ECSIMD_HIP_OK) return rc;

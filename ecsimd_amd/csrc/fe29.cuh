@@ -313,7 +313,11 @@ template <int C> ECS_DEV jpoint29 madd29(const jpoint29& P, const fe29& x2, cons
 // limb IS the value in units of 2^232, p is 2^24 of them -- through p's sparse signed form: five (secp256k1: three) full-rate limb updates, after
 // which |v| < p/2 + a few 2^232.  Applied to X3 and Y3 of every doubling and of the double-add, it closes the loop's invariant
 // (tools/radix29_model.py prove_window_invariant: limbs in [-2.25, 1.25] x 2^29, |value| <= 0.6 p, Z tight).
+// (A dense prime -- a registered curve -- has no sparse form to subtract through, and needs none: its window loop, gjdbl29 below, forms 8 Y^4 as
+// 2 (2 YY)^2, not as 8 x a product, so no value is ever multiplied by more than 4 after its last division by 2^261 and the loop's values close
+// on their own; tools/radix29_model.py prove_gwindow_invariant.  vred29 is the identity there.)
 template <int C> ECS_DEV fe29 vred29(fe29 a) {
+  if constexpr (r29_prime<C>::dense) return a;
   const int32_t k = (a.l[8] + (1 << 23)) >> 24;
   if constexpr (r29_prime<C>::p256) { a.l[0] += k; a.l[3] -= k << 9; a.l[6] -= k << 18; a.l[7] += k << 21; }
   else { a.l[0] += 977 * k; a.l[1] += k << 3; }
@@ -345,31 +349,53 @@ template <int C> ECS_DEV jpoint29 jdbl29(const jpoint29& P) {
 }
 // 2R + T for an affine T = (x2, y2) as (R + T) + R: the mixed addition's by-products X1 H^2, Y1 H^3 are R in the coordinates of R + T, so the second
 // addition is a co-Z one (k_varwin.inc dbl_add: 13M + 5S).
-template <int C> ECS_DEV jpoint29 dbl_add29(const jpoint29& P, const fe29& x2, const fe29& y2) {
-  const fe29 Z1Z1 = sqr29<C>(P.z);
-  const fe29 U2 = mul29<C>(x2, Z1Z1);
-  const fe29 S2 = mul29<C>(y2, mul29<C>(Z1Z1, P.z));
+template <int C> ECS_DEV jpoint29 dbl_add29(const jpoint29& P, const fe29& x2, const fe29& y2, const r29_ctx<C>& cx = r29_ctx<C>{}) {
+  const fe29 Z1Z1 = sqr29<C>(P.z, cx);
+  const fe29 U2 = mul29<C>(x2, Z1Z1, cx);
+  const fe29 S2 = mul29<C>(y2, mul29<C>(Z1Z1, P.z, cx), cx);
   const fe29 H = norm29(sub29(U2, P.x));
   const fe29 r = norm29(sub29(S2, P.y));
-  const fe29 HH = sqr29<C>(H);
-  const fe29 HHH = mul29<C>(H, HH);
-  const fe29 V = mul29<C>(P.x, HH);
-  const fe29 Yh = mul29<C>(P.y, HHH);
-  const fe29 X3 = sub29(sub29(sqr29<C>(r), HHH), dbl29(V));
-  const fe29 Y3 = sub29(mul29<C>(r, norm29(sub29(V, X3))), Yh);
-  const fe29 Z3 = mul29<C>(P.z, H);
+  const fe29 HH = sqr29<C>(H, cx);
+  const fe29 HHH = mul29<C>(H, HH, cx);
+  const fe29 V = mul29<C>(P.x, HH, cx);
+  const fe29 Yh = mul29<C>(P.y, HHH, cx);
+  const fe29 X3 = sub29(sub29(sqr29<C>(r, cx), HHH), dbl29(V));
+  const fe29 Y3 = sub29(mul29<C>(r, norm29(sub29(V, X3)), cx), Yh);
+  const fe29 Z3 = mul29<C>(P.z, H, cx);
   const fe29 dx = norm29(sub29(X3, V));
   const fe29 dy = norm29(sub29(Y3, Yh));
-  const fe29 Cc = sqr29<C>(dx);
-  const fe29 W1 = mul29<C>(X3, Cc);
-  const fe29 W2 = mul29<C>(V, Cc);
-  const fe29 A1 = mul29<C>(Y3, sub29(W1, W2));
+  const fe29 Cc = sqr29<C>(dx, cx);
+  const fe29 W1 = mul29<C>(X3, Cc, cx);
+  const fe29 W2 = mul29<C>(V, Cc, cx);
+  const fe29 A1 = mul29<C>(Y3, sub29(W1, W2), cx);
   jpoint29 Q;
-  const fe29 Qx = sub29(sub29(sqr29<C>(dy), W1), W2);
-  Q.y = vred29<C>(sub29(mul29<C>(dy, sub29(W1, Qx)), A1));               // (nor W1 - Qx beside the carry-passed dy)
+  const fe29 Qx = sub29(sub29(sqr29<C>(dy, cx), W1), W2);
+  Q.y = vred29<C>(sub29(mul29<C>(dy, sub29(W1, Qx), cx), A1));           // (nor W1 - Qx beside the carry-passed dy)
   Q.x = vred29<C>(Qx);
-  Q.z = mul29<C>(Z3, dx);
+  Q.z = mul29<C>(Z3, dx, cx);
   return Q;
+}
+// The doubling of a curve with ANY coefficient a (round 5: the window loop of a curve registered at run time, k_gvarwin.hip), in modified Jacobian
+// coordinates (Cohen-Miyaji-Ono): w = a Z^4 rides beside the point, so alpha = 3 X^2 + w costs no product, and the doubled point's w is 2 (8 Y^4) w --
+// one product (WOUT; the last doubling before an addition does not need it).  3M + 4S (+ 1M), against 4M + 6S with a Z^4 formed from Z every time.
+// 8 Y^4 is 2 (2 YY)^2: a SQUARE of a carry-passed double -- never 8 x a product, whose + p of the reduction would come back as + 8 p, the growth that
+// vred29 is there to undo where the prime has a sparse form.  With it the values close on their own (|X|, |Y| < 3.3 x 2^256 from one doubling
+// to the next): no value reduction on a dense prime.  Five carry passes (tools/radix29_model.py gjdbl29, prove_gwindow_invariant: any odd p < 2^256).
+template <int C, bool WOUT> ECS_DEV jpoint29 gjdbl29(const jpoint29& P, fe29& w, const r29_ctx<C>& cx = r29_ctx<C>{}) {
+  const fe29 Yn = norm29(P.y);
+  const fe29 YY = sqr29<C>(Yn, cx);
+  const fe29 G = norm29<2>(YY);
+  const fe29 B = mul29<C>(P.x, G, cx);
+  const fe29 XX = sqr29<C>(norm29(P.x), cx);
+  const fe29 alpha = norm29(add29(add29(dbl29(XX), XX), w));
+  jpoint29 R;
+  R.z = mul29<C>(dbl29(Yn), P.z, cx);
+  const fe29 X3 = sub29(sqr29<C>(alpha, cx), dbl29(B));
+  const fe29 E4 = sqr29<C>(norm29<1>(YY), cx);
+  R.y = sub29(mul29<C>(alpha, norm29(sub29(B, X3)), cx), dbl29(E4));
+  R.x = X3;
+  if constexpr (WOUT) { w = mul29<C>(norm29<2>(E4), w, cx); }
+  return R;
 }
 // The mixed addition BETWEEN DOUBLINGS (the default GLV loop, k_varwin.inc k_varwin_mult_glv): X3 takes one more carry pass, X3 and Y3 the value
 // reduction -- then the sum lies inside the window loop's invariant again (tools/radix29_model.py prove_glv_invariant).
@@ -381,17 +407,17 @@ template <int C> ECS_DEV jpoint29 madd29v_finish(const jpoint29& P, const fe29& 
 // The co-Z addition with update (curve_group.h:91-116 ZADDU, 5M + 2S): (x1, y1) + (x2, y2) over their common z -> (rx, ry); (x1, y1) is re-expressed
 // over the new z = z dx; dx = x1 - x2 (carry-passed) is handed out -- the ratio of the two Z (k_varwin.inc k_varwin_table_iso walks back through them).
 // (x1, y1) tight products, (x2, y2) a jdbl29 output or a sum of this function: tools/radix29_model.py iso_chain_invariant, prove_iso_table.
-template <int C> ECS_DEV void zaddu29(fe29& x1, fe29& y1, const fe29& x2, const fe29& y2, fe29& z, fe29& rx, fe29& ry, fe29& dx) {
+template <int C> ECS_DEV void zaddu29(fe29& x1, fe29& y1, const fe29& x2, const fe29& y2, fe29& z, fe29& rx, fe29& ry, fe29& dx, const r29_ctx<C>& cx = r29_ctx<C>{}) {
   dx = norm29(sub29(x1, x2));
-  const fe29 Cc = sqr29<C>(dx);
-  const fe29 W1 = mul29<C>(x1, Cc);
-  const fe29 W2 = mul29<C>(x2, Cc);
+  const fe29 Cc = sqr29<C>(dx, cx);
+  const fe29 W1 = mul29<C>(x1, Cc, cx);
+  const fe29 W2 = mul29<C>(x2, Cc, cx);
   const fe29 dy = norm29(sub29(y1, y2));
-  const fe29 D = sqr29<C>(dy);
-  const fe29 A1 = mul29<C>(y1, sub29(W1, W2));
+  const fe29 D = sqr29<C>(dy, cx);
+  const fe29 A1 = mul29<C>(y1, sub29(W1, W2), cx);
   rx = sub29(sub29(D, W1), W2);
-  ry = sub29(mul29<C>(dy, sub29(W1, rx)), A1);
-  z = mul29<C>(z, dx);
+  ry = sub29(mul29<C>(dy, sub29(W1, rx), cx), A1);
+  z = mul29<C>(z, dx, cx);
   x1 = W1; y1 = A1;
 }
 // v = 0 as a FIELD element, for |value| < 2^260: the value reduction leaves |v| < p, where the only multiple of p is the integer 0; a sequential

@@ -84,6 +84,11 @@ void gc_scalar_mult(hipStream_t, const gcurve&, const uint64_t* k, int k_stride,
 constexpr int GCOMB_WINDOWS = 64, GCOMB_ENTRIES = 8;
 void gc_pack_table(hipStream_t, const gcurve& G, const uint64_t* tx, const uint64_t* ty, uint32_t* table, int entries);
 void gc_base_windowed(hipStream_t, const gcurve& G, const words8& order, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, bool constant_time);
+// k_gvarwin.hip: k P on a registered curve with per-lane window tables (the eight odd multiples of P over one Z, the loop on the isomorphic curve; affine
+// classical out, oy may be null).  scratch: gc_varwin_scratch_bytes(n) bytes, 32-byte aligned; k_stride, x, y as for gc_scalar_mult; flags: ECSIMD_HIP_BASE_MGRY.
+inline size_t gc_varwin_scratch_bytes(size_t n) { return n * (8 * 64 + 32 + 3 * 32); }
+void gc_varwin_scalar_mult(hipStream_t, const gcurve& G, const words8& order, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, int flags,
+                           uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n);
 // ... and what ECDSA on a registered curve needs on top (public-data affine addition, the acceptance test, the ladder's three degenerate scalars worked around)
 void gc_affine_add_batched(hipStream_t, const gcurve&, const uint64_t* ax, const uint64_t* ay, const uint64_t* bx, const uint64_t* by, uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n);
 void gc_x_mod_n_equals(hipStream_t, const gmod& order, const uint64_t* x, const uint8_t* finite, const uint64_t* r, uint8_t* ok, size_t n);

@@ -215,11 +215,14 @@ def test_registered_curve_entry_points_that_do_not_exist_say_so(engine, oracle):
     k = engine.fill_random(8, SEED, 1)
     bx, by = engine.scalar_mult_base(cid, k, flags=OUT_AFFINE)
     from ecsimd_amd import ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG
-    for fl in (OUT_AFFINE | ALG_WINDOWED, OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME):
-        with pytest.raises(EcsimdHipError, match="ladder only"):
-            engine.scalar_mult(cid, k, bx, by, flags=fl)                  # a variable base: no per-lane tables on a registered curve
+    from ecsimd_amd import ALG_NO_ENDOMORPHISM
+    for fl in (OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME, OUT_AFFINE | ALG_WINDOWED_SIGNED, OUT_AFFINE | ALG_WINDOWED | ALG_NO_ENDOMORPHISM, OUT_AFFINE | ALG_CONSTANT_TIME):
+        with pytest.raises(EcsimdHipError, match="a registered curve has"):
+            engine.scalar_mult(cid, k, bx, by, flags=fl)                  # a variable base: the public-scalar window loop (k_gvarwin.hip) and the ladder, nothing else
+    with pytest.raises(EcsimdHipError, match="OUT_AFFINE"):
+        engine.scalar_mult(cid, k, bx, by, flags=ALG_WINDOWED)            # the window loop's Jacobian representative is not the reference's
     for fl in (OUT_AFFINE | ALG_WINDOWED_SIGNED, OUT_AFFINE | ALG_WINDOWED_BIG, OUT_AFFINE | ALG_CONSTANT_TIME):
-        with pytest.raises(EcsimdHipError, match="ladder only"):
+        with pytest.raises(EcsimdHipError, match="a registered curve has"):
             engine.scalar_mult_base(cid, k, flags=fl)
     with pytest.raises(EcsimdHipError, match="OUT_AFFINE"):
         engine.scalar_mult_base(cid, k, flags=ALG_WINDOWED)                # the comb's Jacobian representative is not the reference's
@@ -242,6 +245,8 @@ def test_registered_curve_entry_points_that_do_not_exist_say_so(engine, oracle):
         engine.ecdsa_sign(noorder, k, k, k)
     with pytest.raises(EcsimdHipError, match="group order"):
         engine.scalar_mult_base(noorder, k, flags=OUT_AFFINE | ALG_WINDOWED)   # the comb recodes modulo n
+    with pytest.raises(EcsimdHipError, match="group order"):
+        engine.scalar_mult(noorder, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)   # and so does the window loop
 
 
 # ---------------------------------------------------------------- the first application on a registered curve: ECDSA, u1 G + u2 Q, SEC1 (round 5)
@@ -403,6 +408,75 @@ def test_generator_comb_on_a_registered_curve(engine, name):
         wx, wy = (engine.to_numpy(t) for t in engine.scalar_mult_base(cid, engine.to_device(k[40:40 + m].copy()), flags=OUT_AFFINE | ALG_WINDOWED))
         assert np.array_equal(wx, lx[40:40 + m]) and np.array_equal(wy, ly[40:40 + m])
     assert all(t.shape[0] == 0 for t in engine.scalar_mult_base(cid, engine.empty(0), flags=OUT_AFFINE | ALG_WINDOWED))
+
+
+@pytest.mark.parametrize("name", list(REF_CURVES))
+def test_variable_base_window_loop_on_a_registered_curve(engine, name):
+    """scalar_mult(ALG_WINDOWED | OUT_AFFINE) with a registered curve id (k_gvarwin.hip: the lane's eight odd multiples of P over one Z, the window loop in
+    modified Jacobian coordinates on the isomorphic curve -- a general a, a dense prime): the ladder's affine points lane for lane on 2^16 + 77 random 256-bit
+    scalars and lane-distinct base points; the true k P (textbook affine arithmetic on Python integers) on the edge scalars -- 0 and n (infinity: (0, 0)), the
+    three scalars at which the LADDER is wrong, digit patterns that make every window's digit +-1 / +-15; Montgomery-form base points, one shared scalar,
+    the x-only form, ragged and empty batches, and an invalid base point that must not touch its neighbours."""
+    c = REF_CURVES[name]
+    cid = register(c)
+    n_ = c["n"]
+    add, mul = _affine_model(c)
+    from ecsimd_amd import ALG_WINDOWED, BASE_MGRY
+    edge = [0, 1, 2, 3, 15, 16, 17, 31, 32, 33, n_ - 2, n_ - 1, n_, n_ + 1, n_ + 2, 2**256 - n_ - 1, 2**256 - n_, 2**256 - n_ + 1, 2**256 - 1, 2**255, 2**255 - 1,
+            (n_ - 1) // 2, (n_ + 1) // 2, 0x1111111111111111111111111111111111111111111111111111111111111111, 0xffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff0f % n_,
+            0x0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f, 0x1010101010101010101010101010101010101010101010101010101010101011, 2**252, 16**63, 15 * 16**63]
+    N = (1 << 16) + 77
+    rng = np.random.default_rng(sum(name.encode()) + 21)
+    k = rng.integers(0, 2**64, size=(N, 4), dtype=np.uint64)
+    k[:len(edge)] = ints_to_arr(edge)
+    kd = engine.to_device(k)
+    s = engine.fill_random(N, SEED, 41)
+    bx, by = engine.scalar_mult_base(cid, s, flags=OUT_AFFINE)                                         # lane-distinct base points
+    lx, ly = (engine.to_numpy(t) for t in engine.scalar_mult(cid, kd, bx, by, flags=OUT_AFFINE))      # the reference's ladder
+    wx, wy = (engine.to_numpy(t) for t in engine.scalar_mult(cid, kd, bx, by, flags=OUT_AFFINE | ALG_WINDOWED))
+    bxn, byn = engine.to_numpy(bx), engine.to_numpy(by)
+    for i, kv in enumerate(edge):
+        want = mul(kv % n_, (to_int(bxn[i]), to_int(byn[i])))
+        assert (to_int(wx[i]), to_int(wy[i])) == (want if want is not None else (0, 0)), (name, i, hex(kv))
+    assert np.array_equal(wx[len(edge):], lx[len(edge):]) and np.array_equal(wy[len(edge):], ly[len(edge):]), name
+    for i in range(len(edge), len(edge) + 6):                                                            # and a third opinion on a few random lanes
+        assert (to_int(wx[i]), to_int(wy[i])) == mul(to_int(k[i]) % n_, (to_int(bxn[i]), to_int(byn[i])))
+    xo, none = engine.scalar_mult(cid, kd, bx, by, flags=OUT_AFFINE | ALG_WINDOWED, x_only=True)
+    assert none is None and np.array_equal(engine.to_numpy(xo), wx)
+    jx, jy, jz = engine.from_affine(cid, bx, by)                                                        # base points in Montgomery form
+    mx, my = (engine.to_numpy(t) for t in engine.scalar_mult(cid, kd, jx, jy, flags=OUT_AFFINE | ALG_WINDOWED | BASE_MGRY))
+    assert np.array_equal(mx, wx) and np.array_equal(my, wy)
+    k1 = to_int(k[len(edge) + 3])
+    sx, sy = (engine.to_numpy(t) for t in engine.scalar_mult_1s(cid, from_int(k1), bx[:4099].contiguous(), by[:4099].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED))
+    ox, oy = (engine.to_numpy(t) for t in engine.scalar_mult_1s(cid, from_int(k1), bx[:4099].contiguous(), by[:4099].contiguous(), flags=OUT_AFFINE))
+    assert np.array_equal(sx, ox) and np.array_equal(sy, oy)
+    for m in (1, 3, 255, 257):                                                                           # ragged batches
+        a0 = 40
+        rx, ry = (engine.to_numpy(t) for t in engine.scalar_mult(cid, engine.to_device(k[a0:a0 + m].copy()), bx[a0:a0 + m].contiguous(), by[a0:a0 + m].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED))
+        assert np.array_equal(rx, wx[a0:a0 + m]) and np.array_equal(ry, wy[a0:a0 + m])
+    assert all(t.shape[0] == 0 for t in engine.scalar_mult(cid, engine.empty(0), engine.empty(0), engine.empty(0), flags=OUT_AFFINE | ALG_WINDOWED))
+    # an invalid base point (0, 0) and one off the curve: their lanes are garbage or (0, 0), every other lane is what it was
+    bad_x, bad_y = bxn[:600].copy(), byn[:600].copy()
+    bad_x[77] = 0; bad_y[77] = 0
+    bad_y[300, 0] ^= np.uint64(1)
+    rx, ry = (engine.to_numpy(t) for t in engine.scalar_mult(cid, engine.to_device(k[:600].copy()), engine.to_device(bad_x), engine.to_device(bad_y), flags=OUT_AFFINE | ALG_WINDOWED))
+    keep = np.ones(600, dtype=bool); keep[[77, 300]] = False
+    assert np.array_equal(rx[keep], wx[:600][keep]) and np.array_equal(ry[keep], wy[:600][keep])
+    assert not rx[77].any() and not ry[77].any()
+
+
+@pytest.mark.parametrize("cv", [P256, SECP256K1])
+def test_variable_base_window_loop_of_a_builtin_curve_through_the_generic_kernels(engine, cv):
+    """P-256 (a = -3) / secp256k1 (a = 0) registered like any other curve: the generic window loop returns the built-in loops' affine points."""
+    c = CURVE_PARAMS[cv]
+    gid = register(c, generic=True)
+    from ecsimd_amd import ALG_WINDOWED
+    N = 1 << 14
+    k = engine.fill_random(N, SEED, 124)
+    kn = engine.to_numpy(k); kn[:4] = ints_to_arr([0, c["n"], c["n"] - 2, 2]); k = engine.to_device(kn)
+    bx, by = engine.scalar_mult_base(cv, engine.fill_random(N, SEED, 125), flags=OUT_AFFINE)
+    want = [engine.to_numpy(t) for t in engine.scalar_mult(cv, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)]
+    assert same([engine.to_numpy(t) for t in engine.scalar_mult(gid, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)], want), cv
 
 
 @pytest.mark.parametrize("cv", [P256, SECP256K1])

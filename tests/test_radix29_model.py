@@ -450,7 +450,7 @@ def test_the_any_prime_ladder_invariant_and_dense_exact_model():
                 st = out; x1, y1, x2, y2, z = exp
 
 
-COVERED_FUNCTIONS = ["zdau29", "madd29_hr", "madd29_finish", "madd29v_finish", "jdbl29", "dbl_add29", "zaddu29", "mul21_29", "pdbl29", "padd29"]
+COVERED_FUNCTIONS = ["zdau29", "madd29_hr", "madd29_finish", "madd29v_finish", "jdbl29", "dbl_add29", "gjdbl29", "zaddu29", "mul21_29", "pdbl29", "padd29"]
 
 
 def _call_sites(text):
@@ -526,3 +526,141 @@ def test_power_chains_need_no_carry_pass():
     for cv in (m.CURVE_P256, m.CURVE_SECP, m.CURVE_ANY):
         r = m.prove_pow_chain(cv)
         assert r["worst_column_bits"] <= 62 and r["worst_limb_bits"] <= 30, (cv, r)
+
+
+# ---------------------------------------------------------------- round 5: the window loop of a registered curve (fe29.cuh gjdbl29; k_gvarwin.hip)
+_REGISTERED = [("brainpoolP256r1", m.BRAINPOOL_P256), ("sm2", m.SM2_P), ("frp256v1", m.FRP256_P)]
+
+
+def test_the_window_loop_and_table_of_a_registered_curve_close_for_every_odd_prime():
+    """Modified Jacobian doublings with W = a Z^4 carried, the fused double-add and the co-Z chain of the table, on intervals with every limb of p an
+    interval: no overflow, every accumulator inside the invariant again, everything canonicalised inside canon29's domain -- WITHOUT a value reduction."""
+    for cv in [m.CURVE_ANY] + [m.Curve.dense(name, p) for name, p in _REGISTERED]:
+        for prove in (m.prove_gwindow_invariant, m.prove_gtable):
+            r = prove(cv)
+            assert r["worst_column_bits"] <= 63 and r["worst_limb_bits"] <= 31
+
+
+def test_eight_times_a_product_is_what_would_not_close():
+    """Why gjdbl29 forms 8 Y^4 as 2 (2 YY)^2: with 8 x (YY^2) -- P-256's form, whose growth vred29 undoes -- the doublings leave the invariant on a dense prime."""
+    def grow(E, X, Y, Z, Wc):
+        Yn = E.norm(Y); YY = E.sqr(Yn); G = E.norm(YY, 2); B = E.mul(X, G); XX = E.sqr(E.norm(X))
+        alpha = E.norm(E.add(E.add(E.dbl(XX), XX), Wc))
+        X3 = E.sub(E.sqr(alpha), E.dbl(B))
+        E8 = E.dbl(E.norm(E.sqr(YY), 2))
+        return X3, E.sub(E.mul(alpha, E.norm(E.sub(B, X3))), E8), E.mul(E.dbl(Yn), Z), Wc
+    E = m.Bounds(m.CURVE_ANY)
+    inv = m.gwindow_invariant(m.CURVE_ANY)
+    X, Y, Z, Wc = (m.Iv(inv[k].l, inv[k].v) for k in "XYZW")
+    with pytest.raises(AssertionError):
+        for _ in range(8):
+            X, Y, Z, Wc = grow(E, X, Y, Z, Wc)
+            assert Y.within(inv["Y"]), "value escapes"
+
+
+@pytest.mark.parametrize("name,p", _REGISTERED + [("p256 as a dense prime", m.P256)], ids=lambda v: v if isinstance(v, str) else "")
+def test_exact_window_loop_of_a_registered_curve_equals_the_big_int_formulas(name, p):
+    """63 windows (W = a Z^4 from Z, two doublings that carry it, one that does not, a double-add) on integers with the machine limits asserted, against
+    the Jacobian formulas mod p for a random coefficient a."""
+    rng = random.Random(131)
+    cv = m.Curve.dense(name, p)
+    R = 1 << m.RBITS; Rinv = pow(R, -1, p)
+    E = m.Exact(cv)
+    tight = lambda v: m.to_limbs(v * R % p)
+    val = lambda l: m.from_limbs(l) * Rinv % p
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (1 << 255) % p, (1 << 232) - 1, 1 << 232, m.M29]
+    for trial in range(6):
+        pick = (lambda: rng.choice(edge)) if trial < 2 else (lambda: rng.randrange(p))
+        a = (p - 3, 0, rng.randrange(p), rng.randrange(p), p - 1, 1)[trial]
+        ap = tight(a)
+        fx, fy, fz = pick(), pick(), 1
+        X, Y, Z = tight(fx), tight(fy), tight(1)
+        for _ in range(63):
+            Wc = m.gw_of_z(E, Z, ap)
+            assert val(Wc) == a * pow(fz, 4, p) % p
+            for wout in (True, True, False):
+                X, Y, Z, Wc = m.gjdbl29(E, X, Y, Z, Wc, wout)
+                fx, fy, fz = m.jdbl_field(p, a, fx, fy, fz)
+                assert (val(X), val(Y), val(Z)) == (fx, fy, fz)
+                if wout:
+                    assert val(Wc) == a * pow(fz, 4, p) % p
+            x2, y2 = pick(), pick()
+            neg = rng.getrandbits(1)
+            ty = [-v for v in tight(y2)] if neg else tight(y2)
+            X, Y, Z = m.dbl_add29(E, X, Y, Z, tight(x2), ty)
+            fx, fy, fz = m.dbl_add_field(p, fx, fy, fz, x2, (-y2) % p if neg else y2)
+            assert (val(X), val(Y), val(Z)) == (fx, fy, fz)
+
+
+def test_exact_table_of_odd_multiples_over_one_z_on_brainpoolP256r1():
+    """k_gvarwin.hip k_gvw_table on integers with the machine limits asserted: 2P by gjdbl29, (2j + 3) P = 2P + (2j + 1) P by zaddu29, the walk back.  Every
+    entry must be (x_j Zg^2, y_j Zg^3) for the AFFINE (2j + 1) P of the curve; and a window run on those entries with a' = a Zg^4 must give, with Z' Zg, the
+    point the affine law gives on the curve itself."""
+    from ecsimd_amd.curves import NAMED
+    c = NAMED["brainpoolP256r1"]
+    p, a = c["p"], c["a"]
+    cv = m.Curve.dense("brainpoolP256r1", p)
+    R = 1 << m.RBITS; Rinv = pow(R, -1, p)
+    E = m.Exact(cv)
+    tight = lambda v: m.to_limbs(v * R % p)
+    val = lambda l: m.from_limbs(l) * Rinv % p
+    canon = lambda l: m.to_limbs(m.from_limbs(l) % p)
+
+    def add_aff(P, Q):
+        if P[0] == Q[0]:
+            lam = (3 * P[0] * P[0] + a) * pow(2 * P[1], -1, p) % p
+        else:
+            lam = (Q[1] - P[1]) * pow(Q[0] - P[0], -1, p) % p
+        x3 = (lam * lam - P[0] - Q[0]) % p
+        return x3, (lam * (P[0] - x3) - P[1]) % p
+    G = (c["gx"], c["gy"])
+    rng = random.Random(9)
+    P = G
+    for trial in range(12):
+        for _ in range(rng.randrange(1, 30)):
+            P = add_aff(P, G)
+        x1, y1, one = tight(P[0]), tight(P[1]), tight(1)
+        X2, Y2, z, _ = m.gjdbl29(E, x1, y1, one, tight(a), False)
+        zz = E.sqr(z)
+        ax, ay = E.mul(x1, zz), E.mul(y1, E.mul(zz, z))
+        dx2, dy2 = X2, Y2
+        ex, ey, h = [], [], []
+        for j in range(7):
+            ex.append(ax); ey.append(ay)
+            rx, ry, dx2, dy2, z, dx = m.zaddu29(E, dx2, dy2, ax, ay, z)
+            ax, ay = rx, ry
+            h.append(dx)
+        slots = [None] * 8
+        for v in (E.mul(ax, one), E.mul(ay, one), z):
+            assert -p < m.from_limbs(v) < 2 * p                                          # canon29's domain
+        slots[7] = (canon(E.mul(ax, one)), canon(E.mul(ay, one)))
+        zg = canon(z)
+        f = h[6]
+        for j in range(6, -1, -1):
+            f2 = E.sqr(f)
+            vx, vy = E.mul(ex[j], f2), E.mul(ey[j], E.mul(f2, f))
+            assert -p < m.from_limbs(vx) < 2 * p and -p < m.from_limbs(vy) < 2 * p
+            slots[j] = (canon(vx), canon(vy))
+            if j > 0:
+                f = E.mul(f, h[j - 1])
+        Zg = val(zg)
+        assert Zg != 0
+        twoP = add_aff(P, P)
+        kP = P
+        for j in range(8):
+            if j > 0:
+                kP = add_aff(kP, twoP)
+            assert (val(slots[j][0]), val(slots[j][1])) == (kP[0] * Zg * Zg % p, kP[1] * pow(Zg, 3, p) % p), j
+        # one window on the isomorphic curve: 16 (3P) - 5P = 43 P
+        ap = E.mul(tight(a), E.sqr(E.sqr(zg)))
+        X, Y, Z = slots[1][0], slots[1][1], one
+        Wc = m.gw_of_z(E, Z, ap)
+        for wout in (True, True, False):
+            X, Y, Z, Wc = m.gjdbl29(E, X, Y, Z, Wc, wout)
+        X, Y, Z = m.dbl_add29(E, X, Y, Z, slots[2][0], [-v for v in slots[2][1]])
+        zt = val(Z) * Zg % p
+        aff = (val(X) * pow(zt, -2, p) % p, val(Y) * pow(zt, -3, p) % p)
+        want = P
+        for _ in range(42):
+            want = add_aff(want, P)
+        assert aff == want

@@ -357,9 +357,22 @@ def padd(kind, text=None):
     return r, {"x": X, "y": Y, "z": Z}
 
 
+def gjdbl(kind, text=None, wout=True):
+    """fe29.cuh gjdbl29<C, WOUT>: the point and the carried w = a Z^4 (a reference parameter)."""
+    env = dict(_point("P"), w=("in", "w"))
+    r = Device(kind, text, {"WOUT": wout}).call("gjdbl29", [("name", "P"), ("name", "w")], env)
+    X, Y, Z, W3 = m.gjdbl29(Sym(MODEL_CURVE[kind]), env["P.x"], env["P.y"], env["P.z"], ("in", "w"), wout)
+    return dict(r, w=env["w"]), {"x": X, "y": Y, "z": Z, "w": W3}
+
+
+def gjdbl_last(kind, text=None):
+    return gjdbl(kind, text, wout=False)
+
+
 # every (function, curve) pair an interval proof of radix29_model.py speaks about
 COVERED = [(zdau, "p256"), (zdau, "secp256k1"), (zdau, "generic"), (madd, "p256"), (madd, "secp256k1"), (jdbl, "p256"), (jdbl, "secp256k1"),
-           (dbl_add, "p256"), (dbl_add, "secp256k1"), (maddv, "p256"), (maddv, "secp256k1"), (zaddu, "secp256k1"), (pdbl, "secp256k1"), (padd, "secp256k1")]
+           (dbl_add, "p256"), (dbl_add, "secp256k1"), (maddv, "p256"), (maddv, "secp256k1"), (zaddu, "secp256k1"), (pdbl, "secp256k1"), (padd, "secp256k1"),
+           (gjdbl, "generic"), (gjdbl_last, "generic"), (dbl_add, "generic"), (zaddu, "generic")]      # a registered curve's window loop and table (k_gvarwin.hip)
 
 
 def count(node, op):

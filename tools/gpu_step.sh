@@ -146,6 +146,10 @@ import json; d=json.load(open('$out/bench_brainpool_$w.json')); r=d['roofline'];
     ECSIMD_ADAPTER_HOST_TRANSPOSE=1 timeout -k 10 600 ./oracle/_ref/adapter_driver 512 65536 1048576 > "$out/adapter_driver_host_transpose.txt" 2>&1 || rc=$?; tail -4 "$out/adapter_driver_host_transpose.txt"
     timeout -k 10 300 python tools/pcie_rate.py > "$out/pcie_rate.txt" 2>&1 || rc=$?; cat "$out/pcie_rate.txt"
     exit $rc ;;
+  r5_gvarwin)       # round 5: the variable-base window loop of a registered curve (k_gvarwin.hip) -- its tests, then its rates beside the ladder's
+    timeout -k 10 600 python -m pytest tests/test_gpu_curves.py -x -q -m gpu -k "window_loop or do_not_exist or ecdsa_and_double" > "$out/pytest.txt" 2>&1; rc=$?
+    tail -15 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
+    timeout -k 10 500 python tools/gvarwin_perf.py ${1:-22} > "$out/gvarwin_perf.txt" 2>&1; rc=$?; cat "$out/gvarwin_perf.txt"; exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
     timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -15 "$out/pytest.txt"; exit $rc ;;
   *) echo "unknown step $name"; exit 2 ;;

@@ -152,6 +152,8 @@ class Exact:
 
     def vred(self, a):
         """fe29.cuh vred29: v - k p with k = round(top limb / 2^24), through p's sparse signed form."""
+        if self.cv.terms is None or len(self.cv.terms) == NL:        # a dense prime (a registered curve): no sparse form, and no need (fe29.cuh vred29)
+            return list(a)
         k = (a[NL - 1] + (1 << 23)) >> 24
         out = list(a)
         for off, c in self.cv.terms:
@@ -272,6 +274,8 @@ class Bounds:
     def vred(self, a):
         """k ranges over what the top limb's interval allows; the new top limb is the rounding remainder, within [-2^23, 2^23]; the value follows
         from the new limbs (the low limbs are whatever they were, moved by k times p's small terms)."""
+        if self.cv.terms is None or len(self.cv.terms) == NL:        # a dense prime: the identity (fe29.cuh vred29)
+            return a
         assert dict(self.cv.terms)[NL - 1] == 1 << 24
         kr = ((a.l[NL - 1][0] + (1 << 23)) >> 24, (a.l[NL - 1][1] + (1 << 23)) >> 24)
         l = list(a.l)
@@ -589,6 +593,109 @@ def dbl_add_field(p, X, Y, Z, x2, y2):
     Cc = dx * dx % p; W1 = X3 * Cc % p; W2 = V * Cc % p
     Qx = (dy * dy - W1 - W2) % p
     return Qx, (dy * (W1 - Qx) - Y3 * (W1 - W2)) % p, Z3 * dx % p
+
+
+# ---------------------------------------------------------------------------------------------------------------- the window loop of a registered curve (round 5)
+def gjdbl29(E, X, Y, Z, Wc, wout=True):
+    """fe29.cuh gjdbl29<C, WOUT>: the doubling for ANY a in modified Jacobian coordinates, Wc = a Z^4 beside the point; statement for statement.
+    8 Y^4 is 2 (2 YY)^2 -- a square of a carry-passed double, never 8 x a product."""
+    Yn = E.norm(Y)
+    YY = E.sqr(Yn)
+    G = E.norm(YY, 2)
+    B = E.mul(X, G)
+    XX = E.sqr(E.norm(X))
+    alpha = E.norm(E.add(E.add(E.dbl(XX), XX), Wc))
+    Z3 = E.mul(E.dbl(Yn), Z)
+    X3 = E.sub(E.sqr(alpha), E.dbl(B))
+    E4 = E.sqr(E.norm(YY, 1))
+    Y3 = E.sub(E.mul(alpha, E.norm(E.sub(B, X3))), E.dbl(E4))
+    W3 = E.mul(E.norm(E4, 2), Wc) if wout else Wc
+    return X3, Y3, Z3, W3
+
+
+def gwindow_invariant(curve=CURVE_ANY):
+    """The accumulator of k_gvarwin.hip k_gvw_mult between two point operations, in units of p_max = 2^256 for CURVE_ANY: X = alpha^2 - 2B or a co-Z sum,
+    Y a difference of products, Z and W = a' Z^4 products; a table coordinate is to29 of a canonical residue, its y possibly negated; ap = a Zg^4 a product."""
+    p = curve.p
+    B = 1 << W
+    lim = lambda lo, hi, top, vlo, vhi: Iv([(int(lo * B), int(hi * B))] * (NL - 1) + [(-top, top)], (int(vlo * p), int(vhi * p)))
+    return {"X": lim(-2, 1, 1 << 26, -3.25, 3.25), "Y": lim(-2, 1, 1 << 26, -3.3, 2.0), "Z": lim(0, 1, 1 << 25, -0.55, 1.55), "W": lim(0, 1, 1 << 25, -0.2, 1.35),
+            "tx": lim(0, 1, 1 << 24, 0, 1), "ty": lim(-1, 1, 1 << 24, -1, 1), "ap": lim(0, 1, 1 << 25, -0.1, 1.1)}
+
+
+def gw_of_z(E, Z, ap):
+    """k_gvarwin.hip: W = a' Z^4 after an addition (the doublings that follow carry it along)."""
+    return E.mul(ap, E.sqr(E.sqr(Z)))
+
+
+def prove_gwindow_invariant(curve=CURVE_ANY):
+    """One window of k_gvw_mult on intervals, for every odd p < 2^256 at once: W from Z, gjdbl29 with W carried (twice), gjdbl29 without, dbl_add29 (its
+    value reductions are the identity on a dense prime).  No limb or column overflows, and after EVERY operation the accumulator -- W included -- lies
+    inside the invariant again, so the start from a table entry (tight x, +-y, Z = 2^261 mod p, W = a') is covered too."""
+    E = Bounds(curve)
+    inv = gwindow_invariant(curve)
+    c = lambda k: Iv(inv[k].l, inv[k].v)
+    inside = lambda X, Y, Z: X.within(inv["X"]) and Y.within(inv["Y"]) and Z.within(inv["Z"])
+    Wc = gw_of_z(E, c("Z"), c("ap"))
+    assert Wc.within(inv["W"]), Wc
+    assert c("ap").within(inv["W"])                                          # the start: W = a' beside Z = 1
+    X, Y, Z, Wc = c("X"), c("Y"), c("Z"), c("W")
+    for wout in (True, True, False):
+        X, Y, Z, Wn = gjdbl29(E, X, Y, Z, Wc, wout)
+        assert inside(X, Y, Z), (X, Y, Z)
+        if wout:
+            assert Wn.within(inv["W"]), Wn
+            Wc = Wn
+        X, Y, Z, Wc = c("X"), c("Y"), c("Z"), c("W")                         # every doubling from the whole invariant, not from the one before
+    X, Y, Z = dbl_add29(E, c("X"), c("Y"), c("Z"), c("tx"), c("ty"))
+    assert inside(X, Y, Z), (X, Y, Z)
+    return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length()}
+
+
+def prove_gtable(curve=CURVE_ANY):
+    """k_gvarwin.hip k_gvw_table on intervals: 2P = gjdbl29(P) from the tight input point (Z = 1, W = a), P over Z_2 by three products, then seven zaddu29
+    -- the first with the lazy 2P as its (x1, y1), the others with the re-expressed (tight) one -- and the walk back: f, f^2, f^3, X_k f^2, Y_k f^3.
+    Nothing overflows, and whatever is handed to canon29 lies in its domain (-p, 2p) for every p the windowed route is registered for
+    (n >= 2^255, so p > 2^255 - 2^129 by Hasse): a product's value is T / 2^261 + [0, p), so T / 2^261 in (-p_min, p_min) is what to show."""
+    E = Bounds(curve)
+    inv = gwindow_invariant(curve)
+    p = curve.p
+    pmin = (1 << 255) - (1 << 129)
+    c = lambda k: Iv(inv[k].l, inv[k].v)
+    ok = lambda v: -pmin < v.v[0] and v.v[1] - p < pmin                   # v.v[1] = sup(T / 2^261) + p_max
+    one = Iv(inv["tx"].l, inv["tx"].v)
+    ty = Iv(inv["tx"].l, inv["tx"].v)
+    X2, Y2, Z2, _ = gjdbl29(E, c("tx"), ty, one, c("ap"), False)             # (a 2^261 mod p itself is enter29's output: inside "ap")
+    ZZ = E.sqr(Z2)
+    px, py = E.mul(c("tx"), ZZ), E.mul(ty, E.mul(ZZ, Z2))
+    lazy = []
+    x1, y1, x2, y2, z = X2, Y2, px, py, Z2
+    for _ in range(7):
+        lazy.append((x2, y2))
+        rx, ry, W1, A1, z, dx = zaddu29(E, x1, y1, x2, y2, z)
+        x1, y1, x2, y2 = W1, A1, rx, ry
+        assert z.within(inv["Z"]), z
+    tight = lambda: Iv(inv["tx"].l[:NL - 1] + [(-(1 << 22), (1 << 24) + (1 << 22))], (-p // 4, 5 * p // 4))   # any product met here
+    for v in (z, dx, W1, A1):
+        assert v.within(tight()) or v is dx, v
+    f = E.mul(tight(), dx)
+    f2 = E.sqr(tight())
+    f3 = E.mul(tight(), tight())
+    for v in (f, f2, f3):
+        assert v.within(tight()), v
+    for X, Y in lazy + [(x2, y2)]:
+        for v in (E.mul(X, tight()), E.mul(Y, tight())):                     # the last multiple: times the field's 1, a tight constant
+            assert ok(v) and v.within(tight()), v
+    assert ok(z)                                                             # Zg goes to canon29 as it is: a product
+    return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length()}
+
+
+def gjdbl_field(p, X, Y, Z, Wc):
+    """Modified Jacobian doubling on integers mod p: (X3, Y3, Z3, W3) with W = a Z^4."""
+    YY = Y * Y % p; B = 4 * X * YY % p; E8 = 8 * YY * YY % p
+    alpha = (3 * X * X + Wc) % p
+    X3 = (alpha * alpha - 2 * B) % p
+    return X3, (alpha * (B - X3) - E8) % p, 2 * Y * Z % p, 2 * E8 * Wc % p
 
 
 # ---------------------------------------------------------------------------------------------------------------- the complete addition law (a = 0, b = 7)
