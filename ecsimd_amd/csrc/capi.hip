@@ -351,10 +351,10 @@ int run_gladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride,
   gcurve GC; if (!lookup_curve(curve, &GC)) return bad(ctx, "unknown curve id");
   if (x == nullptr && k_stride == 4 && (flags & ECSIMD_HIP_ALG_WINDOWED) && !(flags & (ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM)))
     return run_gcomb(ctx, curve, k, ox, oy, n, flags);          // k G from the generator's table in LDS (k_gcomb.hip)
-  if (x != nullptr && (flags & ECSIMD_HIP_ALG_WINDOWED) && !(flags & (ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM | ECSIMD_HIP_ALG_CONSTANT_TIME)))
-    return run_gvarwin(ctx, curve, k, k_stride, x, y, ox, oy, n, flags, 0);   // k P from the lane's own table of odd multiples (k_gvarwin.hip)
+  if (x != nullptr && (flags & ECSIMD_HIP_ALG_WINDOWED) && !(flags & (ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM)))
+    return run_gvarwin(ctx, curve, k, k_stride, x, y, ox, oy, n, flags, 0);   // k P from the lane's own table of odd multiples (k_gvarwin.hip); ALG_CONSTANT_TIME: every entry read in every window
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM | ECSIMD_HIP_ALG_CONSTANT_TIME))
-    return bad(ctx, "a registered curve has the reference's ladder, ALG_WINDOWED [| ALG_CONSTANT_TIME] for its generator and ALG_WINDOWED (public scalars) for a variable base: the other ALG_* tables exist for P-256 and secp256k1");
+    return bad(ctx, "a registered curve has the reference's ladder and ALG_WINDOWED [| ALG_CONSTANT_TIME] for its generator and for a variable base: the other ALG_* tables exist for P-256 and secp256k1");
   if (n == 0) return ECSIMD_HIP_OK;
   if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
   hipError_t e = hipSetDevice(ctx->device);
@@ -1305,8 +1305,8 @@ int run_gcomb(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, u
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult_base (registered curve, windowed) launch");
 }
-// scalar_mult(registered curve, ALG_WINDOWED | OUT_AFFINE) on a variable base: per-lane tables of the eight odd multiples of P over one Z, the window loop on the
-// isomorphic curve (k_gvarwin.hip), then the shared inversion -- the true k P for every k (k = 0 mod n: (0, 0)), public scalars.  In chunks of 2^22 lanes
+// scalar_mult(registered curve, ALG_WINDOWED [| ALG_CONSTANT_TIME] | OUT_AFFINE) on a variable base: per-lane tables of the eight odd multiples of P over one Z, the
+// window loop on the isomorphic curve (k_gvarwin.hip), then the shared inversion -- the true k P for every k (k = 0 mod n: (0, 0)).  In chunks of 2^22 lanes
 // (640 B of scratch per lane).  `reserve` bytes at the start of the workspace stay untouched (gc_double_scalar_mult).
 int run_gvarwin(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy, size_t n, int flags, size_t reserve) {
   if (!(flags & ECSIMD_HIP_OUT_AFFINE)) return bad(ctx, "ALG_WINDOWED needs OUT_AFFINE");
@@ -1323,7 +1323,7 @@ int run_gvarwin(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride,
   uint64_t* scratch = ctx->workspace + reserve / 8;
   for (size_t first = 0; first < n; first += chunk) {
     const size_t m = (n - first) < chunk ? (n - first) : chunk;
-    launch::gc_varwin_scalar_mult(ctx->stream, rec.G, order_words(rec), k + (size_t)k_stride * first, k_stride, x + 4 * first, y + 4 * first, flags & ECSIMD_HIP_BASE_MGRY,
+    launch::gc_varwin_scalar_mult(ctx->stream, rec.G, order_words(rec), k + (size_t)k_stride * first, k_stride, x + 4 * first, y + 4 * first, flags & (ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_ALG_CONSTANT_TIME),
                                   scratch, ox + 4 * first, oy ? oy + 4 * first : nullptr, m);
   }
   e = hipGetLastError();

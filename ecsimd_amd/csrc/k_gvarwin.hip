@@ -14,8 +14,8 @@
 //                 Jacobian (fe29.cuh gjdbl29): W = a' Z^4 is formed once per window (2S + 1M) and carried through the doublings (1M each), so a
 //                 general a costs 25M + 19S per window where a Z^4 from Z every time would cost 27M + 23S.  A result (X', Y', Z') on the isomorphic
 //                 curve is (X', Y', Z' Zg) on the curve itself: one product at the end.
-// 63 x 44 + 66 (table) + 11 = 2 849 field multiplications against the ladder's 4 064 + 24.  The scalar is PUBLIC here (the table is indexed by its
-// digits): the constant-time algorithm on a registered curve's variable base is the ladder.
+// 63 x 44 + 66 (table) + 11 = 2 849 field multiplications against the ladder's 4 064 + 24.  The default loop indexes the table by the scalar's digits
+// (PUBLIC scalars); k_gvw_mult<true> (ALG_CONSTANT_TIME) reads all eight entries in every window and keeps one under lane masks: secret scalars.
 //
 // Needs what the comb of the generator needs (capi.hip gc_comb_possible): the group order n, n >= 2^255 (k mod n by ONE conditional subtraction) -- and,
 // like every table algorithm in this library, a group of prime order (no multiple (2j + 1) P, 2P, R, T of a point of order n coincides up to sign
@@ -89,7 +89,11 @@ k_gvw_table(gcurve G, const uint64_t* __restrict__ x, const uint64_t* __restrict
 #ifndef GVARWIN_WAVES_PER_SIMD
 #define GVARWIN_WAVES_PER_SIMD 3
 #endif
-__global__ void __launch_bounds__(BLOCK, GVARWIN_WAVES_PER_SIMD)
+// CT (ALG_CONSTANT_TIME: secret scalars): every window reads ALL eight entries of the lane's table -- 512 contiguous bytes at an address made of the lane
+// index alone -- and keeps the wanted one under lane masks, as k_varwin.inc k_varwin_mult_odd<true> does: four rounds of eight 16-byte loads (two whole
+// entries, one 128-byte line), each in flight behind one of the window's four chunks of arithmetic; the first round of the NEXT window is requested before
+// the double-add.  No address, no branch, no lane mask at a memory access depends on the scalar (tests/test_constant_time_isa.py).
+template <bool CT> __global__ void __launch_bounds__(BLOCK, GVARWIN_WAVES_PER_SIMD)
 k_gvw_mult(gcurve G, launch::words8 order8, const uint64_t* __restrict__ k, int k_stride, const uint4* __restrict__ table, const uint64_t* __restrict__ zg,
            uint64_t* __restrict__ ox, uint64_t* __restrict__ oy, uint64_t* __restrict__ oz, size_t n) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -121,28 +125,84 @@ k_gvw_mult(gcurve G, launch::words8 order8, const uint64_t* __restrict__ k, int 
   }
   jpoint29 R;
   uint32_t above = kk.w[7] >> 28;                       // the nibble above the current one (its low bit is the digit's sign)
-  {                                                     // top digit = (k >> 252) | 1, positive
-    fe tx, ty;
-    gvw_load_slot(table, base + (above >> 1), tx, ty);
-    R.x = to29(tx); R.y = to29(ty); R.z = enter29<C>(g_words(G.F.r), cx);
-  }
-#pragma unroll 1
-  for (int w = 62; w >= 0; --w) {
+  auto window = [&](fe29& wz) {                         // W = a' Z^4, then the first two doublings carry it along
+    wz = mul29<C>(ap, sqr29<C>(sqr29<C>(R.z, cx), cx), cx);
+  };
+  if constexpr (CT) {
+    const uint4* mine = table + base * 4;               // this lane's 8 entries: 32 x 16 bytes = four 128-byte lines
+    uint4 q[8];
+    auto request = [&](int pair) {                      // entries 2 pair, 2 pair + 1: ONE line, read once per window
 #pragma unroll
-    for (int j = 7; j > 0; --j) kk.w[j] = __builtin_amdgcn_alignbit(kk.w[j], kk.w[j - 1], 28);   // kk <<= 4
-    kk.w[0] <<= 4;
-    const uint32_t nib = kk.w[7] >> 28;
-    const uint32_t u = nib | 1u;                                        // 1, 3, ..., 15
-    const uint32_t neg = 0u - (uint32_t)((above & 1u) == 0u);          // digit = u - 16 when the nibble above is even
-    const uint32_t mag = neg ? 16u - u : u;
-    above = nib;
-    fe tx, ty;
-    gvw_load_slot(table, base + (mag >> 1), tx, ty);                    // in flight during the doublings
-    fe29 wz = mul29<C>(ap, sqr29<C>(sqr29<C>(R.z, cx), cx), cx);       // W = a' Z^4
-    R = gjdbl29<C, true>(R, wz, cx);
-    R = gjdbl29<C, true>(R, wz, cx);
-    R = gjdbl29<C, false>(R, wz, cx);
-    R = dbl_add29<C>(R, to29(tx), cneg29(neg, to29(ty)), cx);
+      for (int j = 0; j < 8; ++j) q[j] = mine[pair * 8 + j];
+      __builtin_amdgcn_sched_barrier(0);               // the loads stay in front of the arithmetic they hide behind
+    };
+    auto keep = [&](int pair, uint32_t slot, fe& tx, fe& ty) {          // first pair: entry 0 is the default, the others replace it under their masks
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool m = (pair == 0 && h == 0) || slot == (uint32_t)(2 * pair + h);
+        const uint4 a = q[4 * h], b = q[4 * h + 1], c = q[4 * h + 2], d = q[4 * h + 3];
+        tx.w[0] = m ? a.x : tx.w[0]; tx.w[1] = m ? a.y : tx.w[1]; tx.w[2] = m ? a.z : tx.w[2]; tx.w[3] = m ? a.w : tx.w[3];
+        tx.w[4] = m ? b.x : tx.w[4]; tx.w[5] = m ? b.y : tx.w[5]; tx.w[6] = m ? b.z : tx.w[6]; tx.w[7] = m ? b.w : tx.w[7];
+        ty.w[0] = m ? c.x : ty.w[0]; ty.w[1] = m ? c.y : ty.w[1]; ty.w[2] = m ? c.z : ty.w[2]; ty.w[3] = m ? c.w : ty.w[3];
+        ty.w[4] = m ? d.x : ty.w[4]; ty.w[5] = m ? d.y : ty.w[5]; ty.w[6] = m ? d.z : ty.w[6]; ty.w[7] = m ? d.w : ty.w[7];
+      }
+    };
+    {                                                   // top digit = (k >> 252) | 1, positive
+      const uint32_t slot = above >> 1;
+      fe tx, ty;
+      request(0); keep(0, slot, tx, ty); request(1); keep(1, slot, tx, ty);
+      request(2); keep(2, slot, tx, ty); request(3); keep(3, slot, tx, ty);
+      R.x = to29(tx); R.y = to29(ty); R.z = enter29<C>(g_words(G.F.r), cx);
+    }
+    request(0);
+#pragma unroll 1
+    for (int w = 62; w >= 0; --w) {
+      asm volatile("" : "+s"(w));                       // the window counter stays a scalar register: the exit test is an s_cmp (tools/ct_check.py refuses vcc branches)
+#pragma unroll
+      for (int j = 7; j > 0; --j) kk.w[j] = __builtin_amdgcn_alignbit(kk.w[j], kk.w[j - 1], 28);   // kk <<= 4
+      kk.w[0] <<= 4;
+      const uint32_t nib = kk.w[7] >> 28;
+      const uint32_t u = nib | 1u;
+      const uint32_t neg = 0u - (uint32_t)((above & 1u) == 0u);
+      const uint32_t slot = ((neg & (16u - u)) | (~neg & u)) >> 1;
+      above = nib;
+      fe tx, ty;
+      fe29 wz;
+      window(wz);
+      keep(0, slot, tx, ty); request(1);
+      R = gjdbl29<C, true>(R, wz, cx);
+      keep(1, slot, tx, ty); request(2);
+      R = gjdbl29<C, true>(R, wz, cx);
+      keep(2, slot, tx, ty); request(3);
+      R = gjdbl29<C, false>(R, wz, cx);
+      keep(3, slot, tx, ty); request(0);                // the next window's first line (after the last window: read and dropped)
+      R = dbl_add29<C>(R, to29(tx), cneg29(neg, to29(ty)), cx);
+    }
+  } else {
+    {                                                   // top digit = (k >> 252) | 1, positive
+      fe tx, ty;
+      gvw_load_slot(table, base + (above >> 1), tx, ty);
+      R.x = to29(tx); R.y = to29(ty); R.z = enter29<C>(g_words(G.F.r), cx);
+    }
+#pragma unroll 1
+    for (int w = 62; w >= 0; --w) {
+#pragma unroll
+      for (int j = 7; j > 0; --j) kk.w[j] = __builtin_amdgcn_alignbit(kk.w[j], kk.w[j - 1], 28);   // kk <<= 4
+      kk.w[0] <<= 4;
+      const uint32_t nib = kk.w[7] >> 28;
+      const uint32_t u = nib | 1u;                                        // 1, 3, ..., 15
+      const uint32_t neg = 0u - (uint32_t)((above & 1u) == 0u);          // digit = u - 16 when the nibble above is even
+      const uint32_t mag = neg ? 16u - u : u;
+      above = nib;
+      fe tx, ty;
+      gvw_load_slot(table, base + (mag >> 1), tx, ty);                    // in flight during the doublings
+      fe29 wz;
+      window(wz);
+      R = gjdbl29<C, true>(R, wz, cx);
+      R = gjdbl29<C, true>(R, wz, cx);
+      R = gjdbl29<C, false>(R, wz, cx);
+      R = dbl_add29<C>(R, to29(tx), cneg29(neg, to29(ty)), cx);
+    }
   }
   // back on the curve itself: Z = Z' Zg; API Montgomery form (x 2^256 mod p, canonical)
   fe X = leave29<C>(R.x, cx), Y = leave29<C>(R.y, cx), Z = leave29<C>(mul29<C>(R.z, to29(fe_load(zg, i)), cx), cx);
@@ -154,14 +214,15 @@ k_gvw_mult(gcurve G, launch::words8 order8, const uint64_t* __restrict__ k, int 
 }  // namespace
 
 namespace launch {
-// scratch: gc_varwin_scratch_bytes(n), 32-byte aligned.  flags: ECSIMD_HIP_BASE_MGRY.  Affine classical (ox, oy) out; oy may be null.
+// scratch: gc_varwin_scratch_bytes(n), 32-byte aligned.  flags: ECSIMD_HIP_BASE_MGRY | ECSIMD_HIP_ALG_CONSTANT_TIME.  Affine classical (ox, oy) out; oy may be null.
 void gc_varwin_scalar_mult(hipStream_t s, const gcurve& G, const words8& order, const uint64_t* k, int k_stride, const uint64_t* x, const uint64_t* y, int flags,
                            uint64_t* scratch, uint64_t* ox, uint64_t* oy, size_t n) {
   uint4* table = reinterpret_cast<uint4*>(scratch);                      // 8n x 64 B
   uint64_t* zg = scratch + (size_t)GVW_ENTRIES * 8 * n;                    // n x 32 B
   uint64_t* jx = zg + 4 * n; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
   hipLaunchKernelGGL(k_gvw_table, grid_for(n), dim3(BLOCK), 0, s, G, x, y, flags, table, zg, n);
-  hipLaunchKernelGGL(k_gvw_mult, grid_for(n), dim3(BLOCK), 0, s, G, order, k, k_stride, (const uint4*)table, (const uint64_t*)zg, jx, jy, jz, n);
+  if (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) hipLaunchKernelGGL(k_gvw_mult<true>, grid_for(n), dim3(BLOCK), 0, s, G, order, k, k_stride, (const uint4*)table, (const uint64_t*)zg, jx, jy, jz, n);
+  else hipLaunchKernelGGL(k_gvw_mult<false>, grid_for(n), dim3(BLOCK), 0, s, G, order, k, k_stride, (const uint4*)table, (const uint64_t*)zg, jx, jy, jz, n);
   gc_to_affine_batched(s, G, jx, jy, jz, ox, oy, n);
 }
 }  // namespace launch

@@ -419,7 +419,7 @@ TEST(Curves, AnyCurveThroughCurveGroup) {
 }
 
 // The first application on such a curve: a Curve type that also names its order n gets u1 G + u2 Q, ECDSA and the SEC1 codecs on top of the reference's
-// ladder (no window tables exist for a registered curve).  Expected values: textbook affine arithmetic on Python integers (tests/test_gpu_curves.py's model).
+// ladder, and the table-driven algorithms a registered curve has (its generator's comb, the variable-base window loop).  Expected values: textbook affine arithmetic on Python integers (tests/test_gpu_curves.py's model).
 struct curve_brainpoolp256r1_n : curve_brainpoolp256r1 {
   using N = bn256_constant<0xa9fb57dba1eea9bcull, 0x3e660a909d838d71ull, 0x8c397aa3b561a6f7ull, 0x901e0e82974856a7ull>;
 };
@@ -456,6 +456,13 @@ TEST(Curves, EcdsaAndSec1OnARegisteredCurve) {
   const W256 ks(300, [](size_t i, size_t) { bignum_256 b; b.limbs = {0x9e3779b97f4a7c15ull * (i + 1), i * 77, ~i, 0x0123456789abcdefull ^ (i << 20)}; return b; });
   const auto ladder = KG::scalar_mult(ks, KG::WJG(300)).to_affine();                              // the generator's comb (plain and constant-time) = the ladder's points
   EXPECT_TRUE(all(KG::scalar_mult_base_affine(ks) == ladder) && all(KG::scalar_mult_base_affine_secret(ks) == ladder));
+  // a variable base: the lane's own window table (k_gvarwin.hip) = the ladder + to_affine, lane for lane; the curve without its order keeps the ladder
+  const W256 ks2(300, [](size_t i, size_t) { bignum_256 b; b.limbs = {0xd1342543de82ef95ull * (i + 3), i * 131, ~(i << 7), 0xfedcba9876543210ull ^ (i << 33)}; return b; });
+  EXPECT_TRUE(all(KG::scalar_mult_affine(ks2, ladder) == KG::scalar_mult_affine(ks2, ladder, false)));
+  bool no_order_refused = false;
+  try { (void)curve_group<curve_brainpoolp256r1>::scalar_mult_affine(ks2, wide_curve_point<curve_brainpoolp256r1>{ladder.x(), ladder.y()}); }
+  catch (std::exception const&) { no_order_refused = true; }
+  EXPECT_TRUE(no_order_refused);
   hip::mask dec_ok;
   const auto back = sec1_decode<K>(sec1_encode<K>(Q, true), true, dec_ok);                        // compressed: the square root with THIS curve's a and b
   EXPECT_TRUE(dec_ok.count() == 4 && all(back == Q));

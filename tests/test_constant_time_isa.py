@@ -281,3 +281,24 @@ def test_registered_curve_constant_time_comb(tmp_path_factory):
         ct_check.check(asm, "18k_gc_base_windowedILb0E", allow_global_loads=0, allow_lds_reads=True)
     with pytest.raises(ct_check.Violation, match="LDS address"):
         ct_check.check_secret_flow(asm, "18k_gc_base_windowedILb0E", secret_args=[2])
+
+
+def test_registered_curve_constant_time_variable_base_window_loop(tmp_path_factory):
+    """k_gvw_mult<true> (scalar_mult(ALG_WINDOWED | ALG_CONSTANT_TIME) on a registered curve's variable base, k_gvarwin.hip): the built-in constant-time
+    loop's checks -- per window 32 global loads (the lane's eight entries, a 128-byte line at a time) at loop-invariant addresses, one branch on the window
+    counter, nothing branching on a lane mask after the scalar is loaded -- and the secret-flow analysis with the scalar and the Jacobian result secret: no
+    secret reaches an address, a branch, EXEC at a memory access or a lane-crossing instruction.  The default loop, whose one entry per window is addressed
+    by a digit, is refused by both."""
+    asm = assembly(tmp_path_factory, "k_gvarwin")
+    kern = "10k_gvw_multILb1E"
+    rep = ct_check.check(asm, kern, allow_global_loads=32)
+    assert rep["instructions"] > 7000 and len(rep["global_loads"]) == 32 and rep["scratch"] == 0
+    assert all(g.startswith("global_load_dwordx4 ") for g in rep["global_loads"])
+    assert len(rep["branches"]) == 1 and re.match(r"s_cmpk?_(lg|eq|lt|gt|le|ge)_[iu]32 s\d+, \S+ ; s_cbranch_scc[01] ", rep["branches"][0]), rep["branches"]
+    assert ct_check.check_after_secret_load(asm, kern) > 7000
+    flow = ct_check.check_secret_flow(asm, kern, secret_args=[2, 6, 7, 8])             # (gcurve, order, k, k_stride, table, zg, ox, oy, oz, n): the scalar, the Jacobian k P
+    assert flow["secret_loads"] >= 1 and not flow["secret_lds"] and not flow["secret_scratch"]
+    with pytest.raises(ct_check.Violation, match="address"):
+        ct_check.check(asm, "10k_gvw_multILb0E", allow_global_loads=32)
+    with pytest.raises(ct_check.Violation, match="address"):
+        ct_check.check_secret_flow(asm, "10k_gvw_multILb0E", secret_args=[2])

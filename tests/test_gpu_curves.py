@@ -216,9 +216,9 @@ def test_registered_curve_entry_points_that_do_not_exist_say_so(engine, oracle):
     bx, by = engine.scalar_mult_base(cid, k, flags=OUT_AFFINE)
     from ecsimd_amd import ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG
     from ecsimd_amd import ALG_NO_ENDOMORPHISM
-    for fl in (OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME, OUT_AFFINE | ALG_WINDOWED_SIGNED, OUT_AFFINE | ALG_WINDOWED | ALG_NO_ENDOMORPHISM, OUT_AFFINE | ALG_CONSTANT_TIME):
+    for fl in (OUT_AFFINE | ALG_WINDOWED_SIGNED, OUT_AFFINE | ALG_WINDOWED | ALG_NO_ENDOMORPHISM, OUT_AFFINE | ALG_CONSTANT_TIME):
         with pytest.raises(EcsimdHipError, match="a registered curve has"):
-            engine.scalar_mult(cid, k, bx, by, flags=fl)                  # a variable base: the public-scalar window loop (k_gvarwin.hip) and the ladder, nothing else
+            engine.scalar_mult(cid, k, bx, by, flags=fl)                  # a variable base: the window loop (k_gvarwin.hip; plain and constant-time) and the ladder, nothing else
     with pytest.raises(EcsimdHipError, match="OUT_AFFINE"):
         engine.scalar_mult(cid, k, bx, by, flags=ALG_WINDOWED)            # the window loop's Jacobian representative is not the reference's
     for fl in (OUT_AFFINE | ALG_WINDOWED_SIGNED, OUT_AFFINE | ALG_WINDOWED_BIG, OUT_AFFINE | ALG_CONSTANT_TIME):
@@ -413,7 +413,7 @@ def test_generator_comb_on_a_registered_curve(engine, name):
 @pytest.mark.parametrize("name", list(REF_CURVES))
 def test_variable_base_window_loop_on_a_registered_curve(engine, name):
     """scalar_mult(ALG_WINDOWED | OUT_AFFINE) with a registered curve id (k_gvarwin.hip: the lane's eight odd multiples of P over one Z, the window loop in
-    modified Jacobian coordinates on the isomorphic curve -- a general a, a dense prime): the ladder's affine points lane for lane on 2^16 + 77 random 256-bit
+    modified Jacobian coordinates on the isomorphic curve -- a general a, a dense prime -- and its ALG_CONSTANT_TIME form): the ladder's affine points lane for lane on 2^16 + 77 random 256-bit
     scalars and lane-distinct base points; the true k P (textbook affine arithmetic on Python integers) on the edge scalars -- 0 and n (infinity: (0, 0)), the
     three scalars at which the LADDER is wrong, digit patterns that make every window's digit +-1 / +-15; Montgomery-form base points, one shared scalar,
     the x-only form, ragged and empty batches, and an invalid base point that must not touch its neighbours."""
@@ -439,6 +439,12 @@ def test_variable_base_window_loop_on_a_registered_curve(engine, name):
         want = mul(kv % n_, (to_int(bxn[i]), to_int(byn[i])))
         assert (to_int(wx[i]), to_int(wy[i])) == (want if want is not None else (0, 0)), (name, i, hex(kv))
     assert np.array_equal(wx[len(edge):], lx[len(edge):]) and np.array_equal(wy[len(edge):], ly[len(edge):]), name
+    from ecsimd_amd import ALG_CONSTANT_TIME
+    cx_, cy_ = (engine.to_numpy(t) for t in engine.scalar_mult(cid, kd, bx, by, flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME))   # every entry read, lane masks: the same points
+    assert np.array_equal(cx_, wx) and np.array_equal(cy_, wy), name
+    c1x, c1y = (engine.to_numpy(t) for t in engine.scalar_mult_1s(cid, from_int(edge[-7]), bx[:777].contiguous(), by[:777].contiguous(), flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME))
+    l1x, l1y = (engine.to_numpy(t) for t in engine.scalar_mult_1s(cid, from_int(edge[-7]), bx[:777].contiguous(), by[:777].contiguous(), flags=OUT_AFFINE))
+    assert np.array_equal(c1x, l1x) and np.array_equal(c1y, l1y)
     for i in range(len(edge), len(edge) + 6):                                                            # and a third opinion on a few random lanes
         assert (to_int(wx[i]), to_int(wy[i])) == mul(to_int(k[i]) % n_, (to_int(bxn[i]), to_int(byn[i])))
     xo, none = engine.scalar_mult(cid, kd, bx, by, flags=OUT_AFFINE | ALG_WINDOWED, x_only=True)
@@ -476,7 +482,9 @@ def test_variable_base_window_loop_of_a_builtin_curve_through_the_generic_kernel
     kn = engine.to_numpy(k); kn[:4] = ints_to_arr([0, c["n"], c["n"] - 2, 2]); k = engine.to_device(kn)
     bx, by = engine.scalar_mult_base(cv, engine.fill_random(N, SEED, 125), flags=OUT_AFFINE)
     want = [engine.to_numpy(t) for t in engine.scalar_mult(cv, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)]
-    assert same([engine.to_numpy(t) for t in engine.scalar_mult(gid, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)], want), cv
+    from ecsimd_amd import ALG_CONSTANT_TIME
+    for fl in (ALG_WINDOWED, ALG_WINDOWED | ALG_CONSTANT_TIME):
+        assert same([engine.to_numpy(t) for t in engine.scalar_mult(gid, k, bx, by, flags=OUT_AFFINE | fl)], want), (cv, fl)
 
 
 @pytest.mark.parametrize("cv", [P256, SECP256K1])

@@ -150,6 +150,16 @@ import json; d=json.load(open('$out/bench_brainpool_$w.json')); r=d['roofline'];
     timeout -k 10 600 python -m pytest tests/test_gpu_curves.py -x -q -m gpu -k "window_loop or do_not_exist or ecdsa_and_double" > "$out/pytest.txt" 2>&1; rc=$?
     tail -15 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
     timeout -k 10 500 python tools/gvarwin_perf.py ${1:-22} > "$out/gvarwin_perf.txt" 2>&1; rc=$?; cat "$out/gvarwin_perf.txt"; exit $rc ;;
+  r5_gvw_lines)     # round 5: the window loop of a registered curve -- its bench lines (CPU leg: the reference instantiated for the curve + to_affine), rocprofv3 stats + --pmc passes, the soak against the ladder
+    rc=0; mkdir -p "$out/lines"
+    for c in brainpoolP256r1 sm2 frp256v1; do
+      timeout -k 10 400 python3 bench.py --steps 10 --warmup 2 --curve $c --workload windowed > "$out/lines/bench_n1_windowed_variable_base_$c.json" 2> "$out/lines/bench_n1_windowed_variable_base_$c.err" || rc=$?
+      python3 -c "import json; d=json.load(open('$out/lines/bench_n1_windowed_variable_base_$c.json')); print('$c %.3f M/s  frac %.3f' % (d['value']/1e6, d['roofline']['frac']), {k: v for k, v in d['cpu_baseline'].items() if k.startswith('lanes') or k in ('value', 'kind')})" || { tail -5 "$out/lines/bench_n1_windowed_variable_base_$c.err"; rc=1; }
+    done
+    [ $rc -ne 0 ] && exit $rc
+    bash tools/profile.sh r05_windowed_brainpoolP256r1 --workload windowed --curve brainpoolP256r1 > "$out/profile.txt" 2>&1 || { rc=$?; tail -5 "$out/profile.txt"; }
+    echo "profiled rc=$rc"; [ $rc -ne 0 ] && exit $rc
+    timeout -k 10 600 python tools/soak_windowed.py 22 ${1:-4} brainpoolP256r1,sm2,frp256v1 > "$out/soak_alg.txt" 2>&1; rc=$?; tail -4 "$out/soak_alg.txt"; exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
     timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -15 "$out/pytest.txt"; exit $rc ;;
   *) echo "unknown step $name"; exit 2 ;;

@@ -33,8 +33,8 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
         d_x = int(((xo != l[0]).any(dim=1) | (xg != gl[0]).any(dim=1)).sum())
         tot += 3 * n; bad += d_fixed + d_var + d_x
         print(f"{nm} batch {b}: {n} fixed-base + {n} variable-base + {n} x-only lanes, differing: {d_fixed} / {d_var} / {d_x}   [{time.time()-t0:.0f}s]", flush=True)
-# (r5) curves registered at run time: the generator's comb (plain and constant-time) against the ladder, and u1 G + u2 Q (the comb + a ladder pass + an affine
-# addition) against two ladder passes and the same addition -- argv[3] = comma-separated names, e.g. brainpoolP256r1,sm2,frp256v1
+# (r5) curves registered at run time: the generator's comb (plain and constant-time) against the ladder, u1 G + u2 Q (the comb + the window loop + an affine
+# addition) against two ladder passes and the same addition, and the variable-base window loop against the ladder -- argv[3] = comma-separated names, e.g. brainpoolP256r1,sm2,frp256v1
 for nm in (sys.argv[3].split(",") if len(sys.argv) > 3 else []):
     from ecsimd_amd.curves import curve_id
     cv = curve_id(nm)
@@ -50,7 +50,10 @@ for nm in (sys.argv[3].split(",") if len(sys.argv) > 3 else []):
         l = e.scalar_mult(cv, k, gl[0], gl[1], flags=OUT_AFFINE)
         ax, ay, afin = e.affine_add(cv, gl, l)
         d_var = int(((dx != ax).any(dim=1) | (dy != ay).any(dim=1) | (fin != afin)).sum())
-        tot += 2 * n; bad += d_fixed + d_var
-        print(f"{nm} batch {b}: {n} fixed-base (comb, constant-time comb vs ladder) + {n} u1 G + u2 Q lanes, differing: {d_fixed} / {d_var}   [{time.time()-t0:.0f}s]", flush=True)
+        w = e.scalar_mult(cv, k, gl[0], gl[1], flags=OUT_AFFINE | ALG_WINDOWED)            # the lane's own window table (k_gvarwin.hip) against the ladder
+        d_win = int(((w[0] != l[0]).any(dim=1) | (w[1] != l[1]).any(dim=1)).sum())
+        del w
+        tot += 3 * n; bad += d_fixed + d_var + d_win
+        print(f"{nm} batch {b}: {n} fixed-base (comb, constant-time comb vs ladder) + {n} u1 G + u2 Q + {n} variable-base window-loop lanes, differing: {d_fixed} / {d_var} / {d_win}   [{time.time()-t0:.0f}s]", flush=True)
 print(f"TOTAL {tot} scalar multiplications compared across algorithms, {bad} lanes differ")
 sys.exit(1 if bad else 0)
