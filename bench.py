@@ -203,8 +203,8 @@ def main():
         __graft_entry__.build()         # built artefacts normally travel with the snapshot
     if world > 1:
         dist.barrier()
-    if args.curve not in ("p256", "secp256k1") and args.workload not in LADDER_WORKLOADS + ("windowed",):
-        raise SystemExit("a curve registered at run time has the reference's ladder (workloads %s) and the public-scalar window loop (windowed); the other table-driven algorithms exist for p256 / secp256k1" % ", ".join(LADDER_WORKLOADS))
+    if args.curve not in ("p256", "secp256k1") and args.workload not in LADDER_WORKLOADS + ("windowed", "windowed-ct"):
+        raise SystemExit("a curve registered at run time has the reference's ladder (workloads %s) and the window loop (windowed, windowed-ct); the other table-driven algorithms exist for p256 / secp256k1" % ", ".join(LADDER_WORKLOADS))
     curve = curve_id(args.curve)        # 0 / 1, or a run-time registration (host arithmetic only)
     eng = Engine(dev_index)             # raises if the HIP library / a gfx950 device is missing: no fallback
     units = (1 << args.global_log2_batch) if args.scaling == "strong" else (1 << args.log2_batch)
@@ -360,7 +360,9 @@ def base_line(args, world, total_units, n, value, elapsed):
                        "and the loop on the isomorphic curve in modified Jacobian coordinates (a general a)") + f", batch {sizes}, affine out",
         "windowed-ct": f"scalar_mult_{args.curve} variable-base, per-element window tables (8 odd multiples of P) + signed 4-bit windows (odd digits), ALG_CONSTANT_TIME: "
                        f"all 8 entries of the lane's table read in every window, kept under lane masks"
-                       + (" (secp256k1: GLV split k = k1 + k2*lambda on the complete addition law of a = 0 curves)" if args.curve == "secp256k1" else "") + f"; + simultaneous inversion, batch {sizes}, affine out",
+                       + (" (secp256k1: GLV split k = k1 + k2*lambda on the complete addition law of a = 0 curves)" if args.curve == "secp256k1" else "")
+                       + ("" if args.curve in ("p256", "secp256k1") else "; this curve is registered at RUN time: generic kernels (k_gvarwin.hip), the table over one Z, the loop on the isomorphic curve in modified Jacobian coordinates")
+                       + f"; + simultaneous inversion, batch {sizes}, affine out",
     }
     fixed = {"fixed-base": "4-bit window table in LDS (odd digits, 32 KiB)",
              "fixed-base-ct": "ALG_CONSTANT_TIME: odd-digit comb in LDS, every entry of a window read and one kept under lane masks (52 five-bit windows x 16 entries, 53 KB, three 256-thread workgroups per CU)",
@@ -421,7 +423,7 @@ def roofline_object(args, eng, n, avg_ms):
             # leaving products (4), then the shared inversion (the field's generic division steps, priced as P-256's 267)
             fm = (7 + 4 + 7 * 7 + 2 + 7 * 5 + 4) + 4 + 63 * (3 + 8 + 8 + 7 + 18) + 4 + (7 + 267 / share)
         mad32_unit, bytes_unit = int(fm * 136), 160
-        kname = "k_gvw_mult + k_gvw_table + k_gc_to_affine_batched" if registered else ("k_varwin_mult_glv_ct + k_varwin_multiples_chain" if (args.workload == "windowed-ct" and args.curve == "secp256k1") else
+        kname = ("k_gvw_mult<true>" if args.workload == "windowed-ct" else "k_gvw_mult<false>") + " + k_gvw_table + k_gc_to_affine_batched" if registered else ("k_varwin_mult_glv_ct + k_varwin_multiples_chain" if (args.workload == "windowed-ct" and args.curve == "secp256k1") else
                  "k_varwin_mult_odd<true> + k_varwin_odd_multiples" if args.workload == "windowed-ct" else "k_varwin_mult_odd<false> + k_varwin_odd_multiples" if args.curve == "p256"
                  else "k_varwin_mult_glv + k_varwin_table_iso") + ("" if (args.workload == "windowed" and args.curve == "secp256k1") else " + k_varwin_invert_last + k_varwin_chain_to_table") + " + k_to_affine_batched"
     else:

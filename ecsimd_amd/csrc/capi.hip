@@ -1570,7 +1570,7 @@ int ecsimd_hip_ecdsa_sign(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, con
 
 int ecsimd_hip_fe29_raw(ecsimd_hip_ctx* ctx, int curve, int op, const int32_t* in, int32_t* out, size_t n, int swap) {
   REQUIRE_CTX(); if ((!in || !out) && n) return bad(ctx, "fe29_raw: null pointer");
-  if (op < 0 || op > launch::RAW_SQR) return bad(ctx, "fe29_raw: unknown function");
+  if (op < 0 || op > launch::RAW_ZADDU) return bad(ctx, "fe29_raw: unknown function");
   gcurve GC; const bool registered = curve >= ECSIMD_HIP_FIRST_REGISTERED_CURVE;
   if (registered) { if (!lookup_curve(curve, &GC)) return bad(ctx, "unknown curve id"); }
   else REQUIRE_CURVE();

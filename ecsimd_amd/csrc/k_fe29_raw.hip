@@ -34,10 +34,20 @@ template <int C, int OP> __global__ void __launch_bounds__(BLOCK) k_fe29_raw(r29
     O(0, mul29<C>(I(0), I(1), cx));
   } else if constexpr (OP == launch::RAW_SQR) {
     O(0, sqr29<C>(I(0), cx));
-  } else if constexpr (r29_prime<C>::dense) {                                 // a registered curve: the generator's comb runs madd29 with the dense reduction (k_gcomb.hip)
+  } else if constexpr (OP == launch::RAW_ZADDU) {                             // x1, y1, x2, y2, z -> rx, ry, x1', y1', z', dx
+    fe29 x1 = I(0), y1 = I(1), z = I(4), rx, ry, dx;
+    zaddu29<C>(x1, y1, I(2), I(3), z, rx, ry, dx, cx);
+    O(0, rx); O(1, ry); O(2, x1); O(3, y1); O(4, z); O(5, dx);
+  } else if constexpr (r29_prime<C>::dense) {                                 // a registered curve: the generator's comb (madd29) and the window loop (gjdbl29, dbl_add29) with the dense reduction
     const jpoint29 P{I(0), I(1), I(2)};
     jpoint29 R = P;
     if constexpr (OP == launch::RAW_MADD) R = madd29<C>(P, I(3), I(4), cx);
+    else if constexpr (OP == launch::RAW_DBL_ADD) R = dbl_add29<C>(P, I(3), I(4), cx);
+    else if constexpr (OP == launch::RAW_GJDBL) {                             // X, Y, Z, W -> X, Y, Z, W; swap: the doubled point's W is formed (WOUT)
+      fe29 w = I(3);
+      if (swap) R = gjdbl29<C, true>(P, w, cx); else R = gjdbl29<C, false>(P, w, cx);
+      O(3, w);
+    }
     O(0, R.x); O(1, R.y); O(2, R.z);
   } else {                                                                    // the window kernels' functions exist for the two built-in primes
     const jpoint29 P{I(0), I(1), I(2)};
@@ -62,14 +72,14 @@ template <int C> static bool raw_dispatch(hipStream_t s, const r29_ctx<C>& cx, i
     default: break;
   }
   if constexpr (r29_prime<C>::dense) {
-    switch (op) { CASE(RAW_MADD); default: break; }
+    switch (op) { CASE(RAW_MADD); CASE(RAW_DBL_ADD); CASE(RAW_GJDBL); CASE(RAW_ZADDU); default: break; }
   } else {
     switch (op) {
       CASE(RAW_MADD); CASE(RAW_JDBL); CASE(RAW_DBL_ADD); CASE(RAW_MADDV);
       default: break;
     }
     if constexpr (!r29_prime<C>::p256) {
-      switch (op) { CASE(RAW_PDBL); CASE(RAW_PADD); default: break; }
+      switch (op) { CASE(RAW_PDBL); CASE(RAW_PADD); CASE(RAW_ZADDU); default: break; }
     }
   }
 #undef CASE

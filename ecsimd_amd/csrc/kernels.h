@@ -99,9 +99,9 @@ void gc_zdau_repeat(hipStream_t, const gcurve&, const uint64_t* px, const uint64
                     uint64_t* rx, uint64_t* ry, uint64_t* sx, uint64_t* sy, uint64_t* oz, size_t n, int iters, uint64_t swap_bits, int radix);
 
 // k_fe29_raw.hip: one function of fe29.cuh on raw 9-limb operands (the diagnostic entry ecsimd_hip_fe29_raw)
-enum fe29_raw_op { RAW_ZDAU = 0, RAW_MADD = 1, RAW_JDBL = 2, RAW_DBL_ADD = 3, RAW_MADDV = 4, RAW_PDBL = 5, RAW_PADD = 6, RAW_MUL = 7, RAW_SQR = 8 };
-constexpr int fe29_raw_inputs(int op) { return op == RAW_ZDAU ? 6 : op == RAW_MUL ? 2 : op == RAW_SQR ? 1 : (op == RAW_JDBL || op == RAW_PDBL) ? 3 : 5; }
-constexpr int fe29_raw_outputs(int op) { return op == RAW_ZDAU ? 6 : (op == RAW_MUL || op == RAW_SQR) ? 1 : 3; }
+enum fe29_raw_op { RAW_ZDAU = 0, RAW_MADD = 1, RAW_JDBL = 2, RAW_DBL_ADD = 3, RAW_MADDV = 4, RAW_PDBL = 5, RAW_PADD = 6, RAW_MUL = 7, RAW_SQR = 8, RAW_GJDBL = 9, RAW_ZADDU = 10 };
+constexpr int fe29_raw_inputs(int op) { return op == RAW_ZDAU ? 6 : op == RAW_MUL ? 2 : op == RAW_SQR ? 1 : (op == RAW_JDBL || op == RAW_PDBL) ? 3 : op == RAW_GJDBL ? 4 : 5; }
+constexpr int fe29_raw_outputs(int op) { return (op == RAW_ZDAU || op == RAW_ZADDU) ? 6 : (op == RAW_MUL || op == RAW_SQR) ? 1 : op == RAW_GJDBL ? 4 : 3; }
 bool fe29_raw(hipStream_t, int curve, const gcurve* G, int op, const int32_t* in, int32_t* out, size_t n, uint32_t swap);
 
 // k_point_<curve>.hip

@@ -387,7 +387,7 @@ class Engine:
     def fe29_raw(self, curve, op, inputs, swap=0):
         """ecsimd_hip_fe29_raw: one function of the reduced-radix layer on raw int32 limbs; `inputs` is an int32 tensor (n, NIN, 9); returns (n, NOUT, 9)."""
         torch = self.torch
-        nout = 6 if op == 0 else 1 if op in (7, 8) else 3
+        nout = 6 if op in (0, 10) else 1 if op in (7, 8) else 4 if op == 9 else 3
         assert inputs.dtype == torch.int32 and inputs.dim() == 3 and inputs.shape[2] == 9 and inputs.is_contiguous() and inputs.device.index == self.device
         n = inputs.shape[0]
         out = torch.empty((n, nout, 9), dtype=torch.int32, device=self.tdev)

@@ -380,7 +380,9 @@ int ecsimd_hip_ecdsa_sign(ecsimd_hip_ctx*, int curve, const uint64_t* e, const u
  * other entry point can produce such inputs (their operands enter the loops as tight limbs).  op (NIN -> NOUT coordinates):
  *   0 zdau29 (x1, x2, dx, y1, dy, z -> the same six; swap != 0 exchanges the two output points)      1 madd29 (X, Y, Z, x2, y2 -> X, Y, Z)      2 jdbl29 (X, Y, Z ->)
  *   3 dbl_add29 (X, Y, Z, x2, y2 ->)    4 madd29_hr + madd29v_finish    5 pdbl29, 6 padd29 (secp256k1: the complete law)    7 mul29 (a, b -> r)    8 sqr29 (a -> r)
- * curve: 0 / 1 (for secp256k1 the loops' own domain: values x * 2^261 of the CLASSICAL x), or a registered curve id (ops 0, 1, 7, 8: the dense reduction).
+ *   9 gjdbl29 (X, Y, Z, W = a Z^4 -> the same four; swap != 0: the doubled point's W is formed)    10 zaddu29 (x1, y1, x2, y2, z -> rx, ry, x1', y1', z', dx)
+ * curve: 0 / 1 (for secp256k1 the loops' own domain: values x * 2^261 of the CLASSICAL x; ops 0-8, secp256k1 also 10), or a registered curve id (ops 0, 1, 3, 7, 8, 9,
+ * 10: the dense reduction; the window loop of k_gvarwin.hip).
  * Operands outside the proven bounds give whatever 32- / 64-bit wrap-around gives. */
 int ecsimd_hip_fe29_raw(ecsimd_hip_ctx* ctx, int curve, int op, const int32_t* in, int32_t* out, size_t n, int swap);
 /* Diagnostic: the context's grow-only scratch block (device pointer and size; NULL / 0 before the first call that needed one).  What a test reads

@@ -13,7 +13,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OPCODE = {"zdau": 0, "madd": 1, "jdbl": 2, "dbl_add": 3, "maddv": 4, "pdbl": 5, "padd": 6, "mul": 7, "sqr": 8}
+OPCODE = {"zdau": 0, "madd": 1, "jdbl": 2, "dbl_add": 3, "maddv": 4, "pdbl": 5, "padd": 6, "mul": 7, "sqr": 8, "gjdbl": 9, "zaddu": 10}
 
 
 def test_the_device_on_the_proofs_extreme_inputs(engine):
@@ -43,4 +43,6 @@ def test_the_device_on_the_proofs_extreme_inputs(engine):
     with pytest.raises(EcsimdHipError):
         engine.fe29_raw(0, OPCODE["pdbl"], torch.zeros((1, 3, 9), dtype=torch.int32, device=engine.tdev))
     with pytest.raises(EcsimdHipError):
-        engine.fe29_raw(cid["sm2"], OPCODE["jdbl"], torch.zeros((1, 3, 9), dtype=torch.int32, device=engine.tdev))
+        engine.fe29_raw(cid["sm2"], OPCODE["jdbl"], torch.zeros((1, 3, 9), dtype=torch.int32, device=engine.tdev))     # (a registered curve doubles with gjdbl29)
+    with pytest.raises(EcsimdHipError):
+        engine.fe29_raw(0, OPCODE["gjdbl"], torch.zeros((1, 4, 9), dtype=torch.int32, device=engine.tdev))

@@ -10,7 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from ecsimd_amd import Engine, P256, SECP256K1, ALG_WINDOWED, OUT_AFFINE      # noqa: E402
+from ecsimd_amd import Engine, P256, SECP256K1, ALG_WINDOWED, ALG_CONSTANT_TIME, OUT_AFFINE     # noqa: E402
 from ecsimd_amd.engine import register_curve                                 # noqa: E402
 from ecsimd_amd.curves import NAMED                                          # noqa: E402
 from helpers import CURVE_PARAMS, SEED                                        # noqa: E402
@@ -40,15 +40,16 @@ def rates(cid, label, base=None):
     k = eng.fill_random(n, SEED, 1); s = eng.fill_random(n, SEED, 2)
     bx, by = eng.scalar_mult_base(base if base is not None else cid, s, flags=OUT_AFFINE)
     res = {}
-    for fl, what, mults in ((OUT_AFFINE, "ladder + shared inversion", LADDER_MULTS), (OUT_AFFINE | ALG_WINDOWED, "window loop (ALG_WINDOWED)", WINDOW_MULTS)):
+    for fl, what, mults in ((OUT_AFFINE, "ladder + shared inversion", LADDER_MULTS), (OUT_AFFINE | ALG_WINDOWED, "window loop (ALG_WINDOWED)", WINDOW_MULTS),
+                            (OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME, "constant-time window loop", WINDOW_MULTS)):
         out = [eng.empty(n), eng.empty(n), None]                # (x, y, no z: OUT_AFFINE)
         t = timed(lambda: eng.scalar_mult(cid, k, bx, by, flags=fl, out=out))
         r = n / (t * 1e-3)
         print(f"{label:34s} {what:30s} {t:9.2f} ms  {r / 1e6:8.2f} M/s  {r * mults * 136 / 1e12 / peak:6.3f} of the measured multiply peak ({mults} field multiplications x 136 mad32)")
         res[fl] = [eng.to_numpy(o) for o in out[:2]]
-    a, b = res[OUT_AFFINE], res[OUT_AFFINE | ALG_WINDOWED]
-    differ = int(((a[0] != b[0]).any(axis=1) | (a[1] != b[1]).any(axis=1)).sum())
-    print(f"{label:34s} lanes where the two differ: {differ} of {n}")
+    a, b, c_ = res[OUT_AFFINE], res[OUT_AFFINE | ALG_WINDOWED], res[OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME]
+    differ = int(((a[0] != b[0]).any(axis=1) | (a[1] != b[1]).any(axis=1) | (a[0] != c_[0]).any(axis=1) | (a[1] != c_[1]).any(axis=1)).sum())
+    print(f"{label:34s} lanes where the three differ: {differ} of {n}")
     return b
 
 

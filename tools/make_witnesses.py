@@ -5,7 +5,7 @@ ecsimd_amd/csrc/fe29.cuh meets the LARGEST columns and limbs its interval proofs
   * "product" entries: for every interval proof (ladder, comb, window loop, GLV loop, complete law; P-256, secp256k1, and the any-prime ladder on three
     real dense primes) the products and squares whose columns come closest to 2^63, each with an operand pair whose limbs sit at the ends of the boxes the
     proof hands THAT call (tools/radix29_model.py product_witnesses: achieved / proven >= 0.99 on the built-in primes);
-  * "function" entries: whole functions (zdau29, madd29, jdbl29, dbl_add29, madd29v, pdbl29, padd29) on states at vertices of their loop invariants,
+  * "function" entries: whole functions (zdau29, madd29, jdbl29, dbl_add29, gjdbl29, zaddu29, madd29v, pdbl29, padd29) on states at vertices of their loop invariants,
     found by hill-climbing on the exact model's worst column, plus random states inside the invariant box.
 
 The file is DATA minted by this repo's own exact model (not by the reference -- the reference has no such representation); the exact model itself is held
@@ -28,7 +28,8 @@ CURVES = {"p256": m.CURVE_P256, "secp256k1": m.CURVE_SECP}
 CURVES.update({k: m.Curve.dense(k, p) for k, p in DENSE.items()})
 PROOFS = [("ladder", m.prove_invariant, ("p256", "secp256k1")), ("comb", m.prove_comb_invariant, ("p256", "secp256k1")), ("window", m.prove_window_invariant, ("p256", "secp256k1")),
           ("glv", m.prove_glv_invariant, ("secp256k1",)), ("complete", m.prove_complete_invariant, ("secp256k1",))]
-FUNCTIONS = [("zdau", ("p256", "secp256k1", "brainpoolP256r1", "sm2", "frp256v1")), ("madd", ("p256", "secp256k1", "brainpoolP256r1", "sm2", "frp256v1")), ("jdbl", ("p256", "secp256k1")), ("dbl_add", ("p256", "secp256k1")),
+FUNCTIONS = [("zdau", ("p256", "secp256k1", "brainpoolP256r1", "sm2", "frp256v1")), ("madd", ("p256", "secp256k1", "brainpoolP256r1", "sm2", "frp256v1")), ("jdbl", ("p256", "secp256k1")),
+             ("dbl_add", ("p256", "secp256k1", "brainpoolP256r1", "sm2", "frp256v1")), ("gjdbl", ("brainpoolP256r1", "sm2", "frp256v1")), ("zaddu", ("secp256k1", "brainpoolP256r1", "sm2", "frp256v1")),
              ("maddv", ("p256", "secp256k1")), ("pdbl", ("secp256k1",)), ("padd", ("secp256k1",))]
 
 
@@ -51,6 +52,13 @@ def build():
         for what, a, b, r, ach, proven in m.product_witnesses(CURVES[kind], lambda cv: any_comb, top=3, seed=11):
             entries.append({"kind": "product", "proof": "comb, any odd p < 2^256", "curve": kind, "op": "mul" if what == "mul" else "sqr", "swap": 0,
                             "in": [a] + ([b] if b is not None else []), "out": [r], "worst_column": ach, "proven_column": proven})
+    # ... and the window loop and table of a registered curve (k_gvarwin.hip), proven for any odd p as well
+    for proof, fn, seed in (("window loop, any odd p < 2^256", m.prove_gwindow_invariant, 13), ("window table, any odd p < 2^256", m.prove_gtable, 15)):
+        calls = m.proof_calls(fn)(m.CURVE_ANY)
+        for kind in DENSE:
+            for what, a, b, r, ach, proven in m.product_witnesses(CURVES[kind], lambda cv: calls, top=3, seed=seed):
+                entries.append({"kind": "product", "proof": proof, "curve": kind, "op": "mul" if what == "mul" else "sqr", "swap": 0,
+                                "in": [a] + ([b] if b is not None else []), "out": [r], "worst_column": ach, "proven_column": proven})
     for op, kinds in FUNCTIONS:
         for kind in kinds:
             cv = CURVES[kind]

@@ -690,6 +690,23 @@ def prove_gtable(curve=CURVE_ANY):
     return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length()}
 
 
+def gtable_invariant(curve=CURVE_ANY):
+    """What k_gvw_table hands zaddu29 (the witness search's box): (x1, y1) the doubled point as gjdbl29 leaves it or its re-expressed (tight) form, (x2, y2)
+    the running odd multiple -- products at first, co-Z sums afterwards -- and z a product."""
+    p = curve.p
+    box = lambda lo, hi, top, vlo, vhi: Iv([(lo, hi)] * (NL - 1) + [(-top, top)], (int(vlo * p), int(vhi * p)))
+    return {"x1": box(-2 * M29, M29, 1 << 26, -3.25, 3.25), "y1": box(-2 * M29, M29, 1 << 26, -3.3, 2.0), "x2": box(-2 * M29, M29, 1 << 26, -2.5, 1.6),
+            "y2": box(-M29, M29, 1 << 26, -1.5, 1.5), "z": box(0, M29, 1 << 25, -0.55, 1.55)}
+
+
+def prove_gtable_box(curve=CURVE_ANY):
+    """zaddu29 from the whole of gtable_invariant (wider than any state k_gvw_table meets: both points lazy at once): no overflow."""
+    E = Bounds(curve)
+    inv = gtable_invariant(curve)
+    zaddu29(E, *(Iv(inv[k].l, inv[k].v) for k in ("x1", "y1", "x2", "y2", "z")))
+    return {"worst_column_bits": E.worst_col.bit_length(), "worst_limb_bits": E.worst_limb.bit_length()}
+
+
 def gjdbl_field(p, X, Y, Z, Wc):
     """Modified Jacobian doubling on integers mod p: (X3, Y3, Z3, W3) with W = a Z^4."""
     YY = Y * Y % p; B = 4 * X * YY % p; E8 = 8 * YY * YY % p
@@ -786,6 +803,11 @@ OPS = {   # name: (op code of ecsimd_hip_fe29_raw, input names, invariant, model
     "pdbl": (5, ("X", "Y", "Z"), None, _op3(pdbl29), 3),
     "padd": (6, ("X", "Y", "Z", "tx", "ty"), None, _op3(padd29), 3),
 }
+_dense = lambda cv: cv.terms is None or len(cv.terms) == NL
+_iso_as_zaddu = lambda cv: (lambda i: {"x1": i["px"], "y1": i["py"], "x2": i["mx"], "y2": i["my"], "z": i["z"]})(iso_chain_invariant(cv))
+OPS["dbl_add"] = OPS["dbl_add"][:2] + (lambda cv: gwindow_invariant(cv) if _dense(cv) else window_invariant(cv),) + OPS["dbl_add"][3:]
+OPS["gjdbl"] = (9, ("X", "Y", "Z", "W"), gwindow_invariant, lambda E, a, sw: list(gjdbl29(E, *a, wout=bool(sw))), 4)          # swap = WOUT
+OPS["zaddu"] = (10, ("x1", "y1", "x2", "y2", "z"), lambda cv: gtable_invariant(cv) if _dense(cv) else _iso_as_zaddu(cv), _op3(zaddu29), 6)
 OPS["pdbl"] = OPS["pdbl"][:2] + (lambda cv: complete_invariant(cv),) + OPS["pdbl"][3:]
 OPS["padd"] = OPS["padd"][:2] + (lambda cv: complete_invariant(cv),) + OPS["padd"][3:]
 
