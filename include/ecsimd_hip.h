@@ -184,10 +184,10 @@ int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id);
  * a curve registered with its order n >= 2^255 and both with OUT_AFFINE only: scalar_mult_base with ALG_WINDOWED [| ALG_CONSTANT_TIME] -- a 4-bit odd-digit
  * table of multiples of ITS generator in LDS, built from the ladder on first use -- and scalar_mult / scalar_mult_1s with ALG_WINDOWED on a variable base --
  * the lane's own table of the eight odd multiples of P over one Z, 63 windows of three doublings and a fused double-add in modified Jacobian coordinates
- * on the isomorphic curve (any coefficient a; 640 B of context workspace per element, 2^22 at a time; 1.4 x the ladder's rate) -- PUBLIC scalars only: the
- * table is indexed by the scalar's digits, and the group must have prime order (cofactor 1), as every table algorithm here assumes.  Either returns the
- * true k P for every k, (0, 0) for k = 0 mod n.  The other ALG_* shapes, ALG_CONSTANT_TIME on a variable base included, exist for the two built-in
- * curves only), by affine_add, sec1_encode, sec1_decode and -- when n was given, p < 2n, and
+ * on the isomorphic curve (any coefficient a; 640 B of context workspace per element, 2^22 at a time; 1.4 x the ladder's rate) -- public scalars: the table
+ * is indexed by the scalar's digits; with ALG_CONSTANT_TIME every entry of the lane's table is read in every window and one kept under lane masks: SAFE for
+ * secret scalars like the built-in curves' form (1.3 x the ladder).  The group must have prime order (cofactor 1), as every table algorithm here assumes.
+ * Either returns the true k P for every k, (0, 0) for k = 0 mod n.  The other ALG_* shapes exist for the two built-in curves only), by affine_add, sec1_encode, sec1_decode and -- when n was given, p < 2n, and
  * n - u is a good ladder scalar for u in {n - 1, 2^256 - n - 1, 2^256 - n} (every prime-order curve of this size) -- by double_scalar_mult,
  * ecdsa_verify_rx, ecdsa_verify, ecdsa_sign: u1 G (sign: k G, every table entry of a window read) comes from the generator's table, u2 Q (public) from the
  * lane's window table -- correct for every scalar in [0, n); ecdsa_sign's scratch is zeroed like the built-in curves'.  (n < 2^255: passes of the ladder

@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORDER = ["ladder", "ladder_secp256k1", "ladder_ref_compat_p256", "ladder_ref_compat_secp256k1", "ladder_x_only", "ladder_x_only_secp256k1",
          "windowed_variable_base", "windowed_variable_base_secp256k1", "windowed_constant_time", "windowed_constant_time_secp256k1", "fixed_base", "fixed_base_secp256k1", "fixed_base_constant_time", "fixed_base_constant_time_secp256k1", "fixed_base_signed7", "fixed_base_signed7_secp256k1", "fixed_base_big20",
-         "ladder_brainpoolP256r1", "ladder_sm2", "ladder_frp256v1", "ladder_radix32_brainpoolP256r1", "ladder_ref_compat_brainpoolP256r1", "ladder_radix32_p256",
+         "ladder_brainpoolP256r1", "ladder_sm2", "ladder_frp256v1", "windowed_variable_base_brainpoolP256r1", "windowed_variable_base_sm2", "windowed_variable_base_frp256v1", "windowed_constant_time_brainpoolP256r1", "ladder_radix32_brainpoolP256r1", "ladder_ref_compat_brainpoolP256r1", "ladder_radix32_p256",
          "group_mode", "nccl_single_rank_rehearsal"]
 LABEL = {
     "ladder": "**P-256 variable-base ladder, 2²⁴ per step (headline, BASELINE configs[3])**",
@@ -38,6 +38,10 @@ LABEL = {
     "ladder_brainpoolP256r1": "**(r5)** brainpoolP256r1 (a curve registered at run time: generic kernels, dense 9-limb prime in SGPRs), variable-base ladder, 2²⁴",
     "ladder_sm2": "**(r5)** SM2 (registered at run time), variable-base ladder, 2²⁴",
     "ladder_frp256v1": "**(r5)** FRP256v1 (registered at run time), variable-base ladder, 2²⁴",
+    "windowed_variable_base_brainpoolP256r1": "**(r5)** brainpoolP256r1 variable base, per-element window tables over one Z, modified Jacobian doublings on the isomorphic curve (`ALG_WINDOWED`, affine out; `k_gvarwin.hip`)",
+    "windowed_variable_base_sm2": "**(r5)** SM2 variable base, per-element window tables (`ALG_WINDOWED`)",
+    "windowed_variable_base_frp256v1": "**(r5)** FRP256v1 variable base, per-element window tables (`ALG_WINDOWED`)",
+    "windowed_constant_time_brainpoolP256r1": "**(r5)** brainpoolP256r1 variable base, per-element window tables, `ALG_CONSTANT_TIME` (all 8 entries read in every window: secret scalars)",
     "ladder_radix32_brainpoolP256r1": "**(r5)** brainpoolP256r1 ladder on 8 × 32-bit canonical words (`ECSIMD_HIP_LADDER_RADIX32`: generic word-serial reduction)",
     "ladder_ref_compat_brainpoolP256r1": "**(r5)** brainpoolP256r1 ladder with `ECSIMD_HIP_REF_SQUARE_COMPAT`",
     "ladder_radix32_p256": "P-256 ladder on 8 × 32-bit canonical words (`ECSIMD_HIP_LADDER_RADIX32`, rounds 1–3's loop)",
