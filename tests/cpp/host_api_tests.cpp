@@ -459,6 +459,7 @@ TEST(Curves, EcdsaAndSec1OnARegisteredCurve) {
   // a variable base: the lane's own window table (k_gvarwin.hip) = the ladder + to_affine, lane for lane; the curve without its order keeps the ladder
   const W256 ks2(300, [](size_t i, size_t) { bignum_256 b; b.limbs = {0xd1342543de82ef95ull * (i + 3), i * 131, ~(i << 7), 0xfedcba9876543210ull ^ (i << 33)}; return b; });
   EXPECT_TRUE(all(KG::scalar_mult_affine(ks2, ladder) == KG::scalar_mult_affine(ks2, ladder, false)));
+  EXPECT_TRUE(all(KG::scalar_mult_affine_secret(ks2, ladder) == KG::scalar_mult_affine(ks2, ladder, false)));   // ECDH on such a curve: every table entry read in every window
   bool no_order_refused = false;
   try { (void)curve_group<curve_brainpoolp256r1>::scalar_mult_affine(ks2, wide_curve_point<curve_brainpoolp256r1>{ladder.x(), ladder.y()}); }
   catch (std::exception const&) { no_order_refused = true; }

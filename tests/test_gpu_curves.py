@@ -563,7 +563,7 @@ def test_device_group_on_a_registered_curve(engine):
 
 
 def test_registered_curve_entry_points_replay_from_a_hip_graph(engine):
-    """The ladder, the generator's comb (small-batch route and ALG_WINDOWED), u1 G + u2 Q and ecdsa_verify on a registered curve captured into one hipGraph after a
+    """The ladder, the variable-base window loop (plain and constant-time), the generator's comb (small-batch route and ALG_WINDOWED), u1 G + u2 Q and ecdsa_verify on a registered curve captured into one hipGraph after a
     warm-up call (which builds the comb's table and the record of the degenerate scalars and sizes the workspace); new inputs in place, replay = eager calls."""
     import torch
     from ecsimd_amd import ALG_WINDOWED
@@ -572,10 +572,13 @@ def test_registered_curve_entry_points_replay_from_a_hip_graph(engine):
     n = 1 << 14
     k = engine.fill_random(n, SEED, 191, clear_top_bits=1); s = engine.fill_random(n, SEED, 192, clear_top_bits=1)
     bx, by = engine.scalar_mult_base(cid, s, flags=OUT_AFFINE)
-    J = [engine.empty(n) for _ in range(3)]; A = [engine.empty(n) for _ in range(2)]; W = [engine.empty(n) for _ in range(2)]
+    J = [engine.empty(n) for _ in range(3)]; A = [engine.empty(n) for _ in range(2)]; W = [engine.empty(n) for _ in range(2)]; VW = [engine.empty(n) for _ in range(2)]; VC = [engine.empty(n) for _ in range(2)]
+    from ecsimd_amd import ALG_CONSTANT_TIME
 
     def run():
         engine.scalar_mult(cid, k, bx, by, out=J)
+        engine.scalar_mult(cid, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED, out=VW + [None])                          # the lane's own window table: nothing to build beforehand
+        engine.scalar_mult(cid, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME, out=VC + [None])
         engine.scalar_mult_base(cid, k, flags=OUT_AFFINE, out=A + [None])                       # <= 2^16 lanes: the constant-time comb + the patch
         engine.scalar_mult_base(cid, k, flags=OUT_AFFINE | ALG_WINDOWED, out=W + [None])
         return engine.double_scalar_mult(cid, s, k, bx, by), engine.ecdsa_verify(cid, s, k, s, bx, by)
@@ -590,6 +593,8 @@ def test_registered_curve_entry_points_replay_from_a_hip_graph(engine):
     k.copy_(engine.fill_random(n, SEED, 193, clear_top_bits=1))
     g.replay(); torch.cuda.synchronize()
     got = [t.clone() for t in J + A + W + list(D) + [V]]
+    evw = engine.scalar_mult(cid, k, bx, by, flags=OUT_AFFINE)                                      # the window loops' points = the ladder's affine points
+    assert all(torch.equal(a, b) for a, b in zip(VW + VC, list(evw) + list(evw)))
     ej = engine.scalar_mult(cid, k, bx, by)
     ea = engine.scalar_mult_base(cid, k, flags=OUT_AFFINE | LADDER_RADIX32)                      # the ladder itself
     ed = engine.double_scalar_mult(cid, s, k, bx, by); ev = engine.ecdsa_verify(cid, s, k, s, bx, by)

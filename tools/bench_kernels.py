@@ -110,7 +110,7 @@ for cv, nm in ((P256, "p256"), (SECP256K1, "secp256k1")):
     wire = e.sec1_encode(cv, b2x, b2y, False)
     row(f"sec1_decode<{nm}> uncompressed (validation)", n2, timeit(lambda: e.sec1_decode(cv, wire, False)), 4 * 136, 65 + 64, "points")
     del k, s2, b2x, b2y, P2, outj, wire
-# (r5) a curve registered at run time: the reference's layers on the generic kernels, and the first application on top of its ladder (no tables for such a curve)
+# (r5) a curve registered at run time: the reference's layers on the generic kernels, its two table-driven algorithms, and the first application on top of them
 from ecsimd_amd.curves import curve_id
 for nm in ("brainpoolP256r1",):
     cv = curve_id(nm)
@@ -122,12 +122,15 @@ for nm in ("brainpoolP256r1",):
     row(f"scalar_mult<{nm}> ladder, Jacobian out (generic kernels, dense prime)", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=1, out=outj), 5), 555968, 192, "scalar mults")
     row(f"scalar_mult<{nm}> ladder, affine out", n2, timeit(lambda: e.scalar_mult(cv, k, P2[0], P2[1], flags=3, out=outj), 5), 555968 + 19 * 136, 160, "scalar mults")
     row(f"to_affine<{nm}> (simultaneous inversion)", n2, timeit(lambda: e.to_affine(cv, outj)), int((7 + 88 / 32) * 136), 256, "points")
+    vw = int((66 + 4 + 63 * 44 + 4 + 7 + 88 / 32) * 136)              # k_gvarwin.hip: the table over one Z, a' = a Zg^4, 63 windows x (25M + 19S), Z' Zg + the leaving products, the shared inversion
+    row(f"scalar_mult<{nm}> windowed variable base (the lane's table over one Z, modified Jacobian doublings), affine out", n2, timeit(lambda: e.scalar_mult(cv, k, b2x, b2y, flags=2 | 4, out=outj), 5), vw, 160, "scalar mults")
+    row(f"scalar_mult<{nm}> windowed variable base, constant time (every entry read in every window), affine out", n2, timeit(lambda: e.scalar_mult(cv, k, b2x, b2y, flags=2 | 4 | 128, out=outj), 5), vw, 160, "scalar mults")
     u1 = e.fill_random(n2, SEED, 21, clear_top_bits=1)
     comb = 63 * 11 * 136                                               # the generator's 4-bit comb: 63 mixed additions (8M + 3S)
     row(f"scalar_mult_base<{nm}> windowed (the generator's comb in LDS), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 4, out=outj)), comb + int((7 + 88 / 32) * 136), 96, "scalar mults")
     row(f"scalar_mult_base<{nm}> windowed, constant time (every entry of a window read), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 4 | 128, out=outj)), comb + int((7 + 88 / 32) * 136), 96, "scalar mults")
-    two = comb + 555968 + int((2 * (7 + 88 / 32) + 6 + 88 / 32) * 136)   # the comb, one ladder pass, two conversions, the affine addition with its shared inversion
-    row(f"double_scalar_mult<{nm}> u1*G + u2*Q (the comb + one pass of the ladder)", n2, timeit(lambda: e.double_scalar_mult(cv, u1, k, b2x, b2y), 5), two, 160, "verifications")
+    two = comb + vw + int(((7 + 88 / 32) + 6 + 88 / 32) * 136)        # the comb and its conversion, the window loop (its conversion inside vw), the affine addition with its shared inversion
+    row(f"double_scalar_mult<{nm}> u1*G + u2*Q (the comb + the lane's window table)", n2, timeit(lambda: e.double_scalar_mult(cv, u1, k, b2x, b2y), 5), two, 160, "verifications")
     rr = e.fill_random(n2, SEED, 22, clear_top_bits=1); ss = e.fill_random(n2, SEED, 23, clear_top_bits=1)
     row(f"ecdsa_verify<{nm}> (e, r, s, Q -> ok)", n2, timeit(lambda: e.ecdsa_verify(cv, u1, rr, ss, b2x, b2y), 5), two + 6 * 136, 161, "verifications")
     row(f"ecdsa_sign<{nm}> (e, d, k -> r, s: k G on the constant-time comb)", n2, timeit(lambda: e.ecdsa_sign(cv, u1, rr, ss), 5), comb + int((4 + 88 / 32 + 9 + 7) * 136), 160, "signatures")

@@ -160,6 +160,20 @@ import json; d=json.load(open('$out/bench_brainpool_$w.json')); r=d['roofline'];
     bash tools/profile.sh r05_windowed_brainpoolP256r1 --workload windowed --curve brainpoolP256r1 > "$out/profile.txt" 2>&1 || { rc=$?; tail -5 "$out/profile.txt"; }
     echo "profiled rc=$rc"; [ $rc -ne 0 ] && exit $rc
     timeout -k 10 600 python tools/soak_windowed.py 22 ${1:-4} brainpoolP256r1,sm2,frp256v1 > "$out/soak_alg.txt" 2>&1; rc=$?; tail -4 "$out/soak_alg.txt"; exit $rc ;;
+  r5_gvw_profile2)  # round 5: counter passes for the window loop's remaining lines (no bench line without its traffic)
+    rc=0
+    prof() { tag=$1; shift; bash tools/profile.sh "r05_$tag" "$@" > "$out/profile_$tag.txt" 2>&1 || { rc=$?; tail -5 "$out/profile_$tag.txt"; }; echo "profiled $tag rc=$rc"; }
+    prof windowed_sm2 --workload windowed --curve sm2
+    prof windowed_frp256v1 --workload windowed --curve frp256v1
+    prof windowed_ct_brainpoolP256r1 --workload windowed-ct --curve brainpoolP256r1
+    exit $rc ;;
+  r5_gvw_relines)   # round 5: the window loop's bench lines again, with the committed counter traffic in them
+    rc=0; mkdir -p "$out/lines"
+    line() { f=$1; shift; timeout -k 10 400 python3 bench.py --steps 10 --warmup 2 "$@" > "$out/lines/$f.json" 2> "$out/lines/$f.err" || rc=$?
+      python3 -c "import json; d=json.load(open('$out/lines/$f.json')); print('$f %.3f M/s  frac %.3f traffic %s' % (d['value']/1e6, d['roofline']['frac'], d['roofline']['traffic']))" || { tail -5 "$out/lines/$f.err"; rc=1; }; }
+    for c in brainpoolP256r1 sm2 frp256v1; do line bench_n1_windowed_variable_base_$c --curve $c --workload windowed; done
+    line bench_n1_windowed_constant_time_brainpoolP256r1 --curve brainpoolP256r1 --workload windowed-ct
+    exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
     timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -15 "$out/pytest.txt"; exit $rc ;;
   *) echo "unknown step $name"; exit 2 ;;
