@@ -26,7 +26,21 @@ def shipped_flags():
     return flags.replace("$(ARCH)", arch).split()
 
 
+_made = []
+
+
 def assembly(tmp_path_factory, unit, extra=()):
+    """The gfx950 listing of one translation unit.  Without extra flags: the listing the Makefile left beside the object it linked into libecsimd_hip.so
+    (-save-temps=obj; `make` first, a no-op when the tree is built) -- the ISA that SHIPS, and no second compilation (a third of the CPU suite's time until
+    round 5).  With extra flags (the refused build variants): compiled here with the Makefile's own flags."""
+    if not extra:
+        if not _made:
+            subprocess.run(["make", "-j", str(min(8, os.cpu_count() or 1)), "-C", CSRC, "ARCH=gfx950"], check=True, capture_output=True, timeout=1800)
+            _made.append(True)
+        listing = os.path.join(ROOT, "build", "csrc", unit + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+        assert os.path.exists(listing), "the Makefile no longer leaves the device listings in build/csrc (-save-temps=obj)"
+        assert os.path.getmtime(listing) >= os.path.getmtime(os.path.join(CSRC, unit + ".hip")), listing
+        return open(listing).read()
     out = tmp_path_factory.mktemp("isa") / (unit + "".join(extra).replace("=", "_").replace("-", "") + ".s")
     cmd = ["hipcc"] + [f for f in shipped_flags() if f != "-fPIC"] + list(extra) + ["-S", "--cuda-device-only", os.path.join(CSRC, unit + ".hip"), "-o", str(out)]
     subprocess.run(cmd, check=True, capture_output=True, cwd=CSRC, timeout=900)
