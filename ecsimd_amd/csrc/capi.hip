@@ -532,7 +532,48 @@ void u_limbs29(int32_t (&out)[9], const u256& v) {                      // tight
     out[i] = (int32_t)(w & (i < 8 ? 0x1fffffffu : 0xffffffu));
   }
 }
-struct curve_record { gcurve G; u256 a, b, n; bool has_order; gmod N; bool ecdsa_ok; };
+struct curve_record { gcurve G; u256 a, b, n; bool has_order; gmod N; bool ecdsa_ok; bool prime_order; };
+// What a per-lane window table of a VARIABLE base needs beyond the recoding's n >= 2^255: every point on the curve but infinity has order exactly n, so that
+// "no addition inside the loop is exceptional" -- a statement about scalars modulo the ORDER OF THE POINT -- holds for every valid input, not only for
+// multiples of the generator.  That is: the group has order n (n divides #E and lies in p's Hasse interval, where no second multiple of an n >= 2^255 fits)
+// and n is prime.  Checked once per registration on the host: the Hasse test exactly ((|n - p - 1| / 2 rounded up)^2 <= p; conservative by at most one
+// at the interval's edge), primality by Miller-Rabin on 16 fixed bases -- a guard against a wrong parameter set, not against a forged one (the caller vouches
+// for p's primality in the same way).
+bool u_hasse(const u256& n, const u256& p) {
+  u256 p1 = p; { int i = 0; while (i < 4 && ++p1.l[i] == 0) ++i; if (i == 4) return false; }
+  u256 d; if (u_geq(n, p1)) (void)u_sub(d, n, p1); else (void)u_sub(d, p1, n);
+  if (d.l[3] || d.l[2] > 1) return false;                              // 2 sqrt(p) < 2^129
+  unsigned __int128 e = ((unsigned __int128)d.l[1] << 64) | d.l[0];
+  e = ((e >> 1) | ((unsigned __int128)d.l[2] << 127)) + (d.l[0] & 1);   // ceil(d / 2) <= 2^128
+  if (e == 0 && (d.l[2] | d.l[1] | d.l[0])) return false;              // (it was 2^128: beyond sqrt(p))
+  const uint64_t e0 = (uint64_t)e, e1 = (uint64_t)(e >> 64);
+  const unsigned __int128 lo = (unsigned __int128)e0 * e0, mid = (unsigned __int128)e0 * e1, hi = (unsigned __int128)e1 * e1;
+  u256 sq; unsigned __int128 c;
+  sq.l[0] = (uint64_t)lo;
+  c = (lo >> 64) + (uint64_t)mid + (uint64_t)mid; sq.l[1] = (uint64_t)c;
+  c = (c >> 64) + (mid >> 64) + (mid >> 64) + (uint64_t)hi; sq.l[2] = (uint64_t)c;
+  c = (c >> 64) + (hi >> 64); sq.l[3] = (uint64_t)c;
+  if (c >> 64) return false;
+  return u_geq(p, sq);
+}
+bool u_probable_prime(const u256& n) {
+  if (!(n.l[0] & 1u) || (!(n.l[3] | n.l[2] | n.l[1]) && n.l[0] < 128)) return false;       // (the callers' n is odd and >= 2^255)
+  const u256 one = {{1, 0, 0, 0}};
+  u256 nm1; (void)u_sub(nm1, n, one);
+  int s = 0; u256 d = nm1;
+  while (!(d.l[0] & 1u)) { for (int i = 0; i < 3; ++i) d.l[i] = (d.l[i] >> 1) | (d.l[i + 1] << 63); d.l[3] >>= 1; ++s; }
+  static const uint64_t bases[16] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53};
+  for (uint64_t b : bases) {
+    const u256 a = {{b, 0, 0, 0}};
+    u256 x = one;
+    for (int i = 255; i >= 0; --i) { x = u_mul_mod(x, x, n); if ((d.l[i >> 6] >> (i & 63)) & 1u) x = u_mul_mod(x, a, n); }
+    if (u_eq(x, one) || u_eq(x, nm1)) continue;
+    bool witness = true;
+    for (int r = 1; r < s && witness; ++r) { x = u_mul_mod(x, x, n); if (u_eq(x, nm1)) witness = false; }
+    if (witness) return false;
+  }
+  return true;
+}
 // the reference ladder's degenerate scalars for a group of order nn (ladder_degenerate above works on uint64_t[4])
 bool u_ladder_degenerate(const u256& nn, const u256& k) { return ladder_degenerate(nn.l, k.l); }
 struct curve_registry { std::mutex mu; std::vector<curve_record> curves; };
@@ -736,10 +777,22 @@ int ecsimd_hip_register_curve(const uint64_t p[4], const uint64_t a[4], const ui
           o.has_order == rec.has_order && (!rec.has_order || u_eq(o.n, N))) { *curve_id = FIRST_CURVE_ID + (int)i; return ECSIMD_HIP_OK; }
     }
     if (r.curves.size() >= (size_t)MAX_CURVES) return ECSIMD_HIP_ERR_BAD_ARG;
+    rec.prime_order = rec.has_order && (N.l[3] >> 63) != 0 && u_hasse(N, P) && u_probable_prime(N);   // (a new record only: ~0.1 s of host arithmetic)
     r.curves.push_back(rec);
     *curve_id = FIRST_CURVE_ID + (int)r.curves.size() - 1;
     return ECSIMD_HIP_OK;
   } catch (...) { return ECSIMD_HIP_ERR_BAD_ARG; }
+}
+
+int ecsimd_hip_curve_capabilities(int curve, int* caps) {
+  if (!caps) return ECSIMD_HIP_ERR_BAD_ARG;
+  const int all = ECSIMD_HIP_CURVE_HAS_ORDER | ECSIMD_HIP_CURVE_COMB | ECSIMD_HIP_CURVE_ECDSA | ECSIMD_HIP_CURVE_WINDOW_VARIABLE_BASE;
+  if (curve == ECSIMD_HIP_P256 || curve == ECSIMD_HIP_SECP256K1) { *caps = all; return ECSIMD_HIP_OK; }
+  curve_record rec; if (!lookup_curve_record(curve, &rec)) return ECSIMD_HIP_ERR_BAD_ARG;
+  const bool comb = rec.has_order && (rec.n.l[3] >> 63) != 0;
+  *caps = (rec.has_order ? ECSIMD_HIP_CURVE_HAS_ORDER : 0) | (comb ? ECSIMD_HIP_CURVE_COMB : 0) | (rec.has_order && rec.ecdsa_ok ? ECSIMD_HIP_CURVE_ECDSA : 0) |
+          (comb && rec.prime_order ? ECSIMD_HIP_CURVE_WINDOW_VARIABLE_BASE : 0);
+  return ECSIMD_HIP_OK;
 }
 
 int ecsimd_hip_get_constant(int curve, int which, uint64_t out[4]) {
@@ -1197,6 +1250,7 @@ gc_layout gc_plan(uint64_t* base, size_t n, bool win = false) {
 // layout).  Needs the order (the recoding works modulo n) with n >= 2^255 (k mod n by one subtraction).  Every entry comes from the reference's ladder on this
 // curve -- whose degenerate scalars the entries' multipliers must not be (checked; k* by way of n - k* if it is one) -- through the shared inversion.
 bool gc_comb_possible(const curve_record& rec) { return rec.has_order && (rec.n.l[3] >> 63) != 0; }
+bool gc_window_possible(const curve_record& rec) { return gc_comb_possible(rec) && rec.prime_order; }    // a variable base: every point has order n (curve_record)
 int ensure_gc_comb(ecsimd_hip_ctx* ctx, int curve, const curve_record& rec, const uint32_t** out) {
   for (auto& t : ctx->gcomb) if (t.curve == curve) { *out = t.table; return ECSIMD_HIP_OK; }
   if (!gc_comb_possible(rec)) return bad(ctx, "the windowed algorithms on a registered curve need its group order n, n >= 2^255");
@@ -1314,6 +1368,7 @@ int run_gvarwin(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride,
   if (flags & ECSIMD_HIP_LADDER_RADIX32) return bad(ctx, "LADDER_RADIX32 selects a ladder loop: not with ALG_WINDOWED");
   curve_record rec; if (!lookup_curve_record(curve, &rec)) return bad(ctx, "unknown curve id");
   if (!gc_comb_possible(rec)) return bad(ctx, "the windowed algorithms on a registered curve need its group order n, n >= 2^255");
+  if (!gc_window_possible(rec)) return bad(ctx, "ALG_WINDOWED on a variable base needs a group of prime order: n is not a prime in p's Hasse interval (the ladder has no such condition)");
   if (n == 0) return ECSIMD_HIP_OK;
   hipError_t e = hipSetDevice(ctx->device);
   if (e != hipSuccess) return fail(ctx, e, "hipSetDevice");
@@ -1370,7 +1425,7 @@ void gc_safe_mult(hipStream_t s, const curve_record& rec, const gc_layout& L, ui
 int gc_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve_of, const curve_record& rec, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy,
                           uint64_t* rx, uint64_t* ry, uint8_t* finite, size_t n, size_t reserve_behind) {
   (void)hipSetDevice(ctx->device);
-  const bool win = gc_comb_possible(rec);                           // u2 Q from the lane's own window table where the curve has its order (n >= 2^255), else a ladder pass
+  const bool win = gc_window_possible(rec);                         // u2 Q from the lane's own window table where the curve has a prime order n >= 2^255, else a ladder pass
   gc_layout L = gc_plan(nullptr, n, win);
   int rc = ensure_workspace(ctx, L.bytes + reserve_behind);
   if (rc == ECSIMD_HIP_OK) rc = ensure_valid(ctx, (n + 15) / 16 * 16);
@@ -1395,7 +1450,7 @@ int gc_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve_of, const curve_record&
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "double_scalar_mult (registered curve) launch");
 }
 int gc_ecdsa_verify_rx(ecsimd_hip_ctx* ctx, int curve_of, const curve_record& rec, const uint64_t* u1, const uint64_t* u2, const uint64_t* qx, const uint64_t* qy, const uint64_t* r, uint8_t* ok, size_t n, size_t extra) {
-  const gc_layout L0 = gc_plan(nullptr, n, gc_comb_possible(rec));
+  const gc_layout L0 = gc_plan(nullptr, n, gc_window_possible(rec));
   const size_t behind = n * 32 + ((n + 15) / 16) * 16;
   int rc = ensure_workspace(ctx, L0.bytes + behind + extra);
   if (rc != ECSIMD_HIP_OK) return rc;
@@ -1482,7 +1537,7 @@ int ecsimd_hip_ecdsa_verify(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, c
     if (n == 0) return ECSIMD_HIP_OK;
     if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
     (void)hipSetDevice(ctx->device);
-    const gc_layout L0 = gc_plan(nullptr, n, gc_comb_possible(rec));
+    const gc_layout L0 = gc_plan(nullptr, n, gc_window_possible(rec));
     const size_t behind = n * 32 + ((n + 15) / 16) * 16, extra = 2 * n * 32 + ((n + 15) / 16) * 16;
     rc = ensure_workspace(ctx, L0.bytes + behind + extra);
     if (rc != ECSIMD_HIP_OK) return rc;

@@ -456,6 +456,19 @@ def register_curve(p: int, a: int, b: int, gx: int, gy: int, n: int | None = Non
     return cid.value
 
 
+CURVE_HAS_ORDER, CURVE_COMB, CURVE_ECDSA, CURVE_WINDOW_VARIABLE_BASE = 1, 2, 4, 8
+
+
+def curve_capabilities(curve: int) -> int:
+    """ecsimd_hip_curve_capabilities: what an id can do beyond the reference's layers (a mask of CURVE_*; host only)."""
+    lib = load_library()
+    caps = C.c_int(0)
+    rc = lib.ecsimd_hip_curve_capabilities(C.c_int(curve), C.byref(caps))
+    if rc != 0:
+        raise EcsimdHipError(f"ecsimd_hip_curve_capabilities({curve}) -> {rc}: unknown curve id")
+    return caps.value
+
+
 def shard_range_c(n_total: int, member: int, members: int):
     """ecsimd_hip_shard_range: the C ABI's partition of a batch over a device group (pure host arithmetic)."""
     lib = load_library()

@@ -186,7 +186,9 @@ int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id);
  * the lane's own table of the eight odd multiples of P over one Z, 63 windows of three doublings and a fused double-add in modified Jacobian coordinates
  * on the isomorphic curve (any coefficient a; 640 B of context workspace per element, 2^22 at a time; 1.4 x the ladder's rate) -- public scalars: the table
  * is indexed by the scalar's digits; with ALG_CONSTANT_TIME every entry of the lane's table is read in every window and one kept under lane masks: SAFE for
- * secret scalars like the built-in curves' form (1.3 x the ladder).  The group must have prime order (cofactor 1), as every table algorithm here assumes.
+ * secret scalars like the built-in curves' form (1.3 x the ladder).  The group must have prime order (cofactor 1: every valid point then has order n, which
+ * is what "no addition inside the loop is exceptional" rests on) -- CHECKED at registration (n in p's Hasse interval, Miller-Rabin: ecsimd_hip_curve_capabilities);
+ * an id without it keeps the ladder for a variable base (BAD_ARG for the flag, ladder passes inside double_scalar_mult / ecdsa_verify).
  * Either returns the true k P for every k, (0, 0) for k = 0 mod n.  The other ALG_* shapes exist for the two built-in curves only), by affine_add, sec1_encode, sec1_decode and -- when n was given, p < 2n, and
  * n - u is a good ladder scalar for u in {n - 1, 2^256 - n - 1, 2^256 - n} (every prime-order curve of this size) -- by double_scalar_mult,
  * ecdsa_verify_rx, ecdsa_verify, ecdsa_sign: u1 G (sign: k G, every table entry of a window read) comes from the generator's table, u2 Q (public) from the
@@ -198,6 +200,12 @@ int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id);
  * (81 multiply-adds per reduction where P-256's sparse form has 36); LADDER_RADIX32 / REF_SQUARE_COMPAT run them on 8 x 32-bit canonical words.
  * Process-wide, thread-safe, ids live as long as the process. */
 enum { ECSIMD_HIP_CURVE_GENERIC_KERNELS = 1 };
+/* What an id can do beyond the reference's layers (host only, no context): caps = a mask of
+ *   HAS_ORDER (registered with n), COMB (ALG_WINDOWED [| ALG_CONSTANT_TIME] on its generator: n >= 2^255), ECDSA (double_scalar_mult, ecdsa_*: p < 2n and the
+ *   ladder's degenerate scalars have good images), WINDOW_VARIABLE_BASE (ALG_WINDOWED [| ALG_CONSTANT_TIME] on a variable base: n >= 2^255, n lies in p's Hasse
+ *   interval -- so the group HAS order n -- and n passes Miller-Rabin: every point but infinity has order n).  The two built-in ids report all four. */
+enum { ECSIMD_HIP_CURVE_HAS_ORDER = 1, ECSIMD_HIP_CURVE_COMB = 2, ECSIMD_HIP_CURVE_ECDSA = 4, ECSIMD_HIP_CURVE_WINDOW_VARIABLE_BASE = 8 };
+int ecsimd_hip_curve_capabilities(int curve, int* caps);
 int ecsimd_hip_register_curve(const uint64_t p[4], const uint64_t a[4], const uint64_t b[4], const uint64_t gx[4], const uint64_t gy[4],
                               const uint64_t n[4], int flags, int* curve_id);
 

@@ -185,6 +185,25 @@ def test_curve_registry_without_a_gpu(lib, oracle):
     without = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"])
     other = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"] + 2)
     assert len({with_n, without, other}) == 3 and register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"]) == with_n and register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"]) == without
+    # what an id can do beyond the reference's layers is decided at registration, on the host (ecsimd_hip_curve_capabilities): the variable-base window loop
+    # needs a group of PRIME order -- n in p's Hasse interval and a Miller-Rabin prime -- since only then does every valid point have order n
+    from ecsimd_amd.engine import curve_capabilities, CURVE_HAS_ORDER, CURVE_COMB, CURVE_ECDSA, CURVE_WINDOW_VARIABLE_BASE
+    everything = CURVE_HAS_ORDER | CURVE_COMB | CURVE_ECDSA | CURVE_WINDOW_VARIABLE_BASE
+    assert curve_capabilities(P256) == everything and curve_capabilities(SECP256K1) == everything
+    for name, rc in REF_CURVES.items():
+        assert curve_capabilities(register_curve(rc["p"], rc["a"], rc["b"], rc["gx"], rc["gy"], rc["n"])) == everything, name
+    assert curve_capabilities(with_n) == everything and curve_capabilities(without) == 0
+    assert curve_capabilities(other) & (CURVE_HAS_ORDER | CURVE_COMB | CURVE_WINDOW_VARIABLE_BASE) == CURVE_HAS_ORDER | CURVE_COMB      # n + 2 = 3 * 5 * ...: in the interval, not a prime
+    assert (c["n"] + 2) % 3 == 0
+    far = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], CURVE_PARAMS[P256]["n"])                                        # a prime, but 2^253 away from p + 1: not this group's order
+    assert curve_capabilities(far) & (CURVE_COMB | CURVE_WINDOW_VARIABLE_BASE) == CURVE_COMB
+    edge = 2 * int(c["p"] ** 0.5)                                                                                                  # the Hasse bound itself (float sqrt: within 2^-52 of it)
+    for cv in (P256, SECP256K1):                                                                                                   # ... and the generic registration of the built-in curves
+        bc = CURVE_PARAMS[cv]
+        assert curve_capabilities(register_curve(bc["p"], bc["a"], bc["b"], bc["gx"], bc["gy"], bc["n"], generic_kernels=True)) == everything
+    assert abs(c["n"] - c["p"] - 1) < edge
+    with pytest.raises(EcsimdHipError):
+        curve_capabilities(FIRST_REGISTERED_CURVE + 4000)
     cid = C.c_int()
     assert lib.ecsimd_hip_register_curve(None, None, None, None, None, None, C.c_int(0), C.byref(cid)) == -1
     assert lib.ecsimd_hip_get_constant(C.c_int(FIRST_REGISTERED_CURVE + 4000), C.c_int(0), (C.c_uint64 * 4)()) == -1

@@ -247,6 +247,16 @@ def test_registered_curve_entry_points_that_do_not_exist_say_so(engine, oracle):
         engine.scalar_mult_base(noorder, k, flags=OUT_AFFINE | ALG_WINDOWED)   # the comb recodes modulo n
     with pytest.raises(EcsimdHipError, match="group order"):
         engine.scalar_mult(noorder, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)   # and so does the window loop
+    # ... and the window loop of a VARIABLE base needs that order to be a prime in p's Hasse interval (then every valid point has order n): brainpoolP256r1 with
+    # n + 2 = 3 * ... keeps the comb of its generator (a statement about multiples of G alone) and the ladder, and refuses the per-lane tables
+    from ecsimd_amd.engine import curve_capabilities, CURVE_COMB, CURVE_WINDOW_VARIABLE_BASE
+    composite = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"] + 2)
+    assert curve_capabilities(composite) & (CURVE_COMB | CURVE_WINDOW_VARIABLE_BASE) == CURVE_COMB and curve_capabilities(cid) & CURVE_WINDOW_VARIABLE_BASE
+    with pytest.raises(EcsimdHipError, match="prime order"):
+        engine.scalar_mult(composite, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)
+    lx, ly = engine.scalar_mult(composite, k, bx, by, flags=OUT_AFFINE)                    # the ladder has no such condition
+    wx, wy = engine.scalar_mult(cid, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)
+    assert np.array_equal(engine.to_numpy(lx), engine.to_numpy(wx)) and np.array_equal(engine.to_numpy(ly), engine.to_numpy(wy))
 
 
 # ---------------------------------------------------------------- the first application on a registered curve: ECDSA, u1 G + u2 Q, SEC1 (round 5)
