@@ -71,6 +71,16 @@ int main(void) {
     CHECK(ecsimd_hip_scalar_mult_host(ctx, cid, &hk[0][0], NULL, NULL, &lx[0][0], &ly[0][0], NULL, N, ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_BASE_GENERATOR | ECSIMD_HIP_LADDER_RADIX32));   /* the ladder */
     CHECK(ecsimd_hip_scalar_mult_host(ctx, cid, &hk[0][0], NULL, NULL, &cx[0][0], &cy[0][0], NULL, N, ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_BASE_GENERATOR | ECSIMD_HIP_ALG_WINDOWED));   /* the generator's comb */
     if (memcmp(lx, cx, sizeof lx) != 0 || memcmp(ly, cy, sizeof ly) != 0) { fprintf(stderr, "registered curve: the comb differs from the ladder\n"); return 1; }
+    {   /* a variable base through the lane's own window table (k_gvarwin.hip), plain and constant-time: k (k G) = the ladder's points */
+      int caps = 0; uint64_t (*vx)[4] = cx, (*vy)[4] = cy; static uint64_t ex[N][4], ey[N][4];
+      CHECK(ecsimd_hip_curve_capabilities(cid, &caps));
+      if (!(caps & ECSIMD_HIP_CURVE_WINDOW_VARIABLE_BASE)) { fprintf(stderr, "curve_capabilities: %d\n", caps); return 1; }
+      CHECK(ecsimd_hip_scalar_mult_host(ctx, cid, &hk[0][0], &lx[0][0], &ly[0][0], &ex[0][0], &ey[0][0], NULL, N, ECSIMD_HIP_OUT_AFFINE));
+      CHECK(ecsimd_hip_scalar_mult_host(ctx, cid, &hk[0][0], &lx[0][0], &ly[0][0], &vx[0][0], &vy[0][0], NULL, N, ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_ALG_WINDOWED));
+      if (memcmp(ex, vx, sizeof ex) != 0 || memcmp(ey, vy, sizeof ey) != 0) { fprintf(stderr, "registered curve: the window loop differs from the ladder\n"); return 1; }
+      CHECK(ecsimd_hip_scalar_mult_host(ctx, cid, &hk[0][0], &lx[0][0], &ly[0][0], &vx[0][0], &vy[0][0], NULL, N, ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_CONSTANT_TIME));
+      if (memcmp(ex, vx, sizeof ex) != 0 || memcmp(ey, vy, sizeof ey) != 0) { fprintf(stderr, "registered curve: the constant-time window loop differs from the ladder\n"); return 1; }
+    }
     CHECK(ecsimd_hip_malloc(ctx, (void**)&w, N * 32));
     CHECK(ecsimd_hip_memcpy_h2d(ctx, x, lx, N * 32));
     CHECK(ecsimd_hip_lanes_to_wide4(ctx, x, w, 128, 0, N / 4));                       /* N / 4 wides of four lanes, limb-major */
