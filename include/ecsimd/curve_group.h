@@ -17,6 +17,8 @@ struct curve_group {
   using WCP = wide_curve_point<Curve>;
   using WJCP = wide_jacobian_curve_point<Curve>;
   static int curve_id() { return WJCP::curve_id(); }
+  // what this curve's id can do beyond the reference's layers (ecsimd_hip_curve_capabilities): decided once, at registration
+  static bool can(int capability) { static const int caps = [] { int c = 0; hip::check(ecsimd_hip_curve_capabilities(curve_id(), &c), "ecsimd_hip_curve_capabilities"); return c; }(); return (caps & capability) != 0; }
 
   static BN Am() { return curve_constant(8); }      // curve_group.h:32
   static BN Bm() { return curve_constant(9); }      // curve_group.h:31
@@ -70,12 +72,14 @@ struct curve_group {
   // ---- extensions (not in the reference): affine-level entry points over the faster algorithms of the C ABI.
   // Same points as to_affine() of the ladder's result for every scalar where the ladder is non-degenerate.
   // k[i] * P[i], P affine classical -> affine classical.  windowed: per-element tables of 8 multiples of P + signed 4-bit
-  // windows (ECSIMD_HIP_ALG_WINDOWED); otherwise the reference ladder followed by one simultaneous inversion.
+  // windows (ECSIMD_HIP_ALG_WINDOWED); otherwise the reference ladder followed by one simultaneous inversion.  A curve registered at run time has the
+  // tables when it names a prime order N >= 2^255 (ECSIMD_HIP_CURVE_WINDOW_VARIABLE_BASE); without it the same points come from the ladder.
   static WCP scalar_mult_affine(WBN const& x, WCP const& P, bool windowed = true) {
     same_length(x.size(), P.size(), "scalar_mult_affine");
     WCP r{WBN::uninitialized(P.size()), WBN::uninitialized(P.size())};
+    const bool tables = windowed && can(ECSIMD_HIP_CURVE_WINDOW_VARIABLE_BASE);
     hip::check(ecsimd_hip_scalar_mult(hip::context(), curve_id(), x.data(), P.x().data(), P.y().data(), r.x().data(), r.y().data(), nullptr, P.size(),
-                                      ECSIMD_HIP_BASE_CLASSICAL | ECSIMD_HIP_OUT_AFFINE | (windowed ? ECSIMD_HIP_ALG_WINDOWED : 0)), "ecsimd_hip_scalar_mult");
+                                      ECSIMD_HIP_BASE_CLASSICAL | ECSIMD_HIP_OUT_AFFINE | (tables ? ECSIMD_HIP_ALG_WINDOWED : 0)), "ecsimd_hip_scalar_mult");
     return r;
   }
   // A + B for every input, unlike ADD_Z2_1: A = B, A = -B (Z = 0 comes back), A at infinity (Z = 0); B.z must be mgry(1).
@@ -98,8 +102,9 @@ struct curve_group {
   static WCP scalar_mult_affine_secret(WBN const& x, WCP const& P) {
     same_length(x.size(), P.size(), "scalar_mult_affine_secret");
     WCP r{WBN::uninitialized(P.size()), WBN::uninitialized(P.size())};
+    const int alg = can(ECSIMD_HIP_CURVE_WINDOW_VARIABLE_BASE) ? (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_CONSTANT_TIME) : 0;      // (without the tables: the ladder, constant-time as it is)
     hip::check(ecsimd_hip_scalar_mult(hip::context(), curve_id(), x.data(), P.x().data(), P.y().data(), r.x().data(), r.y().data(), nullptr, P.size(),
-                                      ECSIMD_HIP_BASE_CLASSICAL | ECSIMD_HIP_OUT_AFFINE | ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_CONSTANT_TIME), "ecsimd_hip_scalar_mult");
+                                      ECSIMD_HIP_BASE_CLASSICAL | ECSIMD_HIP_OUT_AFFINE | alg), "ecsimd_hip_scalar_mult");
     return r;
   }
   // k[i] * G for SECRET scalars (key generation, ECDSA nonces): an LDS comb with ECSIMD_HIP_ALG_CONSTANT_TIME -- every table entry of a
