@@ -648,16 +648,18 @@ def committed_pipe(args, n):
     how many instructions a scalar multiplication really issues, how many of them multiply, that a SIMD issues one every ~4 cycles all the time, and how much
     of the elapsed time the instruction mix alone accounts for at the measured per-instruction issue costs.  Not measured in this run (like `traffic`)."""
     path = os.path.join(ROOT, "profiles", "pmc_pipe.json")
-    key = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult_refsqr", "ladder-radix32": "k_scalar_mult_radix32", "fixed-base": "fixed_base"}.get(args.workload)
+    key = {"ladder": "k_scalar_mult", "ladder-ref-compat": "k_scalar_mult_refsqr", "ladder-radix32": "k_scalar_mult_radix32", "fixed-base": "fixed_base",
+           "windowed": "varwin", "windowed-ct": "varwin_ct"}.get(args.workload)
     try:
-        rec = json.load(open(path))["kernels"].get(f"{key}_{args.curve}_2^24") if key else None
+        kernels = json.load(open(path))["kernels"]
+        rec = (kernels.get(f"{key}_{args.curve}_2^24") or kernels.get(f"{key}_{args.curve}_2^22")) if key else None      # (the window loops run in chunks of 2^22 lanes)
     except (OSError, ValueError):
         rec = None
     if not rec or "issue_bound_frac" not in rec:
         return {}
     return {"valu_instructions_per_unit": rec["valu_instructions_per_unit"], "multiply_instructions_per_unit": rec["multiply_instructions_per_unit"],
             "cycles_per_valu_instruction_per_simd": rec["cycles_per_valu_instruction_per_simd"], "issue_bound_frac": rec["issue_bound_frac"],
-            "pipe_source": f"profiles/pmc_pipe.json ({rec['source']} + the ISA of build/csrc/{rec['isa_unit']}: tools/pipe_model.py); at 2^24 lanes per launch, not measured in this run"}
+            "pipe_source": f"profiles/pmc_pipe.json ({rec['source']} + the ISA of build/csrc/{rec['isa_unit']}: tools/pipe_model.py; kernel {rec['kernel']}); at 2^{rec['lanes_per_launch'].bit_length() - 1} lanes per launch, not measured in this run"}
 
 
 def committed_traffic(args, n):

@@ -38,6 +38,9 @@ KERNELS = {
     "k_scalar_mult_refsqr_p256_2^24": ("k_ladder_p256_refsqr", "13k_scalar_multILi32E", 254, "ladder_ref_compat", "k_scalar_mult<32>"),
     "k_scalar_mult_refsqr_secp256k1_2^24": ("k_ladder_secp256k1_refsqr", "13k_scalar_multILi32E", 254, "ladder_ref_compat_secp256k1", "k_scalar_mult<32>"),
     "k_scalar_mult_brainpoolP256r1_2^24": ("k_gladder", "16k_gc_scalar_multILi29ELb0E", 254, "ladder_brainpoolP256r1", "k_gc_scalar_mult<29, false>"),
+    # the window loop of a registered curve (k_gvarwin.hip; launched in chunks of 2^22 lanes: 63 windows per launch; the table kernel is 4 % of a chunk)
+    "varwin_brainpoolP256r1_2^22": ("k_gvarwin", "10k_gvw_multILb0E", 63, "windowed_brainpoolP256r1", "k_gvw_mult<false>"),
+    "varwin_ct_brainpoolP256r1_2^22": ("k_gvarwin", "10k_gvw_multILb1E", 63, "windowed_ct_brainpoolP256r1", "k_gvw_mult<true>"),
 }
 
 
