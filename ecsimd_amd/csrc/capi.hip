@@ -84,7 +84,7 @@ struct ecsimd_hip_ctx {
   uint8_t* valid;              // grow-only: per-lane public-key validity of double_scalar_mult / ecdsa_verify_rx
   size_t valid_bytes;
   int ref_square;              // ecsimd_hip_set_ref_square_compat: the reference's square() as written (mul.h:160-212)
-  struct gcomb_entry { int curve; uint32_t* table; uint64_t* special; };
+  struct gcomb_entry { int curve; uint32_t* table; uint64_t* special; uint32_t* table7; };      // table7: the signed 7-bit comb (ALG_WINDOWED_SIGNED)
   std::vector<gcomb_entry> gcomb;   // per registered curve: the 4-bit odd-digit table of multiples of its generator (k_gcomb.hip) and, for the small-batch route, the ladder's
                                     // three degenerate scalars with its affine results for them on G (as base_special); built on first use
   ecsimd_hip_ctx* helper;      // ecsimd_hip_scalar_mult_host: the second stream's context (created on first use, destroyed with this one)
@@ -351,10 +351,12 @@ int run_gladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride,
   gcurve GC; if (!lookup_curve(curve, &GC)) return bad(ctx, "unknown curve id");
   if (x == nullptr && k_stride == 4 && (flags & ECSIMD_HIP_ALG_WINDOWED) && !(flags & (ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM)))
     return run_gcomb(ctx, curve, k, ox, oy, n, flags);          // k G from the generator's table in LDS (k_gcomb.hip)
+  if (x == nullptr && k_stride == 4 && (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED) && !(flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM | ECSIMD_HIP_ALG_CONSTANT_TIME)))
+    return run_gcomb(ctx, curve, k, ox, oy, n, flags);          // ... from the signed 7-bit comb (public scalars)
   if (x != nullptr && (flags & ECSIMD_HIP_ALG_WINDOWED) && !(flags & (ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM)))
     return run_gvarwin(ctx, curve, k, k_stride, x, y, ox, oy, n, flags, 0);   // k P from the lane's own table of odd multiples (k_gvarwin.hip); ALG_CONSTANT_TIME: every entry read in every window
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM | ECSIMD_HIP_ALG_CONSTANT_TIME))
-    return bad(ctx, "a registered curve has the reference's ladder and ALG_WINDOWED [| ALG_CONSTANT_TIME] for its generator and for a variable base: the other ALG_* tables exist for P-256 and secp256k1");
+    return bad(ctx, "a registered curve has the reference's ladder, ALG_WINDOWED [| ALG_CONSTANT_TIME] for its generator and for a variable base, and ALG_WINDOWED_SIGNED for its generator: the other ALG_* tables exist for P-256 and secp256k1");
   if (n == 0) return ECSIMD_HIP_OK;
   if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
   hipError_t e = hipSetDevice(ctx->device);
@@ -623,7 +625,7 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->sink);
   (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->windowct_table[0]); (void)hipFree(ctx->windowct_table[1]); (void)hipFree(ctx->window16_table[0]); (void)hipFree(ctx->window16_table[1]); (void)hipFree(ctx->workspace); (void)hipFree(ctx->valid); (void)hipFree(ctx->base_special[0]); (void)hipFree(ctx->base_special[1]);
-  for (auto& t : ctx->gcomb) { (void)hipFree(t.table); (void)hipFree(t.special); }
+  for (auto& t : ctx->gcomb) { (void)hipFree(t.table); (void)hipFree(t.special); (void)hipFree(t.table7); }
   (void)hipFree(ctx->hstage);
   if (ctx->helper) (void)ecsimd_hip_destroy(ctx->helper);
   (void)hipEventDestroy(ctx->handoff);
@@ -1251,31 +1253,43 @@ gc_layout gc_plan(uint64_t* base, size_t n, bool win = false) {
 // curve -- whose degenerate scalars the entries' multipliers must not be (checked; k* by way of n - k* if it is one) -- through the shared inversion.
 bool gc_comb_possible(const curve_record& rec) { return rec.has_order && (rec.n.l[3] >> 63) != 0; }
 bool gc_window_possible(const curve_record& rec) { return gc_comb_possible(rec) && rec.prime_order; }    // a variable base: every point has order n (curve_record)
-int ensure_gc_comb(ecsimd_hip_ctx* ctx, int curve, const curve_record& rec, const uint32_t** out) {
-  for (auto& t : ctx->gcomb) if (t.curve == curve) { *out = t.table; return ECSIMD_HIP_OK; }
+// bits = 4: that table (summed from the top); bits = 7: the signed comb's 37 windows x 64 odd multiples (2d + 1) 2^(7 w) G (summed from the bottom; the top
+// window's digit is at most 15: its other entries are never read and hold G).
+int ensure_gc_comb(ecsimd_hip_ctx* ctx, int curve, const curve_record& rec, const uint32_t** out, int bits = 4) {
+  for (auto& t : ctx->gcomb) if (t.curve == curve && (bits == 4 ? t.table : t.table7)) { *out = bits == 4 ? t.table : t.table7; return ECSIMD_HIP_OK; }
   if (!gc_comb_possible(rec)) return bad(ctx, "the windowed algorithms on a registered curve need its group order n, n >= 2^255");
   if (capturing(ctx)) return bad(ctx, "a window table would have to be built during stream capture: run this call once before capturing");
-  constexpr int W = launch::GCOMB_WINDOWS, PER = launch::GCOMB_ENTRIES;
-  constexpr size_t table_entries = (size_t)W * PER, entries = table_entries + 1;
+  const int W = bits == 4 ? launch::GCOMB_WINDOWS : launch::GCOMB7_WINDOWS, PER = bits == 4 ? launch::GCOMB_ENTRIES : launch::GCOMB7_ENTRIES;
+  const size_t table_entries = (size_t)W * PER, entries = table_entries + 1;
   std::vector<uint64_t> host_k;
   try { host_k.assign(entries * 4, 0); ctx->gcomb.reserve(ctx->gcomb.size() + 1); } catch (...) { return bad(ctx, "window table: out of host memory"); }
   for (int w = 0; w < W; ++w)
     for (int d = 0; d < PER; ++d) {
       uint64_t* e = &host_k[((size_t)w * PER + d) * 4];
-      const int pos = 4 * w, limb = pos / 64, off = pos % 64;
+      const int pos = bits * w, limb = pos / 64, off = pos % 64;
       const unsigned __int128 v = (unsigned __int128)(2u * (unsigned)d + 1u) << off;
+      if (limb + 1 >= 4 && (uint64_t)(v >> 64) != 0) { e[0] = 1; continue; }        // (2d + 1) 2^pos >= 2^256: beyond the top digit's range, never read
       e[limb] = (uint64_t)v;
       if (limb + 1 < 4) e[limb + 1] = (uint64_t)(v >> 64);
       u256 m; for (int l = 0; l < 4; ++l) m.l[l] = e[l];
       if (u_ladder_degenerate(rec.n, m)) return bad(ctx, "window table: a table multiplier is one of the ladder's degenerate scalars on this curve");
     }
-  // k* = n - 2 (n mod 16), and only if bit 4 of it is clear (k_affine.inc comb_special: the high-to-low order); its point by way of n - k* if the ladder cannot do k*
+  // 4 bits, summed from the top: k* = n - 2 (n mod 16), and only if bit 4 of it is clear (k_affine.inc comb_special); 7 bits, summed from the bottom:
+  // k* = n - 2 (n mod 2^(7 x 36)).  Its point by way of n - k* if the ladder cannot do k*
   uint64_t kstar[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool negate_special = false;
   {
-    u256 m2 = {{2 * (rec.n.l[0] & 15u), 0, 0, 0}}, ks;
+    u256 m2, ks;
+    if (bits == 4) m2 = u256{{2 * (rec.n.l[0] & 15u), 0, 0, 0}};
+    else {
+      const int low = bits * (W - 1);                                            // 252
+      u256 m = rec.n;
+      for (int l = 0; l < 4; ++l) { const int lo = 64 * l; if (low <= lo) m.l[l] = 0; else if (low < lo + 64) m.l[l] &= (1ull << (low - lo)) - 1ull; }
+      for (int l = 3; l > 0; --l) m2.l[l] = (m.l[l] << 1) | (m.l[l - 1] >> 63);
+      m2.l[0] = m.l[0] << 1;                                                     // 2 m < 2^253 < n
+    }
     (void)u_sub(ks, rec.n, m2);
-    const bool have = ((ks.l[0] >> 4) & 1u) == 0;
+    const bool have = bits == 4 ? ((ks.l[0] >> 4) & 1u) == 0 : !u_is_zero(ks);
     if (have) for (int l = 0; l < 4; ++l) kstar[l] = ks.l[l];
     u256 mult = have ? ks : u256{{1, 0, 0, 0}};                  // without a k*: any scalar, the point is never used
     if (have && u_ladder_degenerate(rec.n, ks)) {
@@ -1307,7 +1321,9 @@ int ensure_gc_comb(ecsimd_hip_ctx* ctx, int curve, const curve_record& rec, cons
   if (e == hipSuccess) e = hipGetLastError();
   (void)hipFree(kd);
   if (e != hipSuccess) { (void)hipFree(table); return fail(ctx, e, "window table build (registered curve)"); }
-  ctx->gcomb.push_back({curve, table, nullptr});
+  bool placed = false;
+  for (auto& t : ctx->gcomb) if (t.curve == curve) { (bits == 4 ? t.table : t.table7) = table; placed = true; }
+  if (!placed) ctx->gcomb.push_back({curve, bits == 4 ? table : nullptr, nullptr, bits == 4 ? nullptr : table});
   *out = table;
   return ECSIMD_HIP_OK;
 }
@@ -1350,11 +1366,13 @@ int run_gcomb(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, u
   if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
   (void)hipSetDevice(ctx->device);
   const uint32_t* table = nullptr;
-  int rc = ensure_gc_comb(ctx, curve, rec, &table);
+  const bool seven = (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED) != 0;     // signed 7-bit windows in 148 KiB of LDS: 36 additions instead of 63 (public scalars)
+  int rc = ensure_gc_comb(ctx, curve, rec, &table, seven ? 7 : 4);
   if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 3 * n * 32);
   if (rc != ECSIMD_HIP_OK) return rc;
   uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
-  launch::gc_base_windowed(ctx->stream, rec.G, order_words(rec), k, table, jx, jy, jz, n, (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) != 0);
+  if (seven) launch::gc_base_windowed_s(ctx->stream, rec.G, order_words(rec), k, table, jx, jy, jz, n);
+  else launch::gc_base_windowed(ctx->stream, rec.G, order_words(rec), k, table, jx, jy, jz, n, (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) != 0);
   launch::gc_to_affine_batched(ctx->stream, rec.G, jx, jy, jz, ox, oy, n);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult_base (registered curve, windowed) launch");
@@ -1431,14 +1449,23 @@ int gc_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve_of, const curve_record&
   if (rc == ECSIMD_HIP_OK) rc = ensure_valid(ctx, (n + 15) / 16 * 16);
   if (rc != ECSIMD_HIP_OK) return rc;
   const uint32_t* comb = nullptr;                                   // u1 G from the generator's table where the curve has one (n >= 2^255), else a ladder pass
-  if (gc_comb_possible(rec)) { rc = ensure_gc_comb(ctx, curve_of, rec, &comb); if (rc != ECSIMD_HIP_OK) { if (!capturing(ctx)) return rc; comb = nullptr; } }   // (no table yet and a capture in progress: the ladder)
+  const uint32_t* comb7 = nullptr;                                  // ... preferably the signed 7-bit comb (u1 is public: 36 additions instead of 63)
+  if (gc_comb_possible(rec)) {
+    rc = ensure_gc_comb(ctx, curve_of, rec, &comb7, 7);
+    if (rc != ECSIMD_HIP_OK) {
+      if (!capturing(ctx)) return rc;
+      comb7 = nullptr;
+      rc = ensure_gc_comb(ctx, curve_of, rec, &comb); if (rc != ECSIMD_HIP_OK) comb = nullptr;      // (no table yet and a capture in progress: the other table, else the ladder)
+    }
+  }
   L = gc_plan(ctx->workspace, n, win);
   hipStream_t s = ctx->stream;
   launch::gc_on_curve(s, rec.G, qx, qy, ctx->valid, n);
   for (size_t first = 0; first < n; first += L.chunk) {
     const size_t m = (n - first) < L.chunk ? (n - first) : L.chunk;
-    if (comb) {
-      launch::gc_base_windowed(s, rec.G, order_words(rec), u1 + 4 * first, comb, L.j[0], L.j[1], L.j[2], m, false);
+    if (comb7 || comb) {
+      if (comb7) launch::gc_base_windowed_s(s, rec.G, order_words(rec), u1 + 4 * first, comb7, L.j[0], L.j[1], L.j[2], m);
+      else launch::gc_base_windowed(s, rec.G, order_words(rec), u1 + 4 * first, comb, L.j[0], L.j[1], L.j[2], m, false);
       launch::gc_to_affine_batched(s, rec.G, L.j[0], L.j[1], L.j[2], L.gx, L.gy, m);
     } else gc_safe_mult(s, rec, L, L.adj1, L.neg1, u1 + 4 * first, nullptr, nullptr, L.gx, L.gy, m);                       // u1 G
     if (win) launch::gc_varwin_scalar_mult(s, rec.G, order_words(rec), u2 + 4 * first, 4, qx + 4 * first, qy + 4 * first, 0, L.win, L.px, L.py, m);   // u2 Q (public scalars)

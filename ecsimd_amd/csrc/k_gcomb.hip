@@ -121,9 +121,102 @@ k_gc_base_windowed(gcurve G, launch::words8 order8, const uint64_t* __restrict__
   for (int j = 0; j < 8; ++j) { X.w[j] &= ~zmask; Y.w[j] &= ~zmask; Z.w[j] &= ~zmask; }                   // k = 0 mod n: infinity (Z = 0)
   fe_store(ox, i, X); fe_store(oy, i, Y); fe_store(oz, i, Z);
 }
+
+// ---- signed 7-bit windows, odd digits, summed from the bottom (k_affine.inc k_base_windowed_s<7, false>: ALG_WINDOWED_SIGNED): 37 windows x 64 odd multiples
+// (2d + 1) 2^(7 w) G, 148 KiB of LDS, ONE workgroup of 1 024 threads per CU (four waves per SIMD: 128 registers), 36 mixed additions instead of 63.  The odd
+// one of k mod n and n - k; digit w = ((k >> 7 w) mod 2^8 | 1) - 2^7 for every window but the top one, whose digit is what remains | 1 (at most 15).  No zero
+// digit: the first entry starts the sum, nothing to skip.  The one scalar whose last addition meets R = T is k* = n - 2 (n mod 2^252); the table's tail holds
+// k* G and {k*, 0} as the 4-bit comb's does (tests/test_accumulator_models.py walks the accumulator for the registered curves' orders).  Public scalars.
+constexpr int GS_WB = launch::GCOMB7_BITS, GS_WINDOWS = launch::GCOMB7_WINDOWS, GS_PER = launch::GCOMB7_ENTRIES;
+constexpr int GS_TABLE_WORDS = GS_WINDOWS * GS_PER * 16;      // 151 552 B
+constexpr int GS_BLOCK = 1024;
+__global__ void __launch_bounds__(GS_BLOCK)
+k_gc_base_windowed_s(gcurve G, launch::words8 order8, const uint64_t* __restrict__ k, const uint32_t* __restrict__ table,
+                     uint64_t* __restrict__ ox, uint64_t* __restrict__ oy, uint64_t* __restrict__ oz, size_t n) {
+  extern __shared__ uint4 lds_s[];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(table);
+    for (int e = threadIdx.x; e < GS_TABLE_WORDS / 4; e += GS_BLOCK) lds_s[e] = src[e];
+  }
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const r29_ctx<C>& cx = G.r29;
+  constexpr uint32_t FULL = 1u << GS_WB;
+  fe kf = fe_load(k, i);
+  fe order;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) order.w[j] = order8.w[j];
+  {
+    fe d;
+    const uint32_t borrow = sub8_3(d, kf, order);        // k < 2^256 <= 2n
+    kf = fe_select(borrow, kf, d);
+  }
+  const uint32_t zmask = g_zero_mask(kf);
+  const uint32_t flip = 0u - (uint32_t)((kf.w[0] & 1u) == 0u);
+  {
+    fe nk;
+    (void)sub8_3(nk, order, kf);
+    kf = fe_select(flip, nk, kf);
+  }
+  kf.w[0] = (zmask & 1u) | (kf.w[0] & ~zmask);           // k = 0 mod n: any odd value; replaced by infinity below
+  const uint4* gtab = reinterpret_cast<const uint4*>(table);
+  const uint4* tail = gtab + ((size_t)GS_WINDOWS * GS_PER + 1) * 4;
+  uint32_t special;
+  {
+    const uint4 a = tail[0], b = tail[1];
+    const uint32_t d = (kf.w[0] ^ a.x) | (kf.w[1] ^ a.y) | (kf.w[2] ^ a.z) | (kf.w[3] ^ a.w) | (kf.w[4] ^ b.x) | (kf.w[5] ^ b.y) | (kf.w[6] ^ b.z) | (kf.w[7] ^ b.w);
+    special = 0u - (uint32_t)(d == 0u);
+  }
+  uint32_t kk[9];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) kk[j] = kf.w[j];
+  kk[8] = 0;
+  auto digit = [&](int w, uint32_t& mag, uint32_t& neg) {             // window w (wave-uniform), then shift
+    const uint32_t u = (kk[0] & (2u * FULL - 1u)) | 1u;
+    const uint32_t sneg = 0u - (uint32_t)(u < FULL);
+    const uint32_t smag = sneg ? FULL - u : u - FULL;
+    const bool top = w + 1 >= GS_WINDOWS;                               // what remains: the positive top digit
+    neg = top ? 0u : sneg;
+    mag = top ? (kk[0] | 1u) : smag;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kk[j] = __builtin_amdgcn_alignbit(kk[j + 1], kk[j], GS_WB);
+  };
+  const fe29 one = enter29<C>(g_words(G.F.r), cx);
+  jpoint29 A;
+  {
+    uint32_t mag, neg;
+    digit(0, mag, neg);
+    fe tx, ty;
+    entry_words(&lds_s[(size_t)(mag >> 1) * 4], tx, ty);
+    A.x = to29(tx); A.y = cneg29(neg, to29(ty)); A.z = one;
+  }
+#pragma unroll 1
+  for (int w = 1; w < GS_WINDOWS; ++w) {
+    uint32_t mag, neg;
+    digit(w, mag, neg);
+    fe tx, ty;
+    entry_words(&lds_s[((size_t)w * GS_PER + (mag >> 1)) * 4], tx, ty);
+    A = madd29<C>(A, to29(tx), cneg29(neg, to29(ty)), cx);
+  }
+  if (__builtin_amdgcn_ballot_w64(special != 0u) != 0ull) {
+    fe tx, ty;
+    entry_words(gtab + (size_t)GS_WINDOWS * GS_PER * 4, tx, ty);
+    A.x = select29(special, to29(tx), A.x); A.y = select29(special, to29(ty), A.y); A.z = select29(special, one, A.z);
+  }
+  fe X = leave29<C>(A.x, cx), Y = leave29<C>(A.y, cx), Z = leave29<C>(A.z, cx);
+  Y = fe_select(flip, g_opposite(Y, G.F), Y);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { X.w[j] &= ~zmask; Y.w[j] &= ~zmask; Z.w[j] &= ~zmask; }
+  fe_store(ox, i, X); fe_store(oy, i, Y); fe_store(oz, i, Z);
+}
 }  // namespace
 
 namespace launch {
+void gc_base_windowed_s(hipStream_t s, const gcurve& G, const words8& order, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gc_base_windowed_s), hipFuncAttributeMaxDynamicSharedMemorySize, GS_TABLE_WORDS * 4);
+  hipLaunchKernelGGL(k_gc_base_windowed_s, dim3((unsigned)((n + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), GS_TABLE_WORDS * 4, s, G, order, k, table, ox, oy, oz, n);
+}
 void gc_pack_table(hipStream_t s, const gcurve& G, const uint64_t* tx, const uint64_t* ty, uint32_t* table, int entries) {
   hipLaunchKernelGGL(k_gc_pack_table, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, G, tx, ty, table, entries);
 }

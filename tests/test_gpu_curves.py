@@ -221,7 +221,7 @@ def test_registered_curve_entry_points_that_do_not_exist_say_so(engine, oracle):
             engine.scalar_mult(cid, k, bx, by, flags=fl)                  # a variable base: the window loop (k_gvarwin.hip; plain and constant-time) and the ladder, nothing else
     with pytest.raises(EcsimdHipError, match="OUT_AFFINE"):
         engine.scalar_mult(cid, k, bx, by, flags=ALG_WINDOWED)            # the window loop's Jacobian representative is not the reference's
-    for fl in (OUT_AFFINE | ALG_WINDOWED_SIGNED, OUT_AFFINE | ALG_WINDOWED_BIG, OUT_AFFINE | ALG_CONSTANT_TIME):
+    for fl in (OUT_AFFINE | ALG_WINDOWED_BIG, OUT_AFFINE | ALG_CONSTANT_TIME, OUT_AFFINE | ALG_WINDOWED_SIGNED | ALG_CONSTANT_TIME, OUT_AFFINE | ALG_WINDOWED_SIGNED | ALG_WINDOWED):
         with pytest.raises(EcsimdHipError, match="a registered curve has"):
             engine.scalar_mult_base(cid, k, flags=fl)
     with pytest.raises(EcsimdHipError, match="OUT_AFFINE"):
@@ -387,8 +387,8 @@ def test_sec1_codecs_on_a_registered_curve(engine, oracle, name):
 
 @pytest.mark.parametrize("name", list(REF_CURVES))
 def test_generator_comb_on_a_registered_curve(engine, name):
-    """scalar_mult_base(ALG_WINDOWED [| ALG_CONSTANT_TIME] | OUT_AFFINE) with a registered curve id (k_gcomb.hip: 4-bit odd-digit table of multiples of the
-    curve's generator in LDS, built from the reference's ladder on first use): the ladder's affine points lane for lane on 2^17 + 77 random 256-bit scalars,
+    """scalar_mult_base(ALG_WINDOWED [| ALG_CONSTANT_TIME] | OUT_AFFINE) and (ALG_WINDOWED_SIGNED | OUT_AFFINE) with a registered curve id (k_gcomb.hip: the
+    4-bit and the signed 7-bit odd-digit table of multiples of the curve's generator in LDS, built from the reference's ladder on first use): the ladder's affine points lane for lane on 2^17 + 77 random 256-bit scalars,
     the true k G (textbook affine arithmetic on Python integers) on the edge scalars -- the comb's own exceptional scalar k* = n - 2 (n mod 16) and its images,
     0 and n (infinity: (0, 0)), and the three scalars at which the LADDER is wrong -- and the x-only form."""
     c = REF_CURVES[name]
@@ -397,7 +397,9 @@ def test_generator_comb_on_a_registered_curve(engine, name):
     add, mul = _affine_model(c)
     G = (c["gx"], c["gy"])
     ks = n_ - 2 * (n_ % 16)
+    ks7 = n_ - 2 * (n_ % 2**252)                                             # the signed 7-bit comb's (summed from the bottom)
     edge = [0, 1, 2, 3, 15, 16, 17, 31, 32, 33, n_ - 2, n_ - 1, n_, n_ + 1, n_ + 2, ks, ks - 1, ks + 1, n_ - ks, ks + n_ if ks + n_ < 2**256 else ks, 2**256 - n_ - 1, 2**256 - n_,
+            ks7, ks7 - 1, ks7 + 1, ks7 - 2, ks7 + 2, n_ - ks7, n_ - ks7 + 1, 127, 128, 129, 2**252 - 1, 2**252 + 1, 15 * 2**252 + 1, 2**7 - 1, 2**14 + 1,
             2**256 - n_ + 1, 2**256 - 1, 2**255, 2**255 - 1, (n_ - 1) // 2, (n_ + 1) // 2, 0x1111111111111111111111111111111111111111111111111111111111111111, 2**252, 16**63, 15 * 16**63]
     N = (1 << 17) + 77
     rng = np.random.default_rng(sum(name.encode()) + 9)
@@ -405,8 +407,8 @@ def test_generator_comb_on_a_registered_curve(engine, name):
     k[:len(edge)] = ints_to_arr(edge)
     kd = engine.to_device(k)
     lx, ly = (engine.to_numpy(t) for t in engine.scalar_mult_base(cid, kd, flags=OUT_AFFINE))
-    from ecsimd_amd import ALG_WINDOWED, ALG_CONSTANT_TIME
-    for fl in (ALG_WINDOWED, ALG_WINDOWED | ALG_CONSTANT_TIME):
+    from ecsimd_amd import ALG_WINDOWED, ALG_CONSTANT_TIME, ALG_WINDOWED_SIGNED
+    for fl in (ALG_WINDOWED, ALG_WINDOWED | ALG_CONSTANT_TIME, ALG_WINDOWED_SIGNED):          # (signed 7-bit windows, 37 x 64 entries in 148 KiB of LDS: public scalars)
         wx, wy = (engine.to_numpy(t) for t in engine.scalar_mult_base(cid, kd, flags=OUT_AFFINE | fl))
         for i, kv in enumerate(edge):
             want = mul(kv % n_, G)
@@ -414,9 +416,10 @@ def test_generator_comb_on_a_registered_curve(engine, name):
         assert np.array_equal(wx[len(edge):], lx[len(edge):]) and np.array_equal(wy[len(edge):], ly[len(edge):]), (name, fl)
         xo, none = engine.scalar_mult_base(cid, kd, flags=OUT_AFFINE | fl, x_only=True)
         assert none is None and np.array_equal(engine.to_numpy(xo), wx)
-    for m in (1, 3, 255, 257):                                              # ragged batches: a partial workgroup still loads the whole table
-        wx, wy = (engine.to_numpy(t) for t in engine.scalar_mult_base(cid, engine.to_device(k[40:40 + m].copy()), flags=OUT_AFFINE | ALG_WINDOWED))
-        assert np.array_equal(wx, lx[40:40 + m]) and np.array_equal(wy, ly[40:40 + m])
+    for m in (1, 3, 255, 257, 1023, 1025):                                  # ragged batches: a partial workgroup still loads the whole table
+        for fl in (ALG_WINDOWED, ALG_WINDOWED_SIGNED):
+            wx, wy = (engine.to_numpy(t) for t in engine.scalar_mult_base(cid, engine.to_device(k[60:60 + m].copy()), flags=OUT_AFFINE | fl))
+            assert np.array_equal(wx, lx[60:60 + m]) and np.array_equal(wy, ly[60:60 + m])
     assert all(t.shape[0] == 0 for t in engine.scalar_mult_base(cid, engine.empty(0), flags=OUT_AFFINE | ALG_WINDOWED))
 
 

@@ -64,7 +64,23 @@ for cv, nm in ((P256, "P-256"), (SECP256K1, "secp256k1")):
     b = rates(cv, f"{nm} built-in")
     assert all(np.array_equal(u, v) for u, v in zip(g, b)), "generic window loop != built-in window loop"
 
-# ECDSA verification on a registered curve: u1 G from the comb, u2 Q from the window loop (before: a ladder pass)
+# k G on a registered curve: the 4-bit comb (plain, constant-time) and the signed 7-bit comb (ALG_WINDOWED_SIGNED: 36 additions instead of 63)
+from ecsimd_amd import ALG_WINDOWED_SIGNED     # noqa: E402
+for name in ("brainpoolP256r1", "sm2", "frp256v1"):
+    c = NAMED[name]
+    cid = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"])
+    k = eng.fill_random(n, SEED, 31)
+    res = {}
+    for fl, what in ((ALG_WINDOWED, "4-bit comb"), (ALG_WINDOWED | ALG_CONSTANT_TIME, "4-bit comb, constant time"), (ALG_WINDOWED_SIGNED, "signed 7-bit comb")):
+        out = [eng.empty(n), eng.empty(n), None]
+        t = timed(lambda: eng.scalar_mult_base(cid, k, flags=OUT_AFFINE | fl, out=out))
+        print(f"{name:34s} k G, {what:28s} {t:9.2f} ms  {n / (t * 1e-3) / 1e6:8.2f} M/s")
+        res[fl] = [eng.to_numpy(o) for o in out[:2]]
+    a = res[ALG_WINDOWED]
+    differ = sum(int(((a[0] != b[0]).any(axis=1) | (a[1] != b[1]).any(axis=1)).sum()) for b in (res[ALG_WINDOWED | ALG_CONSTANT_TIME], res[ALG_WINDOWED_SIGNED]))
+    print(f"{name:34s} lanes where the three combs differ: {differ} of {n}")
+
+# ECDSA verification on a registered curve: u1 G from the signed comb, u2 Q from the window loop (before: the 4-bit comb and a ladder pass)
 c = NAMED["brainpoolP256r1"]
 cid = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"])
 m = min(n, 1 << 22)
