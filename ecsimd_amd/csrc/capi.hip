@@ -84,7 +84,7 @@ struct ecsimd_hip_ctx {
   uint8_t* valid;              // grow-only: per-lane public-key validity of double_scalar_mult / ecdsa_verify_rx
   size_t valid_bytes;
   int ref_square;              // ecsimd_hip_set_ref_square_compat: the reference's square() as written (mul.h:160-212)
-  struct gcomb_entry { int curve; uint32_t* table; uint64_t* special; uint32_t* table7; };      // table7: the signed 7-bit comb (ALG_WINDOWED_SIGNED)
+  struct gcomb_entry { int curve; uint32_t* table; uint64_t* special; uint32_t* table7; uint32_t* table5; };      // table7: the signed 7-bit comb (ALG_WINDOWED_SIGNED); table5: the constant-time 5-bit comb
   std::vector<gcomb_entry> gcomb;   // per registered curve: the 4-bit odd-digit table of multiples of its generator (k_gcomb.hip) and, for the small-batch route, the ladder's
                                     // three degenerate scalars with its affine results for them on G (as base_special); built on first use
   ecsimd_hip_ctx* helper;      // ecsimd_hip_scalar_mult_host: the second stream's context (created on first use, destroyed with this one)
@@ -625,7 +625,7 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->sink);
   (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->windowct_table[0]); (void)hipFree(ctx->windowct_table[1]); (void)hipFree(ctx->window16_table[0]); (void)hipFree(ctx->window16_table[1]); (void)hipFree(ctx->workspace); (void)hipFree(ctx->valid); (void)hipFree(ctx->base_special[0]); (void)hipFree(ctx->base_special[1]);
-  for (auto& t : ctx->gcomb) { (void)hipFree(t.table); (void)hipFree(t.special); (void)hipFree(t.table7); }
+  for (auto& t : ctx->gcomb) { (void)hipFree(t.table); (void)hipFree(t.special); (void)hipFree(t.table7); (void)hipFree(t.table5); }
   (void)hipFree(ctx->hstage);
   if (ctx->helper) (void)ecsimd_hip_destroy(ctx->helper);
   (void)hipEventDestroy(ctx->handoff);
@@ -1253,13 +1253,15 @@ gc_layout gc_plan(uint64_t* base, size_t n, bool win = false) {
 // curve -- whose degenerate scalars the entries' multipliers must not be (checked; k* by way of n - k* if it is one) -- through the shared inversion.
 bool gc_comb_possible(const curve_record& rec) { return rec.has_order && (rec.n.l[3] >> 63) != 0; }
 bool gc_window_possible(const curve_record& rec) { return gc_comb_possible(rec) && rec.prime_order; }    // a variable base: every point has order n (curve_record)
-// bits = 4: that table (summed from the top); bits = 7: the signed comb's 37 windows x 64 odd multiples (2d + 1) 2^(7 w) G (summed from the bottom; the top
-// window's digit is at most 15: its other entries are never read and hold G).
+// bits = 4: that table (summed from the top); bits = 7 / 5: the signed comb's 37 windows x 64 / the constant-time comb's 52 windows x 16 odd multiples
+// (2d + 1) 2^(bits w) G (summed from the bottom; the top window's digit is at most 15 / 1: its other entries are never read and hold G).
 int ensure_gc_comb(ecsimd_hip_ctx* ctx, int curve, const curve_record& rec, const uint32_t** out, int bits = 4) {
-  for (auto& t : ctx->gcomb) if (t.curve == curve && (bits == 4 ? t.table : t.table7)) { *out = bits == 4 ? t.table : t.table7; return ECSIMD_HIP_OK; }
+  auto slot = [bits](ecsimd_hip_ctx::gcomb_entry& t) -> uint32_t*& { return bits == 4 ? t.table : bits == 7 ? t.table7 : t.table5; };
+  for (auto& t : ctx->gcomb) if (t.curve == curve && slot(t)) { *out = slot(t); return ECSIMD_HIP_OK; }
   if (!gc_comb_possible(rec)) return bad(ctx, "the windowed algorithms on a registered curve need its group order n, n >= 2^255");
   if (capturing(ctx)) return bad(ctx, "a window table would have to be built during stream capture: run this call once before capturing");
-  const int W = bits == 4 ? launch::GCOMB_WINDOWS : launch::GCOMB7_WINDOWS, PER = bits == 4 ? launch::GCOMB_ENTRIES : launch::GCOMB7_ENTRIES;
+  const int W = bits == 4 ? launch::GCOMB_WINDOWS : bits == 7 ? launch::GCOMB7_WINDOWS : launch::GCOMB5_WINDOWS;
+  const int PER = bits == 4 ? launch::GCOMB_ENTRIES : bits == 7 ? launch::GCOMB7_ENTRIES : launch::GCOMB5_ENTRIES;
   const size_t table_entries = (size_t)W * PER, entries = table_entries + 1;
   std::vector<uint64_t> host_k;
   try { host_k.assign(entries * 4, 0); ctx->gcomb.reserve(ctx->gcomb.size() + 1); } catch (...) { return bad(ctx, "window table: out of host memory"); }
@@ -1274,19 +1276,19 @@ int ensure_gc_comb(ecsimd_hip_ctx* ctx, int curve, const curve_record& rec, cons
       u256 m; for (int l = 0; l < 4; ++l) m.l[l] = e[l];
       if (u_ladder_degenerate(rec.n, m)) return bad(ctx, "window table: a table multiplier is one of the ladder's degenerate scalars on this curve");
     }
-  // 4 bits, summed from the top: k* = n - 2 (n mod 16), and only if bit 4 of it is clear (k_affine.inc comb_special); 7 bits, summed from the bottom:
-  // k* = n - 2 (n mod 2^(7 x 36)).  Its point by way of n - k* if the ladder cannot do k*
+  // 4 bits, summed from the top: k* = n - 2 (n mod 16), and only if bit 4 of it is clear (k_affine.inc comb_special); 7 / 5 bits, summed from the bottom:
+  // k* = n - 2 (n mod 2^(bits (W - 1))) (5 bits: 2^256 - n, one of the ladder's degenerate scalars).  Its point by way of n - k* if the ladder cannot do k*
   uint64_t kstar[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool negate_special = false;
   {
     u256 m2, ks;
     if (bits == 4) m2 = u256{{2 * (rec.n.l[0] & 15u), 0, 0, 0}};
     else {
-      const int low = bits * (W - 1);                                            // 252
+      const int low = bits * (W - 1);                                            // 252 / 255
       u256 m = rec.n;
       for (int l = 0; l < 4; ++l) { const int lo = 64 * l; if (low <= lo) m.l[l] = 0; else if (low < lo + 64) m.l[l] &= (1ull << (low - lo)) - 1ull; }
       for (int l = 3; l > 0; --l) m2.l[l] = (m.l[l] << 1) | (m.l[l - 1] >> 63);
-      m2.l[0] = m.l[0] << 1;                                                     // 2 m < 2^253 < n
+      m2.l[0] = m.l[0] << 1;                                                     // 2 m < n (m = n mod 2^252 < 2^252; m = n - 2^255 < n / 2)
     }
     (void)u_sub(ks, rec.n, m2);
     const bool have = bits == 4 ? ((ks.l[0] >> 4) & 1u) == 0 : !u_is_zero(ks);
@@ -1322,8 +1324,8 @@ int ensure_gc_comb(ecsimd_hip_ctx* ctx, int curve, const curve_record& rec, cons
   (void)hipFree(kd);
   if (e != hipSuccess) { (void)hipFree(table); return fail(ctx, e, "window table build (registered curve)"); }
   bool placed = false;
-  for (auto& t : ctx->gcomb) if (t.curve == curve) { (bits == 4 ? t.table : t.table7) = table; placed = true; }
-  if (!placed) ctx->gcomb.push_back({curve, bits == 4 ? table : nullptr, nullptr, bits == 4 ? nullptr : table});
+  for (auto& t : ctx->gcomb) if (t.curve == curve) { slot(t) = table; placed = true; }
+  if (!placed) { ctx->gcomb.push_back({curve, nullptr, nullptr, nullptr, nullptr}); slot(ctx->gcomb.back()) = table; }
   *out = table;
   return ECSIMD_HIP_OK;
 }
@@ -1367,12 +1369,13 @@ int run_gcomb(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, u
   (void)hipSetDevice(ctx->device);
   const uint32_t* table = nullptr;
   const bool seven = (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED) != 0;     // signed 7-bit windows in 148 KiB of LDS: 36 additions instead of 63 (public scalars)
-  int rc = ensure_gc_comb(ctx, curve, rec, &table, seven ? 7 : 4);
+  const bool five = !seven && (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) != 0;   // the constant-time comb: 5-bit windows, 51 additions, every entry of a window read
+  int rc = ensure_gc_comb(ctx, curve, rec, &table, seven ? 7 : five ? 5 : 4);
   if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 3 * n * 32);
   if (rc != ECSIMD_HIP_OK) return rc;
   uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
-  if (seven) launch::gc_base_windowed_s(ctx->stream, rec.G, order_words(rec), k, table, jx, jy, jz, n);
-  else launch::gc_base_windowed(ctx->stream, rec.G, order_words(rec), k, table, jx, jy, jz, n, (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) != 0);
+  if (seven || five) launch::gc_base_windowed_s(ctx->stream, rec.G, order_words(rec), seven ? 7 : 5, k, table, jx, jy, jz, n);
+  else launch::gc_base_windowed(ctx->stream, rec.G, order_words(rec), k, table, jx, jy, jz, n, false);
   launch::gc_to_affine_batched(ctx->stream, rec.G, jx, jy, jz, ox, oy, n);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ECSIMD_HIP_OK : fail(ctx, e, "scalar_mult_base (registered curve, windowed) launch");
@@ -1464,7 +1467,7 @@ int gc_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve_of, const curve_record&
   for (size_t first = 0; first < n; first += L.chunk) {
     const size_t m = (n - first) < L.chunk ? (n - first) : L.chunk;
     if (comb7 || comb) {
-      if (comb7) launch::gc_base_windowed_s(s, rec.G, order_words(rec), u1 + 4 * first, comb7, L.j[0], L.j[1], L.j[2], m);
+      if (comb7) launch::gc_base_windowed_s(s, rec.G, order_words(rec), 7, u1 + 4 * first, comb7, L.j[0], L.j[1], L.j[2], m);
       else launch::gc_base_windowed(s, rec.G, order_words(rec), u1 + 4 * first, comb, L.j[0], L.j[1], L.j[2], m, false);
       launch::gc_to_affine_batched(s, rec.G, L.j[0], L.j[1], L.j[2], L.gx, L.gy, m);
     } else gc_safe_mult(s, rec, L, L.adj1, L.neg1, u1 + 4 * first, nullptr, nullptr, L.gx, L.gy, m);                       // u1 G
@@ -1614,11 +1617,11 @@ int ecsimd_hip_ecdsa_sign(ecsimd_hip_ctx* ctx, int curve, const uint64_t* e, con
     if (L.chunk != n) return bad(ctx, "ecdsa_sign on a registered curve: at most 2^22 signatures per call");
     rc = ensure_workspace(ctx, L.bytes);
     if (rc != ECSIMD_HIP_OK) return rc;
-    const uint32_t* comb = nullptr;                             // k G from the generator's table, every entry of a window read (constant time), where the curve has one
-    if (gc_comb_possible(rec)) { rc = ensure_gc_comb(ctx, curve, rec, &comb); if (rc != ECSIMD_HIP_OK) { if (!capturing(ctx)) return rc; comb = nullptr; } }   // (no table yet and a capture in progress: the ladder)
+    const uint32_t* comb = nullptr;                             // k G from the generator's constant-time comb (5-bit windows, every entry of a window read), where the curve has one
+    if (gc_comb_possible(rec)) { rc = ensure_gc_comb(ctx, curve, rec, &comb, 5); if (rc != ECSIMD_HIP_OK) { if (!capturing(ctx)) return rc; comb = nullptr; } }   // (no table yet and a capture in progress: the ladder)
     L = gc_plan(ctx->workspace, n);
     if (comb) {
-      launch::gc_base_windowed(ctx->stream, rec.G, order_words(rec), k, comb, L.j[0], L.j[1], L.j[2], n, true);
+      launch::gc_base_windowed_s(ctx->stream, rec.G, order_words(rec), 5, k, comb, L.j[0], L.j[1], L.j[2], n);
       launch::gc_to_affine_batched(ctx->stream, rec.G, L.j[0], L.j[1], L.j[2], L.gx, nullptr, n);
     } else gc_safe_mult(ctx->stream, rec, L, L.adj1, L.neg1, k, nullptr, nullptr, L.gx, nullptr, n);  // x(k G): the negation of a degenerate nonce's product does not touch x
     launch::ecdsa_sign_scalars(ctx->stream, rec.N, e, d, k, L.gx, r, s_, ok, n);

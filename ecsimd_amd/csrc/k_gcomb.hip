@@ -122,27 +122,42 @@ k_gc_base_windowed(gcurve G, launch::words8 order8, const uint64_t* __restrict__
   fe_store(ox, i, X); fe_store(oy, i, Y); fe_store(oz, i, Z);
 }
 
-// ---- signed 7-bit windows, odd digits, summed from the bottom (k_affine.inc k_base_windowed_s<7, false>: ALG_WINDOWED_SIGNED): 37 windows x 64 odd multiples
-// (2d + 1) 2^(7 w) G, 148 KiB of LDS, ONE workgroup of 1 024 threads per CU (four waves per SIMD: 128 registers), 36 mixed additions instead of 63.  The odd
-// one of k mod n and n - k; digit w = ((k >> 7 w) mod 2^8 | 1) - 2^7 for every window but the top one, whose digit is what remains | 1 (at most 15).  No zero
-// digit: the first entry starts the sum, nothing to skip.  The one scalar whose last addition meets R = T is k* = n - 2 (n mod 2^252); the table's tail holds
-// k* G and {k*, 0} as the 4-bit comb's does (tests/test_accumulator_models.py walks the accumulator for the registered curves' orders).  Public scalars.
-constexpr int GS_WB = launch::GCOMB7_BITS, GS_WINDOWS = launch::GCOMB7_WINDOWS, GS_PER = launch::GCOMB7_ENTRIES;
-constexpr int GS_TABLE_WORDS = GS_WINDOWS * GS_PER * 16;      // 151 552 B
-constexpr int GS_BLOCK = 1024;
-__global__ void __launch_bounds__(GS_BLOCK)
+// ---- WB-bit windows with odd digits, summed from the bottom (k_affine.inc k_base_windowed_s<WB, CT>): NW = ceil(256 / WB) windows x 2^(WB-1) odd multiples
+// (2d + 1) 2^(WB w) G in LDS.  The odd one of k mod n and n - k; digit w = ((k >> WB w) mod 2^(WB+1) | 1) - 2^WB for every window but the top one, whose
+// digit is what remains | 1.  No zero digit: the first entry starts the sum, nothing to skip.  The one scalar whose last addition can meet R = T is
+// k* = n - 2 (n mod 2^(WB (NW - 1))); the table's tail holds k* G and {k*, 0} as the 4-bit comb's does (tests/test_accumulator_models.py walks the
+// accumulator for the registered curves' orders).  Two shapes are launched:
+//   <7, false, 1024>  ALG_WINDOWED_SIGNED: 37 x 64 entries, 148 KiB of LDS, ONE workgroup of 1 024 threads per CU (four waves per SIMD: 128 registers), 36 mixed
+//                     additions instead of 63; public scalars (u1 G of a verification);
+//   <5, true, 256>    ALG_WINDOWED | ALG_CONSTANT_TIME and k G of ecdsa_sign: 52 x 16 entries, 53 KB of LDS, three workgroups per CU, 51 additions; every entry
+//                     of a window is read (one LDS address per wave, a broadcast) and the lane's own kept under masks -- no address, branch or EXEC mask
+//                     depends on the scalar (tests/test_constant_time_isa.py).
+template <int WB> struct gswin { static constexpr int WINDOWS = (256 + WB - 1) / WB, PER = 1 << (WB - 1), TABLE_WORDS = WINDOWS * PER * 16; };
+template <int PER, bool CT> ECS_DEV void gs_entry(const uint4* win, uint32_t slot, fe& tx, fe& ty) {
+  if constexpr (!CT) { entry_words(win + slot * 4, tx, ty); return; }
+  entry_words(win, tx, ty);
+#pragma unroll
+  for (int e = 1; e < PER; ++e) {
+    fe ex, ey;
+    entry_words(win + e * 4, ex, ey);
+    const uint32_t m = 0u - (uint32_t)(slot == (uint32_t)e);
+    tx = fe_select(m, ex, tx); ty = fe_select(m, ey, ty);
+  }
+}
+template <int WB, bool CT, int BLK> __global__ void __launch_bounds__(BLK)
 k_gc_base_windowed_s(gcurve G, launch::words8 order8, const uint64_t* __restrict__ k, const uint32_t* __restrict__ table,
                      uint64_t* __restrict__ ox, uint64_t* __restrict__ oy, uint64_t* __restrict__ oz, size_t n) {
+  constexpr int NW = gswin<WB>::WINDOWS, PER = gswin<WB>::PER;
   extern __shared__ uint4 lds_s[];
   {
     const uint4* src = reinterpret_cast<const uint4*>(table);
-    for (int e = threadIdx.x; e < GS_TABLE_WORDS / 4; e += GS_BLOCK) lds_s[e] = src[e];
+    for (int e = threadIdx.x; e < gswin<WB>::TABLE_WORDS / 4; e += BLK) lds_s[e] = src[e];
   }
   __syncthreads();
-  const size_t i = (size_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   const r29_ctx<C>& cx = G.r29;
-  constexpr uint32_t FULL = 1u << GS_WB;
+  constexpr uint32_t FULL = 1u << WB;
   fe kf = fe_load(k, i);
   fe order;
 #pragma unroll
@@ -161,7 +176,7 @@ k_gc_base_windowed_s(gcurve G, launch::words8 order8, const uint64_t* __restrict
   }
   kf.w[0] = (zmask & 1u) | (kf.w[0] & ~zmask);           // k = 0 mod n: any odd value; replaced by infinity below
   const uint4* gtab = reinterpret_cast<const uint4*>(table);
-  const uint4* tail = gtab + ((size_t)GS_WINDOWS * GS_PER + 1) * 4;
+  const uint4* tail = gtab + ((size_t)NW * PER + 1) * 4;
   uint32_t special;
   {
     const uint4 a = tail[0], b = tail[1];
@@ -172,36 +187,36 @@ k_gc_base_windowed_s(gcurve G, launch::words8 order8, const uint64_t* __restrict
 #pragma unroll
   for (int j = 0; j < 8; ++j) kk[j] = kf.w[j];
   kk[8] = 0;
-  auto digit = [&](int w, uint32_t& mag, uint32_t& neg) {             // window w (wave-uniform), then shift
+  auto digit = [&](bool top, uint32_t& mag, uint32_t& neg) {          // the next window (top: wave-uniform), then shift; selects, no branch
     const uint32_t u = (kk[0] & (2u * FULL - 1u)) | 1u;
     const uint32_t sneg = 0u - (uint32_t)(u < FULL);
-    const uint32_t smag = sneg ? FULL - u : u - FULL;
-    const bool top = w + 1 >= GS_WINDOWS;                               // what remains: the positive top digit
+    const uint32_t smag = (sneg & (FULL - u)) | (~sneg & (u - FULL));
     neg = top ? 0u : sneg;
-    mag = top ? (kk[0] | 1u) : smag;
+    mag = top ? (kk[0] | 1u) : smag;                                    // what remains: the positive top digit
 #pragma unroll
-    for (int j = 0; j < 8; ++j) kk[j] = __builtin_amdgcn_alignbit(kk[j + 1], kk[j], GS_WB);
+    for (int j = 0; j < 8; ++j) kk[j] = __builtin_amdgcn_alignbit(kk[j + 1], kk[j], WB);
   };
   const fe29 one = enter29<C>(g_words(G.F.r), cx);
   jpoint29 A;
   {
     uint32_t mag, neg;
-    digit(0, mag, neg);
+    digit(false, mag, neg);
     fe tx, ty;
-    entry_words(&lds_s[(size_t)(mag >> 1) * 4], tx, ty);
+    gs_entry<PER, CT>(&lds_s[0], mag >> 1, tx, ty);
     A.x = to29(tx); A.y = cneg29(neg, to29(ty)); A.z = one;
   }
 #pragma unroll 1
-  for (int w = 1; w < GS_WINDOWS; ++w) {
+  for (int w = 1; w < NW; ++w) {
+    if constexpr (CT) asm volatile("" : "+s"(w));                       // the window counter stays a scalar register: the exit test is an s_cmp
     uint32_t mag, neg;
-    digit(w, mag, neg);
+    digit(w + 1 >= NW, mag, neg);
     fe tx, ty;
-    entry_words(&lds_s[((size_t)w * GS_PER + (mag >> 1)) * 4], tx, ty);
+    gs_entry<PER, CT>(&lds_s[(size_t)w * PER * 4], mag >> 1, tx, ty);
     A = madd29<C>(A, to29(tx), cneg29(neg, to29(ty)), cx);
   }
-  if (__builtin_amdgcn_ballot_w64(special != 0u) != 0ull) {
+  if (CT || __builtin_amdgcn_ballot_w64(special != 0u) != 0ull) {       // constant time: taken by every wave
     fe tx, ty;
-    entry_words(gtab + (size_t)GS_WINDOWS * GS_PER * 4, tx, ty);
+    entry_words(gtab + (size_t)NW * PER * 4, tx, ty);
     A.x = select29(special, to29(tx), A.x); A.y = select29(special, to29(ty), A.y); A.z = select29(special, one, A.z);
   }
   fe X = leave29<C>(A.x, cx), Y = leave29<C>(A.y, cx), Z = leave29<C>(A.z, cx);
@@ -210,12 +225,18 @@ k_gc_base_windowed_s(gcurve G, launch::words8 order8, const uint64_t* __restrict
   for (int j = 0; j < 8; ++j) { X.w[j] &= ~zmask; Y.w[j] &= ~zmask; Z.w[j] &= ~zmask; }
   fe_store(ox, i, X); fe_store(oy, i, Y); fe_store(oz, i, Z);
 }
+static_assert(gswin<7>::WINDOWS == launch::GCOMB7_WINDOWS && gswin<7>::PER == launch::GCOMB7_ENTRIES && gswin<5>::WINDOWS == launch::GCOMB5_WINDOWS && gswin<5>::PER == launch::GCOMB5_ENTRIES, "kernels.h");
 }  // namespace
 
 namespace launch {
-void gc_base_windowed_s(hipStream_t s, const gcurve& G, const words8& order, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gc_base_windowed_s), hipFuncAttributeMaxDynamicSharedMemorySize, GS_TABLE_WORDS * 4);
-  hipLaunchKernelGGL(k_gc_base_windowed_s, dim3((unsigned)((n + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), GS_TABLE_WORDS * 4, s, G, order, k, table, ox, oy, oz, n);
+template <int WB, bool CT, int BLK> static void gcs_launch(hipStream_t s, const gcurve& G, const words8& order, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gc_base_windowed_s<WB, CT, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, gswin<WB>::TABLE_WORDS * 4);
+  hipLaunchKernelGGL((k_gc_base_windowed_s<WB, CT, BLK>), dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), gswin<WB>::TABLE_WORDS * 4, s, G, order, k, table, ox, oy, oz, n);
+}
+// bits = 7: the signed 7-bit comb (public scalars); bits = 5: the constant-time 5-bit comb (every entry of a window read)
+void gc_base_windowed_s(hipStream_t s, const gcurve& G, const words8& order, int bits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) {
+  if (bits == 7) gcs_launch<7, false, 1024>(s, G, order, k, table, ox, oy, oz, n);
+  else gcs_launch<5, true, 256>(s, G, order, k, table, ox, oy, oz, n);
 }
 void gc_pack_table(hipStream_t s, const gcurve& G, const uint64_t* tx, const uint64_t* ty, uint32_t* table, int entries) {
   hipLaunchKernelGGL(k_gc_pack_table, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, G, tx, ty, table, entries);

@@ -297,6 +297,25 @@ def test_registered_curve_constant_time_comb(tmp_path_factory):
         ct_check.check_secret_flow(asm, "18k_gc_base_windowedILb0E", secret_args=[2])
 
 
+def test_registered_curve_constant_time_five_bit_comb(tmp_path_factory):
+    """k_gc_base_windowed_s<5, true, 256> (scalar_mult_base(ALG_WINDOWED | ALG_CONSTANT_TIME) and k G of ecdsa_sign on a registered curve since the second
+    session of round 5): one branch in the window loop (its counter), 64 LDS reads per window (16 entries x 64 B) at loop-invariant addresses, no global
+    access in the loop; no secret (the scalar, the Jacobian k G) reaches an address, a branch, EXEC at a memory access or a lane-crossing instruction -- and
+    the public signed 7-bit comb of the same template, whose LDS address is a digit, is refused by both analyses."""
+    asm = assembly(tmp_path_factory, "k_gcomb")
+    kern = "20k_gc_base_windowed_sILi5ELb1ELi256E"
+    rep = ct_check.check(asm, kern, allow_global_loads=0, allow_lds_reads=True)
+    assert rep["instructions"] > 2400 and rep["lds_reads"] == 64 and rep["scratch"] == 0 and rep["global_loads"] == []
+    assert len(rep["branches"]) == 1 and re.match(r"s_cmpk?_(lg|eq|lt|gt|le|ge)_[iu]32 s\d+, \S+ ; s_cbranch_scc[01] ", rep["branches"][0]), rep["branches"]
+    assert ct_check.check_after_secret_load(asm, kern) > 4000
+    flow = ct_check.check_secret_flow(asm, kern, secret_args=[2, 4, 5, 6])             # (gcurve, order, k, table, ox, oy, oz, n)
+    assert flow["secret_loads"] >= 1 and not flow["secret_lds"] and not flow["secret_scratch"]
+    with pytest.raises(ct_check.Violation, match="LDS address"):
+        ct_check.check(asm, "20k_gc_base_windowed_sILi7ELb0ELi1024E", allow_global_loads=0, allow_lds_reads=True)
+    with pytest.raises(ct_check.Violation, match="LDS address"):
+        ct_check.check_secret_flow(asm, "20k_gc_base_windowed_sILi7ELb0ELi1024E", secret_args=[2])
+
+
 def test_registered_curve_constant_time_variable_base_window_loop(tmp_path_factory):
     """k_gvw_mult<true> (scalar_mult(ALG_WINDOWED | ALG_CONSTANT_TIME) on a registered curve's variable base, k_gvarwin.hip): the built-in constant-time
     loop's checks -- per window 32 global loads (the lane's eight entries, a 128-byte line at a time) at loop-invariant addresses, one branch on the window

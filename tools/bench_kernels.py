@@ -128,14 +128,15 @@ for nm in ("brainpoolP256r1",):
     u1 = e.fill_random(n2, SEED, 21, clear_top_bits=1)
     comb = 63 * 11 * 136                                               # the generator's 4-bit comb: 63 mixed additions (8M + 3S)
     row(f"scalar_mult_base<{nm}> windowed (the generator's comb in LDS), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 4, out=outj)), comb + int((7 + 88 / 32) * 136), 96, "scalar mults")
-    row(f"scalar_mult_base<{nm}> windowed, constant time (every entry of a window read), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 4 | 128, out=outj)), comb + int((7 + 88 / 32) * 136), 96, "scalar mults")
+    comb5 = 51 * 11 * 136                                              # the constant-time 5-bit comb: 51 mixed additions
+    row(f"scalar_mult_base<{nm}> windowed, constant time (5-bit windows, every entry of a window read), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 4 | 128, out=outj)), comb5 + int((7 + 88 / 32) * 136), 96, "scalar mults")
     comb7 = 36 * 11 * 136                                              # the signed 7-bit comb: 36 mixed additions
     row(f"scalar_mult_base<{nm}> signed 7-bit windows (the generator's comb, 148 KiB of LDS), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 8, out=outj)), comb7 + int((7 + 88 / 32) * 136), 96, "scalar mults")
     two = comb7 + vw + int(((7 + 88 / 32) + 6 + 88 / 32) * 136)        # the comb and its conversion, the window loop (its conversion inside vw), the affine addition with its shared inversion
     row(f"double_scalar_mult<{nm}> u1*G + u2*Q (the signed comb + the lane's window table)", n2, timeit(lambda: e.double_scalar_mult(cv, u1, k, b2x, b2y), 5), two, 160, "verifications")
     rr = e.fill_random(n2, SEED, 22, clear_top_bits=1); ss = e.fill_random(n2, SEED, 23, clear_top_bits=1)
     row(f"ecdsa_verify<{nm}> (e, r, s, Q -> ok)", n2, timeit(lambda: e.ecdsa_verify(cv, u1, rr, ss, b2x, b2y), 5), two + 6 * 136, 161, "verifications")
-    row(f"ecdsa_sign<{nm}> (e, d, k -> r, s: k G on the constant-time comb)", n2, timeit(lambda: e.ecdsa_sign(cv, u1, rr, ss), 5), comb + int((4 + 88 / 32 + 9 + 7) * 136), 160, "signatures")
+    row(f"ecdsa_sign<{nm}> (e, d, k -> r, s: k G on the constant-time comb)", n2, timeit(lambda: e.ecdsa_sign(cv, u1, rr, ss), 5), 51 * 11 * 136 + int((4 + 88 / 32 + 9 + 7) * 136), 160, "signatures")
     wire = e.sec1_encode(cv, b2x, b2y, True)
     row(f"sec1_decode<{nm}> compressed (decompression: x^((p+1)/4) in sliding windows on 29-bit limbs)", n2, timeit(lambda: e.sec1_decode(cv, wire, True)), (253 + 64 + 4) * 136, 33 + 64, "points",
         executed_mad32=254 * 126 + 68 * 162 + 6 * 200)                   # sqr29 126 / mul29 162 multiply-adds with the dense reduction; right-hand side and check on canonical words

@@ -147,7 +147,7 @@ import json; d=json.load(open('$out/bench_brainpool_$w.json')); r=d['roofline'];
     timeout -k 10 300 python tools/pcie_rate.py > "$out/pcie_rate.txt" 2>&1 || rc=$?; cat "$out/pcie_rate.txt"
     exit $rc ;;
   r5_gvarwin)       # round 5: the variable-base window loop of a registered curve (k_gvarwin.hip) -- its tests, then its rates beside the ladder's
-    timeout -k 10 600 python -m pytest tests/test_gpu_curves.py -x -q -m gpu -k "window_loop or do_not_exist or ecdsa_and_double or generator_comb or hip_graph" > "$out/pytest.txt" 2>&1; rc=$?
+    timeout -k 10 600 python -m pytest tests/test_gpu_curves.py tests/test_gpu_witness.py -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?
     tail -15 "$out/pytest.txt"; [ $rc -ne 0 ] && exit $rc
     timeout -k 10 500 python tools/gvarwin_perf.py ${1:-22} > "$out/gvarwin_perf.txt" 2>&1; rc=$?; cat "$out/gvarwin_perf.txt"; exit $rc ;;
   r5_gvw_lines)     # round 5: the window loop of a registered curve -- its bench lines (CPU leg: the reference instantiated for the curve + to_affine), rocprofv3 stats + --pmc passes, the soak against the ladder

@@ -64,14 +64,14 @@ for cv, nm in ((P256, "P-256"), (SECP256K1, "secp256k1")):
     b = rates(cv, f"{nm} built-in")
     assert all(np.array_equal(u, v) for u, v in zip(g, b)), "generic window loop != built-in window loop"
 
-# k G on a registered curve: the 4-bit comb (plain, constant-time) and the signed 7-bit comb (ALG_WINDOWED_SIGNED: 36 additions instead of 63)
+# k G on a registered curve: the 4-bit comb, the constant-time 5-bit comb (every entry of a window read: 51 additions) and the signed 7-bit comb (ALG_WINDOWED_SIGNED: 36 additions instead of 63)
 from ecsimd_amd import ALG_WINDOWED_SIGNED     # noqa: E402
 for name in ("brainpoolP256r1", "sm2", "frp256v1"):
     c = NAMED[name]
     cid = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"])
     k = eng.fill_random(n, SEED, 31)
     res = {}
-    for fl, what in ((ALG_WINDOWED, "4-bit comb"), (ALG_WINDOWED | ALG_CONSTANT_TIME, "4-bit comb, constant time"), (ALG_WINDOWED_SIGNED, "signed 7-bit comb")):
+    for fl, what in ((ALG_WINDOWED, "4-bit comb"), (ALG_WINDOWED | ALG_CONSTANT_TIME, "5-bit comb, constant time"), (ALG_WINDOWED_SIGNED, "signed 7-bit comb")):
         out = [eng.empty(n), eng.empty(n), None]
         t = timed(lambda: eng.scalar_mult_base(cid, k, flags=OUT_AFFINE | fl, out=out))
         print(f"{name:34s} k G, {what:28s} {t:9.2f} ms  {n / (t * 1e-3) / 1e6:8.2f} M/s")
@@ -87,6 +87,8 @@ m = min(n, 1 << 22)
 e = eng.fill_random(m, SEED, 11); d = eng.fill_random(m, SEED, 12, clear_top_bits=2); kk = eng.fill_random(m, SEED, 13, clear_top_bits=2)
 r_, s_, ok = eng.ecdsa_sign(cid, e, d, kk)
 qx, qy = eng.scalar_mult_base(cid, d, flags=OUT_AFFINE)
+ts = timed(lambda: eng.ecdsa_sign(cid, e, d, kk))
+print(f"brainpoolP256r1 ecdsa_sign:   {ts:9.2f} ms per 2^{m.bit_length() - 1} signatures  {m / (ts * 1e-3) / 1e6:8.2f} M/s   (k G on the constant-time 5-bit comb)")
 t = timed(lambda: eng.ecdsa_verify(cid, e, r_, s_, qx, qy))
 good = int(eng.to_numpy(eng.ecdsa_verify(cid, e, r_, s_, qx, qy)).sum()), int(eng.to_numpy(ok).sum())
 print(f"brainpoolP256r1 ecdsa_verify: {t:9.2f} ms per 2^{m.bit_length() - 1} signatures  {m / (t * 1e-3) / 1e6:8.2f} M/s   ({good[0]} of {good[1]} signed ones accepted)")
