@@ -89,10 +89,10 @@ struct curve_group {
     hip::check(ecsimd_hip_add_mixed_complete(hip::context(), curve_id(), px(A), py(A), pz(A), px(B), py(B), px(r), py(r), pz(r), A.size()), "ecsimd_hip_add_mixed_complete"); return r;
   }
   // k[i] * G through the 20-bit window table of odd multiples in device memory (12 mixed additions), affine classical.  A curve registered at run time
-  // (one that names its order N) has the 4-bit table of its generator in LDS instead (63 mixed additions).
+  // (one that names its order N) has the signed 7-bit table of its generator in LDS instead (36 mixed additions).
   static WCP scalar_mult_base_affine(WBN const& x) {
     WCP r{WBN::uninitialized(x.size()), WBN::uninitialized(x.size())};
-    const int alg = curve_id() >= ECSIMD_HIP_FIRST_REGISTERED_CURVE ? ECSIMD_HIP_ALG_WINDOWED : ECSIMD_HIP_ALG_WINDOWED_BIG;
+    const int alg = curve_id() >= ECSIMD_HIP_FIRST_REGISTERED_CURVE ? ECSIMD_HIP_ALG_WINDOWED_SIGNED : ECSIMD_HIP_ALG_WINDOWED_BIG;
     hip::check(ecsimd_hip_scalar_mult_base(hip::context(), curve_id(), x.data(), r.x().data(), r.y().data(), nullptr, x.size(),
                                            ECSIMD_HIP_OUT_AFFINE | alg), "ecsimd_hip_scalar_mult_base");
     return r;
