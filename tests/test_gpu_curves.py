@@ -484,6 +484,48 @@ def test_variable_base_window_loop_on_a_registered_curve(engine, name):
     assert not rx[77].any() and not ry[77].any()
 
 
+def test_window_loops_of_a_registered_curve_at_the_full_batch_size(engine):
+    """BASELINE configs[3]'s batch (2^24 scalar multiplications, on one GPU) through the registered curve's window loops, held by properties that need no
+    oracle at that size: every lane equals the reference ladder's affine point; k P + (n - k) P is the point at infinity on every lane; a P + b P = (a + b) P
+    through the batched affine addition; the constant-time loop returns the plain loop's points; u1 G + u2 Q (the signed comb + the window loop) equals the sum of
+    its two halves.  brainpoolP256r1: a random coefficient a, a dense prime."""
+    import torch
+    from ecsimd_amd import ALG_WINDOWED, ALG_CONSTANT_TIME, ALG_WINDOWED_SIGNED
+    c = REF_CURVES["brainpoolP256r1"]
+    cid = register(c)
+    N = 1 << 24
+    nn = engine.to_device(np.tile(from_int(c["n"]), (N, 1)))
+    s = engine.fill_random(N, SEED, 301)
+    bx, by = engine.scalar_mult_base(cid, s, flags=OUT_AFFINE | ALG_WINDOWED_SIGNED)                     # lane-distinct base points
+    k = engine.fill_random(N, SEED, 302, clear_top_bits=1)                                               # < 2^255 <= n
+    w = engine.scalar_mult(cid, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)
+    l = engine.scalar_mult(cid, k, bx, by, flags=OUT_AFFINE)
+    assert torch.equal(w[0], l[0]) and torch.equal(w[1], l[1]), "the window loop and the ladder disagree somewhere in 2^24 lanes"
+    del l
+    ct = engine.scalar_mult(cid, k, bx, by, flags=OUT_AFFINE | ALG_WINDOWED | ALG_CONSTANT_TIME)
+    assert torch.equal(ct[0], w[0]) and torch.equal(ct[1], w[1])
+    del ct
+    nk, borrow = engine.sub(nn, k)
+    assert not bool(borrow.any())
+    m = engine.scalar_mult(cid, nk, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)
+    zx, zy, fin = engine.affine_add(cid, w, m)
+    assert not bool(fin.any()) and not bool(zx.any()) and not bool(zy.any()), "k P + (n - k) P is not the point at infinity somewhere"
+    del m, nk, zx, zy, fin
+    a = engine.fill_random(N, SEED, 303, clear_top_bits=2); b = engine.fill_random(N, SEED, 304, clear_top_bits=2)      # a + b < 2^255
+    ab, carry = engine.add(a, b)
+    assert not bool(carry.any())
+    pa = engine.scalar_mult(cid, a, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)
+    pb = engine.scalar_mult(cid, b, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)
+    sx, sy, fin = engine.affine_add(cid, pa, pb)
+    pab = engine.scalar_mult(cid, ab, bx, by, flags=OUT_AFFINE | ALG_WINDOWED)
+    assert bool(fin.all()) and torch.equal(sx, pab[0]) and torch.equal(sy, pab[1]), "a P + b P != (a + b) P somewhere"
+    del pb, sx, sy, pab, ab
+    ga = engine.scalar_mult_base(cid, b, flags=OUT_AFFINE | ALG_WINDOWED_SIGNED)                         # u1 G + u2 Q against its two halves
+    ex, ey, efin = engine.affine_add(cid, ga, pa)
+    dx, dy, dfin = engine.double_scalar_mult(cid, b, a, bx, by)
+    assert torch.equal(dx, ex) and torch.equal(dy, ey) and torch.equal(dfin, efin)
+
+
 @pytest.mark.parametrize("cv", [P256, SECP256K1])
 def test_variable_base_window_loop_of_a_builtin_curve_through_the_generic_kernels(engine, cv):
     """P-256 (a = -3) / secp256k1 (a = 0) registered like any other curve: the generic window loop returns the built-in loops' affine points."""
