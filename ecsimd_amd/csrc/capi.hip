@@ -84,7 +84,7 @@ struct ecsimd_hip_ctx {
   uint8_t* valid;              // grow-only: per-lane public-key validity of double_scalar_mult / ecdsa_verify_rx
   size_t valid_bytes;
   int ref_square;              // ecsimd_hip_set_ref_square_compat: the reference's square() as written (mul.h:160-212)
-  struct gcomb_entry { int curve; uint32_t* table; uint64_t* special; uint32_t* table7; uint32_t* table5; };      // table7: the signed 7-bit comb (ALG_WINDOWED_SIGNED); table5: the constant-time 5-bit comb
+  struct gcomb_entry { int curve; uint32_t* table; uint64_t* special; uint32_t* table7; uint32_t* table5; uint32_t* table20; };      // table7: the signed 7-bit comb (ALG_WINDOWED_SIGNED); table5: the constant-time 5-bit comb; table20: the 20-bit comb in device memory (ALG_WINDOWED_BIG, 436 MB)
   std::vector<gcomb_entry> gcomb;   // per registered curve: the 4-bit odd-digit table of multiples of its generator (k_gcomb.hip) and, for the small-batch route, the ladder's
                                     // three degenerate scalars with its affine results for them on G (as base_special); built on first use
   ecsimd_hip_ctx* helper;      // ecsimd_hip_scalar_mult_host: the second stream's context (created on first use, destroyed with this one)
@@ -353,10 +353,12 @@ int run_gladder(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, int k_stride,
     return run_gcomb(ctx, curve, k, ox, oy, n, flags);          // k G from the generator's table in LDS (k_gcomb.hip)
   if (x == nullptr && k_stride == 4 && (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED) && !(flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM | ECSIMD_HIP_ALG_CONSTANT_TIME)))
     return run_gcomb(ctx, curve, k, ox, oy, n, flags);          // ... from the signed 7-bit comb (public scalars)
+  if (x == nullptr && k_stride == 4 && (flags & ECSIMD_HIP_ALG_WINDOWED_BIG) && !(flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_NO_ENDOMORPHISM | ECSIMD_HIP_ALG_CONSTANT_TIME)))
+    return run_gcomb(ctx, curve, k, ox, oy, n, flags);          // ... from the 20-bit comb in device memory (public scalars)
   if (x != nullptr && (flags & ECSIMD_HIP_ALG_WINDOWED) && !(flags & (ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM)))
     return run_gvarwin(ctx, curve, k, k_stride, x, y, ox, oy, n, flags, 0);   // k P from the lane's own table of odd multiples (k_gvarwin.hip); ALG_CONSTANT_TIME: every entry read in every window
   if (flags & (ECSIMD_HIP_ALG_WINDOWED | ECSIMD_HIP_ALG_WINDOWED_SIGNED | ECSIMD_HIP_ALG_WINDOWED_BIG | ECSIMD_HIP_ALG_NO_ENDOMORPHISM | ECSIMD_HIP_ALG_CONSTANT_TIME))
-    return bad(ctx, "a registered curve has the reference's ladder, ALG_WINDOWED [| ALG_CONSTANT_TIME] for its generator and for a variable base, and ALG_WINDOWED_SIGNED for its generator: the other ALG_* tables exist for P-256 and secp256k1");
+    return bad(ctx, "a registered curve has the reference's ladder, ALG_WINDOWED [| ALG_CONSTANT_TIME] for its generator and for a variable base, and ALG_WINDOWED_SIGNED / ALG_WINDOWED_BIG for its generator: the other combinations (the GLV split, constant-time forms of the signed and big combs) exist for P-256 and secp256k1 or not at all");
   if (n == 0) return ECSIMD_HIP_OK;
   if (n > (size_t)0x7fffffff * BLOCK) return bad(ctx, "batch too large");
   hipError_t e = hipSetDevice(ctx->device);
@@ -625,7 +627,7 @@ int ecsimd_hip_destroy(ecsimd_hip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->sink);
   (void)hipFree(ctx->window_table[0]); (void)hipFree(ctx->window_table[1]); (void)hipFree(ctx->window6_table[0]); (void)hipFree(ctx->window6_table[1]); (void)hipFree(ctx->windowct_table[0]); (void)hipFree(ctx->windowct_table[1]); (void)hipFree(ctx->window16_table[0]); (void)hipFree(ctx->window16_table[1]); (void)hipFree(ctx->workspace); (void)hipFree(ctx->valid); (void)hipFree(ctx->base_special[0]); (void)hipFree(ctx->base_special[1]);
-  for (auto& t : ctx->gcomb) { (void)hipFree(t.table); (void)hipFree(t.special); (void)hipFree(t.table7); (void)hipFree(t.table5); }
+  for (auto& t : ctx->gcomb) { (void)hipFree(t.table); (void)hipFree(t.special); (void)hipFree(t.table7); (void)hipFree(t.table5); (void)hipFree(t.table20); }
   (void)hipFree(ctx->hstage);
   if (ctx->helper) (void)ecsimd_hip_destroy(ctx->helper);
   (void)hipEventDestroy(ctx->handoff);
@@ -1235,6 +1237,7 @@ int double_scalar_mult_impl(ecsimd_hip_ctx* ctx, int curve, const uint64_t* u1, 
 // scalars kept clear of its three degenerate values (k_gc_ladder_safe_scalars); one shared inversion per product, a batched affine addition.
 namespace {
 constexpr size_t GC_CHUNK = (size_t)1 << 22;
+constexpr size_t GC_BIG_TABLE_WORTH_IT = (size_t)1 << 20;          // u1 G + u2 Q on a registered curve: batches from here on build the 20-bit comb (0.3 s, 436 MB) on first use
 struct gc_layout { size_t chunk; uint64_t *adj1, *adj2, *j[3], *gx, *gy, *px, *py, *win; uint8_t *neg1, *neg2; size_t bytes; };
 // win: u2 Q goes through the window loop (k_gvarwin.hip), whose per-lane tables follow the nine arrays
 gc_layout gc_plan(uint64_t* base, size_t n, bool win = false) {
@@ -1253,15 +1256,16 @@ gc_layout gc_plan(uint64_t* base, size_t n, bool win = false) {
 // curve -- whose degenerate scalars the entries' multipliers must not be (checked; k* by way of n - k* if it is one) -- through the shared inversion.
 bool gc_comb_possible(const curve_record& rec) { return rec.has_order && (rec.n.l[3] >> 63) != 0; }
 bool gc_window_possible(const curve_record& rec) { return gc_comb_possible(rec) && rec.prime_order; }    // a variable base: every point has order n (curve_record)
-// bits = 4: that table (summed from the top); bits = 7 / 5: the signed comb's 37 windows x 64 / the constant-time comb's 52 windows x 16 odd multiples
-// (2d + 1) 2^(bits w) G (summed from the bottom; the top window's digit is at most 15 / 1: its other entries are never read and hold G).
+// bits = 4: that table (summed from the top); bits = 7 / 5 / 20: the signed comb's 37 windows x 64 / the constant-time comb's 52 windows x 16 / the device-memory
+// comb's 13 windows x 2^19 (436 MB; 1.3 GB of temporary memory and 6.8 M ladder passes, ~0.3 s, at its build) odd multiples (2d + 1) 2^(bits w) G (summed from
+// the bottom; the top window's digit is at most 15 / 1 / 65 535: its other entries are never read and hold G).
 int ensure_gc_comb(ecsimd_hip_ctx* ctx, int curve, const curve_record& rec, const uint32_t** out, int bits = 4) {
-  auto slot = [bits](ecsimd_hip_ctx::gcomb_entry& t) -> uint32_t*& { return bits == 4 ? t.table : bits == 7 ? t.table7 : t.table5; };
+  auto slot = [bits](ecsimd_hip_ctx::gcomb_entry& t) -> uint32_t*& { return bits == 4 ? t.table : bits == 7 ? t.table7 : bits == 20 ? t.table20 : t.table5; };
   for (auto& t : ctx->gcomb) if (t.curve == curve && slot(t)) { *out = slot(t); return ECSIMD_HIP_OK; }
   if (!gc_comb_possible(rec)) return bad(ctx, "the windowed algorithms on a registered curve need its group order n, n >= 2^255");
   if (capturing(ctx)) return bad(ctx, "a window table would have to be built during stream capture: run this call once before capturing");
-  const int W = bits == 4 ? launch::GCOMB_WINDOWS : bits == 7 ? launch::GCOMB7_WINDOWS : launch::GCOMB5_WINDOWS;
-  const int PER = bits == 4 ? launch::GCOMB_ENTRIES : bits == 7 ? launch::GCOMB7_ENTRIES : launch::GCOMB5_ENTRIES;
+  const int W = bits == 4 ? launch::GCOMB_WINDOWS : bits == 7 ? launch::GCOMB7_WINDOWS : bits == 20 ? launch::GCOMB20_WINDOWS : launch::GCOMB5_WINDOWS;
+  const int PER = bits == 4 ? launch::GCOMB_ENTRIES : bits == 7 ? launch::GCOMB7_ENTRIES : bits == 20 ? launch::GCOMB20_ENTRIES : launch::GCOMB5_ENTRIES;
   const size_t table_entries = (size_t)W * PER, entries = table_entries + 1;
   std::vector<uint64_t> host_k;
   try { host_k.assign(entries * 4, 0); ctx->gcomb.reserve(ctx->gcomb.size() + 1); } catch (...) { return bad(ctx, "window table: out of host memory"); }
@@ -1325,7 +1329,7 @@ int ensure_gc_comb(ecsimd_hip_ctx* ctx, int curve, const curve_record& rec, cons
   if (e != hipSuccess) { (void)hipFree(table); return fail(ctx, e, "window table build (registered curve)"); }
   bool placed = false;
   for (auto& t : ctx->gcomb) if (t.curve == curve) { slot(t) = table; placed = true; }
-  if (!placed) { ctx->gcomb.push_back({curve, nullptr, nullptr, nullptr, nullptr}); slot(ctx->gcomb.back()) = table; }
+  if (!placed) { ctx->gcomb.push_back({curve, nullptr, nullptr, nullptr, nullptr, nullptr}); slot(ctx->gcomb.back()) = table; }
   *out = table;
   return ECSIMD_HIP_OK;
 }
@@ -1369,12 +1373,13 @@ int run_gcomb(ecsimd_hip_ctx* ctx, int curve, const uint64_t* k, uint64_t* ox, u
   (void)hipSetDevice(ctx->device);
   const uint32_t* table = nullptr;
   const bool seven = (flags & ECSIMD_HIP_ALG_WINDOWED_SIGNED) != 0;     // signed 7-bit windows in 148 KiB of LDS: 36 additions instead of 63 (public scalars)
-  const bool five = !seven && (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) != 0;   // the constant-time comb: 5-bit windows, 51 additions, every entry of a window read
-  int rc = ensure_gc_comb(ctx, curve, rec, &table, seven ? 7 : five ? 5 : 4);
+  const bool big = (flags & ECSIMD_HIP_ALG_WINDOWED_BIG) != 0;          // 20-bit windows over 436 MB in device memory: 12 additions (public scalars)
+  const bool five = !seven && !big && (flags & ECSIMD_HIP_ALG_CONSTANT_TIME) != 0;   // the constant-time comb: 5-bit windows, 51 additions, every entry of a window read
+  int rc = ensure_gc_comb(ctx, curve, rec, &table, seven ? 7 : big ? 20 : five ? 5 : 4);
   if (rc == ECSIMD_HIP_OK) rc = ensure_workspace(ctx, 3 * n * 32);
   if (rc != ECSIMD_HIP_OK) return rc;
   uint64_t* jx = ctx->workspace; uint64_t* jy = jx + 4 * n; uint64_t* jz = jy + 4 * n;
-  if (seven || five) launch::gc_base_windowed_s(ctx->stream, rec.G, order_words(rec), seven ? 7 : 5, k, table, jx, jy, jz, n);
+  if (seven || five || big) launch::gc_base_windowed_s(ctx->stream, rec.G, order_words(rec), seven ? 7 : big ? 20 : 5, k, table, jx, jy, jz, n);
   else launch::gc_base_windowed(ctx->stream, rec.G, order_words(rec), k, table, jx, jy, jz, n, false);
   launch::gc_to_affine_batched(ctx->stream, rec.G, jx, jy, jz, ox, oy, n);
   hipError_t e = hipGetLastError();
@@ -1453,8 +1458,12 @@ int gc_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve_of, const curve_record&
   if (rc != ECSIMD_HIP_OK) return rc;
   const uint32_t* comb = nullptr;                                   // u1 G from the generator's table where the curve has one (n >= 2^255), else a ladder pass
   const uint32_t* comb7 = nullptr;                                  // ... preferably the signed 7-bit comb (u1 is public: 36 additions instead of 63)
+  const uint32_t* comb20 = nullptr;                                 // ... or the 20-bit comb in device memory (12 additions) once it exists or the batch pays for its 436 MB
   if (gc_comb_possible(rec)) {
-    rc = ensure_gc_comb(ctx, curve_of, rec, &comb7, 7);
+    bool have20 = false;
+    for (auto& t : ctx->gcomb) if (t.curve == curve_of && t.table20) have20 = true;
+    if (have20 || (n >= GC_BIG_TABLE_WORTH_IT && !capturing(ctx))) { rc = ensure_gc_comb(ctx, curve_of, rec, &comb20, 20); if (rc != ECSIMD_HIP_OK) comb20 = nullptr; }
+    rc = comb20 ? ECSIMD_HIP_OK : ensure_gc_comb(ctx, curve_of, rec, &comb7, 7);
     if (rc != ECSIMD_HIP_OK) {
       if (!capturing(ctx)) return rc;
       comb7 = nullptr;
@@ -1466,8 +1475,9 @@ int gc_double_scalar_mult(ecsimd_hip_ctx* ctx, int curve_of, const curve_record&
   launch::gc_on_curve(s, rec.G, qx, qy, ctx->valid, n);
   for (size_t first = 0; first < n; first += L.chunk) {
     const size_t m = (n - first) < L.chunk ? (n - first) : L.chunk;
-    if (comb7 || comb) {
-      if (comb7) launch::gc_base_windowed_s(s, rec.G, order_words(rec), 7, u1 + 4 * first, comb7, L.j[0], L.j[1], L.j[2], m);
+    if (comb20 || comb7 || comb) {
+      if (comb20) launch::gc_base_windowed_s(s, rec.G, order_words(rec), 20, u1 + 4 * first, comb20, L.j[0], L.j[1], L.j[2], m);
+      else if (comb7) launch::gc_base_windowed_s(s, rec.G, order_words(rec), 7, u1 + 4 * first, comb7, L.j[0], L.j[1], L.j[2], m);
       else launch::gc_base_windowed(s, rec.G, order_words(rec), u1 + 4 * first, comb, L.j[0], L.j[1], L.j[2], m, false);
       launch::gc_to_affine_batched(s, rec.G, L.j[0], L.j[1], L.j[2], L.gx, L.gy, m);
     } else gc_safe_mult(s, rec, L, L.adj1, L.neg1, u1 + 4 * first, nullptr, nullptr, L.gx, L.gy, m);                       // u1 G

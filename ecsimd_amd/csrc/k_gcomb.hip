@@ -126,13 +126,14 @@ k_gc_base_windowed(gcurve G, launch::words8 order8, const uint64_t* __restrict__
 // (2d + 1) 2^(WB w) G in LDS.  The odd one of k mod n and n - k; digit w = ((k >> WB w) mod 2^(WB+1) | 1) - 2^WB for every window but the top one, whose
 // digit is what remains | 1.  No zero digit: the first entry starts the sum, nothing to skip.  The one scalar whose last addition can meet R = T is
 // k* = n - 2 (n mod 2^(WB (NW - 1))); the table's tail holds k* G and {k*, 0} as the 4-bit comb's does (tests/test_accumulator_models.py walks the
-// accumulator for the registered curves' orders).  Two shapes are launched:
+// accumulator for the registered curves' orders).  Three shapes are launched:
 //   <7, false, 1024>  ALG_WINDOWED_SIGNED: 37 x 64 entries, 148 KiB of LDS, ONE workgroup of 1 024 threads per CU (four waves per SIMD: 128 registers), 36 mixed
 //                     additions instead of 63; public scalars (u1 G of a verification);
+//   <20, false, 256>  ALG_WINDOWED_BIG: 13 x 2^19 entries = 436 MB in DEVICE memory (no LDS), 12 mixed additions behind 13 dependent random 64-byte reads; public scalars;
 //   <5, true, 256>    ALG_WINDOWED | ALG_CONSTANT_TIME and k G of ecdsa_sign: 52 x 16 entries, 53 KB of LDS, three workgroups per CU, 51 additions; every entry
 //                     of a window is read (one LDS address per wave, a broadcast) and the lane's own kept under masks -- no address, branch or EXEC mask
 //                     depends on the scalar (tests/test_constant_time_isa.py).
-template <int WB> struct gswin { static constexpr int WINDOWS = (256 + WB - 1) / WB, PER = 1 << (WB - 1), TABLE_WORDS = WINDOWS * PER * 16; };
+template <int WB> struct gswin { static constexpr int WINDOWS = (256 + WB - 1) / WB, PER = 1 << (WB - 1); static constexpr size_t TABLE_WORDS = (size_t)WINDOWS * PER * 16; };
 template <int PER, bool CT> ECS_DEV void gs_entry(const uint4* win, uint32_t slot, fe& tx, fe& ty) {
   if constexpr (!CT) { entry_words(win + slot * 4, tx, ty); return; }
   entry_words(win, tx, ty);
@@ -148,12 +149,13 @@ template <int WB, bool CT, int BLK> __global__ void __launch_bounds__(BLK)
 k_gc_base_windowed_s(gcurve G, launch::words8 order8, const uint64_t* __restrict__ k, const uint32_t* __restrict__ table,
                      uint64_t* __restrict__ ox, uint64_t* __restrict__ oy, uint64_t* __restrict__ oz, size_t n) {
   constexpr int NW = gswin<WB>::WINDOWS, PER = gswin<WB>::PER;
+  constexpr bool IN_LDS = WB < 16;                        // 20-bit windows: 13 x 2^19 entries = 436 MB stay in device memory, 13 dependent random 64-byte reads per lane
   extern __shared__ uint4 lds_s[];
-  {
+  if constexpr (IN_LDS) {
     const uint4* src = reinterpret_cast<const uint4*>(table);
     for (int e = threadIdx.x; e < gswin<WB>::TABLE_WORDS / 4; e += BLK) lds_s[e] = src[e];
+    __syncthreads();
   }
-  __syncthreads();
   const size_t i = (size_t)blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   const r29_ctx<C>& cx = G.r29;
@@ -202,7 +204,7 @@ k_gc_base_windowed_s(gcurve G, launch::words8 order8, const uint64_t* __restrict
     uint32_t mag, neg;
     digit(false, mag, neg);
     fe tx, ty;
-    gs_entry<PER, CT>(&lds_s[0], mag >> 1, tx, ty);
+    if constexpr (IN_LDS) gs_entry<PER, CT>(&lds_s[0], mag >> 1, tx, ty); else entry_words(gtab + (size_t)(mag >> 1) * 4, tx, ty);
     A.x = to29(tx); A.y = cneg29(neg, to29(ty)); A.z = one;
   }
 #pragma unroll 1
@@ -211,7 +213,7 @@ k_gc_base_windowed_s(gcurve G, launch::words8 order8, const uint64_t* __restrict
     uint32_t mag, neg;
     digit(w + 1 >= NW, mag, neg);
     fe tx, ty;
-    gs_entry<PER, CT>(&lds_s[(size_t)w * PER * 4], mag >> 1, tx, ty);
+    if constexpr (IN_LDS) gs_entry<PER, CT>(&lds_s[(size_t)w * PER * 4], mag >> 1, tx, ty); else entry_words(gtab + ((size_t)w * PER + (mag >> 1)) * 4, tx, ty);
     A = madd29<C>(A, to29(tx), cneg29(neg, to29(ty)), cx);
   }
   if (CT || __builtin_amdgcn_ballot_w64(special != 0u) != 0ull) {       // constant time: taken by every wave
@@ -225,17 +227,20 @@ k_gc_base_windowed_s(gcurve G, launch::words8 order8, const uint64_t* __restrict
   for (int j = 0; j < 8; ++j) { X.w[j] &= ~zmask; Y.w[j] &= ~zmask; Z.w[j] &= ~zmask; }
   fe_store(ox, i, X); fe_store(oy, i, Y); fe_store(oz, i, Z);
 }
+static_assert(gswin<20>::WINDOWS == launch::GCOMB20_WINDOWS && gswin<20>::PER == launch::GCOMB20_ENTRIES, "kernels.h");
 static_assert(gswin<7>::WINDOWS == launch::GCOMB7_WINDOWS && gswin<7>::PER == launch::GCOMB7_ENTRIES && gswin<5>::WINDOWS == launch::GCOMB5_WINDOWS && gswin<5>::PER == launch::GCOMB5_ENTRIES, "kernels.h");
 }  // namespace
 
 namespace launch {
 template <int WB, bool CT, int BLK> static void gcs_launch(hipStream_t s, const gcurve& G, const words8& order, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gc_base_windowed_s<WB, CT, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, gswin<WB>::TABLE_WORDS * 4);
-  hipLaunchKernelGGL((k_gc_base_windowed_s<WB, CT, BLK>), dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), gswin<WB>::TABLE_WORDS * 4, s, G, order, k, table, ox, oy, oz, n);
+  constexpr size_t lds = WB < 16 ? gswin<WB>::TABLE_WORDS * 4 : 0;
+  if (lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gc_base_windowed_s<WB, CT, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_gc_base_windowed_s<WB, CT, BLK>), dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), lds, s, G, order, k, table, ox, oy, oz, n);
 }
-// bits = 7: the signed 7-bit comb (public scalars); bits = 5: the constant-time 5-bit comb (every entry of a window read)
+// bits = 7: the signed 7-bit comb (public scalars); bits = 5: the constant-time 5-bit comb (every entry of a window read); bits = 20: the comb in device memory (public)
 void gc_base_windowed_s(hipStream_t s, const gcurve& G, const words8& order, int bits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n) {
   if (bits == 7) gcs_launch<7, false, 1024>(s, G, order, k, table, ox, oy, oz, n);
+  else if (bits == 20) gcs_launch<20, false, 256>(s, G, order, k, table, ox, oy, oz, n);
   else gcs_launch<5, true, 256>(s, G, order, k, table, ox, oy, oz, n);
 }
 void gc_pack_table(hipStream_t s, const gcurve& G, const uint64_t* tx, const uint64_t* ty, uint32_t* table, int entries) {

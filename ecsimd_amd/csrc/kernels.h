@@ -86,7 +86,7 @@ void gc_pack_table(hipStream_t, const gcurve& G, const uint64_t* tx, const uint6
 void gc_base_windowed(hipStream_t, const gcurve& G, const words8& order, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n, bool constant_time);
 // ... and from signed 7-bit windows with odd digits (37 windows x 64 entries, 148 KiB of LDS, summed from the bottom: ALG_WINDOWED_SIGNED; public scalars)
 // ... and the constant-time 5-bit comb (52 windows x 16 entries, 53 KB of LDS, every entry of a window read: ALG_WINDOWED | ALG_CONSTANT_TIME, k G of ecdsa_sign)
-constexpr int GCOMB7_BITS = 7, GCOMB7_WINDOWS = 37, GCOMB7_ENTRIES = 64, GCOMB5_WINDOWS = 52, GCOMB5_ENTRIES = 16;
+constexpr int GCOMB7_BITS = 7, GCOMB7_WINDOWS = 37, GCOMB7_ENTRIES = 64, GCOMB5_WINDOWS = 52, GCOMB5_ENTRIES = 16, GCOMB20_WINDOWS = 13, GCOMB20_ENTRIES = 1 << 19;   // (20 bits: 436 MB in device memory, ALG_WINDOWED_BIG)
 void gc_base_windowed_s(hipStream_t, const gcurve& G, const words8& order, int bits, const uint64_t* k, const uint32_t* table, uint64_t* ox, uint64_t* oy, uint64_t* oz, size_t n);
 // k_gvarwin.hip: k P on a registered curve with per-lane window tables (the eight odd multiples of P over one Z, the loop on the isomorphic curve; affine
 // classical out, oy may be null).  scratch: gc_varwin_scratch_bytes(n) bytes, 32-byte aligned; k_stride, x, y as for gc_scalar_mult; flags: ECSIMD_HIP_BASE_MGRY.

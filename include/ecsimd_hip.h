@@ -180,11 +180,13 @@ int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id);
  * parameters give 0 / 1 unless flags = ECSIMD_HIP_CURVE_GENERIC_KERNELS, which registers them like any other curve -- how tests hold the generic kernels
  * to the special-form ones bit for bit) is accepted by
  *     from_affine, to_affine, compute_y, on_curve, dblu, zaddu, zdau, add_z2_1, trplu, zdau_repeat, scalar_mult, scalar_mult_1s, scalar_mult_base, scalar_mult_host
- * (flags BASE_* | OUT_* | LADDER_RADIX32 | REF_SQUARE_COMPAT: the reference's ladder; of the table-driven algorithms a registered curve has THREE, all for
+ * (flags BASE_* | OUT_* | LADDER_RADIX32 | REF_SQUARE_COMPAT: the reference's ladder; of the table-driven algorithms a registered curve has all but the GLV split, all for
  * a curve registered with its order n >= 2^255 and all with OUT_AFFINE only: scalar_mult_base with ALG_WINDOWED -- a 4-bit odd-digit table of multiples of
  * ITS generator in LDS, built from the ladder on first use -- with ALG_WINDOWED | ALG_CONSTANT_TIME -- 5-bit windows, 52 x 16 odd multiples in 53 KB of LDS,
  * every entry of a window read and one kept under lane masks: SAFE for secret scalars -- or with ALG_WINDOWED_SIGNED -- signed 7-bit windows, 37 x 64 odd
- * multiples in 148 KiB of LDS, 36 additions instead of 63, public scalars (1.6 x the 4-bit comb) -- and scalar_mult / scalar_mult_1s with ALG_WINDOWED on a variable base --
+ * multiples in 148 KiB of LDS, 36 additions instead of 63, public scalars (1.6 x the 4-bit comb) -- or with ALG_WINDOWED_BIG -- 20-bit windows, 13 x 2^19 odd
+ * multiples in 436 MB of DEVICE memory per curve and context (built on first use: 0.3 s, 1.3 GB of temporary memory), 12 additions, public scalars (3.7 x) --
+ * and scalar_mult / scalar_mult_1s with ALG_WINDOWED on a variable base --
  * the lane's own table of the eight odd multiples of P over one Z, 63 windows of three doublings and a fused double-add in modified Jacobian coordinates
  * on the isomorphic curve (any coefficient a; 640 B of context workspace per element, 2^22 at a time; 1.4 x the ladder's rate) -- public scalars: the table
  * is indexed by the scalar's digits; with ALG_CONSTANT_TIME every entry of the lane's table is read in every window and one kept under lane masks: SAFE for
@@ -193,7 +195,7 @@ int ecsimd_hip_register_modulus(const uint64_t p[4], int flags, int* field_id);
  * an id without it keeps the ladder for a variable base (BAD_ARG for the flag, ladder passes inside double_scalar_mult / ecdsa_verify).
  * Either returns the true k P for every k, (0, 0) for k = 0 mod n.  The other ALG_* shapes exist for the two built-in curves only), by affine_add, sec1_encode, sec1_decode and -- when n was given, p < 2n, and
  * n - u is a good ladder scalar for u in {n - 1, 2^256 - n - 1, 2^256 - n} (every prime-order curve of this size) -- by double_scalar_mult,
- * ecdsa_verify_rx, ecdsa_verify, ecdsa_sign: u1 G comes from the generator's signed comb (sign: k G from the constant-time 5-bit comb), u2 Q (public) from the
+ * ecdsa_verify_rx, ecdsa_verify, ecdsa_sign: u1 G comes from the generator's signed comb -- from the 20-bit comb once that exists or the batch reaches 2^20 -- (sign: k G from the constant-time 5-bit comb), u2 Q (public) from the
  * lane's window table -- correct for every scalar in [0, n); ecdsa_sign's scratch is zeroed like the built-in curves'.  (n < 2^255: passes of the ladder
  * instead, the scalars kept clear of its three degenerate values: u -> n - u and the result negated.)  Like the built-in curves', a call of
  * scalar_mult_base(OUT_AFFINE) without an algorithm flag on up to 2^16 lanes takes that comb (constant time) and returns the ladder's affine bits, its

@@ -170,10 +170,10 @@ def test_the_family_is_the_gpu_tests_family():
     assert len(family(P256, 10)) > 16797 + 100
 
 
-@pytest.mark.parametrize("shape", ["top4", "bottom5", "bottom7"])
+@pytest.mark.parametrize("shape", ["top4", "bottom5", "bottom7", "bottom20"])
 @pytest.mark.parametrize("name", ["brainpoolP256r1", "sm2", "frp256v1"])
 def test_generator_comb_of_a_registered_curve(name, shape):
-    """k_gcomb.hip runs the top4 shape (ALG_WINDOWED; small batches), the bottom5 shape (ALG_WINDOWED | ALG_CONSTANT_TIME, ecdsa_sign) and the bottom7 shape (ALG_WINDOWED_SIGNED) with the order of a curve registered at
+    """k_gcomb.hip runs the top4 shape (ALG_WINDOWED; small batches), the bottom5 shape (ALG_WINDOWED | ALG_CONSTANT_TIME, ecdsa_sign) the bottom7 shape (ALG_WINDOWED_SIGNED) and the bottom20 shape (ALG_WINDOWED_BIG) with the order of a curve registered at
     run time (n >= 2^255 is what capi.hip ensure_gc_comb asks for): the same walk with that n -- no addition is exceptional except the last one at
     k* = n - 2 (n mod 16) when bit 4 of it is clear (top4) / at k* = n - 2 (n mod 2^252) (bottom7)."""
     from oracle.loader import REF_CURVES
@@ -184,7 +184,7 @@ def test_generator_comb_of_a_registered_curve(name, shape):
     ks = kstar(n, bits, windows, top)
     last = 0 if top else windows - 1
     fam = arr_to_ints(digit_pattern_operands()[::100])
-    for v in (ks, n - 2 * (n % 16), n - 2 * (n % (1 << 252)), n - 2 * (n % (1 << 255))):
+    for v in (ks, n - 2 * (n % 16), n - 2 * (n % (1 << 252)), n - 2 * (n % (1 << 255)), n - 2 * (n % (1 << 240))):
         fam += [v, v + 1, v - 1, v + 2, v - 2, n - v, n - v + 1, n - v - 1, v + n, n - v + n]
     fam += [1, 2, 3, n - 1, n - 2, n + 1, n + 2, (n - 1) // 2, (n + 1) // 2, (1 << 256) - n, (1 << 256) - n - 1, (1 << 256) - n + 1, M256, 1 << 255, (1 << 255) - 1]
     rng = random.Random(sum(name.encode()))

@@ -221,7 +221,7 @@ def test_registered_curve_entry_points_that_do_not_exist_say_so(engine, oracle):
             engine.scalar_mult(cid, k, bx, by, flags=fl)                  # a variable base: the window loop (k_gvarwin.hip; plain and constant-time) and the ladder, nothing else
     with pytest.raises(EcsimdHipError, match="OUT_AFFINE"):
         engine.scalar_mult(cid, k, bx, by, flags=ALG_WINDOWED)            # the window loop's Jacobian representative is not the reference's
-    for fl in (OUT_AFFINE | ALG_WINDOWED_BIG, OUT_AFFINE | ALG_CONSTANT_TIME, OUT_AFFINE | ALG_WINDOWED_SIGNED | ALG_CONSTANT_TIME, OUT_AFFINE | ALG_WINDOWED_SIGNED | ALG_WINDOWED):
+    for fl in (OUT_AFFINE | ALG_CONSTANT_TIME, OUT_AFFINE | ALG_WINDOWED_SIGNED | ALG_CONSTANT_TIME, OUT_AFFINE | ALG_WINDOWED_SIGNED | ALG_WINDOWED, OUT_AFFINE | ALG_WINDOWED_BIG | ALG_CONSTANT_TIME):
         with pytest.raises(EcsimdHipError, match="a registered curve has"):
             engine.scalar_mult_base(cid, k, flags=fl)
     with pytest.raises(EcsimdHipError, match="OUT_AFFINE"):
@@ -398,8 +398,10 @@ def test_generator_comb_on_a_registered_curve(engine, name):
     G = (c["gx"], c["gy"])
     ks = n_ - 2 * (n_ % 16)
     ks7 = n_ - 2 * (n_ % 2**252)                                             # the signed 7-bit comb's (summed from the bottom)
+    ks20 = n_ - 2 * (n_ % 2**240)                                            # the 20-bit comb's
     edge = [0, 1, 2, 3, 15, 16, 17, 31, 32, 33, n_ - 2, n_ - 1, n_, n_ + 1, n_ + 2, ks, ks - 1, ks + 1, n_ - ks, ks + n_ if ks + n_ < 2**256 else ks, 2**256 - n_ - 1, 2**256 - n_,
             ks7, ks7 - 1, ks7 + 1, ks7 - 2, ks7 + 2, n_ - ks7, n_ - ks7 + 1, 127, 128, 129, 2**252 - 1, 2**252 + 1, 15 * 2**252 + 1, 2**7 - 1, 2**14 + 1,
+            ks20, ks20 - 1, ks20 + 1, n_ - ks20, 2**20 - 1, 2**20, 2**20 + 1, 2**240 - 1, 2**240 + 1, 65535 * 2**240 + 1, 2**21 - 1,
             2**256 - n_ + 1, 2**256 - 1, 2**255, 2**255 - 1, (n_ - 1) // 2, (n_ + 1) // 2, 0x1111111111111111111111111111111111111111111111111111111111111111, 2**252, 16**63, 15 * 16**63]
     N = (1 << 17) + 77
     rng = np.random.default_rng(sum(name.encode()) + 9)
@@ -407,8 +409,8 @@ def test_generator_comb_on_a_registered_curve(engine, name):
     k[:len(edge)] = ints_to_arr(edge)
     kd = engine.to_device(k)
     lx, ly = (engine.to_numpy(t) for t in engine.scalar_mult_base(cid, kd, flags=OUT_AFFINE))
-    from ecsimd_amd import ALG_WINDOWED, ALG_CONSTANT_TIME, ALG_WINDOWED_SIGNED
-    for fl in (ALG_WINDOWED, ALG_WINDOWED | ALG_CONSTANT_TIME, ALG_WINDOWED_SIGNED):          # (signed 7-bit windows, 37 x 64 entries in 148 KiB of LDS: public scalars)
+    from ecsimd_amd import ALG_WINDOWED, ALG_CONSTANT_TIME, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG
+    for fl in (ALG_WINDOWED, ALG_WINDOWED | ALG_CONSTANT_TIME, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG):   # (4-bit; constant-time 5-bit; signed 7-bit in 148 KiB of LDS; 20-bit in 436 MB of device memory)
         wx, wy = (engine.to_numpy(t) for t in engine.scalar_mult_base(cid, kd, flags=OUT_AFFINE | fl))
         for i, kv in enumerate(edge):
             want = mul(kv % n_, G)
@@ -417,9 +419,9 @@ def test_generator_comb_on_a_registered_curve(engine, name):
         xo, none = engine.scalar_mult_base(cid, kd, flags=OUT_AFFINE | fl, x_only=True)
         assert none is None and np.array_equal(engine.to_numpy(xo), wx)
     for m in (1, 3, 255, 257, 1023, 1025):                                  # ragged batches: a partial workgroup still loads the whole table
-        for fl in (ALG_WINDOWED, ALG_WINDOWED_SIGNED):
-            wx, wy = (engine.to_numpy(t) for t in engine.scalar_mult_base(cid, engine.to_device(k[60:60 + m].copy()), flags=OUT_AFFINE | fl))
-            assert np.array_equal(wx, lx[60:60 + m]) and np.array_equal(wy, ly[60:60 + m])
+        for fl in (ALG_WINDOWED, ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG):
+            wx, wy = (engine.to_numpy(t) for t in engine.scalar_mult_base(cid, engine.to_device(k[70:70 + m].copy()), flags=OUT_AFFINE | fl))
+            assert np.array_equal(wx, lx[70:70 + m]) and np.array_equal(wy, ly[70:70 + m])
     assert all(t.shape[0] == 0 for t in engine.scalar_mult_base(cid, engine.empty(0), flags=OUT_AFFINE | ALG_WINDOWED))
 
 

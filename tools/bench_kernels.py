@@ -132,8 +132,10 @@ for nm in ("brainpoolP256r1",):
     row(f"scalar_mult_base<{nm}> windowed, constant time (5-bit windows, every entry of a window read), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 4 | 128, out=outj)), comb5 + int((7 + 88 / 32) * 136), 96, "scalar mults")
     comb7 = 36 * 11 * 136                                              # the signed 7-bit comb: 36 mixed additions
     row(f"scalar_mult_base<{nm}> signed 7-bit windows (the generator's comb, 148 KiB of LDS), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 8, out=outj)), comb7 + int((7 + 88 / 32) * 136), 96, "scalar mults")
-    two = comb7 + vw + int(((7 + 88 / 32) + 6 + 88 / 32) * 136)        # the comb and its conversion, the window loop (its conversion inside vw), the affine addition with its shared inversion
-    row(f"double_scalar_mult<{nm}> u1*G + u2*Q (the signed comb + the lane's window table)", n2, timeit(lambda: e.double_scalar_mult(cv, u1, k, b2x, b2y), 5), two, 160, "verifications")
+    comb20 = 12 * 11 * 136                                             # the 20-bit comb in device memory: 12 mixed additions
+    row(f"scalar_mult_base<{nm}> 20-bit windows (the generator's comb in device memory), affine out", n2, timeit(lambda: e.scalar_mult_base(cv, k, flags=2 | 32, out=outj)), comb20 + int((7 + 88 / 32) * 136), 96 + 832, "scalar mults")
+    two = comb20 + vw + int(((7 + 88 / 32) + 6 + 88 / 32) * 136)        # the comb and its conversion, the window loop (its conversion inside vw), the affine addition with its shared inversion
+    row(f"double_scalar_mult<{nm}> u1*G + u2*Q (the 20-bit comb + the lane's window table)", n2, timeit(lambda: e.double_scalar_mult(cv, u1, k, b2x, b2y), 5), two, 160, "verifications")
     rr = e.fill_random(n2, SEED, 22, clear_top_bits=1); ss = e.fill_random(n2, SEED, 23, clear_top_bits=1)
     row(f"ecdsa_verify<{nm}> (e, r, s, Q -> ok)", n2, timeit(lambda: e.ecdsa_verify(cv, u1, rr, ss, b2x, b2y), 5), two + 6 * 136, 161, "verifications")
     row(f"ecdsa_sign<{nm}> (e, d, k -> r, s: k G on the constant-time comb)", n2, timeit(lambda: e.ecdsa_sign(cv, u1, rr, ss), 5), 51 * 11 * 136 + int((4 + 88 / 32 + 9 + 7) * 136), 160, "signatures")

@@ -65,20 +65,20 @@ for cv, nm in ((P256, "P-256"), (SECP256K1, "secp256k1")):
     assert all(np.array_equal(u, v) for u, v in zip(g, b)), "generic window loop != built-in window loop"
 
 # k G on a registered curve: the 4-bit comb, the constant-time 5-bit comb (every entry of a window read: 51 additions) and the signed 7-bit comb (ALG_WINDOWED_SIGNED: 36 additions instead of 63)
-from ecsimd_amd import ALG_WINDOWED_SIGNED     # noqa: E402
+from ecsimd_amd import ALG_WINDOWED_SIGNED, ALG_WINDOWED_BIG     # noqa: E402
 for name in ("brainpoolP256r1", "sm2", "frp256v1"):
     c = NAMED[name]
     cid = register_curve(c["p"], c["a"], c["b"], c["gx"], c["gy"], c["n"])
     k = eng.fill_random(n, SEED, 31)
     res = {}
-    for fl, what in ((ALG_WINDOWED, "4-bit comb"), (ALG_WINDOWED | ALG_CONSTANT_TIME, "5-bit comb, constant time"), (ALG_WINDOWED_SIGNED, "signed 7-bit comb")):
+    for fl, what in ((ALG_WINDOWED, "4-bit comb"), (ALG_WINDOWED | ALG_CONSTANT_TIME, "5-bit comb, constant time"), (ALG_WINDOWED_SIGNED, "signed 7-bit comb"), (ALG_WINDOWED_BIG, "20-bit comb, device memory")):
         out = [eng.empty(n), eng.empty(n), None]
         t = timed(lambda: eng.scalar_mult_base(cid, k, flags=OUT_AFFINE | fl, out=out))
         print(f"{name:34s} k G, {what:28s} {t:9.2f} ms  {n / (t * 1e-3) / 1e6:8.2f} M/s")
         res[fl] = [eng.to_numpy(o) for o in out[:2]]
     a = res[ALG_WINDOWED]
-    differ = sum(int(((a[0] != b[0]).any(axis=1) | (a[1] != b[1]).any(axis=1)).sum()) for b in (res[ALG_WINDOWED | ALG_CONSTANT_TIME], res[ALG_WINDOWED_SIGNED]))
-    print(f"{name:34s} lanes where the three combs differ: {differ} of {n}")
+    differ = sum(int(((a[0] != b[0]).any(axis=1) | (a[1] != b[1]).any(axis=1)).sum()) for b in (res[ALG_WINDOWED | ALG_CONSTANT_TIME], res[ALG_WINDOWED_SIGNED], res[ALG_WINDOWED_BIG]))
+    print(f"{name:34s} lanes where the four combs differ: {differ} of {n}")
 
 # ECDSA verification on a registered curve: u1 G from the signed comb, u2 Q from the window loop (before: the 4-bit comb and a ladder pass)
 c = NAMED["brainpoolP256r1"]
