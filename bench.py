@@ -203,8 +203,8 @@ def main():
         __graft_entry__.build()         # built artefacts normally travel with the snapshot
     if world > 1:
         dist.barrier()
-    if args.curve not in ("p256", "secp256k1") and args.workload not in LADDER_WORKLOADS + ("windowed", "windowed-ct"):
-        raise SystemExit("a curve registered at run time has the reference's ladder (workloads %s) and the window loop (windowed, windowed-ct); the other table-driven algorithms exist for p256 / secp256k1" % ", ".join(LADDER_WORKLOADS))
+    if args.curve not in ("p256", "secp256k1") and args.workload == "ladder-x":
+        raise SystemExit("ladder-x (the ladder without Z) exists for p256 / secp256k1; a curve registered at run time has every other workload")
     curve = curve_id(args.curve)        # 0 / 1, or a run-time registration (host arithmetic only)
     eng = Engine(dev_index)             # raises if the HIP library / a gfx950 device is missing: no fallback
     units = (1 << args.global_log2_batch) if args.scaling == "strong" else (1 << args.log2_batch)
@@ -368,6 +368,8 @@ def base_line(args, world, total_units, n, value, elapsed):
              "fixed-base-ct": "ALG_CONSTANT_TIME: odd-digit comb in LDS, every entry of a window read and one kept under lane masks (52 five-bit windows x 16 entries, 53 KB, three 256-thread workgroups per CU)",
              "fixed-base-signed": "signed 7-bit window table in LDS (odd digits, 148 KiB)",
              "fixed-base-big": "20-bit window table of odd multiples (436 MB) in device memory"}
+    if args.curve not in ("p256", "secp256k1"):
+        fixed = {k: v + "; this curve is registered at RUN time: generic kernels (k_gcomb.hip), the dense 9-limb prime in SGPRs, the table built from the reference's ladder on first use" for k, v in fixed.items()}
     return {
         "metric": "P-256 scalar mults/sec (batched)" if args.curve == "p256" else f"{args.curve} scalar mults/sec (batched)",
         "value": value, "unit": "scalar_mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -434,6 +436,9 @@ def roofline_object(args, eng, n, avg_ms):
         mad32_unit, bytes_unit = int((adds * 11 + 7 + (267 if args.curve == "p256" else 270) / share) * 136), 96
         kname = {"fixed-base": "k_base_windowed<false>", "fixed-base-ct": "k_base_windowed_s<5, true, 256>",
                  "fixed-base-signed": "k_base_windowed_s<7, false>", "fixed-base-big": "k_base_windowed_g"}[args.workload] + " + k_to_affine_batched"
+        if args.curve not in ("p256", "secp256k1"):
+            kname = {"fixed-base": "k_gc_base_windowed<false>", "fixed-base-ct": "k_gc_base_windowed_s<5, true, 256>", "fixed-base-signed": "k_gc_base_windowed_s<7, false, 1024>",
+                     "fixed-base-big": "k_gc_base_windowed_s<20, false, 256>"}[args.workload] + " + k_gc_to_affine_batched"
     achieved = n / (avg_ms * 1e-3) * mad32_unit / 1e12
     traffic, traffic_src = committed_traffic(args, n)
     return {
@@ -464,7 +469,7 @@ def attach_cpu_baseline(args, result, eng, curve, k, bx, by, out, failures):
             if comp is not None:
                 result["cpu_baseline"]["competitor_openssl"] = comp
         else:
-            result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures)
+            result["cpu_baseline"] = cpu_baseline_affine(eng, curve, k, out, args.cpu_seconds, failures, name=args.curve)
     except (CheckerUnavailable, OSError) as exc:
         result["cpu_baseline"] = {"value": None, "unit": "scalar_mults/s", "cores": usable_cores(), "kind": "unavailable",
                                   "sample": "the CPU checkers could not be loaded here", "error": repr(exc)[:300]}
@@ -717,10 +722,16 @@ def cpu_baseline_affine(eng, curve, k, gpu_out, target_s, failures, base=None, x
     cores = usable_cores()
     impl, kind = load_checkers()
     builtin = name in (None, "p256", "secp256k1")
-    if not builtin:                                     # a curve registered at run time (variable base only): below, `curve` is the checker's id
-        assert base is not None
+    if not builtin:                                     # a curve registered at run time: below, `curve` is the checker's id
         curve = checker_curve(impl, name)
-    c = impl.constants(curve) if base is None else None
+    if base is not None:
+        c = None
+    elif builtin:
+        c = impl.constants(curve)
+    else:                                               # the generator of a registered curve: its public parameters (ecsimd_amd/curves.py)
+        from ecsimd_amd.curves import NAMED
+        lim = lambda v: np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+        c = {"gx": lim(NAMED[name]["gx"]), "gy": lim(NAMED[name]["gy"])}
     m0 = 256 * cores
     kn = eng.to_numpy(k[:m0])
     points = (lambda m_: (np.tile(c["gx"], (m_, 1)), np.tile(c["gy"], (m_, 1)))) if base is None else \

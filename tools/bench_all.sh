@@ -37,6 +37,10 @@ run bench_n1_ladder_radix32_brainpoolP256r1 --steps 4 --warmup 1 --curve brainpo
 run bench_n1_ladder_ref_compat_brainpoolP256r1 --steps 4 --warmup 1 --curve brainpoolP256r1 --workload ladder-ref-compat
 run bench_n1_windowed_variable_base_brainpoolP256r1 --steps 10 --warmup 2 --curve brainpoolP256r1 --workload windowed
 run bench_n1_windowed_constant_time_brainpoolP256r1 --steps 10 --warmup 2 --curve brainpoolP256r1 --workload windowed-ct
+run bench_n1_fixed_base_brainpoolP256r1 --steps 20 --warmup 2 --curve brainpoolP256r1 --workload fixed-base
+run bench_n1_fixed_base_constant_time_brainpoolP256r1 --steps 20 --warmup 2 --curve brainpoolP256r1 --workload fixed-base-ct
+run bench_n1_fixed_base_signed7_brainpoolP256r1 --steps 20 --warmup 2 --curve brainpoolP256r1 --workload fixed-base-signed
+run bench_n1_fixed_base_big20_brainpoolP256r1 --steps 20 --warmup 2 --curve brainpoolP256r1 --workload fixed-base-big
 run bench_n1_windowed_variable_base_sm2 --steps 10 --warmup 2 --curve sm2 --workload windowed
 run bench_n1_windowed_variable_base_frp256v1 --steps 10 --warmup 2 --curve frp256v1 --workload windowed
 run bench_n1_ladder_radix32_p256 --steps 10 --warmup 2 --workload ladder-radix32

@@ -167,12 +167,25 @@ import json; d=json.load(open('$out/bench_brainpool_$w.json')); r=d['roofline'];
     prof windowed_frp256v1 --workload windowed --curve frp256v1
     prof windowed_ct_brainpoolP256r1 --workload windowed-ct --curve brainpoolP256r1
     exit $rc ;;
+  r5_gcomb_profile) # round 5: counter passes for the registered curve's four combs
+    rc=0
+    prof() { tag=$1; shift; bash tools/profile.sh "r05_$tag" "$@" > "$out/profile_$tag.txt" 2>&1 || { rc=$?; tail -5 "$out/profile_$tag.txt"; }; echo "profiled $tag rc=$rc"; }
+    prof fixed_base_brainpoolP256r1 --workload fixed-base --curve brainpoolP256r1
+    prof fixed_base_ct_brainpoolP256r1 --workload fixed-base-ct --curve brainpoolP256r1
+    prof fixed_base_signed_brainpoolP256r1 --workload fixed-base-signed --curve brainpoolP256r1
+    prof fixed_base_big_brainpoolP256r1 --workload fixed-base-big --curve brainpoolP256r1
+    exit $rc ;;
   r5_gvw_relines)   # round 5: the window loop's bench lines again, with the committed counter traffic in them
     rc=0; mkdir -p "$out/lines"
     line() { f=$1; shift; timeout -k 10 400 python3 bench.py --steps 10 --warmup 2 "$@" > "$out/lines/$f.json" 2> "$out/lines/$f.err" || rc=$?
       python3 -c "import json; d=json.load(open('$out/lines/$f.json')); print('$f %.3f M/s  frac %.3f traffic %s' % (d['value']/1e6, d['roofline']['frac'], d['roofline']['traffic']))" || { tail -5 "$out/lines/$f.err"; rc=1; }; }
     for c in brainpoolP256r1 sm2 frp256v1; do line bench_n1_windowed_variable_base_$c --curve $c --workload windowed; done
     line bench_n1_windowed_constant_time_brainpoolP256r1 --curve brainpoolP256r1 --workload windowed-ct
+    [ "$1" = "fixed" ] || exit $rc
+    line bench_n1_fixed_base_brainpoolP256r1 --curve brainpoolP256r1 --workload fixed-base --steps 20
+    line bench_n1_fixed_base_constant_time_brainpoolP256r1 --curve brainpoolP256r1 --workload fixed-base-ct --steps 20
+    line bench_n1_fixed_base_signed7_brainpoolP256r1 --curve brainpoolP256r1 --workload fixed-base-signed --steps 20
+    line bench_n1_fixed_base_big20_brainpoolP256r1 --curve brainpoolP256r1 --workload fixed-base-big --steps 20
     exit $rc ;;
   pytest_gpu)       # the whole GPU suite, as the driver runs it
     timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/pytest.txt" 2>&1; rc=$?; tail -15 "$out/pytest.txt"; exit $rc ;;
