@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORDER = ["ladder", "ladder_secp256k1", "ladder_ref_compat_p256", "ladder_ref_compat_secp256k1", "ladder_x_only", "ladder_x_only_secp256k1",
          "windowed_variable_base", "windowed_variable_base_secp256k1", "windowed_constant_time", "windowed_constant_time_secp256k1", "fixed_base", "fixed_base_secp256k1", "fixed_base_constant_time", "fixed_base_constant_time_secp256k1", "fixed_base_signed7", "fixed_base_signed7_secp256k1", "fixed_base_big20",
-         "ladder_brainpoolP256r1", "ladder_sm2", "ladder_frp256v1", "windowed_variable_base_brainpoolP256r1", "windowed_variable_base_sm2", "windowed_variable_base_frp256v1", "windowed_constant_time_brainpoolP256r1", "ladder_radix32_brainpoolP256r1", "ladder_ref_compat_brainpoolP256r1", "ladder_radix32_p256",
+         "ladder_brainpoolP256r1", "ladder_sm2", "ladder_frp256v1", "windowed_variable_base_brainpoolP256r1", "windowed_variable_base_sm2", "windowed_variable_base_frp256v1", "windowed_constant_time_brainpoolP256r1", "fixed_base_brainpoolP256r1", "fixed_base_constant_time_brainpoolP256r1", "fixed_base_signed7_brainpoolP256r1", "fixed_base_big20_brainpoolP256r1", "ladder_radix32_brainpoolP256r1", "ladder_ref_compat_brainpoolP256r1", "ladder_radix32_p256",
          "group_mode", "nccl_single_rank_rehearsal"]
 LABEL = {
     "ladder": "**P-256 variable-base ladder, 2²⁴ per step (headline, BASELINE configs[3])**",
@@ -42,6 +42,10 @@ LABEL = {
     "windowed_variable_base_sm2": "**(r5)** SM2 variable base, per-element window tables (`ALG_WINDOWED`)",
     "windowed_variable_base_frp256v1": "**(r5)** FRP256v1 variable base, per-element window tables (`ALG_WINDOWED`)",
     "windowed_constant_time_brainpoolP256r1": "**(r5)** brainpoolP256r1 variable base, per-element window tables, `ALG_CONSTANT_TIME` (all 8 entries read in every window: secret scalars)",
+    "fixed_base_brainpoolP256r1": "**(r5)** brainpoolP256r1 fixed base, 4-bit windows in LDS (the registered curve's generator; `k_gcomb.hip`)",
+    "fixed_base_constant_time_brainpoolP256r1": "**(r5)** brainpoolP256r1 fixed base, `ALG_CONSTANT_TIME` (5-bit windows in LDS, every entry read: secret scalars)",
+    "fixed_base_signed7_brainpoolP256r1": "**(r5)** brainpoolP256r1 fixed base, signed 7-bit windows in LDS (`ALG_WINDOWED_SIGNED`)",
+    "fixed_base_big20_brainpoolP256r1": "**(r5)** brainpoolP256r1 fixed base, 20-bit windows, 436 MB table in device memory (`ALG_WINDOWED_BIG`)",
     "ladder_radix32_brainpoolP256r1": "**(r5)** brainpoolP256r1 ladder on 8 × 32-bit canonical words (`ECSIMD_HIP_LADDER_RADIX32`: generic word-serial reduction)",
     "ladder_ref_compat_brainpoolP256r1": "**(r5)** brainpoolP256r1 ladder with `ECSIMD_HIP_REF_SQUARE_COMPAT`",
     "ladder_radix32_p256": "P-256 ladder on 8 × 32-bit canonical words (`ECSIMD_HIP_LADDER_RADIX32`, rounds 1–3's loop)",
