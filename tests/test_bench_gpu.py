@@ -42,11 +42,12 @@ def test_group_mode_matches_the_plain_line_at_one_gpu():
 
 # roofline.frac floors per workload: profiles/r04/bench_n1_*.json (r05 for the lines that are new this round) minus 4 % (boxes differ by that much in clock)
 FLOORS = {"ladder": 0.86, "ladder-ref-compat": 0.63, "fixed-base": 0.86, "windowed": 0.83, "fixed-base-ct": 0.76, "brainpoolP256r1": 0.63,
-          ("windowed", "brainpoolP256r1"): 0.62, ("windowed-ct", "brainpoolP256r1"): 0.58}   # the registered curve's window loop: 0.66 / 0.62 in profiles/r05
+          ("windowed", "brainpoolP256r1"): 0.62, ("windowed-ct", "brainpoolP256r1"): 0.58,   # the registered curve's window loop: 0.66 / 0.62 in profiles/r05
+          ("fixed-base-signed", "brainpoolP256r1"): 0.58, ("fixed-base-ct", "brainpoolP256r1"): 0.56}   # ... and its signed / constant-time combs: 0.63 / 0.61
 
 
 @pytest.mark.parametrize("workload,curve", [("ladder-ref-compat", "p256"), ("ladder-ref-compat", "secp256k1"), ("fixed-base", "p256"), ("windowed", "p256"), ("fixed-base-ct", "p256"), ("ladder", "brainpoolP256r1"),
-                                            ("windowed", "brainpoolP256r1"), ("windowed-ct", "brainpoolP256r1")])
+                                            ("windowed", "brainpoolP256r1"), ("windowed-ct", "brainpoolP256r1"), ("fixed-base-signed", "brainpoolP256r1"), ("fixed-base-ct", "brainpoolP256r1")])
 def test_every_workload_stays_at_its_committed_fraction_of_the_roof(workload, curve):
     """a regression guard per workload, not only for the headline -- the reference-compatible ladder (the mode that is identical to
     the reference on every lane), BASELINE configs[2]'s LDS comb, the windowed variable-base path, the constant-time comb, and a curve registered at run time (its ladder and its window loop, plain and constant-time)."""
